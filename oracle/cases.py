@@ -1,0 +1,128 @@
+"""Golden-case runners shared by the fixture generator and the parity tests.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  A runner takes an implementation
+(the real reference, the oracle, or the HIP product) as a namespace of builders,
+drives it on recipe-generated weights/inputs and returns {name: ndarray}.
+``gen_golden.py`` runs them on the real reference and stores the result;
+the tests run them on the oracle (CPU) and on the HIP engine (GPU) and compare.
+"""
+import numpy as np
+import torch
+
+from . import recipe
+
+# name -> (builder attr, builder kwargs, input shape, seed)
+NET_CASES = {
+    'ConvGenerator64':   ('ConvGenerator64', {}, (2, 128), 11),
+    'ConvGenerator32':   ('ConvGenerator32', {}, (3, 128), 12),
+    'SNDiscriminator64': ('SNDiscriminator64', {}, (2, 3, 64, 64), 13),
+    'SNDiscriminator32': ('SNDiscriminator32', {}, (3, 3, 32, 32), 14),
+    'SRResNet':          ('SRResNet', {}, (2, 3, 12, 12), 15),
+    'Discriminator96':   ('Discriminator96', {}, (2, 3, 96, 96), 16),
+    'Resnet6Blocks':     ('Resnet6Blocks', {}, (1, 3, 32, 32), 17),
+    'ConvDiscriminator': ('ConvDiscriminator', {}, (1, 3, 64, 64), 18),
+}
+
+BUFFER_LEAVES = ('running_mean', 'running_var', 'num_batches_tracked', 'weight_u', 'weight_v')
+
+
+def run_net_case(networks, name, device='cpu'):
+    """Seeded weights -> train-mode forward -> loss=(out*R).sum() -> backward."""
+    attr, kw, xshape, seed = NET_CASES[name]
+    net = getattr(networks, attr)(**kw)
+    recipe.fill(net, seed)
+    net = net.to(device)
+    net.train()
+    x = recipe.tensor(seed, 1000, xshape).to(device)
+    if len(xshape) == 4:
+        x = torch.tanh(x)
+    x.requires_grad_(True)
+    out = net(x)
+    r = recipe.tensor(seed, 1001, tuple(out.shape)).to(device)
+    loss = (out * r).sum()
+    loss.backward()
+    res = {'out': out.detach().cpu().numpy(), 'loss': np.float64(loss.item())}
+    recipe.pack_summary('dx', x.grad.cpu(), res)
+    for k, p in net.named_parameters():
+        recipe.pack_summary(f'grad/{k}', p.grad.cpu(), res)
+    for k, b in net.state_dict().items():
+        if k.rsplit('.', 1)[-1] in BUFFER_LEAVES:
+            res[f'buf/{k}'] = b.detach().cpu().numpy()
+    return res
+
+
+DCGAN_CFG = {'G': 'ConvGenerator64', 'D': 'SNDiscriminator64', 'opt': 'Adam',
+             'opt_param': {'lr': 2.0e-4, 'betas': [0.5, 0.999]}, 'type': 'DCGAN'}
+WBOX_CFG = {'gamma_0': 0.1, 'string': 'EXAMPLE A', 'target': 'G'}
+
+
+def run_dcgan_steps(make_cfg, models, device, n_steps=3, batch=4, seed=21, wbox=True):
+    """n G+D steps in the order of experiments/image_generation.py:86-101 (update_d on
+    {real_sample, latent}, then update_g on {fake_sample: model.fake_sample}) with the
+    white-box wrapper (configure_protection, image_generation.py:75-84)."""
+    model = models.DCGAN(make_cfg(DCGAN_CFG), device=device)
+    recipe.fill(model.G.module, seed)
+    recipe.fill(model.D.module, seed + 1)
+    model.G.to(device[0])
+    model.D.to(device[0])
+    if wbox:
+        model = models.WhiteBoxWrapper(model, make_cfg(WBOX_CFG))
+    res = {}
+    for s in range(n_steps):
+        x = torch.tanh(recipe.tensor(seed, 2000 + s, (batch, 3, 64, 64)))
+        z = recipe.tensor(seed, 3000 + s, (batch, 128))
+        model.update_d({'real_sample': x, 'latent': z})
+        model.update_g({'fake_sample': model.fake_sample})
+        for k, v in model.get_metrics().items():
+            res[f'step{s}/metric/{k}'] = np.float64(v)
+        if s == 0:
+            res['step0/fake_sample'] = model.fake_sample.detach().cpu().numpy()
+    sd = model.state_dict()
+    for net in ('G', 'D'):
+        for k, v in sd[net].items():
+            leaf = k.rsplit('.', 1)[-1]
+            v = v.detach().cpu()
+            if leaf in BUFFER_LEAVES or v.numel() <= 512:
+                res[f'final/{net}/{k}'] = v.numpy()
+            else:
+                recipe.pack_summary(f'final/{net}/{k}', v, res)
+    for opt in ('optG', 'optD'):
+        st = sd[opt]['state']
+        for idx in sorted(st):
+            recipe.pack_summary(f'final/{opt}/{idx}/exp_avg', st[idx]['exp_avg'].cpu(), res)
+            recipe.pack_summary(f'final/{opt}/{idx}/exp_avg_sq', st[idx]['exp_avg_sq'].cpu(), res)
+            res[f'final/{opt}/{idx}/step'] = np.float64(float(st[idx]['step']))
+    for k, v in sd['sign'].items() if wbox else ():
+        res[f'final/sign/{k}'] = v.detach().cpu().numpy()
+    if wbox:
+        res['final/ber'] = np.float64(float(model.loss_model.compute_ber(model.G)))
+    return res
+
+
+SIGN_CASES = {'ConvGenerator64': 448, 'SRResNet': 2112, 'Resnet9Blocks': 5248}
+
+
+def run_sign_case(networks, SignLossModel, make_cfg, name, string='EXAMPLE A', seed=31):
+    """Bits/signs assigned per norm layer, the sign-loss value and the BER after a
+    deterministic corruption of gamma (zeros count as errors, sign_model.py:58)."""
+    net = getattr(networks, name)()
+    recipe.fill(net, seed)
+    slm = SignLossModel(net, make_cfg({'gamma_0': 0.1, 'string': string}))
+    res = {}
+    signs = [b.detach().cpu().numpy() for _, b in slm.named_buffers()]
+    res['signs'] = np.concatenate(signs).astype(np.int8)
+    res['names'] = np.array([k for k, _ in slm.named_buffers()])
+    res['ber_clean'] = np.float64(float(slm.compute_ber(net)))
+    res['loss_clean'] = np.float64(float(slm(net).detach()))
+    g = np.random.default_rng([seed, 77])
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.InstanceNorm2d)) and m.weight is not None:
+                n = m.weight.numel()
+                flip = torch.from_numpy(g.random(n) < 0.2)
+                zero = torch.from_numpy(g.random(n) < 0.05)
+                m.weight[flip] = -m.weight[flip]
+                m.weight[zero] = 0.0
+    res['ber_corrupt'] = np.float64(float(slm.compute_ber(net)))
+    res['loss_corrupt'] = np.float64(float(slm(net).detach()))
+    return res

@@ -1,0 +1,64 @@
+"""Import the REAL reference (``/root/reference``) for golden-vector generation.
+
+TEST INFRASTRUCTURE, build-container only: the reference does not exist on the GPU
+box and never travels (no source, no bytecode).  The reference's package
+``__init__`` files import torchvision / pytorch_msssim / pdqhash, which are absent
+from this image, so the torch-only hot-path files are loaded by file path and the
+``networks`` / ``tools`` packages are pre-seeded in ``sys.modules`` with exactly
+those classes; ``models`` then imports unmodified.
+"""
+import importlib
+import importlib.util
+import os
+import sys
+import types
+
+REF = os.environ.get('IPRGAN_REFERENCE', '/root/reference')
+
+
+def available():
+    return os.path.isdir(os.path.join(REF, 'networks'))
+
+
+def _load(modname, relpath):
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load():
+    """Returns (networks, tools, models) namespaces of the real reference."""
+    sys.dont_write_bytecode = True              # never write __pycache__ into /root/reference
+    if 'ref_models_loaded' in sys.modules:
+        m = sys.modules['ref_models_loaded']
+        return m.networks, m.tools, m.models
+    networks = types.ModuleType('networks')
+    for f in ('conv_generator', 'sn_discriminator', 'conv_discriminator', 'sr_resnet',
+              'discriminator_96', 'resnet_generator'):
+        mod = _load(f'_ref_net_{f}', f'networks/{f}.py')
+        for k, v in vars(mod).items():
+            if not k.startswith('__'):
+                setattr(networks, k, v)
+    tools = types.ModuleType('tools')
+    sm = _load('_ref_tools_sign_model', 'tools/sign_model.py')
+    tools.SignLossModel = sm.SignLossModel
+    tools.BitGenerator = sm.BitGenerator
+    saved = {k: sys.modules.get(k) for k in ('networks', 'tools', 'models')}
+    sys.modules['networks'] = networks
+    sys.modules['tools'] = tools
+    sys.path.insert(0, REF)
+    try:
+        models = importlib.import_module('models')
+        configs = _load('_ref_configs', 'configs/__init__.py')
+    finally:
+        sys.path.remove(REF)
+    holder = types.ModuleType('ref_models_loaded')
+    holder.networks, holder.tools, holder.models, holder.Config = networks, tools, models, configs.Config
+    sys.modules['ref_models_loaded'] = holder
+    return networks, tools, models
+
+
+def Config(entries):
+    load()
+    return sys.modules['ref_models_loaded'].Config(entries)
