@@ -1,0 +1,157 @@
+/* libiprgan_hip.so — C ABI of the MI355X (gfx950) kernels behind ipr-gan's G+D training step.
+ *
+ * Drop-in boundary.  The reference has no native code: its
+ * "kernel layer" is torch ATen/cuDNN reached through torch.nn modules
+ * (networks/<net>.py) and torch.optim / torch.nn.functional (models/<model>.py).  Each entry point
+ * below replaces the ATen op named in its comment at the cited reference call site.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory unless noted
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*); no allocation, no sync
+ *   - return 0 on success, non-zero on error; text via iprgan_last_error() (thread-local)
+ *   - activations are fp32 NHWC with the channel count padded to a multiple of 4
+ *     ("C4" = (C+3)&~3; RGB images are NHWC4 with a zero 4th channel)
+ *   - "prepared" conv weights are tap-major K-vectors, produced by iprgan_conv_weight_prep
+ */
+#ifndef IPRGAN_H
+#define IPRGAN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPRGAN_VERSION 100
+
+enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3 };
+enum { IPRGAN_PAD_ZERO = 0, IPRGAN_PAD_REFLECT = 1 };
+
+/* One 2-D convolution / transposed convolution layer.
+ * Conv2d:          x[B,H,W,Cin]  -> y[B,OH,OW,Cout], OH=(H+2*pad-KH)/stride+1
+ * ConvTranspose2d: x[B,H,W,Cin]  -> y[B,OH,OW,Cout], OH=(H-1)*stride-2*pad+KH+outpad */
+typedef struct {
+  int32_t B, H, W, Cin, Cout;
+  int32_t KH, KW, stride, pad, outpad;
+  int32_t transposed;     /* 0 = Conv2d, 1 = ConvTranspose2d */
+  int32_t pad_mode;       /* IPRGAN_PAD_*: reflect = ReflectionPad2d(pad) folded into the gather */
+  int32_t act;            /* IPRGAN_ACT_* fused into the forward epilogue */
+  float   slope;          /* LeakyReLU negative slope */
+} iprgan_conv_desc;
+
+const char* iprgan_last_error(void);
+int iprgan_version(void);
+
+/* ---- layout ------------------------------------------------------------------------ */
+/* NCHW [B,C,H,W] -> NHWC [B,H,W,C4] (pad channels zero) and back (drops pad channels).   */
+int iprgan_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+int iprgan_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+/* dst[b][a][k] = src[a][b][k] (NCHW-flatten <-> NHWC-flatten order of Linear weights,
+ * networks/conv_generator.py:26 and sn_discriminator.py:32) */
+int iprgan_permute_021(const float* src, float* dst, int A, int Bd, int K, void* stream);
+
+/* ---- convolution (replaces aten::conv2d / conv_transpose2d + their backward;
+ *      networks/sn_discriminator.py:9-18, conv_generator.py:8,21, sr_resnet.py:22,
+ *      discriminator_96.py:7-21, resnet_generator.py:7-34, conv_discriminator.py:6-21) ---- */
+/* sizes (in floats) of the two prepared-weight buffers and of the wgrad workspace */
+size_t iprgan_conv_wfwd_floats(const iprgan_conv_desc* d);
+size_t iprgan_conv_wbwd_floats(const iprgan_conv_desc* d);
+size_t iprgan_conv_wgrad_ws_floats(const iprgan_conv_desc* d);
+/* w: PyTorch layout (Conv2d [Cout,Cin,KH,KW]; ConvTranspose2d [Cin,Cout,KH,KW]).
+ * inv_scale: optional device scalar; weights are multiplied by 1/(*inv_scale) (spectral-norm sigma).
+ * wfwd / wbwd (either may be NULL): tap-major operands for forward and for backward-data. */
+int iprgan_conv_weight_prep(const iprgan_conv_desc* d, const float* w, const float* inv_scale,
+                            float* wfwd, float* wbwd, void* stream);
+/* y = act(conv(x, w) + bias); bias may be NULL (length Cout). */
+int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd, const float* bias,
+                    float* y, void* stream);
+/* dx = conv_bwd_data(dy, w) [* act'(x_out_prev)]: if prev_out != NULL the result is multiplied by the
+ * derivative of activation prev_act evaluated from the saved OUTPUT prev_out of the previous layer
+ * (same shape as dx), i.e. the previous layer's activation backward is fused into this epilogue. */
+int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx,
+                         const float* prev_out, int prev_act, float prev_slope, void* stream);
+/* dw (PyTorch layout, overwritten) = conv_bwd_weight(x, dy); db (optional, length Cout) = sum dy.
+ * ws: workspace of iprgan_conv_wgrad_ws_floats(d) floats. Deterministic (fixed-order split reduce). */
+int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const float* dy, float* dw,
+                           float* db, float* ws, void* stream);
+/* dz = dy * act'(out) elementwise (activation backward from the saved output), n floats. */
+int iprgan_act_bwd(const float* dy, const float* out, float* dz, size_t n, int act, float slope,
+                   void* stream);
+
+/* ---- GEMV head: SN-Linear 512*md*md -> 1 (networks/sn_discriminator.py:21) -------------- */
+/* y[b] = dot(x[b,:], w)/(*inv_scale) + bias[0];  x [B,K] */
+int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const float* inv_scale,
+                    float* y, int B, int K, void* stream);
+/* dx[b,k] = dy[b]*w[k]/(*inv_scale) [* act'(prev_out)];  dw[k] = sum_b dy[b]*x[b,k] (gradient w.r.t.
+ * the NORMALISED weight w/sigma; feed it to iprgan_sn_bwd);  db[0] = sum dy.  dx/dw/db may be NULL. */
+int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float* inv_scale,
+                    float* dx, float* dw, float* db, const float* prev_out, int prev_act,
+                    float prev_slope, int B, int K, void* stream);
+
+/* ---- BatchNorm2d (networks/conv_generator.py:9, sr_resnet.py:23, discriminator_96.py:31) -- */
+size_t iprgan_bn_ws_floats(int M, int C);
+/* training forward: batch statistics over M=B*H*W rows of x[M,C]; y = act((x-mean)*invstd*g+b);
+ * save_mean/save_invstd [C] out; running stats updated in place (momentum, unbiased var) when
+ * running_mean != NULL.  eval forward: use_running=1 normalises with the running stats. */
+int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                  float* ws, int M, int C, float eps, float momentum, int use_running, int act,
+                  float slope, void* stream);
+/* backward through act + BN: inputs x (pre-norm), y (post-act output), dy.  dx, dgamma, dbeta out. */
+int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+                  const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                  float* dbeta, float* ws, int M, int C, int act, float slope, void* stream);
+
+/* ---- spectral norm (torch.nn.utils.spectral_norm at networks/sn_discriminator.py:9,11,18,21) */
+size_t iprgan_sn_ws_floats(int rows, int cols);
+/* one power iteration on W_mat[rows,cols] (row-major = weight.view(Cout,-1)): updates u[rows], v[cols]
+ * in place (skipped when training==0) and writes sigma = u.(W v) to *sigma (device). eps = 1e-12. */
+int iprgan_sn_power_iter(const float* w, float* u, float* v, float* sigma, float* ws, int rows,
+                         int cols, float eps, int training, void* stream);
+/* dW_orig = (dW_sn - (sum dW_sn*W)/sigma * u v^T) / sigma   (autograd through sigma, u,v constant) */
+int iprgan_sn_bwd(const float* dwsn, const float* w, const float* u, const float* v,
+                  const float* sigma, float* dw, float* ws, int rows, int cols, void* stream);
+
+/* ---- losses (models/dcgan.py:33-40, srgan.py:36-59, cyclegan.py:122-142) ------------------ */
+enum { IPRGAN_LOSS_HINGE_REAL = 0,   /* mean(relu(1-x)) */
+       IPRGAN_LOSS_HINGE_FAKE = 1,   /* mean(relu(1+x)) */
+       IPRGAN_LOSS_NEG_MEAN = 2,     /* -mean(x) */
+       IPRGAN_LOSS_BCE_ONES = 3,     /* BCE-with-logits vs 1 */
+       IPRGAN_LOSS_BCE_ZEROS = 4,    /* BCE-with-logits vs 0 */
+       IPRGAN_LOSS_MSE_ONES = 5, IPRGAN_LOSS_MSE_ZEROS = 6,
+       IPRGAN_LOSS_MSE = 7, IPRGAN_LOSS_L1 = 8 };  /* two-input forms use y */
+size_t iprgan_loss_ws_floats(size_t n);
+int iprgan_loss_fwd(int kind, const float* x, const float* y, float* loss, float* ws, size_t n,
+                    void* stream);
+/* dx = (*gscale) * dloss/dx ; gscale is a device scalar (upstream gradient), may be NULL (=1). */
+int iprgan_loss_bwd(int kind, const float* x, const float* y, const float* gscale, float* dx,
+                    size_t n, void* stream);
+
+/* ---- sign-loss watermark (tools/sign_model.py:42-60) --------------------------------------- */
+/* gammas/signs/dgammas: HOST arrays of nlayer DEVICE pointers, sizes: HOST array of channel counts.
+ * loss = sum_l mean(relu(gamma0 - gamma_l*sign_l)).  Pointer tables are copied into the launch. */
+int iprgan_sign_loss_fwd(const float* const* gammas, const float* const* signs, const int* sizes,
+                         int nlayer, float gamma0, float* loss, void* stream);
+/* dgamma_l = (*gscale) * (-sign/n_l) * [gamma0 - gamma*sign > 0]  (overwrites dgammas[l]) */
+int iprgan_sign_loss_bwd(const float* const* gammas, const float* const* signs,
+                         float* const* dgammas, const int* sizes, int nlayer, float gamma0,
+                         const float* gscale, void* stream);
+/* counts[0] = #(sign(gamma) != sign_bit) (sign(0)=0 counts as an error), counts[1] = total bits;
+ * int64 device output, bit-exact. */
+int iprgan_sign_ber(const float* const* gammas, const float* const* signs, const int* sizes,
+                    int nlayer, long long* counts, void* stream);
+
+/* ---- Adam (torch.optim.Adam.step at models/dcgan.py:69,78) --------------------------------- */
+/* multi-tensor: HOST arrays of n DEVICE pointers; step is the 1-based step count after increment. */
+int iprgan_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
+                     float* const* exp_avg_sq, const long long* sizes, int n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* ---- misc elementwise ----------------------------------------------------------------------- */
+int iprgan_fill(float* p, float v, size_t n, void* stream);
+int iprgan_axpy(float* y, const float* x, float a, size_t n, void* stream);   /* y += a*x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPRGAN_H */

@@ -1,0 +1,95 @@
+// Shared host/device helpers for libiprgan_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "iprgan.h"
+
+namespace iprgan {
+
+void set_error(const char* fmt, ...);
+
+#define IPR_CHECK(cond, ...)                 \
+  do {                                       \
+    if (!(cond)) {                           \
+      ::iprgan::set_error(__VA_ARGS__);      \
+      return 1;                              \
+    }                                        \
+  } while (0)
+
+#define IPR_LAUNCH_CHECK()                                                       \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      ::iprgan::set_error("%s:%d launch failed: %s", __FILE__, __LINE__,         \
+                          hipGetErrorString(e__));                               \
+      return 2;                                                                  \
+    }                                                                            \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int rup(int a, int b) { return cdiv(a, b) * b; }
+static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// Exact unsigned division by a runtime-constant divisor for n < 2^31 (Granlund-Montgomery):
+// q = (umulhi(n, mul) + n) >> shift.
+struct FastDiv {
+  uint32_t mul, shift, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.shift = l;
+  f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  return f;
+}
+__host__ __device__ static inline uint32_t fdiv(uint32_t n, const FastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t t = __umulhi(n, f.mul);
+#else
+  uint32_t t = (uint32_t)(((uint64_t)n * f.mul) >> 32);
+#endif
+  return (t + n) >> f.shift;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024; every thread gets the result. smem: >= 16 floats.
+__device__ __forceinline__ float block_sum(float v, float* smem) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += smem[i];   // fixed order: deterministic
+  return r;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  switch (act) {
+    case IPRGAN_ACT_RELU: return v > 0.f ? v : 0.f;
+    case IPRGAN_ACT_LRELU: return v > 0.f ? v : v * slope;
+    case IPRGAN_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+// derivative of the activation expressed through its OUTPUT o
+__device__ __forceinline__ float act_grad_from_out(float o, int act, float slope) {
+  switch (act) {
+    case IPRGAN_ACT_RELU: return o > 0.f ? 1.f : 0.f;
+    case IPRGAN_ACT_LRELU: return o > 0.f ? 1.f : slope;
+    case IPRGAN_ACT_TANH: return 1.f - o * o;
+    default: return 1.f;
+  }
+}
+
+}  // namespace iprgan

@@ -1,0 +1,717 @@
+// Implicit-GEMM convolution family for gfx950 on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// One "gather-GEMM" kernel serves Conv2d forward, Conv2d backward-data (sub-pixel phases for
+// stride > 1, no zero insertion), ConvTranspose2d forward (= backward-data form) and
+// ConvTranspose2d backward-data (= forward form):
+//     out[b, y*osy+ooy, x*osx+oox, n] = sum_{tap,c} in[b, y*isy+dy(tap), x*isx+dx(tap), c] * Wt[n][tap*Cs+c]
+// A (activations, NHWC, channels contiguous) and B (tap-major weight K-vectors) tiles are staged
+// through LDS in 16-byte chunks with an XOR swizzle that makes the ds_read_b128 fragment reads
+// conflict-free; each wave owns (32*WM)x(32*WN) of the block tile and issues 4 MFMAs per
+// fragment pair (k = 8 per ds_read_b128 pair: lane half h supplies k = 4h+j to MFMA j).
+// A second kernel computes backward-weight as a split-M GEMM into partial slabs that a
+// fixed-order reduce sums (deterministic) and scatters into PyTorch's weight layout.
+#include "common.h"
+
+namespace iprgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Phase {
+  int th, tw, ntap;
+  int dy0, dx0, dys, dxs;
+  int wbase, wsy, wsx;
+  int ooy, oox, ohg, owg;
+  int M, steps;
+  FastDiv d_owg, d_plane, d_tw;
+};
+
+struct GConvArgs {
+  const float* in;
+  const float* wt;
+  const float* bias;
+  float* out;
+  const float* aux;
+  int B, IH, IW, Cs, c4n;
+  FastDiv d_c4n;
+  int Kp;
+  int OH, OW, Ns, N;
+  int isy, isx, osy, osx;
+  int pad_mode, act;
+  float slope;
+  int aux_act;
+  float aux_slope;
+  int nphase;
+  Phase ph[4];
+};
+
+#define ROW_INVALID (-(1 << 28))
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+
+template <int WGM, int WGN, int WM, int WN>
+__global__ __launch_bounds__(256) void gconv_kernel(const GConvArgs a) {
+  constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int TILE4 = (BM + BN) * 8;          // float4 per stage buffer
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+
+  const Phase& p = a.ph[blockIdx.z];
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= p.M) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int chunk = tid & 7, lrow = tid >> 3;
+
+  // per-row gather state (rows are fixed for the whole K loop)
+  int abase[RA], aiy[RA], aix[RA];
+  const int plane = p.ohg * p.owg;
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    if (m < p.M) {
+      const int b = fdiv(m, p.d_plane);
+      const int rem = m - b * plane;
+      const int y = fdiv(rem, p.d_owg);
+      const int x = rem - y * p.owg;
+      abase[i] = b * a.IH * a.IW;
+      aiy[i] = y * a.isy;
+      aix[i] = x * a.isx;
+    } else {
+      abase[i] = 0; aiy[i] = ROW_INVALID; aix[i] = 0;
+    }
+  }
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[RA], rb[RB];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto gload = [&](int step) {
+    const int q = step * 8 + chunk;
+    const int t = fdiv(q, a.d_c4n);
+    const int c4 = q - t * a.c4n;
+    const bool valid = t < p.ntap;
+    const int ty = fdiv(t, p.d_tw);
+    const int tx = t - ty * p.tw;
+    const int dy = p.dy0 + ty * p.dys, dx = p.dx0 + tx * p.dxs;
+    const int wk = (p.wbase + ty * p.wsy + tx * p.wsx) * a.Cs + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int iy = aiy[i] + dy, ix = aix[i] + dx;
+      bool ok;
+      if (a.pad_mode == IPRGAN_PAD_REFLECT) {
+        ok = valid && aiy[i] != ROW_INVALID;
+        iy = reflect_idx(iy, a.IH);
+        ix = reflect_idx(ix, a.IW);
+      } else {
+        ok = valid && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      }
+      const f32x4* src = (const f32x4*)(a.in + ((size_t)(abase[i] + iy * a.IW + ix) * a.Cs + c4 * 4));
+      ra[i] = ok ? *src : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int n = n0 + lrow + 32 * i;
+      const f32x4* src = (const f32x4*)(a.wt + ((size_t)n * a.Kp + wk));
+      rb[i] = valid ? *src : zero4;
+    }
+  };
+  auto lstore = [&](int buf) {
+    f32x4* A4 = lds + buf * TILE4;
+    f32x4* B4 = A4 + BM * 8;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int r = lrow + 32 * i;
+      A4[r * 8 + (chunk ^ ((r >> 1) & 7))] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int r = lrow + 32 * i;
+      B4[r * 8 + (chunk ^ ((r >> 1) & 7))] = rb[i];
+    }
+  };
+  auto compute = [&](int buf) {
+    const f32x4* A4 = lds + buf * TILE4;
+    const f32x4* B4 = A4 + BM * 8;
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      f32x4 af[WM], bf[WN];
+      const int c = 2 * kq + half;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int r = (wm * WM + i) * 32 + l31;
+        af[i] = A4[r * 8 + (c ^ ((r >> 1) & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int r = (wn * WN + j) * 32 + l31;
+        bf[j] = B4[r * 8 + (c ^ ((r >> 1) & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int steps = p.steps;
+  if (steps > 0) {
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+      const bool more = s + 1 < steps;
+      if (more) gload(s + 1);
+      compute(s & 1);
+      if (more) lstore((s + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m >= p.M) continue;
+      const int b = fdiv(m, p.d_plane);
+      const int rem = m - b * plane;
+      const int y = fdiv(rem, p.d_owg);
+      const int x = rem - y * p.owg;
+      const size_t opix = (size_t)(b * a.OH + y * a.osy + p.ooy) * a.OW + x * a.osx + p.oox;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int n = n0 + (wn * WN + j) * 32 + l31;
+        if (n >= a.Ns) continue;
+        float v = acc[i][j][r];
+        if (a.bias && n < a.N) v += a.bias[n];
+        v = act_apply(v, a.act, a.slope);
+        const size_t idx = opix * a.Ns + n;
+        if (a.aux) v *= act_grad_from_out(a.aux[idx], a.aux_act, a.aux_slope);
+        a.out[idx] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward-weight: ws[split][n][k] = sum_{m in split} P[m][n] * Qg[m][k],  k = tap*Qs + c
+// ------------------------------------------------------------------------------------------
+struct WGradArgs {
+  const float* P;
+  const float* Q;
+  float* ws;
+  int Ps, Pvalid;            // channel stride of P, number of readable channels (= Ps)
+  int QH, QW, Qs, c4n;
+  FastDiv d_c4n, d_pw, d_plane, d_tw;
+  int PH, PW, M;
+  int isy, isx, pad, tw, ntap, pad_mode;
+  int Kw, Nrows;             // slab row length / rows
+  int chunks_per_split;
+};
+
+template <int WGM, int WGN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
+  constexpr int BN = WGM * WM * 32;   // tile over n (P channels)  -> MFMA rows
+  constexpr int BK = WGN * WN * 32;   // tile over k (tap,c)       -> MFMA cols
+  constexpr int CP = BN / 4, CQ = BK / 4;          // 16-B chunks per tile row
+  constexpr int RPP = 256 / CP, RPQ = 256 / CQ;    // rows per pass
+  constexpr int NP = 32 / RPP, NQ = 32 / RPQ;      // passes per 32-row chunk
+  constexpr int STAGE = 32 * (BN + BK);            // floats per stage
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  float* ldsf = (float*)lds;
+
+  const int k0 = blockIdx.x * BK, n0 = blockIdx.y * BN, split = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int cp = tid % CP, rp = tid / CP;
+  const int cq = tid % CQ, rq = tid / CQ;
+
+  // this thread's fixed k-chunk of the Q tile
+  const int q = k0 / 4 + cq;
+  const int t = fdiv(q, a.d_c4n);
+  const int c4 = q - t * a.c4n;
+  const bool qvalid = t < a.ntap;
+  const int ty = fdiv(t, a.d_tw), tx = t - ty * a.tw;
+  const int dy = ty - a.pad, dx = tx - a.pad;
+  const bool pvalid = (n0 + cp * 4) < a.Pvalid;
+  const int plane = a.PH * a.PW;
+
+  const int chunk_begin = split * a.chunks_per_split;
+  int chunk_end = chunk_begin + a.chunks_per_split;
+  const int total_chunks = (a.M + 31) / 32;
+  if (chunk_end > total_chunks) chunk_end = total_chunks;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 rP[NP], rQ[NQ];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto gload = [&](int ch) {
+    const int mb = ch * 32;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int m = mb + rp + RPP * i;
+      rP[i] = zero4;
+      if (pvalid && m < a.M) rP[i] = *(const f32x4*)(a.P + ((size_t)m * a.Ps + n0 + cp * 4));
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int m = mb + rq + RPQ * i;
+      rQ[i] = zero4;
+      if (qvalid && m < a.M) {
+        const int b = fdiv(m, a.d_plane);
+        const int rem = m - b * plane;
+        const int y = fdiv(rem, a.d_pw);
+        const int x = rem - y * a.PW;
+        int iy = y * a.isy + dy, ix = x * a.isx + dx;
+        bool ok = true;
+        if (a.pad_mode == IPRGAN_PAD_REFLECT) {
+          iy = reflect_idx(iy, a.QH);
+          ix = reflect_idx(ix, a.QW);
+        } else {
+          ok = (unsigned)iy < (unsigned)a.QH && (unsigned)ix < (unsigned)a.QW;
+        }
+        if (ok) rQ[i] = *(const f32x4*)(a.Q + ((size_t)((b * a.QH + iy) * a.QW + ix) * a.Qs + c4 * 4));
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* Pt = ldsf + buf * STAGE;
+    float* Qt = Pt + 32 * BN;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *(f32x4*)(Pt + (rp + RPP * i) * BN + cp * 4) = rP[i];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) *(f32x4*)(Qt + (rq + RPQ * i) * BK + cq * 4) = rQ[i];
+  };
+  auto compute = [&](int buf) {
+    const float* Pt = ldsf + buf * STAGE;
+    const float* Qt = Pt + 32 * BN;
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int row = 2 * kk + half;
+      float af[WM], bf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = Pt[row * BN + (wm * WM + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[j] = Qt[row * BK + (wn * WN + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (chunk_begin < chunk_end) {
+    gload(chunk_begin);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+      const bool more = ch + 1 < chunk_end;
+      if (more) gload(ch + 1);
+      compute(buf);
+      if (more) lstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  const int half = lane >> 5, l31 = lane & 31;
+  float* slab = a.ws + (size_t)split * a.Nrows * a.Kw;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n >= a.Nrows) continue;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int k = k0 + (wn * WN + j) * 32 + l31;
+        if (k < a.Kw) slab[(size_t)n * a.Kw + k] = acc[i][j][r];
+      }
+    }
+}
+
+// sum the split slabs in fixed order and scatter into PyTorch weight layout
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
+                                    int Nrows, int Kw, int N, int C, int Qs, int ntap, FastDiv d_qs,
+                                    long long sn, long long sc) {
+  const long long total = (long long)N * ntap * Qs;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % (ntap * Qs));
+    const int n = (int)(i / (ntap * Qs));
+    const int tap = fdiv(kk, d_qs);
+    const int c = kk - tap * Qs;
+    if (c >= C) continue;
+    float s = 0.f;
+    const float* p = ws + (size_t)n * Kw + kk;
+    for (int sp = 0; sp < nsplit; ++sp) s += p[(size_t)sp * Nrows * Kw];
+    dw[n * sn + c * sc + tap] = s;
+  }
+}
+
+// prepared-weight builder: w[D0][D1][ntap] (PyTorch) -> ot[R0][K0] (row d0, k = tap*C4(D1)+d1)
+//                                                      and it[R1][K1] (row d1, k = tap*C4(D0)+d0)
+__global__ void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale,
+                                   float* __restrict__ dst, int rows_alloc, int Kp, int Drow,
+                                   int Dcol, int Cs, int ntap, int row_is_d0) {
+  const float sc = inv_scale ? *inv_scale : 1.f;
+  const long long total = (long long)rows_alloc * Kp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp);
+    const int r = (int)(i / Kp);
+    const int tap = k / Cs, c = k - tap * Cs;
+    float v = 0.f;
+    if (r < Drow && tap < ntap && c < Dcol) {
+      const long long src = row_is_d0 ? ((long long)r * Dcol + c) * ntap + tap
+                                      : ((long long)c * Drow + r) * ntap + tap;
+      v = w[src];
+      if (inv_scale) v = v / sc;
+    }
+    dst[i] = v;
+  }
+}
+
+// column sums of x[M][Cs] in two deterministic stages (bias gradient)
+__global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int M,
+                                      int Cs, int rows_per_block) {
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= Cs) return;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += x[(size_t)r * Cs + c];
+  part[(size_t)blockIdx.x * Cs + c] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk,
+                                    int Cs, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * Cs + c];
+  out[c] = s;
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
+                               float* __restrict__ dz, size_t n, int act, float slope) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    dz[i] = dy[i] * act_grad_from_out(out[i], act, slope);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static inline int c4(int c) { return (c + 3) & ~3; }
+
+struct Shape {
+  int OH, OW;
+};
+static Shape out_shape(const iprgan_conv_desc* d) {
+  Shape s;
+  if (d->transposed) {
+    s.OH = (d->H - 1) * d->stride - 2 * d->pad + d->KH + d->outpad;
+    s.OW = (d->W - 1) * d->stride - 2 * d->pad + d->KW + d->outpad;
+  } else {
+    s.OH = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+    s.OW = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  }
+  return s;
+}
+
+static void finish_phase(Phase& p, int B, int Cs) {
+  p.ntap = p.th * p.tw;
+  p.M = B * p.ohg * p.owg;
+  p.steps = cdiv(p.ntap * Cs, 32);
+  p.d_owg = make_fastdiv(p.owg > 0 ? p.owg : 1);
+  p.d_plane = make_fastdiv(p.ohg * p.owg > 0 ? p.ohg * p.owg : 1);
+  p.d_tw = make_fastdiv(p.tw > 0 ? p.tw : 1);
+}
+
+// "forward form": out grid = full output, gather with stride; used by Conv2d fwd and ConvT bwd-data
+static void geom_forward_form(GConvArgs& a, int B, int IH, int IW, int Cred, int OH, int OW, int N,
+                              int KH, int KW, int stride, int pad) {
+  a.B = B; a.IH = IH; a.IW = IW; a.Cs = c4(Cred); a.c4n = a.Cs / 4; a.d_c4n = make_fastdiv(a.c4n);
+  a.Kp = rup(KH * KW * a.Cs, 32);
+  a.OH = OH; a.OW = OW; a.Ns = c4(N); a.N = N;
+  a.isy = a.isx = stride; a.osy = a.osx = 1;
+  a.nphase = 1;
+  Phase& p = a.ph[0];
+  p.th = KH; p.tw = KW; p.dy0 = -pad; p.dx0 = -pad; p.dys = p.dxs = 1;
+  p.wbase = 0; p.wsy = KW; p.wsx = 1; p.ooy = p.oox = 0; p.ohg = OH; p.owg = OW;
+  finish_phase(p, B, a.Cs);
+}
+
+// "backward-data form": out = the larger (input-side) image, gather from the smaller one, one
+// phase per output residue mod stride; used by Conv2d bwd-data and ConvT fwd.
+// (OHs, OWs) = dims of the gathered (small) image; (H, W) = dims of the produced image.
+static void geom_bwd_form(GConvArgs& a, int B, int OHs, int OWs, int Cred, int H, int W, int N,
+                          int KH, int KW, int stride, int pad) {
+  a.B = B; a.IH = OHs; a.IW = OWs; a.Cs = c4(Cred); a.c4n = a.Cs / 4; a.d_c4n = make_fastdiv(a.c4n);
+  a.Kp = rup(KH * KW * a.Cs, 32);
+  a.OH = H; a.OW = W; a.Ns = c4(N); a.N = N;
+  a.isy = a.isx = 1; a.osy = a.osx = stride;
+  a.nphase = stride * stride;
+  for (int py = 0; py < stride; ++py)
+    for (int px = 0; px < stride; ++px) {
+      Phase& p = a.ph[py * stride + px];
+      const int ky0 = (py + pad) % stride, kx0 = (px + pad) % stride;
+      p.th = ky0 < KH ? (KH - ky0 + stride - 1) / stride : 0;
+      p.tw = kx0 < KW ? (KW - kx0 + stride - 1) / stride : 0;
+      p.dy0 = (py + pad - ky0) / stride; p.dx0 = (px + pad - kx0) / stride;
+      p.dys = p.dxs = -1;
+      p.wbase = ky0 * KW + kx0; p.wsy = stride * KW; p.wsx = stride;
+      p.ooy = py; p.oox = px;
+      p.ohg = H > py ? (H - py + stride - 1) / stride : 0;
+      p.owg = W > px ? (W - px + stride - 1) / stride : 0;
+      if (p.th == 0 || p.tw == 0) { p.th = p.tw = 0; }
+      finish_phase(p, B, a.Cs);
+    }
+}
+
+template <int WGM, int WGN, int WM, int WN>
+static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
+  constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+  int maxM = 0;
+  for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
+  if (maxM == 0) return 0;
+  const size_t smem = 2 * (size_t)(BM + BN) * 8 * sizeof(f32x4);
+  auto kern = gconv_kernel<WGM, WGN, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.nphase);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+static int launch_gconv(const GConvArgs& a, hipStream_t st) {
+  IPR_CHECK(a.nphase >= 1 && a.nphase <= 4, "conv: stride %d unsupported (max 2)", a.osy);
+  int maxM = 0;
+  for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
+  const int N = a.Ns;
+  // tile choice: widest tile that still yields >= ~1.5 blocks per CU (256 CUs), else smaller
+  auto blocks = [&](int bm, int bn) { return (long long)cdiv(maxM, bm) * cdiv(N, bn) * a.nphase; };
+  if (N <= 32) return launch_gconv_t<4, 1, 1, 1>(a, st);
+  if (N >= 128 && blocks(128, 128) >= 384) return launch_gconv_t<2, 2, 2, 2>(a, st);
+  if (blocks(128, 64) >= 384) return launch_gconv_t<2, 2, 2, 1>(a, st);
+  return launch_gconv_t<2, 2, 1, 1>(a, st);
+}
+
+// ---- backward-weight ------------------------------------------------------------------------
+struct WGradPlan {
+  int N, Cq, Ps, Qs, ntap, Kw, Nrows, bn, bk, tiles, nsplit, cps, M, colblk;
+};
+#define COLSUM_ROWS 1024
+static WGradPlan wgrad_plan(const iprgan_conv_desc* d) {
+  WGradPlan p;
+  const Shape s = out_shape(d);
+  // P = grid-aligned tensor (Conv2d: dy [OH,OW,Cout]; ConvT: x [H,W,Cin]); Q = gathered tensor
+  p.N = d->transposed ? d->Cin : d->Cout;
+  p.Cq = d->transposed ? d->Cout : d->Cin;
+  p.Ps = c4(p.N); p.Qs = c4(p.Cq);
+  p.ntap = d->KH * d->KW;
+  const int PH = d->transposed ? d->H : s.OH, PW = d->transposed ? d->W : s.OW;
+  p.M = d->B * PH * PW;
+  const int K = p.ntap * p.Qs;
+  p.bn = p.N >= 128 ? 128 : (p.N > 32 ? 64 : 32);
+  p.bk = (p.bn == 32) ? 128 : (K >= 128 && p.bn == 128 ? 128 : 64);
+  if (p.bn == 64) p.bk = 64;
+  p.Kw = rup(K, p.bk);
+  p.Nrows = rup(p.N, p.bn);
+  p.tiles = (p.Kw / p.bk) * (p.Nrows / p.bn);
+  const int chunks = cdiv(p.M, 32);
+  int want = cdiv(768, p.tiles);
+  if (want < 1) want = 1;
+  if (want > chunks) want = chunks;
+  p.cps = cdiv(chunks, want);
+  p.nsplit = cdiv(chunks, p.cps);
+  const int dyM = d->B * s.OH * s.OW;
+  p.colblk = cdiv(dyM, COLSUM_ROWS);
+  return p;
+}
+
+template <int WGM, int WGN, int WM, int WN>
+static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
+  constexpr int BN = WGM * WM * 32, BK = WGN * WN * 32;
+  const size_t smem = 2 * (size_t)32 * (BN + BK) * sizeof(float);
+  auto kern = wgrad_kernel<WGM, WGN, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(p.Kw / BK, p.Nrows / BN, p.nsplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace iprgan
+
+using namespace iprgan;
+
+extern "C" {
+
+size_t iprgan_conv_wfwd_floats(const iprgan_conv_desc* d) {
+  // Conv2d fwd uses rows=Cout,k=(tap,Cin); ConvT fwd uses rows=Cout,k=(tap,Cin) as well
+  return (size_t)rup(d->Cout, 128) * rup(d->KH * d->KW * c4(d->Cin), 32);
+}
+size_t iprgan_conv_wbwd_floats(const iprgan_conv_desc* d) {
+  return (size_t)rup(d->Cin, 128) * rup(d->KH * d->KW * c4(d->Cout), 32);
+}
+
+int iprgan_conv_weight_prep(const iprgan_conv_desc* d, const float* w, const float* inv_scale,
+                            float* wfwd, float* wbwd, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int ntap = d->KH * d->KW;
+  // PyTorch weight dims: Conv2d [D0=Cout][D1=Cin], ConvT [D0=Cin][D1=Cout]
+  // fwd operand: rows = Cout, reduce = Cin ; bwd operand: rows = Cin, reduce = Cout
+  for (int which = 0; which < 2; ++which) {
+    float* dst = which == 0 ? wfwd : wbwd;
+    if (!dst) continue;
+    const int rows = which == 0 ? d->Cout : d->Cin, red = which == 0 ? d->Cin : d->Cout;
+    // which==0: conv -> rows=Cout=D0 (1); convT -> rows=Cout=D1 (0)
+    // which==1: conv -> rows=Cin=D1 (0);  convT -> rows=Cin=D0 (1)
+    const int row_is_d0 = ((which == 0) != (d->transposed != 0)) ? 1 : 0;
+    const int Cs = c4(red), Kp = rup(ntap * Cs, 32), R = rup(rows, 128);
+    const long long total = (long long)R * Kp;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(weight_prep_kernel, dim3(blocks), dim3(256), 0, st, w, inv_scale, dst, R, Kp,
+                       rows, red, Cs, ntap, row_is_d0);
+    IPR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd, const float* bias,
+                    float* y, void* stream) {
+  IPR_CHECK(d->stride >= 1 && d->stride <= 2, "conv_fwd: stride %d unsupported", d->stride);
+  GConvArgs a;
+  memset(&a, 0, sizeof(a));
+  const Shape s = out_shape(d);
+  if (!d->transposed) {
+    geom_forward_form(a, d->B, d->H, d->W, d->Cin, s.OH, s.OW, d->Cout, d->KH, d->KW, d->stride, d->pad);
+    a.pad_mode = d->pad_mode;
+  } else {
+    IPR_CHECK(d->pad_mode == IPRGAN_PAD_ZERO, "conv_transpose: reflect pad unsupported");
+    geom_bwd_form(a, d->B, d->H, d->W, d->Cin, s.OH, s.OW, d->Cout, d->KH, d->KW, d->stride, d->pad);
+  }
+  a.in = x; a.wt = wfwd; a.bias = bias; a.out = y; a.aux = nullptr;
+  a.act = d->act; a.slope = d->slope;
+  return launch_gconv(a, (hipStream_t)stream);
+}
+
+int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx,
+                         const float* prev_out, int prev_act, float prev_slope, void* stream) {
+  IPR_CHECK(d->stride >= 1 && d->stride <= 2, "conv_bwd_data: stride %d unsupported", d->stride);
+  IPR_CHECK(d->pad_mode == IPRGAN_PAD_ZERO, "conv_bwd_data: reflect pad needs the fold path");
+  GConvArgs a;
+  memset(&a, 0, sizeof(a));
+  const Shape s = out_shape(d);
+  if (!d->transposed) {
+    geom_bwd_form(a, d->B, s.OH, s.OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad);
+  } else {
+    geom_forward_form(a, d->B, s.OH, s.OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad);
+  }
+  a.in = dy; a.wt = wbwd; a.bias = nullptr; a.out = dx;
+  a.act = IPRGAN_ACT_NONE; a.slope = 0.f;
+  a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope;
+  return launch_gconv(a, (hipStream_t)stream);
+}
+
+size_t iprgan_conv_wgrad_ws_floats(const iprgan_conv_desc* d) {
+  const WGradPlan p = wgrad_plan(d);
+  return (size_t)p.nsplit * p.Nrows * p.Kw + (size_t)p.colblk * c4(d->Cout);
+}
+
+int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const float* dy, float* dw,
+                           float* db, float* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const WGradPlan p = wgrad_plan(d);
+  const Shape s = out_shape(d);
+  WGradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = d->transposed ? x : dy;
+  a.Q = d->transposed ? dy : x;
+  a.ws = ws;
+  a.Ps = p.Ps; a.Pvalid = p.Ps;
+  a.QH = d->transposed ? s.OH : d->H; a.QW = d->transposed ? s.OW : d->W;
+  a.Qs = p.Qs; a.c4n = p.Qs / 4; a.d_c4n = make_fastdiv(a.c4n);
+  a.PH = d->transposed ? d->H : s.OH; a.PW = d->transposed ? d->W : s.OW;
+  a.M = p.M;
+  a.d_pw = make_fastdiv(a.PW); a.d_plane = make_fastdiv(a.PH * a.PW); a.d_tw = make_fastdiv(d->KW);
+  a.isy = a.isx = d->stride; a.pad = d->pad; a.tw = d->KW; a.ntap = p.ntap;
+  a.pad_mode = d->pad_mode;
+  a.Kw = p.Kw; a.Nrows = p.Nrows; a.chunks_per_split = p.cps;
+  int rc;
+  if (p.bn == 128 && p.bk == 128) rc = launch_wgrad_t<2, 2, 2, 2>(a, p, st);
+  else if (p.bn == 64) rc = launch_wgrad_t<2, 2, 1, 1>(a, p, st);
+  else if (p.bn == 128) rc = launch_wgrad_t<2, 2, 2, 1>(a, p, st);
+  else rc = launch_wgrad_t<1, 4, 1, 1>(a, p, st);     // bn == 32, bk == 128
+  if (rc) return rc;
+  {
+    const long long total = (long long)p.N * p.ntap * p.Qs;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const long long sn = (long long)p.Cq * p.ntap, sc = p.ntap;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, p.nsplit,
+                       p.Nrows, p.Kw, p.N, p.Cq, p.Qs, p.ntap, make_fastdiv(p.Qs), sn, sc);
+    IPR_LAUNCH_CHECK();
+  }
+  if (db) {
+    const int Cs = c4(d->Cout), M = d->B * s.OH * s.OW;
+    float* part = ws + (size_t)p.nsplit * p.Nrows * p.Kw;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.colblk, cdiv(Cs, 64)), dim3(64), 0, st, dy, part,
+                       M, Cs, COLSUM_ROWS);
+    IPR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(d->Cout, 64)), dim3(64), 0, st, part, db,
+                       p.colblk, Cs, d->Cout);
+    IPR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int iprgan_act_bwd(const float* dy, const float* out, float* dz, size_t n, int act, float slope,
+                   void* stream) {
+  if (n == 0) return 0;
+  const int blocks = (int)(cdivz(n, 256) < 8192 ? cdivz(n, 256) : 8192);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, out, dz, n,
+                     act, slope);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

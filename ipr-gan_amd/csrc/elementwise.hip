@@ -1,0 +1,432 @@
+// HBM-/latency-bound helpers of the G+D step: layout changes at the NCHW API boundary, the
+// GEMV head of SNDiscriminator, fused loss forward/gradient-seed kernels, the multi-tensor
+// sign-loss / bit-error-rate kernels (tools/sign_model.py:42-60) and multi-tensor Adam.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace iprgan {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- layout --------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C,
+                                    int HW, int Cs) {
+  const size_t total = (size_t)B * HW * Cs;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cs);
+    const size_t pix = i / Cs;
+    const int p = (int)(pix % HW);
+    const size_t b = pix / HW;
+    dst[i] = c < C ? src[(b * C + c) * HW + p] : 0.f;
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C,
+                                    int HW, int Cs) {
+  const size_t total = (size_t)B * C * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const size_t bc = i / HW;
+    const int c = (int)(bc % C);
+    const size_t b = bc / C;
+    dst[i] = src[(b * HW + p) * Cs + c];
+  }
+}
+// dst[b][a][k] = src[a][b][k]
+__global__ void permute_021_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int Bd,
+                                   int K) {
+  const size_t total = (size_t)A * Bd * K;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const size_t ba = i / K;
+    const int a = (int)(ba % A);
+    const size_t b = ba / A;
+    dst[i] = src[((size_t)a * Bd + b) * K + k];
+  }
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+__global__ void axpy_kernel(float* y, const float* x, float a, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] += a * x[i];
+}
+
+// ---- GEMV head -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ inv_scale,
+                                                       float* __restrict__ y, int K) {
+  __shared__ float sh[16];
+  const float* xr = x + (size_t)blockIdx.x * K;
+  float s = 0.f;
+  for (int k = threadIdx.x * 4; k < K; k += blockDim.x * 4) {
+    const float4 a = *(const float4*)(xr + k), b = *(const float4*)(w + k);
+    s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) {
+    const float sc = inv_scale ? *inv_scale : 1.f;
+    y[blockIdx.x] = s / sc + (bias ? bias[0] : 0.f);
+  }
+}
+__global__ void gemv_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                   const float* __restrict__ inv_scale, float* __restrict__ dx,
+                                   const float* __restrict__ prev_out, int prev_act, float prev_slope,
+                                   int B, int K) {
+  const float sc = inv_scale ? *inv_scale : 1.f;
+  const size_t total = (size_t)B * K;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const int b = (int)(i / K);
+    float v = dy[b] * (w[k] / sc);
+    if (prev_out) v *= act_grad_from_out(prev_out[i], prev_act, prev_slope);
+    dx[i] = v;
+  }
+}
+__global__ void gemv_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                   float* __restrict__ dw, float* __restrict__ db, int B, int K) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K && dw) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dy[b] * x[(size_t)b * K + k];
+    dw[k] = s;
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dy[b];
+    db[0] = s;
+  }
+}
+
+// ---- losses --------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_neg_abs(float x) { return log1pf(expf(-fabsf(x))); }
+
+__device__ __forceinline__ float loss_term(int kind, float x, float y) {
+  switch (kind) {
+    case IPRGAN_LOSS_HINGE_REAL: return fmaxf(1.f - x, 0.f);
+    case IPRGAN_LOSS_HINGE_FAKE: return fmaxf(1.f + x, 0.f);
+    case IPRGAN_LOSS_NEG_MEAN: return -x;
+    case IPRGAN_LOSS_BCE_ONES: return fmaxf(-x, 0.f) + softplus_neg_abs(x);
+    case IPRGAN_LOSS_BCE_ZEROS: return fmaxf(x, 0.f) + softplus_neg_abs(x);
+    case IPRGAN_LOSS_MSE_ONES: return (x - 1.f) * (x - 1.f);
+    case IPRGAN_LOSS_MSE_ZEROS: return x * x;
+    case IPRGAN_LOSS_MSE: return (x - y) * (x - y);
+    default: return fabsf(x - y);
+  }
+}
+__device__ __forceinline__ float loss_grad(int kind, float x, float y) {
+  switch (kind) {
+    case IPRGAN_LOSS_HINGE_REAL: return (1.f - x) > 0.f ? -1.f : 0.f;
+    case IPRGAN_LOSS_HINGE_FAKE: return (1.f + x) > 0.f ? 1.f : 0.f;
+    case IPRGAN_LOSS_NEG_MEAN: return -1.f;
+    case IPRGAN_LOSS_BCE_ONES: return 1.f / (1.f + expf(-x)) - 1.f;
+    case IPRGAN_LOSS_BCE_ZEROS: return 1.f / (1.f + expf(-x));
+    case IPRGAN_LOSS_MSE_ONES: return 2.f * (x - 1.f);
+    case IPRGAN_LOSS_MSE_ZEROS: return 2.f * x;
+    case IPRGAN_LOSS_MSE: return 2.f * (x - y);
+    default: { const float d = x - y; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+  }
+}
+#define LOSS_BLOCKS 256
+__global__ __launch_bounds__(256) void loss_partial_kernel(int kind, const float* __restrict__ x,
+                                                           const float* __restrict__ y,
+                                                           float* __restrict__ part, size_t n) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s += loss_term(kind, x[i], y ? y[i] : 0.f);
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void loss_final_kernel(const float* __restrict__ part, int nb, float inv_n, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < nb; ++i) s += part[i];
+    *loss = s * inv_n;
+  }
+}
+__global__ void loss_bwd_kernel(int kind, const float* __restrict__ x, const float* __restrict__ y,
+                                const float* __restrict__ gscale, float* __restrict__ dx, size_t n,
+                                float inv_n) {
+  const float g = (gscale ? *gscale : 1.f) * inv_n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dx[i] = g * loss_grad(kind, x[i], y ? y[i] : 0.f);
+}
+
+// ---- sign loss / BER (multi-tensor: pointer table travels in the kernel arguments) ----------
+#define SIGN_MAX_LAYERS 64
+struct SignTable {
+  const float* gamma[SIGN_MAX_LAYERS];
+  const float* sign[SIGN_MAX_LAYERS];
+  float* dgamma[SIGN_MAX_LAYERS];
+  int size[SIGN_MAX_LAYERS];
+  int nlayer;
+};
+__global__ __launch_bounds__(256) void sign_loss_fwd_kernel(const SignTable t, float gamma0,
+                                                            float* __restrict__ loss, int accumulate) {
+  __shared__ float sh[16];
+  float total = 0.f;
+  for (int l = 0; l < t.nlayer; ++l) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < t.size[l]; i += blockDim.x)
+      s += fmaxf(gamma0 - t.gamma[l][i] * t.sign[l][i], 0.f);
+    total += block_sum(s, sh) / (float)t.size[l];
+  }
+  if (threadIdx.x == 0) *loss = accumulate ? *loss + total : total;
+}
+__global__ void sign_loss_bwd_kernel(const SignTable t, float gamma0, const float* __restrict__ gscale) {
+  const int l = blockIdx.x;
+  const float g = (gscale ? *gscale : 1.f) / (float)t.size[l];
+  for (int i = threadIdx.x; i < t.size[l]; i += blockDim.x) {
+    const float b = t.sign[l][i];
+    t.dgamma[l][i] = (gamma0 - t.gamma[l][i] * b) > 0.f ? -b * g : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void sign_ber_kernel(const SignTable t, long long* __restrict__ counts,
+                                                       int accumulate) {
+  __shared__ int sh[4];
+  int err = 0, tot = 0;
+  for (int l = 0; l < t.nlayer; ++l) {
+    for (int i = threadIdx.x; i < t.size[l]; i += blockDim.x) {
+      const float g = t.gamma[l][i], b = t.sign[l][i];
+      const bool same = (g > 0.f && b > 0.f) || (g < 0.f && b < 0.f);
+      err += same ? 0 : 1;
+    }
+    tot += t.size[l];
+  }
+  // exact integer reduction: wave ballot-free shuffle sum, then 4 waves through LDS
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) err += __shfl_xor(err, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = err;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long e = (long long)sh[0] + sh[1] + sh[2] + sh[3];
+    counts[0] = accumulate ? counts[0] + e : e;
+    counts[1] = accumulate ? counts[1] + tot : tot;
+  }
+}
+
+// ---- Adam (multi-tensor) ---------------------------------------------------------------------
+#define ADAM_MAX_TENSORS 48
+struct AdamTable {
+  float* p[ADAM_MAX_TENSORS];
+  const float* g[ADAM_MAX_TENSORS];
+  float* m[ADAM_MAX_TENSORS];
+  float* v[ADAM_MAX_TENSORS];
+  long long n[ADAM_MAX_TENSORS];
+};
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float beta1, float beta2, float eps,
+                                                   float weight_decay, float step_size, float bc2_sqrt) {
+  const int ti = blockIdx.y;
+  const long long n = t.n[ti];
+  float* __restrict__ p = t.p[ti];
+  const float* __restrict__ g = t.g[ti];
+  float* __restrict__ m = t.m[ti];
+  float* __restrict__ v = t.v[ti];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (weight_decay != 0.f) gi += weight_decay * pi;
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);          // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;      // mul_(beta2).addcmul_(g, g, 1-beta2)
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+static inline int grid_for(size_t n, int cap) {
+  size_t b = cdivz(n, 256);
+  if (b < 1) b = 1;
+  return (int)(b < (size_t)cap ? b : (size_t)cap);
+}
+
+}  // namespace iprgan
+
+using namespace iprgan;
+
+extern "C" {
+
+const char* iprgan_last_error(void) { return g_err; }
+int iprgan_version(void) { return IPRGAN_VERSION; }
+
+int iprgan_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, void* stream) {
+  const int Cs = (C + 3) & ~3;
+  const size_t n = (size_t)B * H * W * Cs;
+  if (!n) return 0;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, B, C, H * W, Cs);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, void* stream) {
+  const int Cs = (C + 3) & ~3;
+  const size_t n = (size_t)B * H * W * C;
+  if (!n) return 0;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, B, C, H * W, Cs);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_permute_021(const float* src, float* dst, int A, int Bd, int K, void* stream) {
+  const size_t n = (size_t)A * Bd * K;
+  if (!n) return 0;
+  hipLaunchKernelGGL(permute_021_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, A, Bd, K);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_fill(float* p, float v, size_t n, void* stream) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_axpy(float* y, const float* x, float a, size_t n, void* stream) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, y, x, a, n);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const float* inv_scale, float* y,
+                    int B, int K, void* stream) {
+  IPR_CHECK(K % 4 == 0, "gemv_fwd: K=%d must be a multiple of 4", K);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, w, bias, inv_scale, y, K);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float* inv_scale, float* dx,
+                    float* dw, float* db, const float* prev_out, int prev_act, float prev_slope, int B,
+                    int K, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) return 0;
+  if (dx) {
+    hipLaunchKernelGGL(gemv_bwd_dx_kernel, dim3(grid_for((size_t)B * K, 4096)), dim3(256), 0, st, w, dy,
+                       inv_scale, dx, prev_out, prev_act, prev_slope, B, K);
+    IPR_LAUNCH_CHECK();
+  }
+  if (dw || db) {
+    hipLaunchKernelGGL(gemv_bwd_dw_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, x, dy, dw, db, B, K);
+    IPR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+size_t iprgan_loss_ws_floats(size_t n) { (void)n; return LOSS_BLOCKS; }
+int iprgan_loss_fwd(int kind, const float* x, const float* y, float* loss, float* ws, size_t n,
+                    void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  IPR_CHECK(kind >= 0 && kind <= IPRGAN_LOSS_L1, "loss_fwd: bad kind %d", kind);
+  IPR_CHECK(n > 0, "loss_fwd: empty input");
+  IPR_CHECK(kind < IPRGAN_LOSS_MSE || y, "loss_fwd: kind %d needs a second input", kind);
+  const int nb = grid_for(n, LOSS_BLOCKS);
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, st, kind, x, y, ws, n);
+  IPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, ws, nb, 1.0f / (float)n, loss);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_loss_bwd(int kind, const float* x, const float* y, const float* gscale, float* dx, size_t n,
+                    void* stream) {
+  IPR_CHECK(kind >= 0 && kind <= IPRGAN_LOSS_L1, "loss_bwd: bad kind %d", kind);
+  if (!n) return 0;
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, kind, x, y,
+                     gscale, dx, n, 1.0f / (float)n);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+static int fill_sign_table(SignTable& t, const float* const* gammas, const float* const* signs,
+                           float* const* dgammas, const int* sizes, int begin, int nlayer) {
+  int cnt = nlayer - begin;
+  if (cnt > SIGN_MAX_LAYERS) cnt = SIGN_MAX_LAYERS;
+  memset(&t, 0, sizeof(t));
+  for (int i = 0; i < cnt; ++i) {
+    t.gamma[i] = gammas[begin + i];
+    t.sign[i] = signs[begin + i];
+    t.dgamma[i] = dgammas ? dgammas[begin + i] : nullptr;
+    t.size[i] = sizes[begin + i];
+  }
+  t.nlayer = cnt;
+  return cnt;
+}
+
+int iprgan_sign_loss_fwd(const float* const* gammas, const float* const* signs, const int* sizes, int nlayer,
+                         float gamma0, float* loss, void* stream) {
+  IPR_CHECK(nlayer > 0, "sign_loss_fwd: no layers");
+  for (int b = 0; b < nlayer; b += SIGN_MAX_LAYERS) {
+    SignTable t;
+    fill_sign_table(t, gammas, signs, nullptr, sizes, b, nlayer);
+    hipLaunchKernelGGL(sign_loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, gamma0, loss,
+                       b > 0 ? 1 : 0);
+    IPR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+int iprgan_sign_loss_bwd(const float* const* gammas, const float* const* signs, float* const* dgammas,
+                         const int* sizes, int nlayer, float gamma0, const float* gscale, void* stream) {
+  for (int b = 0; b < nlayer; b += SIGN_MAX_LAYERS) {
+    SignTable t;
+    const int cnt = fill_sign_table(t, gammas, signs, dgammas, sizes, b, nlayer);
+    hipLaunchKernelGGL(sign_loss_bwd_kernel, dim3(cnt), dim3(256), 0, (hipStream_t)stream, t, gamma0, gscale);
+    IPR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+int iprgan_sign_ber(const float* const* gammas, const float* const* signs, const int* sizes, int nlayer,
+                    long long* counts, void* stream) {
+  IPR_CHECK(nlayer > 0, "sign_ber: no layers");
+  for (int b = 0; b < nlayer; b += SIGN_MAX_LAYERS) {
+    SignTable t;
+    fill_sign_table(t, gammas, signs, nullptr, sizes, b, nlayer);
+    hipLaunchKernelGGL(sign_ber_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, counts, b > 0 ? 1 : 0);
+    IPR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int iprgan_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
+                     float* const* exp_avg_sq, const long long* sizes, int n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, void* stream) {
+  IPR_CHECK(step >= 1, "adam_step: step must be >= 1");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  for (int b = 0; b < n; b += ADAM_MAX_TENSORS) {
+    AdamTable t;
+    memset(&t, 0, sizeof(t));
+    int cnt = n - b;
+    if (cnt > ADAM_MAX_TENSORS) cnt = ADAM_MAX_TENSORS;
+    long long maxn = 0;
+    for (int i = 0; i < cnt; ++i) {
+      t.p[i] = params[b + i]; t.g[i] = grads[b + i]; t.m[i] = exp_avg[b + i]; t.v[i] = exp_avg_sq[b + i];
+      t.n[i] = sizes[b + i];
+      if (t.n[i] > maxn) maxn = t.n[i];
+    }
+    const int gx = grid_for((size_t)maxn, 256);
+    hipLaunchKernelGGL(adam_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, t, beta1, beta2, eps,
+                       weight_decay, step_size, bc2_sqrt);
+    IPR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // extern "C"

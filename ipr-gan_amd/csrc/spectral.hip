@@ -1,0 +1,162 @@
+// Spectral-norm power iteration and its backward for W_mat[rows][cols] (row-major view of the
+// layer weight, dim=0), one iteration per training forward, eps = 1e-12 in both normalisations:
+//   v <- normalize(W^T u);  u <- normalize(W v);  sigma = u . (W v)
+// (torch.nn.utils.spectral_norm as used at reference networks/sn_discriminator.py:9,11,18,21).
+// HBM/latency-bound (W <= 4.7 MB); all reductions are fixed-order (deterministic).
+#include "common.h"
+
+namespace iprgan {
+
+#define SN_MAX_RSPLIT 8
+
+// t_part[rs][j] = sum_{i in row split rs} W[i][j]*u[i]
+__global__ void sn_wtu_partial_kernel(const float* __restrict__ w, const float* __restrict__ u,
+                                      float* __restrict__ tpart, int rows, int cols, int rows_per_split) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  const int r0 = blockIdx.y * rows_per_split;
+  int r1 = r0 + rows_per_split;
+  if (r1 > rows) r1 = rows;
+  float s = 0.f;
+  for (int i = r0; i < r1; ++i) s += w[(size_t)i * cols + j] * u[i];
+  tpart[(size_t)blockIdx.y * cols + j] = s;
+}
+
+// single block: t = sum of partials; v = t / max(||t||, eps)
+__global__ __launch_bounds__(1024) void sn_v_final_kernel(const float* __restrict__ tpart, int nsplit,
+                                                           int cols, float eps, float* __restrict__ v) {
+  __shared__ float sh[16];
+  float ss = 0.f;
+  for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+    float t = 0.f;
+    for (int s = 0; s < nsplit; ++s) t += tpart[(size_t)s * cols + j];
+    ss += t * t;
+  }
+  const float nrm = sqrtf(block_sum(ss, sh));
+  const float inv = 1.f / fmaxf(nrm, eps);
+  for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+    float t = 0.f;
+    for (int s = 0; s < nsplit; ++s) t += tpart[(size_t)s * cols + j];
+    v[j] = t * inv;
+  }
+}
+
+// s[i] = sum_j W[i][j]*v[j]: one wave per row
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ v,
+                                                    float* __restrict__ s, int rows, int cols) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* wr = w + (size_t)row * cols;
+  float acc = 0.f;
+  for (int j = lane; j < cols; j += 64) acc += wr[j] * v[j];
+  acc = wave_sum(acc);
+  if (lane == 0) s[row] = acc;
+}
+
+// single block: u = s / max(||s||, eps); sigma = u . s  (training) or sigma = u_old . s (eval)
+__global__ __launch_bounds__(1024) void sn_u_final_kernel(const float* __restrict__ s, int rows, float eps,
+                                                           float* __restrict__ u, float* __restrict__ sigma,
+                                                           int training) {
+  __shared__ float sh[16];
+  if (training) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) ss += s[i] * s[i];
+    const float nrm = sqrtf(block_sum(ss, sh));
+    const float inv = 1.f / fmaxf(nrm, eps);
+    float d = 0.f;
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+      const float un = s[i] * inv;
+      u[i] = un;
+      d += un * s[i];
+    }
+    d = block_sum(d, sh);
+    if (threadIdx.x == 0) *sigma = d;
+  } else {
+    float d = 0.f;
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) d += u[i] * s[i];
+    d = block_sum(d, sh);
+    if (threadIdx.x == 0) *sigma = d;
+  }
+}
+
+__global__ __launch_bounds__(256) void sn_dot_partial_kernel(const float* __restrict__ a,
+                                                             const float* __restrict__ b,
+                                                             float* __restrict__ part, size_t n) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s += a[i] * b[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dwsn,
+                                                           const float* __restrict__ u,
+                                                           const float* __restrict__ v,
+                                                           const float* __restrict__ sigma,
+                                                           const float* __restrict__ part, int npart,
+                                                           float* __restrict__ dw, int rows, int cols) {
+  float dot = 0.f;
+  for (int i = 0; i < npart; ++i) dot += part[i];   // same fixed order in every thread
+  const float sg = *sigma;
+  const float coef = dot / sg;
+  const size_t n = (size_t)rows * cols;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+    dw[i] = (dwsn[i] - coef * u[r] * v[c]) / sg;
+  }
+}
+
+}  // namespace iprgan
+
+using namespace iprgan;
+
+#define SN_DOT_BLOCKS 128
+
+extern "C" {
+
+size_t iprgan_sn_ws_floats(int rows, int cols) {
+  return (size_t)SN_MAX_RSPLIT * cols + rows + SN_DOT_BLOCKS + 16;
+}
+
+int iprgan_sn_power_iter(const float* w, float* u, float* v, float* sigma, float* ws, int rows, int cols,
+                         float eps, int training, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  float* tpart = ws;
+  float* s = ws + (size_t)SN_MAX_RSPLIT * cols;
+  if (training) {
+    int nsplit = rows / 32;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > SN_MAX_RSPLIT) nsplit = SN_MAX_RSPLIT;
+    const int rps = cdiv(rows, nsplit);
+    nsplit = cdiv(rows, rps);
+    hipLaunchKernelGGL(sn_wtu_partial_kernel, dim3(cdiv(cols, 256), nsplit), dim3(256), 0, st, w, u, tpart,
+                       rows, cols, rps);
+    IPR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_v_final_kernel, dim3(1), dim3(1024), 0, st, tpart, nsplit, cols, eps, v);
+    IPR_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(sn_wv_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, v, s, rows, cols);
+  IPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sn_u_final_kernel, dim3(1), dim3(1024), 0, st, s, rows, eps, u, sigma, training);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+int iprgan_sn_bwd(const float* dwsn, const float* w, const float* u, const float* v, const float* sigma,
+                  float* dw, float* ws, int rows, int cols, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)rows * cols;
+  float* part = ws + (size_t)SN_MAX_RSPLIT * cols + rows;
+  int nb = (int)(cdivz(n, 1024) < SN_DOT_BLOCKS ? cdivz(n, 1024) : SN_DOT_BLOCKS);
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(sn_dot_partial_kernel, dim3(nb), dim3(256), 0, st, dwsn, w, part, n);
+  IPR_LAUNCH_CHECK();
+  const int blocks = (int)(cdivz(n, 256) < 2048 ? cdivz(n, 256) : 2048);
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dwsn, u, v, sigma, part, nb, dw,
+                     rows, cols);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+"""ctypes binding of libiprgan_hip.so (the C ABI declared in include/iprgan.h).
+
+There is no CPU or ATen fallback behind these calls: if the shared library is missing,
+or an op is handed a non-GPU tensor, the call raises.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C ipr-gan_amd/csrc`` and travels with the repo.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libiprgan_hip.so')
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+(LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_NEG_MEAN, LOSS_BCE_ONES, LOSS_BCE_ZEROS,
+ LOSS_MSE_ONES, LOSS_MSE_ZEROS, LOSS_MSE, LOSS_L1) = range(9)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ('B', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad', 'outpad',
+                 'transposed', 'pad_mode', 'act')] + [('slope', C.c_float)]
+
+
+_P, _F, _I, _Z, _LL = C.c_void_p, C.c_float, C.c_int, C.c_size_t, C.c_longlong
+_D = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes).  Every symbol declared in include/iprgan.h must be listed here;
+# tests/test_abi.py cross-checks the header, this table and the built library.
+SIGNATURES = {
+    'iprgan_last_error': (C.c_char_p, []),
+    'iprgan_version': (_I, []),
+    'iprgan_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'iprgan_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'iprgan_permute_021': (_I, [_P, _P, _I, _I, _I, _P]),
+    'iprgan_conv_wfwd_floats': (_Z, [_D]),
+    'iprgan_conv_wbwd_floats': (_Z, [_D]),
+    'iprgan_conv_wgrad_ws_floats': (_Z, [_D]),
+    'iprgan_conv_weight_prep': (_I, [_D, _P, _P, _P, _P, _P]),
+    'iprgan_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P]),
+    'iprgan_conv_bwd_data': (_I, [_D, _P, _P, _P, _P, _I, _F, _P]),
+    'iprgan_conv_bwd_weight': (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    'iprgan_act_bwd': (_I, [_P, _P, _P, _Z, _I, _F, _P]),
+    'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P]),
+    'iprgan_bn_ws_floats': (_Z, [_I, _I]),
+    'iprgan_bn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P]),
+    'iprgan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    'iprgan_sn_ws_floats': (_Z, [_I, _I]),
+    'iprgan_sn_power_iter': (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
+    'iprgan_sn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'iprgan_loss_ws_floats': (_Z, [_Z]),
+    'iprgan_loss_fwd': (_I, [_I, _P, _P, _P, _P, _Z, _P]),
+    'iprgan_loss_bwd': (_I, [_I, _P, _P, _P, _P, _Z, _P]),
+    'iprgan_sign_loss_fwd': (_I, [_P, _P, _P, _I, _F, _P, _P]),
+    'iprgan_sign_loss_bwd': (_I, [_P, _P, _P, _P, _I, _F, _P, _P]),
+    'iprgan_sign_ber': (_I, [_P, _P, _P, _I, _P, _P]),
+    'iprgan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P]),
+    'iprgan_fill': (_I, [_P, _F, _Z, _P]),
+    'iprgan_axpy': (_I, [_P, _P, _F, _Z, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises if it has not been built - there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'or `make -C ipr-gan_amd/csrc`. iprgan has no CPU/ATen fallback for its kernels.')
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed ({rc}): {lib.iprgan_last_error().decode()}')
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses anything that is not a contiguous fp32
+    GPU tensor so that a CPU tensor can never silently reach a kernel."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('iprgan kernels need GPU tensors (got a CPU tensor); there is no CPU path')
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError(f'iprgan kernels need contiguous float32 tensors (got {t.dtype}, '
+                           f'contiguous={t.is_contiguous()})')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr_table(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t)
+    return arr

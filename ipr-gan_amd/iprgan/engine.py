@@ -1,0 +1,345 @@
+"""Chain executor: a network is a list of layer ops whose forward/backward enqueue HIP kernels.
+
+One ``torch.autograd.Function`` (``ChainFn``) runs a whole network so PyTorch's autograd sees a
+single node per G / D pass (it is used for the graph only: which pass feeds which loss, and
+``.grad`` accumulation); everything inside is ours: NHWC activations, fused bias/activation
+epilogues, the previous layer's activation derivative fused into the next dgrad epilogue,
+spectral-norm power iteration, BatchNorm statistics, deterministic split reductions.
+
+Parameters and buffers stay ordinary tensors owned by the nn.Module tree (state_dict / .to() /
+optimizers keep working, SURVEY.md section 8b "State/ownership").
+"""
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+class Op:
+    """One layer.  ``params`` lists the nn.Parameters it reads (order = gradient order)."""
+    params = ()
+    out_act = (L.ACT_NONE, 0.0)     # activation fused in this op's forward (derivative from output)
+    fuses_prev_act = False          # can multiply its dx by the producer's act'(x) in the epilogue
+
+    def forward(self, x, st, train):
+        raise NotImplementedError
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        """dy: gradient w.r.t. this op's output (pre-activation if ``st['dy_is_preact']``).
+        prev_act: (act, slope) of the producer to fuse into dx, or None.  Returns (dx, [param grads])."""
+        raise NotImplementedError
+
+
+class ToNHWC(Op):
+    """API boundary: NCHW image -> NHWC4 (networks take/return NCHW like the reference)."""
+
+    def __init__(self, channels):
+        self.channels = channels
+
+    def forward(self, x, st, train):
+        return ops.nchw_to_nhwc(x)
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        return (ops.nhwc_to_nchw(dy, self.channels) if need_dx else None), []
+
+
+class ToNCHW(Op):
+    def __init__(self, channels):
+        self.channels = channels
+
+    def forward(self, x, st, train):
+        return ops.nhwc_to_nchw(x, self.channels)
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        return (ops.nchw_to_nhwc(dy) if need_dx else None), []
+
+
+class View(Op):
+    """Reinterpret a flat [B, H*W*C] activation as NHWC [B,H,W,C] (no data movement)."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+        self.fuses_prev_act = False
+
+    def forward(self, x, st, train):
+        st['in_shape'] = tuple(x.shape)
+        return x.view(x.shape[0], *self.shape)
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        return dy.view(st['in_shape']), []
+
+
+class Conv(Op):
+    """Conv2d / ConvTranspose2d (+bias, +activation), optionally spectrally normalised
+    (weight_orig / weight_u / weight_v of torch.nn.utils.spectral_norm)."""
+    fuses_prev_act = True
+
+    def __init__(self, spec, module, sn=False):
+        self.spec, self.m, self.is_sn = spec, module, sn
+        self.out_act = (spec.act, spec.slope)
+
+    # tensors are fetched from the module at call time: .to()/load_state_dict may replace buffers
+    @property
+    def weight(self):
+        return self.m.weight_orig if self.is_sn else self.m.weight
+
+    @property
+    def bias(self):
+        return self.m.bias
+
+    @property
+    def sn(self):
+        return (self.m.weight_u, self.m.weight_v) if self.is_sn else None
+
+    @property
+    def params(self):
+        return (self.weight,) + ((self.bias,) if self.bias is not None else ())
+
+    def forward(self, x, st, train):
+        sp = self.spec
+        B, H, W, _ = x.shape
+        d = sp.desc(B, H, W)
+        sigma = None
+        if self.sn is not None:
+            u, v = self.sn
+            sigma = ops.sn_power_iter(self.weight, u, v, train)
+            st['u'], st['v'] = u.clone(), v.clone()     # this pass's u, v (later passes overwrite the buffers)
+        wf, _ = ops.conv_prep(sp, d, self.weight, sigma, fwd=True, bwd=False)
+        y = ops.conv_fwd(sp, d, x, wf, self.bias)
+        st.update(x=x, y=y, d=d, sigma=sigma)
+        return y
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        sp, d, sigma = self.spec, st['d'], st['sigma']
+        if sp.act != L.ACT_NONE and not st.get('dy_is_preact', False):
+            dy = ops.act_bwd(dy, st['y'], sp.act, sp.slope)
+        grads = []
+        if need_w:
+            dw, db = ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, self.bias is not None)
+            if self.sn is not None:
+                dw = ops.sn_bwd(dw, self.weight, st['u'], st['v'], sigma)
+            grads = [dw] + ([db] if self.bias is not None else [])
+        dx = None
+        if need_dx:
+            _, wb = ops.conv_prep(sp, d, self.weight, sigma, fwd=False, bwd=True)
+            if prev_act is not None:
+                dx = ops.conv_bwd_data(sp, d, dy, wb, st['x'], prev_act[0], prev_act[1])
+            else:
+                dx = ops.conv_bwd_data(sp, d, dy, wb)
+        return dx, grads
+
+
+class LinearNHWC(Op):
+    """nn.Linear(K -> C*H*W) whose output is consumed as NHWC [B,H,W,C] although the weight rows
+    are in the reference's NCHW-flatten order (networks/conv_generator.py:26): rows are permuted
+    (c,hw)->(hw,c) on the fly, then it is a 1x1 conv on [B,1,1,K]."""
+    fuses_prev_act = False
+
+    def __init__(self, module, channels, hw, act=L.ACT_RELU):
+        self.m, self.C, self.HW = module, channels, hw
+        self.spec = ops.ConvSpec(module.in_features, channels * hw, 1, act=act)
+        self.out_act = (act, 0.0)
+
+    @property
+    def weight(self):
+        return self.m.weight
+
+    @property
+    def bias(self):
+        return self.m.bias
+
+    @property
+    def params(self):
+        return (self.m.weight, self.m.bias)
+
+    def forward(self, x, st, train):
+        B, K = x.shape
+        d = self.spec.desc(B, 1, 1)
+        wp = ops.permute_021(self.weight, self.C, self.HW, K)
+        bp = ops.permute_021(self.bias, self.C, self.HW, 1)
+        x4 = x.contiguous().view(B, 1, 1, K)
+        if self.spec.is_identity_prep:
+            wf = wp
+        else:
+            wf, _ = ops.conv_prep(self.spec, d, wp.view(self.C * self.HW, K, 1, 1))
+        y = ops.conv_fwd(self.spec, d, x4, wf, bp).view(B, self.C * self.HW)
+        st.update(x=x4, y=y, d=d, wp=wp)
+        return y
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        sp, d = self.spec, st['d']
+        B, K = d.B, sp.cin
+        if not st.get('dy_is_preact', False):
+            dy = ops.act_bwd(dy, st['y'], sp.act, 0.0)
+        dy4 = dy.view(B, 1, 1, sp.cout)
+        grads = []
+        if need_w:
+            dwp, dbp = ops.conv_bwd_weight(sp, d, st['x'], dy4, (sp.cout, K, 1, 1), True)
+            dw = ops.permute_021(dwp, self.HW, self.C, K).view(sp.cout, K)
+            db = ops.permute_021(dbp, self.HW, self.C, 1)
+            grads = [dw, db]
+        dx = None
+        if need_dx:
+            _, wb = ops.conv_prep(sp, d, st['wp'].view(sp.cout, K, 1, 1), fwd=False, bwd=True)
+            dx = ops.conv_bwd_data(sp, d, dy4, wb).view(B, K)
+        return dx, grads
+
+
+class BatchNorm(Op):
+    """BatchNorm2d (+activation) over NHWC; owns nothing, mutates the module's running stats."""
+
+    def __init__(self, bn_module, act=L.ACT_NONE, slope=0.0):
+        self.m = bn_module
+        self.act, self.slope = act, slope
+        self.out_act = (L.ACT_NONE, 0.0)     # handles its own activation derivative
+
+    @property
+    def params(self):
+        return (self.m.weight, self.m.bias)
+
+    def forward(self, x, st, train):
+        m = self.m
+        use_batch = train or not m.track_running_stats
+        track = train and m.track_running_stats
+        mom = m.momentum
+        if track and m.num_batches_tracked is not None:
+            m.num_batches_tracked.add_(1)
+            if mom is None:
+                mom = 1.0 / float(m.num_batches_tracked)
+        y, mean, invstd = ops.bn_fwd(x, m.weight, m.bias,
+                                     m.running_mean if (track or not use_batch) else None,
+                                     m.running_var if (track or not use_batch) else None,
+                                     m.eps, mom if mom is not None else 0.0, use_batch, self.act, self.slope)
+        st.update(x=x, y=y, mean=mean, invstd=invstd)
+        return y
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        dx, dg, db = ops.bn_bwd(st['x'], st['y'], dy, self.m.weight, st['mean'], st['invstd'],
+                                self.act, self.slope)
+        return dx, [dg, db]
+
+
+class GemvHead(Op):
+    """flatten (NCHW order in the reference, sn_discriminator.py:27-32) + SN Linear(K -> 1) + view(-1).
+    Our activations are NHWC, so the weight vector is permuted (c,hw)->(hw,c) per pass."""
+    fuses_prev_act = True
+
+    def __init__(self, module, channels, hw):
+        self.m, self.C, self.HW = module, channels, hw
+
+    @property
+    def weight(self):
+        return self.m.weight_orig
+
+    @property
+    def bias(self):
+        return self.m.bias
+
+    @property
+    def u(self):
+        return self.m.weight_u
+
+    @property
+    def v(self):
+        return self.m.weight_v
+
+    @property
+    def params(self):
+        return (self.m.weight_orig, self.m.bias)
+
+    def forward(self, x, st, train):
+        B = x.shape[0]
+        K = self.C * self.HW
+        sigma = ops.sn_power_iter(self.weight, self.u, self.v, train)
+        st['u'], st['v'] = self.u.clone(), self.v.clone()
+        wp = ops.permute_021(self.weight, self.C, self.HW, 1)
+        x2 = x.view(B, K)
+        y = ops.gemv_fwd(x2, wp, self.bias, sigma)
+        st.update(x=x2, xshape=tuple(x.shape), wp=wp, sigma=sigma)
+        return y
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        pa, ps = prev_act if prev_act is not None else (L.ACT_NONE, 0.0)
+        dx, dwp, db = ops.gemv_bwd(st['x'], st['wp'], dy.contiguous(), st['sigma'], need_dx, need_w,
+                                   st['x'] if prev_act is not None else None, pa, ps)
+        grads = []
+        if need_w:
+            dwsn = ops.permute_021(dwp, self.HW, self.C, 1).view(1, -1)
+            grads = [ops.sn_bwd(dwsn, self.weight, st['u'], st['v'], st['sigma']), db]
+        return (dx.view(st['xshape']) if dx is not None else None), grads
+
+
+class Chain:
+    """A sequential network plan.  ``ops`` run in order; parameters are collected in op order."""
+
+    def __init__(self, ops_list):
+        self.ops = list(ops_list)
+
+    @property
+    def params(self):
+        return [p for op in self.ops for p in op.params]
+
+    def __call__(self, x, train):
+        if not x.is_cuda:
+            raise RuntimeError('iprgan networks run on the HIP kernels only: input must be a GPU tensor '
+                               '(there is no CPU fallback; use the reference/oracle for CPU runs)')
+        L.load()
+        return ChainFn.apply(self, bool(train), x, *self.params)
+
+
+class ChainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, chain, train, x, *params):
+        stash = []
+        h = x.detach()
+        if h.dtype != torch.float32:
+            raise RuntimeError('iprgan networks take float32 inputs')
+        for op in chain.ops:
+            st = {}
+            h = op.forward(h, st, train)
+            stash.append(st)
+        ctx.chain, ctx.stash = chain, stash
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        chain, stash = ctx.chain, ctx.stash
+        need_x = ctx.needs_input_grad[2]
+        need_p = ctx.needs_input_grad[3:]
+        ops_list = chain.ops
+        # which ops need to produce dx: everything after the first op that has a trainable parameter
+        # needing a gradient, or all of them when the input itself needs one
+        first_needed = 0 if need_x else None
+        pi = 0
+        op_need_w = []
+        for i, op in enumerate(ops_list):
+            n = len(op.params)
+            w = any(need_p[pi:pi + n]) if n else False
+            op_need_w.append(w)
+            if w and first_needed is None:
+                first_needed = i
+            pi += n
+        grads_per_op = [None] * len(ops_list)
+        g = dy.contiguous()
+        for i in range(len(ops_list) - 1, -1, -1):
+            op, st = ops_list[i], stash[i]
+            if first_needed is None or i < first_needed:
+                break
+            need_dx = (i > first_needed) or (need_x and i == 0)
+            prev = ops_list[i - 1] if i > 0 else None
+            fuse = None
+            if need_dx and prev is not None and op.fuses_prev_act and prev.out_act[0] != L.ACT_NONE:
+                fuse = prev.out_act
+                stash[i - 1]['dy_is_preact'] = True
+            g, pg = op.backward(g, st, need_dx, op_need_w[i], fuse)
+            grads_per_op[i] = pg
+        out = []
+        pi = 0
+        for i, op in enumerate(ops_list):
+            n = len(op.params)
+            pg = grads_per_op[i] or [None] * n
+            for k in range(n):
+                out.append(pg[k] if (k < len(pg) and need_p[pi + k]) else None)
+            pi += n
+        ctx.stash = None
+        return (None, None, g if need_x else None, *out)

@@ -1,0 +1,217 @@
+"""Functional wrappers over the C ABI: allocate outputs/workspaces from PyTorch's caching
+allocator (plumbing) and enqueue the HIP kernels on the current stream.  No autograd here and
+no ATen arithmetic; activations are fp32 NHWC tensors [B,H,W,C4] (C4 = channels padded to 4).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvDesc, call, ptr, query, stream
+
+
+def c4(c):
+    return (c + 3) & ~3
+
+
+def empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# ---- layout ---------------------------------------------------------------------------------
+def nchw_to_nhwc(x):
+    B, Cc, H, W = x.shape
+    y = empty((B, H, W, c4(Cc)), x)
+    call('iprgan_nchw_to_nhwc', ptr(x.contiguous()), ptr(y), B, Cc, H, W, stream())
+    return y
+
+
+def nhwc_to_nchw(x, channels):
+    B, H, W, _ = x.shape
+    y = empty((B, channels, H, W), x)
+    call('iprgan_nhwc_to_nchw', ptr(x), ptr(y), B, channels, H, W, stream())
+    return y
+
+
+def permute_021(src, A, Bd, K):
+    """dst[b][a][k] = src[a][b][k]; returns a flat tensor of A*Bd*K floats."""
+    dst = empty((A * Bd * K,), src)
+    call('iprgan_permute_021', ptr(src), ptr(dst), A, Bd, K, stream())
+    return dst
+
+
+def act_bwd(dy, out, act, slope=0.0):
+    dz = torch.empty_like(dy)
+    call('iprgan_act_bwd', ptr(dy), ptr(out), ptr(dz), dy.numel(), act, float(slope), stream())
+    return dz
+
+
+# ---- convolution ------------------------------------------------------------------------------
+class ConvSpec:
+    """Static description of one Conv2d / ConvTranspose2d layer (include/iprgan.h: iprgan_conv_desc)."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, outpad=0, transposed=False,
+                 pad_mode=L.PAD_ZERO, act=L.ACT_NONE, slope=0.0):
+        self.cin, self.cout, self.k = cin, cout, k
+        self.stride, self.pad, self.outpad = stride, pad, outpad
+        self.transposed, self.pad_mode, self.act, self.slope = transposed, pad_mode, act, slope
+
+    def out_hw(self, H, W):
+        if self.transposed:
+            f = lambda n: (n - 1) * self.stride - 2 * self.pad + self.k + self.outpad
+        else:
+            f = lambda n: (n + 2 * self.pad - self.k) // self.stride + 1
+        return f(H), f(W)
+
+    def desc(self, B, H, W):
+        return ConvDesc(B, H, W, self.cin, self.cout, self.k, self.k, self.stride, self.pad,
+                        self.outpad, int(self.transposed), self.pad_mode, self.act, float(self.slope))
+
+    @property
+    def is_identity_prep(self):
+        """1x1 convs whose PyTorch weight already is the forward operand (rows=Cout, k=Cin)."""
+        return (self.k == 1 and not self.transposed and self.cin % 32 == 0 and self.cout % 128 == 0)
+
+
+def conv_prep(spec, d, w, sigma=None, fwd=True, bwd=False):
+    wf = wb = None
+    if fwd:
+        wf = empty((query('iprgan_conv_wfwd_floats', C.byref(d)),), w)
+    if bwd:
+        wb = empty((query('iprgan_conv_wbwd_floats', C.byref(d)),), w)
+    call('iprgan_conv_weight_prep', C.byref(d), ptr(w), ptr(sigma), ptr(wf), ptr(wb), stream())
+    return wf, wb
+
+
+def conv_fwd(spec, d, x, wfwd, bias):
+    OH, OW = spec.out_hw(d.H, d.W)
+    y = empty((d.B, OH, OW, c4(spec.cout)), x)
+    call('iprgan_conv_fwd', C.byref(d), ptr(x), ptr(wfwd), ptr(bias), ptr(y), stream())
+    return y
+
+
+def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0):
+    dx = empty((d.B, d.H, d.W, c4(spec.cin)), dy)
+    call('iprgan_conv_bwd_data', C.byref(d), ptr(dy), ptr(wbwd), ptr(dx), ptr(prev_out), prev_act,
+         float(prev_slope), stream())
+    return dx
+
+
+def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias):
+    dw = empty(tuple(w_shape), x)
+    db = empty((spec.cout,), x) if want_bias else None
+    ws = empty((query('iprgan_conv_wgrad_ws_floats', C.byref(d)),), x)
+    call('iprgan_conv_bwd_weight', C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), stream())
+    return dw, db
+
+
+# ---- GEMV head ----------------------------------------------------------------------------------
+def gemv_fwd(x2d, w, bias, sigma):
+    B, K = x2d.shape
+    y = empty((B,), x2d)
+    call('iprgan_gemv_fwd', ptr(x2d), ptr(w), ptr(bias), ptr(sigma), ptr(y), B, K, stream())
+    return y
+
+
+def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0):
+    B, K = x2d.shape
+    dx = torch.empty_like(x2d) if need_dx else None
+    dw = empty((K,), x2d) if need_dw else None
+    db = empty((1,), x2d) if need_dw else None
+    call('iprgan_gemv_bwd', ptr(x2d), ptr(w), ptr(dy), ptr(sigma), ptr(dx), ptr(dw), ptr(db),
+         ptr(prev_out), prev_act, float(prev_slope), B, K, stream())
+    return dx, dw, db
+
+
+# ---- batch norm -----------------------------------------------------------------------------------
+def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, act, slope=0.0):
+    C_ = x.shape[-1]
+    M = x.numel() // C_
+    y = torch.empty_like(x)
+    mean, invstd = empty((C_,), x), empty((C_,), x)
+    ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    call('iprgan_bn_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+         ptr(mean), ptr(invstd), ptr(ws), M, C_, float(eps), float(momentum), 0 if training else 1,
+         act, float(slope), stream())
+    return y, mean, invstd
+
+
+def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0):
+    C_ = x.shape[-1]
+    M = x.numel() // C_
+    dx = torch.empty_like(x)
+    dgamma, dbeta = empty((C_,), x), empty((C_,), x)
+    ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    call('iprgan_bn_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
+         ptr(dgamma), ptr(dbeta), ptr(ws), M, C_, act, float(slope), stream())
+    return dx, dgamma, dbeta
+
+
+# ---- spectral norm ----------------------------------------------------------------------------------
+def sn_power_iter(w_orig, u, v, training, eps=1e-12):
+    rows = w_orig.shape[0]
+    cols = w_orig.numel() // rows
+    sigma = empty((1,), w_orig)
+    ws = empty((query('iprgan_sn_ws_floats', rows, cols),), w_orig)
+    call('iprgan_sn_power_iter', ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(ws), rows, cols,
+         float(eps), 1 if training else 0, stream())
+    return sigma
+
+
+def sn_bwd(dwsn, w_orig, u, v, sigma):
+    rows = w_orig.shape[0]
+    cols = w_orig.numel() // rows
+    dw = torch.empty_like(w_orig)
+    ws = empty((query('iprgan_sn_ws_floats', rows, cols),), w_orig)
+    call('iprgan_sn_bwd', ptr(dwsn), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(dw), ptr(ws), rows,
+         cols, stream())
+    return dw
+
+
+# ---- losses ---------------------------------------------------------------------------------------
+def loss_fwd(kind, x, y=None):
+    out = empty((), x)
+    ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
+    call('iprgan_loss_fwd', kind, ptr(x), ptr(y), ptr(out), ptr(ws), x.numel(), stream())
+    return out
+
+
+def loss_bwd(kind, x, y, gscale):
+    dx = torch.empty_like(x)
+    call('iprgan_loss_bwd', kind, ptr(x), ptr(y), ptr(gscale), ptr(dx), x.numel(), stream())
+    return dx
+
+
+# ---- sign loss ------------------------------------------------------------------------------------
+def _int_table(sizes):
+    return (C.c_int * len(sizes))(*sizes)
+
+
+def sign_loss_fwd(gammas, signs, gamma0):
+    out = empty((), gammas[0])
+    call('iprgan_sign_loss_fwd', L.ptr_table(gammas), L.ptr_table(signs),
+         _int_table([g.numel() for g in gammas]), len(gammas), float(gamma0), ptr(out), stream())
+    return out
+
+
+def sign_loss_bwd(gammas, signs, gamma0, gscale):
+    grads = [torch.empty_like(g) for g in gammas]
+    call('iprgan_sign_loss_bwd', L.ptr_table(gammas), L.ptr_table(signs), L.ptr_table(grads),
+         _int_table([g.numel() for g in gammas]), len(gammas), float(gamma0), ptr(gscale), stream())
+    return grads
+
+
+def sign_ber_counts(gammas, signs):
+    counts = torch.empty((2,), dtype=torch.int64, device=gammas[0].device)
+    call('iprgan_sign_ber', L.ptr_table(gammas), L.ptr_table(signs),
+         _int_table([g.numel() for g in gammas]), len(gammas), counts.data_ptr(), stream())
+    return counts
+
+
+# ---- Adam -----------------------------------------------------------------------------------------
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    n = len(params)
+    sizes = (C.c_longlong * n)(*[p.numel() for p in params])
+    call('iprgan_adam_step', L.ptr_table(params), L.ptr_table(grads), L.ptr_table(exp_avg),
+         L.ptr_table(exp_avg_sq), sizes, n, float(lr), float(beta1), float(beta2), float(eps),
+         float(weight_decay), int(step), stream())

@@ -1,0 +1,101 @@
+"""GPU parity of the HIP engine at network and training-step level.
+
+Checked against (1) the golden vectors captured from the real reference (tests/golden, made by
+oracle/gen_golden.py) and (2) the CPU oracle run live on the same seeded inputs.  fp32 tolerance:
+5e-4 relative (+5e-5 absolute) on outputs/gradients/metrics after up to three optimizer steps -
+the fp32 MFMA is an exact fmaf chain, differences come from summation order only.  Sign buffers and
+the bit-error rate must match exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, gan, nets, recipe, sign
+from test_oracle_golden import compare
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 5e-4, 5e-5
+HIP_NETS = ['ConvGenerator64', 'ConvGenerator32', 'SNDiscriminator64', 'SNDiscriminator32']
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('name', HIP_NETS)
+def test_net_vs_reference_golden(name, golden, dev):
+    from iprgan import networks
+    res = cases.run_net_case(networks, name, device=dev)
+    compare(res, golden('net_' + name), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('name', ['ConvGenerator64', 'SNDiscriminator64'])
+def test_net_eval_mode_vs_oracle(name, dev):
+    """eval(): BatchNorm uses running stats, spectral norm skips the power iteration."""
+    from iprgan import networks
+    attr, kw, xshape, seed = cases.NET_CASES[name]
+    a, b = getattr(nets, attr)(), getattr(networks, attr)()
+    recipe.fill(a, seed); recipe.fill(b, seed)
+    b.to(dev); a.eval(); b.eval()
+    x = recipe.tensor(seed, 5, xshape)
+    with torch.no_grad():
+        ya, yb = a(x), b(x.to(dev))
+    np.testing.assert_allclose(yb.cpu().numpy(), ya.numpy(), rtol=RTOL, atol=ATOL)
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(va, vb.cpu()), f'{k} changed in eval mode'
+
+
+@pytest.mark.parametrize('wbox', [True, False])
+def test_dcgan_steps_vs_reference_golden(wbox, golden, dev):
+    from iprgan import Config, models
+    res = cases.run_dcgan_steps(Config, models, [dev], n_steps=3 if wbox else 2, wbox=wbox)
+    compare(res, golden('dcgan_steps_wbox' if wbox else 'dcgan_steps_plain'), rtol=2e-3, atol=2e-4)
+
+
+def test_dcgan_bs128_step_vs_oracle(dev):
+    """The BASELINE config (DCGAN-64 + sign loss, batch 128) for one step against the live oracle."""
+    from iprgan import Config, models
+    torch.manual_seed(0)
+    ref = cases.run_dcgan_steps(gan.Cfg, gan, gan.CPU, n_steps=1, batch=128, seed=5)
+    res = cases.run_dcgan_steps(Config, models, [dev], n_steps=1, batch=128, seed=5)
+    for k, v in ref.items():
+        if '::' in k or np.asarray(v).dtype.kind in 'iuU':
+            continue
+        np.testing.assert_allclose(np.asarray(res[k]), v, rtol=2e-3, atol=2e-4, err_msg=k)
+    assert res['final/ber'] == ref['final/ber'] == 0.0
+
+
+@pytest.mark.parametrize('name', ['ConvGenerator64'])
+def test_sign_model_bit_exact(name, golden, dev):
+    from iprgan import Config, networks, tools
+
+    class OnDev:                       # build nets directly on the GPU
+        def __getattr__(self, k):
+            return lambda: getattr(networks, k)().to(dev)
+    res = cases.run_sign_case(OnDev(), tools.SignLossModel, Config, name)
+    ref = golden('sign_' + name)
+    assert np.array_equal(res['signs'], ref['signs'])
+    assert list(res['names']) == list(ref['names'])
+    assert res['ber_clean'] == 0.0 and res['ber_corrupt'] == ref['ber_corrupt']
+    np.testing.assert_allclose(res['loss_corrupt'], ref['loss_corrupt'], rtol=1e-5)
+
+
+def test_checkpoint_roundtrip_with_oracle(dev):
+    """state_dict layout is the reference's: an engine checkpoint loads into the oracle and back."""
+    from iprgan import Config, models
+    m = models.WhiteBoxWrapper(models.DCGAN(Config(cases.DCGAN_CFG), device=[dev]), Config(cases.WBOX_CFG))
+    o = gan.WhiteBoxWrapper(gan.DCGAN(gan.Cfg(cases.DCGAN_CFG)), gan.Cfg(cases.WBOX_CFG))
+    x, z = torch.tanh(torch.randn(4, 3, 64, 64)), torch.randn(4, 128)
+    for mm in (m, o):
+        mm.update_d({'real_sample': x, 'latent': z})
+        mm.update_g({'fake_sample': mm.fake_sample})
+    sd = m.state_dict()
+    assert list(sd) == list(o.state_dict()) == ['G', 'D', 'optG', 'optD', 'sign']
+    assert list(sd['G']) == list(o.state_dict()['G']) and list(sd['D']) == list(o.state_dict()['D'])
+    cpu_sd = {k: ({kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+                  if k in ('G', 'D', 'sign') else v) for k, v in sd.items()}
+    o.load_state_dict(cpu_sd, strict=True)
+    m.load_state_dict(o.state_dict(), strict=True)
+    for k, v in m.state_dict()['G'].items():
+        assert torch.equal(v.cpu(), cpu_sd['G'][k]), k

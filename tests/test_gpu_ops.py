@@ -1,0 +1,283 @@
+"""GPU parity of every C-ABI kernel against plain PyTorch fp32 CPU ops (the arithmetic the reference
+reaches through torch.nn).  Tolerances: fp32 MFMA is an exact fmaf chain, only the summation order
+differs from the CPU, so conv results are compared at 2e-4 of the tensor's max magnitude; integer
+results (bit-error counts) must be exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def to_nhwc(x):          # CPU helper: NCHW -> NHWC with channel padding to 4
+    B, C, H, W = x.shape
+    out = torch.zeros(B, H, W, (C + 3) & ~3)
+    out[..., :C] = x.permute(0, 2, 3, 1)
+    return out.contiguous()
+
+
+def from_nhwc(y, C):
+    return y[..., :C].permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, tol=2e-4, what=''):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(1e-6, float(b.abs().max()))
+    err = float((a - b).abs().max()) / scale
+    assert err <= tol, f'{what}: rel-to-max err {err:.3e} > {tol}'
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def test_layout_roundtrip(dev):
+    from iprgan import ops
+    x = rnd(3, 3, 9, 7)
+    y = ops.nchw_to_nhwc(x.to(dev))
+    assert torch.equal(y.cpu(), to_nhwc(x))
+    assert torch.equal(ops.nhwc_to_nchw(y, 3).cpu(), x)
+    x = rnd(2, 20, 5, 6, seed=1)
+    assert torch.equal(ops.nhwc_to_nchw(ops.nchw_to_nhwc(x.to(dev)), 20).cpu(), x)
+    src = rnd(6 * 5 * 4, seed=2)
+    p = ops.permute_021(src.to(dev), 6, 5, 4).cpu()
+    assert torch.equal(p, src.view(6, 5, 4).permute(1, 0, 2).reshape(-1))
+
+
+CONVS = [
+    # cin, cout, k, stride, pad, outpad, transposed, H, W, B, act
+    (64, 64, 3, 1, 1, 0, False, 16, 16, 2, 'lrelu'),
+    (64, 128, 4, 2, 1, 0, False, 16, 16, 3, 'lrelu'),
+    (128, 256, 3, 1, 1, 0, False, 8, 8, 4, 'none'),
+    (3, 64, 3, 1, 1, 0, False, 16, 16, 2, 'lrelu'),
+    (32, 48, 3, 1, 1, 0, False, 7, 9, 2, 'relu'),          # ragged sizes, Cout not a tile multiple
+    (64, 32, 3, 2, 1, 0, False, 15, 13, 2, 'none'),        # odd spatial, stride 2
+    (128, 64, 4, 2, 1, 0, True, 8, 8, 2, 'none'),          # DCGAN G up-conv
+    (512, 256, 4, 2, 1, 0, True, 4, 4, 2, 'none'),
+    (64, 3, 3, 1, 1, 0, True, 16, 16, 2, 'tanh'),          # DCGAN G head
+    (64, 32, 3, 2, 1, 1, True, 6, 5, 2, 'relu'),           # CycleGAN up-conv (output_padding)
+    (256, 512, 3, 1, 1, 0, False, 8, 8, 2, 'lrelu'),
+    (128, 128, 1, 1, 0, 0, False, 5, 5, 2, 'none'),        # 1x1
+    (512, 64, 6, 1, 0, 0, False, 6, 6, 3, 'lrelu'),        # D96 "FC" conv
+]
+ACT = {'none': (0, 0.0), 'relu': (1, 0.0), 'lrelu': (2, 0.1), 'tanh': (3, 0.0)}
+
+
+def ref_act(y, name):
+    return {'none': lambda t: t, 'relu': F.relu, 'lrelu': lambda t: F.leaky_relu(t, 0.1),
+            'tanh': torch.tanh}[name](y)
+
+
+@pytest.mark.parametrize('cfg', CONVS, ids=lambda c: '-'.join(map(str, c)))
+def test_conv_fwd_bwd(dev, cfg):
+    from iprgan import ops
+    cin, cout, k, s, p, op, tr, H, W, B, act = cfg
+    x = rnd(B, cin, H, W, seed=1)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = rnd(*wshape, seed=2, scale=(cin * k * k) ** -0.5)
+    b = rnd(cout, seed=3, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    if tr:
+        pre = F.conv_transpose2d(xr, wr, br, stride=s, padding=p, output_padding=op)
+    else:
+        pre = F.conv2d(xr, wr, br, stride=s, padding=p)
+    yr = ref_act(pre, act)
+    g = rnd(*yr.shape, seed=4)
+    yr.backward(g)
+
+    spec = ops.ConvSpec(cin, cout, k, s, p, op, tr, act=ACT[act][0], slope=ACT[act][1])
+    d = spec.desc(B, H, W)
+    xd, wd, bd = to_nhwc(x).to(dev), w.to(dev), b.to(dev)
+    wf, wb = ops.conv_prep(spec, d, wd, None, fwd=True, bwd=True)
+    y = ops.conv_fwd(spec, d, xd, wf, bd)
+    close(from_nhwc(y.cpu(), cout), yr, what='fwd')
+    if cout % 4:
+        assert float(y[..., cout:].abs().max()) == 0.0, 'pad channels must stay zero'
+    gd = to_nhwc(g).to(dev)
+    dz = ops.act_bwd(gd, y, *ACT[act]) if act != 'none' else gd
+    dw, db = ops.conv_bwd_weight(spec, d, xd, dz, wshape, True)
+    close(dw, wr.grad, what='wgrad')
+    close(db, br.grad, what='bgrad')
+    dx = ops.conv_bwd_data(spec, d, dz, wb)
+    close(from_nhwc(dx.cpu(), cin), xr.grad, what='dgrad')
+
+
+def test_conv_dgrad_fused_prev_act(dev):
+    from iprgan import ops
+    cin, cout, k = 64, 64, 3
+    x_pre = rnd(2, cin, 8, 8, seed=1)
+    x = F.leaky_relu(x_pre, 0.1).requires_grad_()
+    w = rnd(cout, cin, k, k, seed=2, scale=0.05)
+    y = F.conv2d(x, w, None, padding=1)
+    g = rnd(*y.shape, seed=3)
+    y.backward(g)
+    want = x.grad * torch.where(x > 0, 1.0, 0.1)
+    spec = ops.ConvSpec(cin, cout, k, 1, 1)
+    d = spec.desc(2, 8, 8)
+    _, wb = ops.conv_prep(spec, d, w.to(dev), None, fwd=False, bwd=True)
+    xd = to_nhwc(x.detach()).to(dev)
+    dx = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb, xd, 2, 0.1)
+    close(from_nhwc(dx.cpu(), cin), want, what='fused dgrad')
+
+
+def test_conv_sn_scale(dev):
+    from iprgan import ops
+    w = rnd(64, 64, 3, 3, seed=5, scale=0.05)
+    x = rnd(2, 64, 8, 8, seed=6)
+    sigma = torch.tensor([1.7])
+    spec = ops.ConvSpec(64, 64, 3, 1, 1)
+    d = spec.desc(2, 8, 8)
+    wf, _ = ops.conv_prep(spec, d, w.to(dev), sigma.to(dev))
+    y = ops.conv_fwd(spec, d, to_nhwc(x).to(dev), wf, None)
+    close(from_nhwc(y.cpu(), 64), F.conv2d(x, w / sigma, padding=1), what='sn-scaled conv')
+
+
+@pytest.mark.parametrize('M,C,act', [(2 * 16 * 16, 64, 'relu'), (777, 128, 'lrelu'), (5000, 256, 'none'), (3, 64, 'relu')])
+def test_batchnorm(dev, M, C, act):
+    from iprgan import ops
+    x = rnd(M, C, seed=1) * 2 + 0.5
+    gamma, beta = rnd(C, seed=2) * 0.5 + 1, rnd(C, seed=3) * 0.1
+    rm, rv = rnd(C, seed=4) * 0.1, torch.rand(C) + 0.5
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    xr = x.clone().view(M, C, 1, 1).requires_grad_()
+    yr = ref_act(bn(xr), act)
+    g = rnd(M, C, seed=5)
+    yr.backward(g.view(M, C, 1, 1))
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    xd = x.to(dev).view(1, M, 1, C)
+    y, mean, invstd = ops.bn_fwd(xd, gamma.to(dev), beta.to(dev), rmd, rvd, 1e-5, 0.1, True, *ACT[act])
+    close(y.view(M, C), yr.view(M, C), 1e-4, 'bn fwd')
+    close(rmd, bn.running_mean, 1e-5, 'running_mean')
+    close(rvd, bn.running_var, 1e-5, 'running_var')
+    dx, dg, db = ops.bn_bwd(xd, y, g.to(dev).view(1, M, 1, C), gamma.to(dev), mean, invstd, *ACT[act])
+    close(dx.view(M, C), xr.grad.view(M, C), 2e-4, 'bn dx')
+    close(dg, bn.weight.grad, 2e-4, 'bn dgamma')
+    close(db, bn.bias.grad, 2e-4, 'bn dbeta')
+    # eval mode uses running stats
+    bn.eval()
+    ye = ref_act(bn(x.view(M, C, 1, 1)), act)
+    y2, _, _ = ops.bn_fwd(xd, gamma.to(dev), beta.to(dev), rmd, rvd, 1e-5, 0.1, False, *ACT[act])
+    close(y2.view(M, C), ye.view(M, C), 1e-4, 'bn eval')
+
+
+@pytest.mark.parametrize('rows,cols', [(64, 27), (512, 2304), (1, 32768), (128, 2048)])
+def test_spectral_norm(dev, rows, cols):
+    from iprgan import ops
+    w = rnd(rows, cols, seed=1, scale=cols ** -0.5)
+    u = F.normalize(rnd(rows, seed=2), dim=0)
+    v = F.normalize(rnd(cols, seed=3), dim=0)
+    # torch semantics (nn/utils/spectral_norm.py compute_weight)
+    v1 = F.normalize(torch.mv(w.t(), u), dim=0, eps=1e-12)
+    u1 = F.normalize(torch.mv(w, v1), dim=0, eps=1e-12)
+    wr = w.clone().requires_grad_()
+    sig = torch.dot(u1, torch.mv(wr, v1))
+    wsn = wr / sig
+    g = rnd(rows, cols, seed=4)
+    wsn.backward(g)
+    ud, vd, wd = u.to(dev), v.to(dev), w.to(dev)
+    sigma = ops.sn_power_iter(wd, ud, vd, True)
+    close(ud, u1, 1e-5, 'u'); close(vd, v1, 1e-5, 'v'); close(sigma, sig.view(1), 1e-5, 'sigma')
+    dw = ops.sn_bwd(g.to(dev), wd, ud, vd, sigma)
+    close(dw, wr.grad, 1e-4, 'sn bwd')
+    u_before = ud.clone()
+    s2 = ops.sn_power_iter(wd, ud, vd, False)           # eval: no update
+    assert torch.equal(u_before, ud)
+    close(s2, torch.dot(u1, torch.mv(w, v1)).view(1), 1e-5, 'sigma eval')
+
+
+def test_gemv_head(dev):
+    from iprgan import ops
+    B, K = 5, 2048
+    x, w = rnd(B, K, seed=1), rnd(K, seed=2, scale=0.02)
+    b, sigma, g = torch.tensor([0.3]), torch.tensor([1.3]), rnd(B, seed=3)
+    y = ops.gemv_fwd(x.to(dev), w.to(dev), b.to(dev), sigma.to(dev))
+    close(y, x @ (w / sigma) + b, 1e-5, 'gemv fwd')
+    dx, dw, db = ops.gemv_bwd(x.to(dev), w.to(dev), g.to(dev), sigma.to(dev), True, True)
+    close(dx, g[:, None] * (w / sigma)[None], 1e-5, 'gemv dx')
+    close(dw, g @ x, 1e-5, 'gemv dw')
+    close(db, g.sum().view(1), 1e-5, 'gemv db')
+
+
+LOSSES = {
+    0: lambda x, y: F.relu(1 - x).mean(), 1: lambda x, y: F.relu(1 + x).mean(), 2: lambda x, y: -x.mean(),
+    3: lambda x, y: F.binary_cross_entropy_with_logits(x, torch.ones_like(x)),
+    4: lambda x, y: F.binary_cross_entropy_with_logits(x, torch.zeros_like(x)),
+    5: lambda x, y: F.mse_loss(x, torch.ones_like(x)), 6: lambda x, y: F.mse_loss(x, torch.zeros_like(x)),
+    7: F.mse_loss, 8: F.l1_loss,
+}
+
+
+@pytest.mark.parametrize('kind', list(LOSSES))
+@pytest.mark.parametrize('n', [7, 128, 100003])
+def test_losses(dev, kind, n):
+    from iprgan import tools
+    x = (rnd(n, seed=1) * 2).requires_grad_()
+    y = rnd(n, seed=2)
+    ref = LOSSES[kind](x, y) * 1.7
+    ref.backward()
+    xd = x.detach().to(dev).requires_grad_()
+    out = tools.loss_value(kind, xd, y.to(dev) if kind >= 7 else None) * 1.7
+    out.backward()
+    close(out, ref, 1e-5, 'loss')
+    close(xd.grad, x.grad, 1e-5, 'loss grad')
+
+
+def test_sign_loss_and_ber_exact(dev):
+    from iprgan import ops
+    g = np.random.default_rng(5)
+    sizes = [256, 128, 64, 7]
+    gammas = [torch.from_numpy(g.standard_normal(n).astype(np.float32) * 0.3) for n in sizes]
+    gammas[0][:5] = 0.0                                   # sign(0) = 0 counts as an error
+    signs = [torch.from_numpy((g.integers(0, 2, n) * 2 - 1).astype(np.float32)) for n in sizes]
+    gr = [t.clone().requires_grad_() for t in gammas]
+    ref = sum(F.relu(0.1 - a * b).mean() for a, b in zip(gr, signs))
+    (ref * 2.5).backward()
+    gd, sd = [t.to(dev) for t in gammas], [t.to(dev) for t in signs]
+    loss = ops.sign_loss_fwd(gd, sd, 0.1)
+    close(loss, ref, 1e-6, 'sign loss')
+    grads = ops.sign_loss_bwd(gd, sd, 0.1, torch.tensor(2.5, device=dev))
+    for a, b in zip(grads, gr):
+        close(a, b.grad, 1e-6, 'sign grad')
+    counts = ops.sign_ber_counts(gd, sd).cpu()
+    wrong = sum(int((a.sign() != b).sum()) for a, b in zip(gammas, signs))
+    assert counts.tolist() == [wrong, sum(sizes)]
+
+
+def test_adam_matches_torch(dev):
+    from iprgan import optim
+    shapes = [(64, 3, 3, 3), (64,), (1000, 17), (1,)] * 20        # > one launch table
+    ps = [rnd(*s, seed=i) for i, s in enumerate(shapes)]
+    ref = [p.clone().requires_grad_() for p in ps]
+    mine = [p.clone().to(dev).requires_grad_() for p in ps]
+    o1 = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+    o2 = optim.Adam(mine, lr=2e-4, betas=(0.5, 0.999))
+    for it in range(3):
+        for i, (a, b) in enumerate(zip(ref, mine)):
+            g = rnd(*a.shape, seed=100 * it + i)
+            a.grad, b.grad = g.clone(), g.to(dev)
+        o1.step(); o2.step()
+    for a, b in zip(ref, mine):
+        close(b, a, 1e-6, 'adam param')
+    sd1, sd2 = o1.state_dict(), o2.state_dict()
+    assert sd1['param_groups'][0]['betas'] == sd2['param_groups'][0]['betas']
+    assert set(sd2['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+    close(sd2['state'][2]['exp_avg_sq'], sd1['state'][2]['exp_avg_sq'], 1e-6, 'exp_avg_sq')
+    assert float(sd2['state'][0]['step']) == 3.0
+
+
+def test_cpu_tensor_is_refused(dev):
+    from iprgan import networks, ops
+    with pytest.raises(RuntimeError):
+        ops.loss_fwd(0, torch.zeros(4))
+    with pytest.raises(RuntimeError):
+        networks.ConvGenerator32()(torch.zeros(2, 128))
