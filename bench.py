@@ -1,0 +1,176 @@
+"""bench.py — imgs/sec of one G+D training step, DCGAN-64 + sign-loss watermark, batch 128 per GPU.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is launched by
+``python -m torch.distributed.run --nproc-per-node N ...`` (one process per GPU, RCCL).  Rank 0
+prints ONE JSON line.
+
+A "step" is the body of the reference's hot loop, ``ImageGeneration.train()``
+(experiments/image_generation.py:86-101): ``model.update_d({real_sample, latent})`` then
+``model.update_g({fake_sample: model.fake_sample})`` with ``models.WhiteBoxWrapper`` on top
+(configs/DCGAN: gamma_0 0.1, string 'EXAMPLE A'), fp32, Adam(2e-4, (0.5, 0.999)) on G and D.
+Inputs are synthetic (x = tanh(randn), z = randn) and already resident in HBM
+when the timed region starts; weights are random-init.  Nothing is skipped: both optimizer steps,
+spectral-norm power iterations, BatchNorm statistics and the sign loss run inside the timed region.
+
+Extra objects on the JSON line:
+  roofline      the conv kernel with the largest share of device time: algorithmic FLOPs
+                (2*B*OH*OW*Cout*Cin*KH*KW per launch) / HIP-event launch durations, against the fp32
+                MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md)
+  cpu_baseline  the CPU oracle (oracle/gan.py, plain PyTorch fp32: the reference's own arithmetic)
+                timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'ipr-gan_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BATCH = 128
+PEAK_FP32_MFMA = 157.3e12
+DCGAN_CFG = {'G': 'ConvGenerator64', 'D': 'SNDiscriminator64', 'opt': 'Adam',
+             'opt_param': {'lr': 2.0e-4, 'betas': [0.5, 0.999]}, 'type': 'DCGAN'}
+WBOX_CFG = {'gamma_0': 0.1, 'string': 'EXAMPLE A', 'target': 'G'}
+GFLOP_PER_IMG = 3 * 0.8279 + 8 * 0.8699      # necessary fwd+dgrad+wgrad
+
+
+def build_model(device):
+    from iprgan import Config, models
+    model = models.DCGAN(Config(DCGAN_CFG), device=[device])
+    return models.WhiteBoxWrapper(model, Config(WBOX_CFG))
+
+
+def step(model, x, z):
+    model.update_d({'real_sample': x, 'latent': z})
+    model.update_g({'fake_sample': model.fake_sample})
+
+
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def cpu_baseline(max_timed=3, budget_s=25.0):
+    """The oracle's step on the host CPU: 1 warm-up + up to max_timed steps of the same workload
+    (stops early once budget_s of CPU time is spent)."""
+    from oracle import gan
+    torch.manual_seed(1234)
+    threads = torch.get_num_threads()            # torch's default = cores this process may use
+    m = gan.WhiteBoxWrapper(gan.DCGAN(gan.Cfg(DCGAN_CFG)), gan.Cfg(WBOX_CFG))
+    x, z = torch.tanh(torch.randn(BATCH, 3, 64, 64)), torch.randn(BATCH, 128)
+    t0 = time.perf_counter()
+    step(m, x, z)
+    log(f'cpu baseline warm-up step {time.perf_counter() - t0:.1f}s on {threads} threads')
+    n_timed, t0 = 0, time.perf_counter()
+    while n_timed < max_timed and (n_timed == 0 or time.perf_counter() - t0 < budget_s):
+        step(m, x, z)
+        n_timed += 1
+    dt = (time.perf_counter() - t0) / n_timed
+    return {'value': round(BATCH / dt, 2), 'unit': 'img/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n_timed} timed steps (+1 warm-up) of DCGAN-64+sign-loss B={BATCH}, fp32, '
+                      f'torch {torch.__version__} CPU, {threads} threads; {dt * 1e3:.0f} ms/step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU path)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from iprgan import _lib
+    torch.manual_seed(1234 + rank)
+    model = build_model(device)
+    pool = 8                                      # synthetic batches resident in HBM, cycled
+    xs = [torch.tanh(torch.randn(BATCH, 3, 64, 64, device=device)) for _ in range(pool)]
+    zs = [torch.randn(BATCH, 128, device=device) for _ in range(pool)]
+
+    log(f'model built on {device}; warm-up {args.warmup} steps')
+    for i in range(args.warmup):
+        step(model, xs[i % pool], zs[i % pool])
+    torch.cuda.synchronize()
+    log('warm-up done; timing')
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    _lib.prof_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(model, xs[i % pool], zs[i % pool])
+    fence()
+    elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    log(f'timed {args.steps} steps in {elapsed:.3f}s')
+    kernels = [k for k in _lib.prof_results() if k['launches']]
+    metrics = model.get_metrics()
+    assert all(v == v for v in metrics.values()), f'non-finite metrics {metrics}'
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = BATCH * world * args.steps / elapsed
+        dom = max(kernels, key=lambda k: k['ms']) if kernels else None
+        roof = None
+        if dom:
+            ach = dom['flops'] / (dom['ms'] * 1e-3)
+            roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(ach / 1e12, 2),
+                    'peak': round(PEAK_FP32_MFMA / 1e12, 1), 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_FP32_MFMA, 4), 'traffic': None,
+                    'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2)}
+        conv_ms = sum(k['ms'] for k in kernels)
+        conv_flops = sum(k['flops'] for k in kernels)
+        out = {
+            'metric': 'imgs/sec G+D step (DCGAN-64 bs128)', 'value': round(value, 1), 'unit': 'img/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'DCGAN-64 (ConvGenerator64 + SNDiscriminator64) + sign-loss white-box '
+                                   'watermark, G+D step, batch 128 per GPU, fp32, Adam',
+                       'global_batch': BATCH * world, 'parallelism': f'dp{world}'},
+            'roofline': roof,
+            'conv_kernels': {'device_ms_per_step': round(conv_ms / args.steps, 3),
+                             'tflops': round(conv_flops / max(conv_ms, 1e-9) / 1e9, 2),
+                             'mfma_util_pct': round(100 * conv_flops / max(conv_ms, 1e-9) / 1e9 / 157.3, 1),
+                             'by_kernel': [{'name': k['name'], 'launches': k['launches'],
+                                            'ms': round(k['ms'], 2),
+                                            'tflops': round(k['flops'] / max(k['ms'], 1e-9) / 1e9, 2)}
+                                           for k in kernels]},
+            'step_algorithmic_tflops': round(GFLOP_PER_IMG * BATCH * world / ms, 2),
+            'metrics_last_step': {k: round(v, 5) for k, v in metrics.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

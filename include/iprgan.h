@@ -142,10 +142,19 @@ int iprgan_sign_ber(const float* const* gammas, const float* const* signs, const
                     int nlayer, long long* counts, void* stream);
 
 /* ---- Adam (torch.optim.Adam.step at models/dcgan.py:69,78) --------------------------------- */
-/* multi-tensor: HOST arrays of n DEVICE pointers; step is the 1-based step count after increment. */
+/* multi-tensor: HOST arrays of n DEVICE pointers; step is the 1-based step count after increment.
+ * Hyper-parameters are doubles: 1-beta and the bias corrections are formed in double like torch does. */
 int iprgan_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
-                     float* const* exp_avg_sq, const long long* sizes, int n, float lr, float beta1,
-                     float beta2, float eps, float weight_decay, int step, void* stream);
+                     float* const* exp_avg_sq, const long long* sizes, int n, double lr, double beta1,
+                     double beta2, double eps, double weight_decay, int step, void* stream);
+
+/* ---- measurement (bench.py roofline): when enabled, every conv-family launch is bracketed by HIP
+ * events on its own stream; collect() waits for them and accumulates per-kernel launch count, device
+ * milliseconds and algorithmic FLOPs (2*B*OH*OW*Cout*Cin*KH*KW per forward / dgrad / wgrad launch). */
+int iprgan_prof_enable(int on);
+int iprgan_prof_collect(void);
+int iprgan_prof_num_kernels(void);
+int iprgan_prof_get(int i, char* name, int name_len, long long* launches, double* ms, double* flops);
 
 /* ---- misc elementwise ----------------------------------------------------------------------- */
 int iprgan_fill(float* p, float v, size_t n, void* stream);

@@ -10,9 +10,42 @@
 // fragment pair (k = 8 per ds_read_b128 pair: lane half h supplies k = 4h+j to MFMA j).
 // A second kernel computes backward-weight as a split-M GEMM into partial slabs that a
 // fixed-order reduce sums (deterministic) and scatters into PyTorch's weight layout.
+#include <vector>
+
 #include "common.h"
 
 namespace iprgan {
+
+// ---- optional per-kernel timing (bench.py roofline): HIP events on the launch stream ------------
+struct ProfSlot {
+  const char* name;
+  long long launches;
+  double ms, flops;
+};
+static ProfSlot g_slots[] = {
+    {"gconv_kernel<128x128>", 0, 0, 0}, {"gconv_kernel<128x64>", 0, 0, 0},
+    {"gconv_kernel<64x64>", 0, 0, 0},   {"gconv_kernel<128x32>", 0, 0, 0},
+    {"wgrad_kernel<128x128>", 0, 0, 0}, {"wgrad_kernel<128x64>", 0, 0, 0},
+    {"wgrad_kernel<64x64>", 0, 0, 0},   {"wgrad_kernel<32x128>", 0, 0, 0},
+};
+static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
+struct ProfRec { hipEvent_t a, b; int slot; double flops; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_free_events;
+static hipEvent_t prof_event() {
+  hipEvent_t e;
+  if (!g_free_events.empty()) { e = g_free_events.back(); g_free_events.pop_back(); return e; }
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct ProfScope {
+  bool on; hipStream_t st; ProfRec r;
+  ProfScope(hipStream_t s, int slot, double flops) : on(g_prof_on && g_recs.size() < 65536), st(s) {
+    if (on) { r.a = prof_event(); r.b = prof_event(); r.slot = slot; r.flops = flops; (void)hipEventRecord(r.a, st); }
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); g_recs.push_back(r); } }
+};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -43,6 +76,7 @@ struct GConvArgs {
   float aux_slope;
   int nphase;
   Phase ph[4];
+  double flops;   // algorithmic 2*MAC of this launch (host-side bookkeeping only)
 };
 
 #define ROW_INVALID (-(1 << 28))
@@ -226,6 +260,7 @@ struct WGradArgs {
   int isy, isx, pad, tw, ntap, pad_mode;
   int Kw, Nrows;             // slab row length / rows
   int chunks_per_split;
+  double flops;
 };
 
 template <int WGM, int WGN, int WM, int WN>
@@ -513,6 +548,7 @@ static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.nphase);
+  ProfScope prof(st, BM == 128 ? (BN == 128 ? 0 : (BN == 64 ? 1 : 3)) : 2, a.flops);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
   IPR_LAUNCH_CHECK();
   return 0;
@@ -575,6 +611,7 @@ static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st
     attr_set = true;
   }
   dim3 grid(p.Kw / BK, p.Nrows / BN, p.nsplit);
+  ProfScope prof(st, BN == 128 ? (BK == 128 ? 4 : 5) : (BN == 64 ? 6 : 7), a.flops);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
   IPR_LAUNCH_CHECK();
   return 0;
@@ -631,6 +668,7 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
     geom_bwd_form(a, d->B, d->H, d->W, d->Cin, s.OH, s.OW, d->Cout, d->KH, d->KW, d->stride, d->pad);
   }
   a.in = x; a.wt = wfwd; a.bias = bias; a.out = y; a.aux = nullptr;
+  a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = d->act; a.slope = d->slope;
   return launch_gconv(a, (hipStream_t)stream);
 }
@@ -648,6 +686,7 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
     geom_forward_form(a, d->B, s.OH, s.OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad);
   }
   a.in = dy; a.wt = wbwd; a.bias = nullptr; a.out = dx;
+  a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = IPRGAN_ACT_NONE; a.slope = 0.f;
   a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope;
   return launch_gconv(a, (hipStream_t)stream);
@@ -677,6 +716,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   a.isy = a.isx = d->stride; a.pad = d->pad; a.tw = d->KW; a.ntap = p.ntap;
   a.pad_mode = d->pad_mode;
   a.Kw = p.Kw; a.Nrows = p.Nrows; a.chunks_per_split = p.cps;
+  a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   int rc;
   if (p.bn == 128 && p.bk == 128) rc = launch_wgrad_t<2, 2, 2, 2>(a, p, st);
   else if (p.bn == 64) rc = launch_wgrad_t<2, 2, 1, 1>(a, p, st);
@@ -701,6 +741,32 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
                        p.colblk, Cs, d->Cout);
     IPR_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+int iprgan_prof_enable(int on) {
+  if (on) {
+    for (int i = 0; i < g_nslots; ++i) { g_slots[i].launches = 0; g_slots[i].ms = 0; g_slots[i].flops = 0; }
+  }
+  g_prof_on = on != 0;
+  return 0;
+}
+int iprgan_prof_collect(void) {
+  for (auto& r : g_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      g_slots[r.slot].launches += 1; g_slots[r.slot].ms += ms; g_slots[r.slot].flops += r.flops;
+    }
+    g_free_events.push_back(r.a); g_free_events.push_back(r.b);
+  }
+  g_recs.clear();
+  return 0;
+}
+int iprgan_prof_num_kernels(void) { return g_nslots; }
+int iprgan_prof_get(int i, char* name, int name_len, long long* launches, double* ms, double* flops) {
+  IPR_CHECK(i >= 0 && i < g_nslots, "prof_get: bad index %d", i);
+  snprintf(name, name_len, "%s", g_slots[i].name);
+  *launches = g_slots[i].launches; *ms = g_slots[i].ms; *flops = g_slots[i].flops;
   return 0;
 }
 

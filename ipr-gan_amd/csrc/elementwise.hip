@@ -228,8 +228,9 @@ struct AdamTable {
   float* v[ADAM_MAX_TENSORS];
   long long n[ADAM_MAX_TENSORS];
 };
-__global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float beta1, float beta2, float eps,
-                                                   float weight_decay, float step_size, float bc2_sqrt) {
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float omb1, float beta2, float omb2,
+                                                   float eps, float weight_decay, float step_size,
+                                                   float bc2_sqrt) {
   const int ti = blockIdx.y;
   const long long n = t.n[ti];
   float* __restrict__ p = t.p[ti];
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float beta
     float gi = g[i];
     const float pi = p[i];
     if (weight_decay != 0.f) gi += weight_decay * pi;
-    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);          // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;      // mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float mi = m[i] + (gi - m[i]) * omb1;               // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * beta2 + omb2 * gi * gi;           // mul_(beta2).addcmul_(g, g, 1-beta2)
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
@@ -403,12 +404,12 @@ int iprgan_sign_ber(const float* const* gammas, const float* const* signs, const
 }
 
 int iprgan_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
-                     float* const* exp_avg_sq, const long long* sizes, int n, float lr, float beta1,
-                     float beta2, float eps, float weight_decay, int step, void* stream) {
+                     float* const* exp_avg_sq, const long long* sizes, int n, double lr, double beta1,
+                     double beta2, double eps, double weight_decay, int step, void* stream) {
   IPR_CHECK(step >= 1, "adam_step: step must be >= 1");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   for (int b = 0; b < n; b += ADAM_MAX_TENSORS) {
     AdamTable t;
@@ -422,8 +423,9 @@ int iprgan_adam_step(float* const* params, const float* const* grads, float* con
       if (t.n[i] > maxn) maxn = t.n[i];
     }
     const int gx = grid_for((size_t)maxn, 256);
-    hipLaunchKernelGGL(adam_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, t, beta1, beta2, eps,
-                       weight_decay, step_size, bc2_sqrt);
+    hipLaunchKernelGGL(adam_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, t,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)weight_decay, step_size, bc2_sqrt);
     IPR_LAUNCH_CHECK();
   }
   return 0;

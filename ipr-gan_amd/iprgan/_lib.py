@@ -57,7 +57,11 @@ SIGNATURES = {
     'iprgan_sign_loss_fwd': (_I, [_P, _P, _P, _I, _F, _P, _P]),
     'iprgan_sign_loss_bwd': (_I, [_P, _P, _P, _P, _I, _F, _P, _P]),
     'iprgan_sign_ber': (_I, [_P, _P, _P, _I, _P, _P]),
-    'iprgan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P]),
+    'iprgan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
+    'iprgan_prof_enable': (_I, [_I]),
+    'iprgan_prof_collect': (_I, []),
+    'iprgan_prof_num_kernels': (_I, []),
+    'iprgan_prof_get': (_I, [_I, C.c_char_p, _I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'iprgan_fill': (_I, [_P, _F, _Z, _P]),
     'iprgan_axpy': (_I, [_P, _P, _F, _Z, _P]),
 }
@@ -114,3 +118,19 @@ def ptr_table(tensors):
     for i, t in enumerate(tensors):
         arr[i] = ptr(t)
     return arr
+
+
+def prof_enable(on):
+    call('iprgan_prof_enable', 1 if on else 0)
+
+
+def prof_results():
+    """[{name, launches, ms, flops}] accumulated since prof_enable(True); waits for pending events."""
+    call('iprgan_prof_collect')
+    out = []
+    for i in range(query('iprgan_prof_num_kernels')):
+        name = C.create_string_buffer(96)
+        n, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
+        call('iprgan_prof_get', i, name, 96, C.byref(n), C.byref(ms), C.byref(fl))
+        out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value))
+    return out

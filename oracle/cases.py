@@ -108,6 +108,7 @@ def run_sign_case(networks, SignLossModel, make_cfg, name, string='EXAMPLE A', s
     net = getattr(networks, name)()
     recipe.fill(net, seed)
     slm = SignLossModel(net, make_cfg({'gamma_0': 0.1, 'string': string}))
+    slm = slm.to(next(net.parameters()).device)      # as models/wrappers.py:83-86 does
     res = {}
     signs = [b.detach().cpu().numpy() for _, b in slm.named_buffers()]
     res['signs'] = np.concatenate(signs).astype(np.int8)

@@ -40,10 +40,25 @@ class Cfg(dict):
 CPU = [torch.device('cpu')]
 
 
+class _CpuDataParallel(nn.Module):
+    """What ``DataParallel(net, device_ids=[None])`` degenerates to on a CPU-only machine: a
+    passthrough that owns ``.module`` (state_dict keys get the 'module.' prefix).  On a machine that
+    HAS a GPU, torch's DataParallel would move the module to cuda:0 even for device=[cpu]; the oracle
+    must stay on the CPU there, hence this explicit shell."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
 def _wrap(net, device):
-    # models/dcgan.py:13-17 — DataParallel on CPU is a passthrough but prefixes keys with 'module.'
-    ids = [d.index for d in device]
-    return DataParallel(net.to(device[0]), device_ids=ids)
+    # models/dcgan.py:13-17
+    if device[0].type == 'cpu':
+        return _CpuDataParallel(net)
+    return DataParallel(net.to(device[0]), device_ids=[d.index for d in device])
 
 
 class Model:

@@ -50,7 +50,8 @@ def test_net_eval_mode_vs_oracle(name, dev):
 def test_dcgan_steps_vs_reference_golden(wbox, golden, dev):
     from iprgan import Config, models
     res = cases.run_dcgan_steps(Config, models, [dev], n_steps=3 if wbox else 2, wbox=wbox)
-    compare(res, golden('dcgan_steps_wbox' if wbox else 'dcgan_steps_plain'), rtol=2e-3, atol=2e-4)
+    compare(res, golden('dcgan_steps_wbox' if wbox else 'dcgan_steps_plain'), rtol=2e-3, atol=2e-4,
+            weight_atol=4 * 2e-4 * (3 if wbox else 2))       # 2*lr*steps, see compare()
 
 
 def test_dcgan_bs128_step_vs_oracle(dev):
@@ -62,7 +63,8 @@ def test_dcgan_bs128_step_vs_oracle(dev):
     for k, v in ref.items():
         if '::' in k or np.asarray(v).dtype.kind in 'iuU':
             continue
-        np.testing.assert_allclose(np.asarray(res[k]), v, rtol=2e-3, atol=2e-4, err_msg=k)
+        is_w = k.startswith(('final/G/', 'final/D/')) and k.rsplit('.', 1)[-1] not in cases.BUFFER_LEAVES
+        np.testing.assert_allclose(np.asarray(res[k]), v, rtol=2e-3, atol=8e-4 if is_w else 2e-4, err_msg=k)
     assert res['final/ber'] == ref['final/ber'] == 0.0
 
 
