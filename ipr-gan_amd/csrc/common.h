@@ -10,6 +10,9 @@
 namespace iprgan {
 
 void set_error(const char* fmt, ...);
+// norm.hip: deterministic column sums of x[M][Cs] -> out[C] (bias gradients)
+size_t colsum_ws_floats(int M, int Cs);
+int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st);
 
 #define IPR_CHECK(cond, ...)                 \
   do {                                       \

@@ -394,22 +394,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
     }
 }
 
-// sum the split slabs in fixed order and scatter into PyTorch weight layout
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
-                                    int Nrows, int Kw, int N, int C, int Qs, int ntap, FastDiv d_qs,
-                                    long long sn, long long sc) {
-  const long long total = (long long)N * ntap * Qs;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int kk = (int)(i % (ntap * Qs));
-    const int n = (int)(i / (ntap * Qs));
+// sum the split slabs in fixed order and scatter into PyTorch weight layout.
+// block = 64 consecutive slab elements x 4 split lanes (lane l sums splits l, l+4, ... then lanes 0..3)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws,
+                                                           float* __restrict__ dw, int nsplit, int Nrows,
+                                                           int Kw, int N, int C, int Qs, int ntap,
+                                                           FastDiv d_qs, FastDiv d_row, long long sn,
+                                                           long long sc) {
+  __shared__ float sh[4][64];
+  const int e = threadIdx.x & 63, lane = threadIdx.x >> 6;
+  const int rowlen = ntap * Qs;
+  const long long total = (long long)N * rowlen;
+  const long long i = (long long)blockIdx.x * 64 + e;
+  float s = 0.f;
+  int n = 0, kk = 0;
+  if (i < total) {
+    n = fdiv((uint32_t)i, d_row);
+    kk = (int)(i - (long long)n * rowlen);
+    const float* p = ws + (size_t)n * Kw + kk;
+    const size_t slab = (size_t)Nrows * Kw;
+    for (int sp = lane; sp < nsplit; sp += 4) s += p[(size_t)sp * slab];
+  }
+  sh[lane][e] = s;
+  __syncthreads();
+  if (lane == 0 && i < total) {
     const int tap = fdiv(kk, d_qs);
     const int c = kk - tap * Qs;
-    if (c >= C) continue;
-    float s = 0.f;
-    const float* p = ws + (size_t)n * Kw + kk;
-    for (int sp = 0; sp < nsplit; ++sp) s += p[(size_t)sp * Nrows * Kw];
-    dw[n * sn + c * sc + tap] = s;
+    if (c < C) dw[n * sn + c * sc + tap] = sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e];
   }
 }
 
@@ -434,27 +445,6 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __r
     }
     dst[i] = v;
   }
-}
-
-// column sums of x[M][Cs] in two deterministic stages (bias gradient)
-__global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int M,
-                                      int Cs, int rows_per_block) {
-  const int c = blockIdx.y * blockDim.x + threadIdx.x;
-  if (c >= Cs) return;
-  const int r0 = blockIdx.x * rows_per_block;
-  int r1 = r0 + rows_per_block;
-  if (r1 > M) r1 = M;
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += x[(size_t)r * Cs + c];
-  part[(size_t)blockIdx.x * Cs + c] = s;
-}
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk,
-                                    int Cs, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * Cs + c];
-  out[c] = s;
 }
 
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
@@ -569,9 +559,8 @@ static int launch_gconv(const GConvArgs& a, hipStream_t st) {
 
 // ---- backward-weight ------------------------------------------------------------------------
 struct WGradPlan {
-  int N, Cq, Ps, Qs, ntap, Kw, Nrows, bn, bk, tiles, nsplit, cps, M, colblk;
+  int N, Cq, Ps, Qs, ntap, Kw, Nrows, bn, bk, tiles, nsplit, cps, M;
 };
-#define COLSUM_ROWS 1024
 static WGradPlan wgrad_plan(const iprgan_conv_desc* d) {
   WGradPlan p;
   const Shape s = out_shape(d);
@@ -595,8 +584,6 @@ static WGradPlan wgrad_plan(const iprgan_conv_desc* d) {
   if (want > chunks) want = chunks;
   p.cps = cdiv(chunks, want);
   p.nsplit = cdiv(chunks, p.cps);
-  const int dyM = d->B * s.OH * s.OW;
-  p.colblk = cdiv(dyM, COLSUM_ROWS);
   return p;
 }
 
@@ -694,7 +681,8 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
 
 size_t iprgan_conv_wgrad_ws_floats(const iprgan_conv_desc* d) {
   const WGradPlan p = wgrad_plan(d);
-  return (size_t)p.nsplit * p.Nrows * p.Kw + (size_t)p.colblk * c4(d->Cout);
+  const Shape s = out_shape(d);
+  return (size_t)p.nsplit * p.Nrows * p.Kw + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout));
 }
 
 int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -725,21 +713,18 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   if (rc) return rc;
   {
     const long long total = (long long)p.N * p.ntap * p.Qs;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    IPR_CHECK(total < (1ll << 31), "conv_bwd_weight: weight too large");
     const long long sn = (long long)p.Cq * p.ntap, sc = p.ntap;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, p.nsplit,
-                       p.Nrows, p.Kw, p.N, p.Cq, p.Qs, p.ntap, make_fastdiv(p.Qs), sn, sc);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, ws, dw,
+                       p.nsplit, p.Nrows, p.Kw, p.N, p.Cq, p.Qs, p.ntap, make_fastdiv(p.Qs),
+                       make_fastdiv(p.ntap * p.Qs), sn, sc);
     IPR_LAUNCH_CHECK();
   }
   if (db) {
     const int Cs = c4(d->Cout), M = d->B * s.OH * s.OW;
     float* part = ws + (size_t)p.nsplit * p.Nrows * p.Kw;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(p.colblk, cdiv(Cs, 64)), dim3(64), 0, st, dy, part,
-                       M, Cs, COLSUM_ROWS);
-    IPR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(d->Cout, 64)), dim3(64), 0, st, part, db,
-                       p.colblk, Cs, d->Cout);
-    IPR_LAUNCH_CHECK();
+    const int rc2 = colsum_launch(dy, db, part, M, Cs, d->Cout, st);
+    if (rc2) return rc2;
   }
   return 0;
 }

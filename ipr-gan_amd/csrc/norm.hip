@@ -1,71 +1,141 @@
-// BatchNorm2d (training / eval) over NHWC activations x[M][C], HBM-bound.
-// Statistics are reduced in two deterministic stages: each block takes a fixed slice of rows and
-// emits (local mean, local M2) per channel; the finalize kernel merges the slices in slice order
-// with Chan's parallel-variance formula (stable: no E[x^2]-E[x]^2 cancellation), writes
-// mean/invstd and updates the running statistics exactly as torch.nn.BatchNorm2d does
-// (biased variance to normalise, unbiased into running_var; reference networks/conv_generator.py:9).
+// BatchNorm2d (training / eval) and bias-gradient column sums over NHWC activations x[M][C]: HBM-bound.
+//
+// Column reductions share one shape: a 256-thread block = TC channel-quads (16-byte loads, coalesced
+// along C) x TR row lanes; it walks a fixed slice of rows, reduces the row lanes through LDS and emits
+// one partial per (slice, channel).  A second kernel sums the slices in slice order, so the result is
+// deterministic (no float atomics).  Variance uses sums shifted by the tensor's first row
+// (var = E[(x-s)^2] - E[x-s]^2 with s = x[0][c], s within a few sigma of the mean), which removes the
+// E[x^2]-E[x]^2 cancellation while keeping a single pass over x.
+// Semantics follow torch.nn.BatchNorm2d (biased variance to normalise, unbiased into running_var;
+// reference networks/conv_generator.py:9, sr_resnet.py:23, discriminator_96.py:31).
 #include "common.h"
 
 namespace iprgan {
 
-#define BN_ROWS_PER_BLOCK 512
-#define BN_CH_PER_BLOCK 64   // threads = 64 channels x 4 row lanes
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x,
-                                                               float* __restrict__ part, int M, int C) {
-  __shared__ float sh[4][BN_CH_PER_BLOCK];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int c = blockIdx.y * BN_CH_PER_BLOCK + cl;
-  const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
-  int r1 = r0 + BN_ROWS_PER_BLOCK;
+struct ColGeom {
+  int TC, TR, gy, NB, rows_per_block;
+};
+static ColGeom col_geom(int M, int C) {
+  ColGeom g;
+  const int cq = C / 4;
+  g.TC = cq < 64 ? cq : 64;
+  // TC must divide 256 for the thread layout: round down to a power of two
+  int tc = 1;
+  while (tc * 2 <= g.TC) tc *= 2;
+  g.TC = tc;
+  g.TR = 256 / g.TC;
+  g.gy = cdiv(cq, g.TC);
+  int nb = cdiv(M, g.TR * 4);
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  g.rows_per_block = rup(cdiv(M, nb), g.TR);
+  g.NB = cdiv(M, g.rows_per_block);
+  return g;
+}
+
+// MODE 0: s0 = sum x                     (bias gradient)
+// MODE 1: s0 = sum (x-s), s1 = sum (x-s)^2            (BN statistics, s = x[0][c])
+// MODE 2: s0 = sum dz, s1 = sum dz*xhat, dz = dy*act'(y), xhat = (x-mean)*invstd   (BN backward)
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ y,
+                                                        const float* __restrict__ dy,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        float* __restrict__ part, int M, int C, int TC,
+                                                        int rows_per_block, int act, float slope) {
+  __shared__ f32x4 sh[2][256];
+  const int TR = 256 / TC;
+  const int tc = threadIdx.x % TC, tr = threadIdx.x / TC;
+  const int cq = blockIdx.y * TC + tc;
+  const bool ok = cq * 4 < C;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
-  const int cnt = r1 - r0;
-  const bool okc = c < C;
-  float s = 0.f;
-  if (okc)
-    for (int r = r0 + rg; r < r1; r += 4) s += x[(size_t)r * C + c];
-  sh[rg][cl] = s;
-  __syncthreads();
-  const float lmean = (sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]) / (float)cnt;
-  __syncthreads();
-  float m2 = 0.f;
-  if (okc)
-    for (int r = r0 + rg; r < r1; r += 4) {
-      const float d = x[(size_t)r * C + c] - lmean;
-      m2 += d * d;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {1.f, 1.f, 1.f, 1.f};
+    if (MODE == 1) p0 = *(const f32x4*)(x + cq * 4);
+    if (MODE == 2) { p0 = *(const f32x4*)(mean + cq * 4); p1 = *(const f32x4*)(invstd + cq * 4); }
+    for (int r = r0 + tr; r < r1; r += TR) {
+      const size_t off = (size_t)r * C + cq * 4;
+      if (MODE == 0) {
+        a0 += *(const f32x4*)(x + off);
+      } else if (MODE == 1) {
+        const f32x4 d = *(const f32x4*)(x + off) - p0;
+        a0 += d;
+        a1 += d * d;
+      } else {
+        const f32x4 xv = *(const f32x4*)(x + off), yv = *(const f32x4*)(y + off), gv = *(const f32x4*)(dy + off);
+        f32x4 dz;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dz[k] = gv[k] * act_grad_from_out(yv[k], act, slope);
+        a0 += dz;
+        a1 += dz * ((xv - p0) * p1);
+      }
     }
-  sh[rg][cl] = m2;
+  }
+  sh[0][threadIdx.x] = a0;
+  sh[1][threadIdx.x] = a1;
   __syncthreads();
-  if (rg == 0 && okc) {
-    float* p = part + ((size_t)blockIdx.x * 2) * C;
-    p[c] = lmean;
-    p[C + c] = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
+  if (tr == 0 && ok) {
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TR; ++i) { s0 += sh[0][i * TC + tc]; s1 += sh[1][i * TC + tc]; }
+    float* p = part + ((size_t)blockIdx.x * 2) * C + cq * 4;
+    *(f32x4*)p = s0;
+    if (MODE != 0) *(f32x4*)(p + C) = s1;
   }
 }
 
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblk, int M, int C,
-                                      float eps, float momentum, float* __restrict__ running_mean,
-                                      float* __restrict__ running_var, float* __restrict__ save_mean,
-                                      float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float mean = 0.f, m2 = 0.f;
-  int n = 0;
-  for (int b = 0; b < nblk; ++b) {
-    int cnt = M - b * BN_ROWS_PER_BLOCK;
-    if (cnt > BN_ROWS_PER_BLOCK) cnt = BN_ROWS_PER_BLOCK;
-    const float lm = part[((size_t)b * 2) * C + c], lm2 = part[((size_t)b * 2 + 1) * C + c];
-    const float delta = lm - mean;
-    const int nn = n + cnt;
-    mean += delta * ((float)cnt / (float)nn);
-    m2 += lm2 + delta * delta * ((float)n * (float)cnt / (float)nn);
-    n = nn;
-  }
-  const float var = m2 / (float)M;
+// sums the NB slice partials of 64 channels with 4 lanes each (slice order within a lane, then lanes)
+__device__ __forceinline__ void final_sums(const float* __restrict__ part, int NB, int C, int c, int lane,
+                                           float (*sh)[4][64], float& s0, float& s1, bool two) {
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C)
+    for (int b = lane; b < NB; b += 4) {
+      a0 += part[((size_t)b * 2) * C + c];
+      if (two) a1 += part[((size_t)b * 2 + 1) * C + c];
+    }
+  const int cl = threadIdx.x & 63;
+  sh[0][lane][cl] = a0;
+  sh[1][lane][cl] = a1;
+  __syncthreads();
+  s0 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+  s1 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int NB, int Cs,
+                                                           int C, float* __restrict__ out) {
+  __shared__ float sh[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+  float s0, s1;
+  final_sums(part, NB, Cs, c, lane, sh, s0, s1, false);
+  if (lane == 0 && c < C) out[c] = s0;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ part,
+                                                             const float* __restrict__ x, int NB, int M,
+                                                             int C, float eps, float momentum,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var,
+                                                             float* __restrict__ save_mean,
+                                                             float* __restrict__ save_invstd) {
+  __shared__ float sh[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+  float s0, s1;
+  final_sums(part, NB, C, c, lane, sh, s0, s1, true);
+  if (lane != 0 || c >= C) return;
+  const float invM = 1.0f / (float)M;
+  const float d = s0 * invM;                 // E[x - s]
+  const float mean = x[c] + d;
+  float var = s1 * invM - d * d;             // biased variance
+  if (var < 0.f) var = 0.f;
   save_mean[c] = mean;
   save_invstd[c] = 1.0f / sqrtf(var + eps);
   if (running_mean) {
-    const float unb = M > 1 ? m2 / (float)(M - 1) : var;
+    const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
   }
@@ -80,97 +150,75 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean,
   save_invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 
-// y = act((x-mean)*invstd*gamma+beta), float4 over [M][C] (C % 4 == 0)
-__global__ void bn_apply_kernel(const float4* __restrict__ x, float4* __restrict__ y,
+// y = act((x-mean)*invstd*gamma+beta), 16 B per lane over [M][C]
+__global__ void bn_apply_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                 size_t n4, int C4n, int act, float slope) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4n) * 4;
-    const float4 v = x[i];
-    float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+    const f32x4 v = x[i];
+    f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float g = gamma ? gamma[c + k] : 1.f, b = beta ? beta[c + k] : 0.f;
-      o[k] = act_apply((in[k] - mean[c + k]) * invstd[c + k] * g + b, act, slope);
+      o[k] = act_apply((v[k] - mean[c + k]) * invstd[c + k] * g + b, act, slope);
     }
-    y[i] = make_float4(o[0], o[1], o[2], o[3]);
+    y[i] = o;
   }
 }
 
-// backward stage 1: per block slice, s1 = sum dz, s2 = sum dz*xhat, dz = dy*act'(y)
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x,
-                                                             const float* __restrict__ y,
-                                                             const float* __restrict__ dy,
-                                                             const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd,
-                                                             float* __restrict__ part, int M, int C,
-                                                             int act, float slope) {
-  __shared__ float sh[2][4][BN_CH_PER_BLOCK];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int c = blockIdx.y * BN_CH_PER_BLOCK + cl;
-  const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
-  int r1 = r0 + BN_ROWS_PER_BLOCK;
-  if (r1 > M) r1 = M;
-  float s1 = 0.f, s2 = 0.f;
-  if (c < C) {
-    const float mu = mean[c], is = invstd[c];
-    for (int r = r0 + rg; r < r1; r += 4) {
-      const size_t i = (size_t)r * C + c;
-      const float dz = dy[i] * act_grad_from_out(y[i], act, slope);
-      s1 += dz;
-      s2 += dz * (x[i] - mu) * is;
-    }
-  }
-  sh[0][rg][cl] = s1;
-  sh[1][rg][cl] = s2;
-  __syncthreads();
-  if (rg == 0 && c < C) {
-    float* p = part + ((size_t)blockIdx.x * 2) * C;
-    p[c] = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
-    p[C + c] = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
-  }
-}
-
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C,
-                                    float* __restrict__ sums, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += part[((size_t)b * 2) * C + c];
-    s2 += part[((size_t)b * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int NB, int C,
+                                                           float* __restrict__ sums,
+                                                           float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+  __shared__ float sh[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+  float s1, s2;
+  final_sums(part, NB, C, c, lane, sh, s1, s2, true);
+  if (lane != 0 || c >= C) return;
   sums[c] = s1;
   sums[C + c] = s2;
   if (dgamma) dgamma[c] = s2;
   if (dbeta) dbeta[c] = s1;
 }
 
-__global__ void bn_bwd_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ y,
-                                    const float4* __restrict__ dy, float4* __restrict__ dx,
+__global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ y,
+                                    const f32x4* __restrict__ dy, f32x4* __restrict__ dx,
                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ sums,
                                     size_t n4, int C4n, int C, float invM, int act, float slope) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4n) * 4;
-    const float4 xv = x[i], yv = y[i], gv = dy[i];
-    const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, yi[4] = {yv.x, yv.y, yv.z, yv.w},
-                gi[4] = {gv.x, gv.y, gv.z, gv.w};
-    float o[4];
+    const f32x4 xv = x[i], yv = y[i], gv = dy[i];
+    f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float is = invstd[c + k];
-      const float xh = (xi[k] - mean[c + k]) * is;
-      const float dz = gi[k] * act_grad_from_out(yi[k], act, slope);
+      const float xh = (xv[k] - mean[c + k]) * is;
+      const float dz = gv[k] * act_grad_from_out(yv[k], act, slope);
       const float g = gamma ? gamma[c + k] : 1.f;
       o[k] = g * is * (dz - sums[c + k] * invM - xh * sums[C + c + k] * invM);
     }
-    dx[i] = make_float4(o[0], o[1], o[2], o[3]);
+    dx[i] = o;
   }
+}
+
+// used by conv_igemm.hip for the bias gradient
+size_t colsum_ws_floats(int M, int Cs) {
+  const ColGeom g = col_geom(M, Cs);
+  return (size_t)g.NB * 2 * Cs;
+}
+int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st) {
+  const ColGeom g = col_geom(M, Cs);
+  hipLaunchKernelGGL(colreduce_kernel<0>, dim3(g.NB, g.gy), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                     nullptr, ws, M, Cs, g.TC, g.rows_per_block, 0, 0.f);
+  IPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, g.NB, Cs, C, out);
+  IPR_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // namespace iprgan
@@ -180,7 +228,8 @@ using namespace iprgan;
 extern "C" {
 
 size_t iprgan_bn_ws_floats(int M, int C) {
-  return (size_t)cdiv(M, BN_ROWS_PER_BLOCK) * 2 * C + 2 * (size_t)C;
+  const ColGeom g = col_geom(M, C);
+  return (size_t)g.NB * 2 * C + 2 * (size_t)C;
 }
 
 int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
@@ -194,18 +243,18 @@ int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* bet
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, running_mean,
                        running_var, eps, C, save_mean, save_invstd);
   } else {
-    const int nblk = cdiv(M, BN_ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk, cdiv(C, BN_CH_PER_BLOCK)), dim3(256), 0, st,
-                       x, ws, M, C);
+    const ColGeom g = col_geom(M, C);
+    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.NB, g.gy), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                       nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f);
     IPR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, nblk, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, x, g.NB, M, C, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd);
   }
   IPR_LAUNCH_CHECK();
   const size_t n4 = (size_t)M * C / 4;
   const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)x, (float4*)y,
-                     gamma, beta, save_mean, save_invstd, n4, C / 4, act, slope);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)x, (f32x4*)y, gamma,
+                     beta, save_mean, save_invstd, n4, C / 4, act, slope);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -215,19 +264,19 @@ int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* 
                   float* dbeta, float* ws, int M, int C, int act, float slope, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   IPR_CHECK(C % 4 == 0, "bn_bwd: C=%d must be a multiple of 4", C);
-  const int nblk = cdiv(M, BN_ROWS_PER_BLOCK);
-  float* sums = ws + (size_t)nblk * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, cdiv(C, BN_CH_PER_BLOCK)), dim3(256), 0, st, x, y,
-                     dy, save_mean, save_invstd, ws, M, C, act, slope);
+  const ColGeom g = col_geom(M, C);
+  float* sums = ws + (size_t)g.NB * 2 * C;
+  hipLaunchKernelGGL(colreduce_kernel<2>, dim3(g.NB, g.gy), dim3(256), 0, st, x, y, dy, save_mean,
+                     save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope);
   IPR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, nblk, C, sums, dgamma,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, g.NB, C, sums, dgamma,
                      dbeta);
   IPR_LAUNCH_CHECK();
   const size_t n4 = (size_t)M * C / 4;
   const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)x,
-                     (const float4*)y, (const float4*)dy, (float4*)dx, gamma, save_mean, save_invstd,
-                     sums, n4, C / 4, C, 1.0f / (float)M, act, slope);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)x, (const f32x4*)y,
+                     (const f32x4*)dy, (f32x4*)dx, gamma, save_mean, save_invstd, sums, n4, C / 4, C,
+                     1.0f / (float)M, act, slope);
   IPR_LAUNCH_CHECK();
   return 0;
 }

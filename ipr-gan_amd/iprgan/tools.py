@@ -85,7 +85,9 @@ class SignLossModel(nn.Module):
         """bit errors / bits; the count is an exact int64 device reduction (sign(0) is an error)."""
         gammas, signs = self._pairs(model)
         counts = ops.sign_ber_counts([g.detach() for g in gammas], signs)
-        return counts[0].to(torch.float32) / int(sum(s.numel() for s in signs))
+        # tensor / tensor is an IEEE division on the GPU (tensor / python-scalar multiplies by a
+        # rounded reciprocal and can differ from the reference's CPU result in the last bit)
+        return counts[0].to(torch.float32) / counts[1].to(torch.float32)
 
 
 class _LossFn(torch.autograd.Function):

@@ -76,7 +76,16 @@ def run_dcgan_steps(make_cfg, models, device, n_steps=3, batch=4, seed=21, wbox=
         for k, v in model.get_metrics().items():
             res[f'step{s}/metric/{k}'] = np.float64(v)
         if s == 0:
+            # after ONE step the optimizer moments are (1-beta)*grad: a tight check of every gradient
             res['step0/fake_sample'] = model.fake_sample.detach().cpu().numpy()
+            sd0 = model.state_dict()
+            for opt in ('optG', 'optD'):
+                for idx in sorted(sd0[opt]['state']):
+                    recipe.pack_summary(f'step0/{opt}/{idx}/exp_avg', sd0[opt]['state'][idx]['exp_avg'].cpu(), res)
+            for net in ('G', 'D'):
+                for k, v in sd0[net].items():
+                    if k.rsplit('.', 1)[-1] in BUFFER_LEAVES:
+                        res[f'step0/{net}/{k}'] = v.detach().cpu().numpy().copy()
     sd = model.state_dict()
     for net in ('G', 'D'):
         for k, v in sd[net].items():

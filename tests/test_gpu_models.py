@@ -46,12 +46,35 @@ def test_net_eval_mode_vs_oracle(name, dev):
         assert torch.equal(va, vb.cpu()), f'{k} changed in eval mode'
 
 
+def step_policy(steps, lr=2e-4):
+    """Tolerances for multi-step training parity.
+    step 0 (metrics, generated images, Adam first moments = (1-beta1)*grad of EVERY parameter, BN/SN
+    buffers): tight, 1e-3 - this is the gradient-level parity claim.
+    later steps: Adam moves each weight by ~lr*sign(m)/..., so where a gradient is at rounding-noise
+    level the update direction is noise and two correct fp32 implementations drift apart by up to
+    2*lr per step in such weights; GAN dynamics then feed that back into later gradients.  Weights get
+    an absolute slack of 2*lr*steps, later metrics 1e-2; the moments after the last step are compared
+    by overall magnitude only (10 %): at batch 4 they are dominated by that feedback."""
+    def policy(k):
+        if k.startswith('step0/'):
+            return (1e-3, 1e-4)
+        if k.startswith('step'):
+            return (1e-2, 1e-3)
+        leaf = k.rsplit('.', 1)[-1]
+        if k.startswith(('final/optG', 'final/optD')):
+            return (0.1, 1e-3, 'scale')
+        if k.startswith(('final/G/', 'final/D/')) and leaf not in cases.BUFFER_LEAVES:
+            return (2e-3, 2 * lr * steps)
+        return (1e-2, 1e-3)
+    return policy
+
+
 @pytest.mark.parametrize('wbox', [True, False])
 def test_dcgan_steps_vs_reference_golden(wbox, golden, dev):
     from iprgan import Config, models
-    res = cases.run_dcgan_steps(Config, models, [dev], n_steps=3 if wbox else 2, wbox=wbox)
-    compare(res, golden('dcgan_steps_wbox' if wbox else 'dcgan_steps_plain'), rtol=2e-3, atol=2e-4,
-            weight_atol=4 * 2e-4 * (3 if wbox else 2))       # 2*lr*steps, see compare()
+    steps = 3 if wbox else 2
+    res = cases.run_dcgan_steps(Config, models, [dev], n_steps=steps, wbox=wbox)
+    compare(res, golden('dcgan_steps_wbox' if wbox else 'dcgan_steps_plain'), policy=step_policy(steps))
 
 
 def test_dcgan_bs128_step_vs_oracle(dev):
