@@ -74,6 +74,8 @@ struct GConvArgs {
   float slope;
   int aux_act;
   float aux_slope;
+  unsigned in_bytes, wt_bytes;
+  int linear_out;
   int nphase;
   Phase ph[4];
   double flops;   // algorithmic 2*MAC of this launch (host-side bookkeeping only)
@@ -86,38 +88,62 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
   return i >= n ? 2 * (n - 1) - i : i;
 }
 
-template <int WGM, int WGN, int WM, int WN>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define OOB_OFFSET 0x80000000u     // buffer voffset beyond any tensor (< 2 GiB): the load returns 0
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+}
+
+// FAST: zero padding and Cs % 32 == 0, so every 32-wide K step lies inside ONE tap: the tap walk is
+// wave-uniform (scalar registers), borders are handled by the buffer bounds check (no branches).
+// !FAST: reflect padding and/or Cs in {4,8,16} (taps change inside a K step; RGB layers).
+template <int WGM, int WGN, int WM, int WN, bool FAST>
 __global__ __launch_bounds__(256) void gconv_kernel(const GConvArgs a) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
-  constexpr int TILE4 = (BM + BN) * 8;          // float4 per stage buffer
+  constexpr int TILE4 = (BM + BN) * 8;          // 16-byte chunks per stage buffer
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
 
-  const Phase& p = a.ph[blockIdx.z];
+  const int pz = blockIdx.z;
+  const int pM = a.ph[pz].M;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  if (m0 >= p.M) return;
+  if (m0 >= pM) return;
+  // phase constants into scalars once (the K loop must not re-read the kernel arguments)
+  const int p_ntap = a.ph[pz].ntap, p_tw = a.ph[pz].tw, p_steps = a.ph[pz].steps;
+  const int p_dy0 = a.ph[pz].dy0, p_dx0 = a.ph[pz].dx0, p_dys = a.ph[pz].dys, p_dxs = a.ph[pz].dxs;
+  const int p_wbase = a.ph[pz].wbase, p_wsy = a.ph[pz].wsy, p_wsx = a.ph[pz].wsx;
+  const int p_owg = a.ph[pz].owg, plane = a.ph[pz].ohg * a.ph[pz].owg;
+  const FastDiv d_plane = a.ph[pz].d_plane, d_owg = a.ph[pz].d_owg, d_tw = a.ph[pz].d_tw;
+  const int IH = a.IH, IW = a.IW, Cs = a.Cs;
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int chunk = tid & 7, lrow = tid >> 3;
 
-  // per-row gather state (rows are fixed for the whole K loop)
-  int abase[RA], aiy[RA], aix[RA];
-  const int plane = p.ohg * p.owg;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+
+  // per-row gather state (rows are fixed for the whole K loop): byte offset of (b, y*isy, x*isx, c=chunk*4)
+  int aiy[RA], aix[RA];
+  unsigned arow[RA], wrow[RB];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int m = m0 + lrow + 32 * i;
-    if (m < p.M) {
-      const int b = fdiv(m, p.d_plane);
+    if (m < pM) {
+      const int b = fdiv(m, d_plane);
       const int rem = m - b * plane;
-      const int y = fdiv(rem, p.d_owg);
-      const int x = rem - y * p.owg;
-      abase[i] = b * a.IH * a.IW;
+      const int y = fdiv(rem, d_owg);
+      const int x = rem - y * p_owg;
       aiy[i] = y * a.isy;
       aix[i] = x * a.isx;
+      arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * 4u + (FAST ? chunk * 16u : 0u);
     } else {
-      abase[i] = 0; aiy[i] = ROW_INVALID; aix[i] = 0;
+      aiy[i] = ROW_INVALID; aix[i] = 0; arow[i] = 0;
     }
   }
+#pragma unroll
+  for (int i = 0; i < RB; ++i) wrow[i] = (unsigned)((n0 + lrow + 32 * i) * a.Kp) * 4u + (FAST ? chunk * 16u : 0u);
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -128,36 +154,47 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[RA], rb[RB];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // wave-uniform tap walk for the FAST path
+  int u_c4 = 0, u_ty = 0, u_tx = 0;
 
   auto gload = [&](int step) {
-    const int q = step * 8 + chunk;
-    const int t = fdiv(q, a.d_c4n);
-    const int c4 = q - t * a.c4n;
-    const bool valid = t < p.ntap;
-    const int ty = fdiv(t, p.d_tw);
-    const int tx = t - ty * p.tw;
-    const int dy = p.dy0 + ty * p.dys, dx = p.dx0 + tx * p.dxs;
-    const int wk = (p.wbase + ty * p.wsy + tx * p.wsx) * a.Cs + c4 * 4;
+    if (FAST) {
+      const int dy = p_dy0 + u_ty * p_dys, dx = p_dx0 + u_tx * p_dxs;
+      const int tapoff = ((dy * IW + dx) * Cs + u_c4 * 4) * 4;                         // bytes, uniform
+      const unsigned wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c4 * 4) * 4u;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      int iy = aiy[i] + dy, ix = aix[i] + dx;
-      bool ok;
-      if (a.pad_mode == IPRGAN_PAD_REFLECT) {
-        ok = valid && aiy[i] != ROW_INVALID;
-        iy = reflect_idx(iy, a.IH);
-        ix = reflect_idx(ix, a.IW);
-      } else {
-        ok = valid && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      for (int i = 0; i < RA; ++i) {
+        const bool ok = (unsigned)(aiy[i] + dy) < (unsigned)IH && (unsigned)(aix[i] + dx) < (unsigned)IW;
+        ra[i] = buf_load4(rs_in, ok ? arow[i] + (unsigned)tapoff : OOB_OFFSET);
       }
-      const f32x4* src = (const f32x4*)(a.in + ((size_t)(abase[i] + iy * a.IW + ix) * a.Cs + c4 * 4));
-      ra[i] = ok ? *src : zero4;
-    }
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int n = n0 + lrow + 32 * i;
-      const f32x4* src = (const f32x4*)(a.wt + ((size_t)n * a.Kp + wk));
-      rb[i] = valid ? *src : zero4;
+      for (int i = 0; i < RB; ++i) rb[i] = buf_load4(rs_wt, wrow[i] + wk);
+      u_c4 += 8;
+      if (u_c4 >= a.c4n) { u_c4 = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
+    } else {
+      const int q = step * 8 + chunk;
+      const int t = fdiv(q, a.d_c4n);
+      const int c4 = q - t * a.c4n;
+      const bool valid = t < p_ntap;
+      const int ty = fdiv(t, d_tw);
+      const int tx = t - ty * p_tw;
+      const int dy = p_dy0 + ty * p_dys, dx = p_dx0 + tx * p_dxs;
+      const unsigned wk = (unsigned)((p_wbase + ty * p_wsy + tx * p_wsx) * Cs + c4 * 4) * 4u;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        int iy = aiy[i] + dy, ix = aix[i] + dx;
+        bool ok = valid && aiy[i] != ROW_INVALID;
+        if (a.pad_mode == IPRGAN_PAD_REFLECT) {
+          iy = reflect_idx(iy, IH);
+          ix = reflect_idx(ix, IW);
+        } else {
+          ok = ok && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+        }
+        const int tapoff = (((iy - aiy[i]) * IW + (ix - aix[i])) * Cs + c4 * 4) * 4;
+        ra[i] = buf_load4(rs_in, ok ? arow[i] + (unsigned)tapoff : OOB_OFFSET);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) rb[i] = buf_load4(rs_wt, valid ? wrow[i] + wk : OOB_OFFSET);
     }
   };
   auto lstore = [&](int buf) {
@@ -204,13 +241,12 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvArgs a) {
     }
   };
 
-  const int steps = p.steps;
-  if (steps > 0) {
+  if (p_steps > 0) {
     gload(0);
     lstore(0);
     __syncthreads();
-    for (int s = 0; s < steps; ++s) {
-      const bool more = s + 1 < steps;
+    for (int s = 0; s < p_steps; ++s) {
+      const bool more = s + 1 < p_steps;
       if (more) gload(s + 1);
       compute(s & 1);
       if (more) lstore((s + 1) & 1);
@@ -220,17 +256,23 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvArgs a) {
 
   // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int half = lane >> 5, l31 = lane & 31;
+  const int ooy = a.ph[pz].ooy, oox = a.ph[pz].oox;
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (m >= p.M) continue;
-      const int b = fdiv(m, p.d_plane);
-      const int rem = m - b * plane;
-      const int y = fdiv(rem, p.d_owg);
-      const int x = rem - y * p.owg;
-      const size_t opix = (size_t)(b * a.OH + y * a.osy + p.ooy) * a.OW + x * a.osx + p.oox;
+      if (m >= pM) continue;
+      size_t opix;
+      if (a.linear_out) {
+        opix = (size_t)m;
+      } else {
+        const int b = fdiv(m, d_plane);
+        const int rem = m - b * plane;
+        const int y = fdiv(rem, d_owg);
+        const int x = rem - y * p_owg;
+        opix = (size_t)(b * a.OH + y * a.osy + ooy) * a.OW + x * a.osx + oox;
+      }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int n = n0 + (wn * WN + j) * 32 + l31;
@@ -260,6 +302,7 @@ struct WGradArgs {
   int isy, isx, pad, tw, ntap, pad_mode;
   int Kw, Nrows;             // slab row length / rows
   int chunks_per_split;
+  unsigned p_bytes, q_bytes;
   double flops;
 };
 
@@ -304,35 +347,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 rP[NP], rQ[NQ];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.P, 0, a.p_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)a.Q, 0, a.q_bytes, 0x00020000);
+  const int M = a.M, PW = a.PW, QH = a.QH, QW = a.QW, Qs = a.Qs, Ps = a.Ps, isy = a.isy, isx = a.isx;
+  const FastDiv d_plane = a.d_plane, d_pw = a.d_pw;
+  const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
+  const unsigned pcol = (unsigned)(n0 + cp * 4) * 4u, qcol = (unsigned)c4 * 16u;
 
   auto gload = [&](int ch) {
     const int mb = ch * 32;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int m = mb + rp + RPP * i;
-      rP[i] = zero4;
-      if (pvalid && m < a.M) rP[i] = *(const f32x4*)(a.P + ((size_t)m * a.Ps + n0 + cp * 4));
+      const bool ok = pvalid && m < M;
+      rP[i] = buf_load4(rs_p, ok ? (unsigned)(m * Ps) * 4u + pcol : OOB_OFFSET);
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int m = mb + rq + RPQ * i;
-      rQ[i] = zero4;
-      if (qvalid && m < a.M) {
-        const int b = fdiv(m, a.d_plane);
-        const int rem = m - b * plane;
-        const int y = fdiv(rem, a.d_pw);
-        const int x = rem - y * a.PW;
-        int iy = y * a.isy + dy, ix = x * a.isx + dx;
-        bool ok = true;
-        if (a.pad_mode == IPRGAN_PAD_REFLECT) {
-          iy = reflect_idx(iy, a.QH);
-          ix = reflect_idx(ix, a.QW);
-        } else {
-          ok = (unsigned)iy < (unsigned)a.QH && (unsigned)ix < (unsigned)a.QW;
-        }
-        if (ok) rQ[i] = *(const f32x4*)(a.Q + ((size_t)((b * a.QH + iy) * a.QW + ix) * a.Qs + c4 * 4));
+      const int b = fdiv(m, d_plane);
+      const int rem = m - b * plane;
+      const int y = fdiv(rem, d_pw);
+      const int x = rem - y * PW;
+      int iy = y * isy + dy, ix = x * isx + dx;
+      bool ok = qvalid && m < M;
+      if (reflect) {
+        iy = reflect_idx(iy, QH);
+        ix = reflect_idx(ix, QW);
+      } else {
+        ok = ok && (unsigned)iy < (unsigned)QH && (unsigned)ix < (unsigned)QW;
       }
+      rQ[i] = buf_load4(rs_q, ok ? (unsigned)(((b * QH + iy) * QW + ix) * Qs) * 4u + qcol : OOB_OFFSET);
     }
   };
   auto lstore = [&](int buf) {
@@ -524,14 +570,14 @@ static void geom_bwd_form(GConvArgs& a, int B, int OHs, int OWs, int Cred, int H
     }
 }
 
-template <int WGM, int WGN, int WM, int WN>
-static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
+template <int WGM, int WGN, int WM, int WN, bool FAST>
+static int launch_gconv_tf(const GConvArgs& a, hipStream_t st) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   if (maxM == 0) return 0;
   const size_t smem = 2 * (size_t)(BM + BN) * 8 * sizeof(f32x4);
-  auto kern = gconv_kernel<WGM, WGN, WM, WN>;
+  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -544,7 +590,21 @@ static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-static int launch_gconv(const GConvArgs& a, hipStream_t st) {
+template <int WGM, int WGN, int WM, int WN>
+static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
+  const bool fast = a.pad_mode == IPRGAN_PAD_ZERO && (a.Cs % 32) == 0;
+  return fast ? launch_gconv_tf<WGM, WGN, WM, WN, true>(a, st) : launch_gconv_tf<WGM, WGN, WM, WN, false>(a, st);
+}
+
+static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
+  GConvArgs a = ain;
+  {
+    const unsigned long long inb = (unsigned long long)a.B * a.IH * a.IW * a.Cs * 4ull;
+    const unsigned long long wtb = (unsigned long long)rup(a.N, 128) * a.Kp * 4ull;
+    IPR_CHECK(inb < 0x7fffffffull && wtb < 0x7fffffffull, "conv: tensor larger than 2 GiB (%llu / %llu bytes)", inb, wtb);
+    a.in_bytes = (unsigned)inb; a.wt_bytes = (unsigned)wtb;
+    a.linear_out = (a.nphase == 1 && a.osy == 1 && a.osx == 1 && a.ph[0].ooy == 0 && a.ph[0].oox == 0) ? 1 : 0;
+  }
   IPR_CHECK(a.nphase >= 1 && a.nphase <= 4, "conv: stride %d unsupported (max 2)", a.osy);
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
@@ -704,6 +764,12 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   a.isy = a.isx = d->stride; a.pad = d->pad; a.tw = d->KW; a.ntap = p.ntap;
   a.pad_mode = d->pad_mode;
   a.Kw = p.Kw; a.Nrows = p.Nrows; a.chunks_per_split = p.cps;
+  {
+    const unsigned long long pb = (unsigned long long)a.M * a.Ps * 4ull;
+    const unsigned long long qb = (unsigned long long)d->B * a.QH * a.QW * a.Qs * 4ull;
+    IPR_CHECK(pb < 0x7fffffffull && qb < 0x7fffffffull, "conv_bwd_weight: tensor larger than 2 GiB");
+    a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
+  }
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   int rc;
   if (p.bn == 128 && p.bk == 128) rc = launch_wgrad_t<2, 2, 2, 2>(a, p, st);

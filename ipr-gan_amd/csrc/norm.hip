@@ -89,12 +89,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   }
 }
 
-// sums the NB slice partials of 64 channels with 4 lanes each (slice order within a lane, then lanes)
+// sums the NB slice partials of 64 channels with FL lanes each (slice order within a lane, then lanes)
+#define FL 16
 __device__ __forceinline__ void final_sums(const float* __restrict__ part, int NB, int C, int c, int lane,
-                                           float (*sh)[4][64], float& s0, float& s1, bool two) {
+                                           float (*sh)[FL][64], float& s0, float& s1, bool two) {
   float a0 = 0.f, a1 = 0.f;
   if (c < C)
-    for (int b = lane; b < NB; b += 4) {
+    for (int b = lane; b < NB; b += FL) {
       a0 += part[((size_t)b * 2) * C + c];
       if (two) a1 += part[((size_t)b * 2 + 1) * C + c];
     }
@@ -102,27 +103,28 @@ __device__ __forceinline__ void final_sums(const float* __restrict__ part, int N
   sh[0][lane][cl] = a0;
   sh[1][lane][cl] = a1;
   __syncthreads();
-  s0 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
-  s1 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+  s0 = s1 = 0.f;
+#pragma unroll
+  for (int l = 0; l < FL; ++l) { s0 += sh[0][l][cl]; s1 += sh[1][l][cl]; }
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int NB, int Cs,
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int NB, int Cs,
                                                            int C, float* __restrict__ out) {
-  __shared__ float sh[2][4][64];
+  __shared__ float sh[2][FL][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
   float s0, s1;
   final_sums(part, NB, Cs, c, lane, sh, s0, s1, false);
   if (lane == 0 && c < C) out[c] = s0;
 }
 
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ part,
+__global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ part,
                                                              const float* __restrict__ x, int NB, int M,
                                                              int C, float eps, float momentum,
                                                              float* __restrict__ running_mean,
                                                              float* __restrict__ running_var,
                                                              float* __restrict__ save_mean,
                                                              float* __restrict__ save_invstd) {
-  __shared__ float sh[2][4][64];
+  __shared__ float sh[2][FL][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
   float s0, s1;
   final_sums(part, NB, C, c, lane, sh, s0, s1, true);
@@ -169,11 +171,11 @@ __global__ void bn_apply_kernel(const f32x4* __restrict__ x, f32x4* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int NB, int C,
+__global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ part, int NB, int C,
                                                            float* __restrict__ sums,
                                                            float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta) {
-  __shared__ float sh[2][4][64];
+  __shared__ float sh[2][FL][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
   float s1, s2;
   final_sums(part, NB, C, c, lane, sh, s1, s2, true);
@@ -216,7 +218,7 @@ int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, h
   hipLaunchKernelGGL(colreduce_kernel<0>, dim3(g.NB, g.gy), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                      nullptr, ws, M, Cs, g.TC, g.rows_per_block, 0, 0.f);
   IPR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, g.NB, Cs, C, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, st, ws, g.NB, Cs, C, out);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -247,7 +249,7 @@ int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* bet
     hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.NB, g.gy), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                        nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f);
     IPR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, x, g.NB, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, st, ws, x, g.NB, M, C, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd);
   }
   IPR_LAUNCH_CHECK();
@@ -269,7 +271,7 @@ int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* 
   hipLaunchKernelGGL(colreduce_kernel<2>, dim3(g.NB, g.gy), dim3(256), 0, st, x, y, dy, save_mean,
                      save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope);
   IPR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, g.NB, C, sums, dgamma,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, st, ws, g.NB, C, sums, dgamma,
                      dbeta);
   IPR_LAUNCH_CHECK();
   const size_t n4 = (size_t)M * C / 4;

@@ -41,16 +41,23 @@ __global__ __launch_bounds__(1024) void sn_v_final_kernel(const float* __restric
   }
 }
 
-// s[i] = sum_j W[i][j]*v[j]: one wave per row
+// s[i] = sum_j W[i][j]*v[j]: one 256-thread block per row (16-B loads when cols % 4 == 0)
 __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ v,
                                                     float* __restrict__ s, int rows, int cols) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= rows) return;
+  __shared__ float sh[16];
+  const int row = blockIdx.x;
   const float* wr = w + (size_t)row * cols;
   float acc = 0.f;
-  for (int j = lane; j < cols; j += 64) acc += wr[j] * v[j];
-  acc = wave_sum(acc);
-  if (lane == 0) s[row] = acc;
+  if ((cols & 3) == 0) {
+    for (int j = threadIdx.x * 4; j < cols; j += 1024) {
+      const float4 a = *(const float4*)(wr + j), b = *(const float4*)(v + j);
+      acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+  } else {
+    for (int j = threadIdx.x; j < cols; j += 256) acc += wr[j] * v[j];
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) s[row] = acc;
 }
 
 // single block: u = s / max(||s||, eps); sigma = u . s  (training) or sigma = u_old . s (eval)
@@ -136,7 +143,7 @@ int iprgan_sn_power_iter(const float* w, float* u, float* v, float* sigma, float
     hipLaunchKernelGGL(sn_v_final_kernel, dim3(1), dim3(1024), 0, st, tpart, nsplit, cols, eps, v);
     IPR_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(sn_wv_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, w, v, s, rows, cols);
+  hipLaunchKernelGGL(sn_wv_kernel, dim3(rows), dim3(256), 0, st, w, v, s, rows, cols);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(sn_u_final_kernel, dim3(1), dim3(1024), 0, st, s, rows, eps, u, sigma, training);
   IPR_LAUNCH_CHECK();
