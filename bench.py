@@ -138,11 +138,18 @@ def main():
         value = BATCH * world * args.steps / elapsed
         dom = max(kernels, key=lambda k: k['ms']) if kernels else None
         roof = None
+        traffic = None
+        try:          # HBM bytes per launch from the committed PMC passes (profiles/: separate rocprofv3 runs)
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]
+            traffic = json.load(open(tf))['kernels'][dom['name']]['hbm_bytes_per_launch']
+        except Exception:
+            pass
         if dom:
             ach = dom['flops'] / (dom['ms'] * 1e-3)
             roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(ach / 1e12, 2),
                     'peak': round(PEAK_FP32_MFMA / 1e12, 1), 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_FP32_MFMA, 4), 'traffic': None,
+                    'frac': round(ach / PEAK_FP32_MFMA, 4), 'traffic': traffic,
                     'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2)}
         conv_ms = sum(k['ms'] for k in kernels)
         conv_flops = sum(k['flops'] for k in kernels)

@@ -1,0 +1,77 @@
+"""CPU: host-side logic of the engine that needs no kernel - module trees / state_dict layout,
+sign-bit assignment, config object, wrapper delegation, optimizer state layout, loud failure."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, gan, nets, recipe, sign
+
+
+def test_product_networks_mirror_reference_state_dict():
+    from iprgan import networks
+    for name in ('ConvGenerator32', 'ConvGenerator64', 'SNDiscriminator32', 'SNDiscriminator64'):
+        a, b = getattr(nets, name)(), getattr(networks, name)()
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa) == list(sb), name
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+        assert [n for n, _ in a.named_modules()] == [n for n, _ in b.named_modules()]
+        b.load_state_dict(sa)                                   # interchangeable checkpoints
+
+
+def test_bitgenerator_matches_reference_bits(golden):
+    from iprgan import tools
+    bits = tools.BitGenerator('EXAMPLE A').get(200)
+    assert np.array_equal(np.array(bits, dtype=np.int8), golden('bits_EXAMPLE_A')['bits'])
+    assert tools.BitGenerator(None).get(5) is not None          # random mode (sign_model.py:16-17)
+
+
+def test_create_signs_bit_exact_on_product_generator(golden):
+    from iprgan import Config, networks, tools
+    net = networks.ConvGenerator64()
+    recipe.fill(net, 31)
+    slm = tools.SignLossModel(net, Config({'gamma_0': 0.1, 'string': 'EXAMPLE A'}))
+    ref = golden('sign_ConvGenerator64')
+    signs = np.concatenate([b.numpy() for _, b in slm.named_buffers()]).astype(np.int8)
+    assert np.array_equal(signs, ref['signs'])
+    assert [k for k, _ in slm.named_buffers()] == list(ref['names'])
+    for (_, b), m in zip(slm.named_buffers(), [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]):
+        assert torch.equal(torch.sign(m.weight.data), b)        # gamma <- |gamma| * bit
+
+
+def test_config_semantics(tmp_path):
+    from iprgan import Config
+    c = Config({'a': 1, 'b': {'c': [1, 2], 'd': {'e': 'x'}}})
+    assert c.a == 1 and c['b'].c == [1, 2] and c.b.d.e == 'x' and c.get('zz', 7) == 7
+    c.b['c'] = 5
+    c['n'] = 3
+    assert c.to_dict() == {'a': 1, 'b': {'c': 5, 'd': {'e': 'x'}}, 'n': 3}
+    p = tmp_path / 'c.yaml'
+    p.write_text(c.to_yaml())
+    assert Config.parse(str(p)).to_dict() == c.to_dict()
+
+
+def test_models_build_on_cpu_but_refuse_to_compute():
+    from iprgan import Config, models
+    m = models.DCGAN(Config(cases.DCGAN_CFG))
+    w = models.WhiteBoxWrapper(m, Config(cases.WBOX_CFG))
+    assert list(w.state_dict()) == ['G', 'D', 'optG', 'optD', 'sign']
+    assert w.G is m.G and w.no_such_attribute is None           # models/base.py:52-58
+    assert all(k.startswith('module.') for k in m.G.state_dict())
+    assert list(w.state_dict()['sign']) == ['module_convs_0_1', 'module_convs_1_1', 'module_convs_2_1']
+    with pytest.raises(RuntimeError, match='no CPU'):
+        w.update_d({'real_sample': torch.zeros(2, 3, 64, 64), 'latent': torch.zeros(2, 128)})
+
+
+def test_adam_state_dict_layout_is_torch_compatible():
+    from iprgan import optim
+    p = [torch.nn.Parameter(torch.zeros(3, 3)), torch.nn.Parameter(torch.zeros(4))]
+    mine = optim.Adam(p, lr=2e-4, betas=[0.5, 0.999])
+    ref = torch.optim.Adam(p, lr=2e-4, betas=(0.5, 0.999))
+    a, b = mine.state_dict()['param_groups'][0], ref.state_dict()['param_groups'][0]
+    for k in ('lr', 'betas', 'eps', 'weight_decay', 'params'):
+        assert a[k] == b[k], k
+    for q in p:
+        q.grad = torch.ones_like(q)
+    ref.step()
+    mine.load_state_dict(ref.state_dict())                      # a torch.optim.Adam checkpoint loads
+    assert set(mine.state_dict()['state'][0]) >= {'step', 'exp_avg', 'exp_avg_sq'}
