@@ -68,7 +68,8 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
 /* dx = conv_bwd_data(dy, w) [* act'(x_out_prev)]: if prev_out != NULL the result is multiplied by the
  * derivative of activation prev_act evaluated from the saved OUTPUT prev_out of the previous layer
  * (same shape as dx), i.e. the previous layer's activation backward is fused into this epilogue. */
-int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx,
+size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d);   /* non-zero only for reflect padding */
+int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
                          const float* prev_out, int prev_act, float prev_slope, void* stream);
 /* dw (PyTorch layout, overwritten) = conv_bwd_weight(x, dy); db (optional, length Cout) = sum dy.
  * ws: workspace of iprgan_conv_wgrad_ws_floats(d) floats. Deterministic (fixed-order split reduce). */
@@ -101,6 +102,33 @@ int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* bet
 int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                   float* dbeta, float* ws, int M, int C, int act, float slope, void* stream);
+
+/* ---- InstanceNorm2d (networks/resnet_generator.py:8-49 affine, conv_discriminator.py:10-18 plain):
+ * per-(sample, channel) statistics over HW rows of x[B,HW,C]; gamma/beta may be NULL; never tracks
+ * running stats (same in eval).  save_mean/save_invstd are [B,C]. */
+size_t iprgan_instnorm_ws_floats(int B, int HW, int C);
+int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
+                        float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,
+                        void* stream);
+int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+                        const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                        float* dbeta, float* ws, int B, int HW, int C, int act, float slope, void* stream);
+
+/* ---- PReLU / PixelShuffle / MaxPool / residual add / reflection-pad backward ----------------------------
+ * nn.PReLU() with one slope (sr_resnet.py:7,14,43): y = x>0 ? x : alpha*x; dalpha = sum dy*x*[x<=0];
+ * ws >= iprgan_loss_ws_floats(n) floats.  PixelShuffle(2) (sr_resnet.py:42) on NHWC: src [B,H,W,4C] ->
+ * dst [B,2H,2W,C] (inverse=1: the other way, i.e. its gradient).  MaxPool2d(2,2) (VGG19 features,
+ * vgg.py:33): gradient to the first maximum of each window.  reflect_fold: gradient of
+ * ReflectionPad2d(pad) - dxp [B,H+2p,W+2p,C] summed back onto dx [B,H,W,C] (times act'(prev_out) if given). */
+int iprgan_prelu_fwd(const float* x, const float* alpha, float* y, size_t n, void* stream);
+int iprgan_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, float* ws,
+                     size_t n, void* stream);
+int iprgan_pixel_shuffle2(const float* src, float* dst, int B, int H, int W, int C, int inverse, void* stream);
+int iprgan_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int iprgan_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+int iprgan_add(const float* a, const float* b, float* out, size_t n, void* stream);
+int iprgan_reflect_fold(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope,
+                        int B, int H, int W, int C, int pad, void* stream);
 
 /* ---- spectral norm (torch.nn.utils.spectral_norm at networks/sn_discriminator.py:9,11,18,21) */
 size_t iprgan_sn_ws_floats(int rows, int cols);

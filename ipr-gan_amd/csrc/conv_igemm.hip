@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvArgs a) {
   const int p_owg = a.ph[pz].owg, plane = a.ph[pz].ohg * a.ph[pz].owg;
   const FastDiv d_plane = a.ph[pz].d_plane, d_owg = a.ph[pz].d_owg, d_tw = a.ph[pz].d_tw;
   const int IH = a.IH, IW = a.IW, Cs = a.Cs;
+  const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -164,8 +165,18 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvArgs a) {
       const unsigned wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c4 * 4) * 4u;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        const bool ok = (unsigned)(aiy[i] + dy) < (unsigned)IH && (unsigned)(aix[i] + dx) < (unsigned)IW;
-        ra[i] = buf_load4(rs_in, ok ? arow[i] + (unsigned)tapoff : OOB_OFFSET);
+        const int iy = aiy[i] + dy, ix = aix[i] + dx;
+        bool ok;
+        unsigned off;
+        if (reflect) {            // wave-uniform branch: ReflectionPad2d folded into the gather
+          ok = aiy[i] != ROW_INVALID;
+          const int ry = reflect_idx(iy, IH), rx = reflect_idx(ix, IW);
+          off = arow[i] + (unsigned)((((ry - aiy[i]) * IW + (rx - aix[i])) * Cs + u_c4 * 4) * 4);
+        } else {
+          ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+          off = arow[i] + (unsigned)tapoff;
+        }
+        ra[i] = buf_load4(rs_in, ok ? off : OOB_OFFSET);
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i) rb[i] = buf_load4(rs_wt, wrow[i] + wk);
@@ -592,7 +603,7 @@ static int launch_gconv_tf(const GConvArgs& a, hipStream_t st) {
 
 template <int WGM, int WGN, int WM, int WN>
 static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
-  const bool fast = a.pad_mode == IPRGAN_PAD_ZERO && (a.Cs % 32) == 0;
+  const bool fast = (a.Cs % 32) == 0;
   return fast ? launch_gconv_tf<WGM, WGN, WM, WN, true>(a, st) : launch_gconv_tf<WGM, WGN, WM, WN, false>(a, st);
 }
 
@@ -720,23 +731,35 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
   return launch_gconv(a, (hipStream_t)stream);
 }
 
-int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx,
+size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d) {
+  if (d->pad_mode != IPRGAN_PAD_REFLECT) return 0;
+  return (size_t)d->B * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * c4(d->Cin);
+}
+
+int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
                          const float* prev_out, int prev_act, float prev_slope, void* stream) {
   IPR_CHECK(d->stride >= 1 && d->stride <= 2, "conv_bwd_data: stride %d unsupported", d->stride);
-  IPR_CHECK(d->pad_mode == IPRGAN_PAD_ZERO, "conv_bwd_data: reflect pad needs the fold path");
   GConvArgs a;
   memset(&a, 0, sizeof(a));
   const Shape s = out_shape(d);
-  if (!d->transposed) {
+  const bool reflect = d->pad_mode == IPRGAN_PAD_REFLECT;
+  if (reflect) {
+    // gradient w.r.t. the reflection-padded image (a zero-pad conv with pad 0 over H+2p), then fold
+    IPR_CHECK(!d->transposed && ws, "conv_bwd_data: reflect pad needs a Conv2d and a workspace");
+    geom_bwd_form(a, d->B, s.OH, s.OW, d->Cout, d->H + 2 * d->pad, d->W + 2 * d->pad, d->Cin, d->KH, d->KW,
+                  d->stride, 0);
+  } else if (!d->transposed) {
     geom_bwd_form(a, d->B, s.OH, s.OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad);
   } else {
     geom_forward_form(a, d->B, s.OH, s.OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad);
   }
-  a.in = dy; a.wt = wbwd; a.bias = nullptr; a.out = dx;
+  a.in = dy; a.wt = wbwd; a.bias = nullptr; a.out = reflect ? ws : dx;
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = IPRGAN_ACT_NONE; a.slope = 0.f;
-  a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope;
-  return launch_gconv(a, (hipStream_t)stream);
+  if (!reflect) { a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; }
+  const int rc = launch_gconv(a, (hipStream_t)stream);
+  if (rc || !reflect) return rc;
+  return iprgan_reflect_fold(ws, dx, prev_out, prev_act, prev_slope, d->B, d->H, d->W, c4(d->Cin), d->pad, stream);
 }
 
 size_t iprgan_conv_wgrad_ws_floats(const iprgan_conv_desc* d) {

@@ -166,6 +166,142 @@ __global__ void loss_bwd_kernel(int kind, const float* __restrict__ x, const flo
     dx[i] = g * loss_grad(kind, x[i], y ? y[i] : 0.f);
 }
 
+
+// ---- PReLU with ONE learnable slope (nn.PReLU(), networks/sr_resnet.py:7,14,43) ---------------------
+__global__ void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                 float* __restrict__ y, size_t n) {
+  const float a = *alpha;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = v > 0.f ? v : a * v;
+  }
+}
+// dx = dy * (x>0 ? 1 : alpha); part[block] = sum dy*x*[x<=0]
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ alpha, float* __restrict__ dx,
+                                                        float* __restrict__ part, size_t n) {
+  __shared__ float sh[16];
+  const float a = *alpha;
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i], g = dy[i];
+    dx[i] = v > 0.f ? g : a * g;
+    s += v > 0.f ? 0.f : g * v;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void sum_partials_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < nb; ++i) s += part[i];
+    *out = s;
+  }
+}
+
+// ---- PixelShuffle(2) on NHWC: out[b,2h+i,2w+j,c] = in[b,h,w,c*4+i*2+j] (networks/sr_resnet.py:42) ----
+// inverse=1 runs the permutation backwards (the gradient).
+__global__ void pixel_shuffle2_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H,
+                                      int W, int C, int inverse) {
+  const size_t total = (size_t)B * H * W * C * 4;
+  for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total;
+       o += (size_t)gridDim.x * blockDim.x) {
+    // o indexes the shuffled tensor [B,2H,2W,C]
+    const int c = (int)(o % C);
+    size_t t = o / C;
+    const int ox = (int)(t % (2 * W));
+    t /= 2 * W;
+    const int oy = (int)(t % (2 * H));
+    const size_t b = t / (2 * H);
+    const size_t in = ((b * H + (oy >> 1)) * W + (ox >> 1)) * (size_t)(4 * C) + c * 4 + (oy & 1) * 2 + (ox & 1);
+    if (inverse) dst[in] = src[o]; else dst[o] = src[in];
+  }
+}
+
+// ---- MaxPool2d(2,2) on NHWC (VGG19 features, networks/vgg.py) ---------------------------------------------
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W,
+                                    int C) {
+  const int OH = H / 2, OW = W / 2;
+  const size_t total = (size_t)B * OH * OW * C;
+  for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < total;
+       o += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(o % C);
+    size_t t = o / C;
+    const int ox = (int)(t % OW);
+    t /= OW;
+    const int oy = (int)(t % OH);
+    const size_t b = t / OH;
+    const float* p = x + ((b * H + 2 * oy) * W + 2 * ox) * (size_t)C + c;
+    const float v0 = p[0], v1 = p[C], v2 = p[(size_t)W * C], v3 = p[(size_t)W * C + C];
+    y[o] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+  }
+}
+// gradient goes to the FIRST maximum in window order (row-major), like aten::max_pool2d_with_indices
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    float* __restrict__ dx, int B, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2;
+  const size_t total = (size_t)B * H * W * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int ix = (int)(t % W);
+    t /= W;
+    const int iy = (int)(t % H);
+    const size_t b = t / H;
+    const int oy = iy >> 1, ox = ix >> 1;
+    float g = 0.f;
+    if (oy < OH && ox < OW) {
+      const float* p = x + ((b * H + 2 * oy) * W + 2 * ox) * (size_t)C + c;
+      const float v[4] = {p[0], p[C], p[(size_t)W * C], p[(size_t)W * C + C]};
+      int arg = 0;
+      float m = v[0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) if (v[k] > m) { m = v[k]; arg = k; }
+      if (arg == (iy & 1) * 2 + (ix & 1)) g = dy[((b * OH + oy) * OW + ox) * (size_t)C + c];
+    }
+    dx[i] = g;
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                           size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i];
+}
+
+// ---- ReflectionPad2d(p) backward: fold the gradient of the padded image back (resnet_generator.py:6,33,43,47)
+__device__ __forceinline__ int refl_pre(int i, int n, int p, int* out) {
+  // padded-coordinate preimages (0-based in the padded image) of interior index i
+  int k = 0;
+  out[k++] = i + p;
+  if (i >= 1 && i <= p) out[k++] = p - i;
+  if (i <= n - 2 && i >= n - 1 - p) out[k++] = p + 2 * (n - 1) - i;
+  return k;
+}
+__global__ void reflect_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx,
+                                    const float* __restrict__ prev_out, int prev_act, float prev_slope, int B,
+                                    int H, int W, int C, int p) {
+  const int HP = H + 2 * p, WP = W + 2 * p;
+  const size_t total = (size_t)B * H * W * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const size_t b = t / H;
+    int ys[3], xs[3];
+    const int ny = refl_pre(y, H, p, ys), nx = refl_pre(x, W, p, xs);
+    float s = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int q = 0; q < nx; ++q) s += dxp[((b * HP + ys[a]) * WP + xs[q]) * (size_t)C + c];
+    if (prev_out) s *= act_grad_from_out(prev_out[i], prev_act, prev_slope);
+    dx[i] = s;
+  }
+}
+
 // ---- sign loss / BER (multi-tensor: pointer table travels in the kernel arguments) ----------
 #define SIGN_MAX_LAYERS 64
 struct SignTable {
@@ -327,6 +463,63 @@ int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float
     hipLaunchKernelGGL(gemv_bwd_dw_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, x, dy, dw, db, B, K);
     IPR_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+
+int iprgan_prelu_fwd(const float* x, const float* alpha, float* y, size_t n, void* stream) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, n);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, float* ws,
+                     size_t n, void* stream) {
+  if (!n) return 0;
+  const int nb = grid_for(n, LOSS_BLOCKS);
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, dy, alpha, dx, ws, n);
+  IPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, dalpha);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_pixel_shuffle2(const float* src, float* dst, int B, int H, int W, int C, int inverse, void* stream) {
+  const size_t n = (size_t)B * H * W * C * 4;
+  if (!n) return 0;
+  hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     B, H, W, C, inverse);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+  const size_t n = (size_t)B * (H / 2) * (W / 2) * C;
+  if (!n) return 0;
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+  const size_t n = (size_t)B * H * W * C;
+  if (!n) return 0;
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, x, dy, dx,
+                     B, H, W, C);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_add(const float* a, const float* b, float* out, size_t n, void* stream) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_reflect_fold(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope, int B,
+                        int H, int W, int C, int pad, void* stream) {
+  const size_t n = (size_t)B * H * W * C;
+  IPR_CHECK(pad < H && pad < W, "reflect_fold: pad %d must be smaller than the image", pad);
+  if (!n) return 0;
+  hipLaunchKernelGGL(reflect_fold_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, dxp, dx,
+                     prev_out, prev_act, prev_slope, B, H, W, C, pad);
+  IPR_LAUNCH_CHECK();
   return 0;
 }
 

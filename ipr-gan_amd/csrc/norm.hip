@@ -46,6 +46,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
                                                         const float* __restrict__ invstd,
                                                         float* __restrict__ part, int M, int C, int TC,
                                                         int rows_per_block, int act, float slope) {
+  // blockIdx.z = group (InstanceNorm: one group per sample; BatchNorm: a single group)
+  const int grp = blockIdx.z;
+  x += (size_t)grp * M * C;
+  if (MODE == 2) { y += (size_t)grp * M * C; dy += (size_t)grp * M * C; mean += (size_t)grp * C; invstd += (size_t)grp * C; }
+  part += (size_t)grp * gridDim.x * 2 * C;
   __shared__ f32x4 sh[2][256];
   const int TR = 256 / TC;
   const int tc = threadIdx.x % TC, tr = threadIdx.x / TC;
@@ -124,6 +129,11 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
                                                              float* __restrict__ running_var,
                                                              float* __restrict__ save_mean,
                                                              float* __restrict__ save_invstd) {
+  const int grp = blockIdx.y;
+  part += (size_t)grp * NB * 2 * C;
+  x += (size_t)grp * M * C;
+  save_mean += (size_t)grp * C;
+  save_invstd += (size_t)grp * C;
   __shared__ float sh[2][FL][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
   float s0, s1;
@@ -156,16 +166,17 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean,
 __global__ void bn_apply_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ mean, const float* __restrict__ invstd,
-                                size_t n4, int C4n, int act, float slope) {
+                                size_t n4, int C4n, size_t per_group4, int act, float slope) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4n) * 4;
+    const size_t go = (i / per_group4) * (size_t)C4n * 4;     // group offset into mean/invstd
     const f32x4 v = x[i];
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float g = gamma ? gamma[c + k] : 1.f, b = beta ? beta[c + k] : 0.f;
-      o[k] = act_apply((v[k] - mean[c + k]) * invstd[c + k] * g + b, act, slope);
+      o[k] = act_apply((v[k] - mean[go + c + k]) * invstd[go + c + k] * g + b, act, slope);
     }
     y[i] = o;
   }
@@ -175,6 +186,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restr
                                                            float* __restrict__ sums,
                                                            float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta) {
+  const int grp = blockIdx.y;
+  part += (size_t)grp * NB * 2 * C;
+  sums += (size_t)grp * 2 * C;
   __shared__ float sh[2][FL][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
   float s1, s2;
@@ -190,22 +204,38 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ x, const f32x4* __
                                     const f32x4* __restrict__ dy, f32x4* __restrict__ dx,
                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ sums,
-                                    size_t n4, int C4n, int C, float invM, int act, float slope) {
+                                    size_t n4, int C4n, int C, size_t per_group4, float invM, int act,
+                                    float slope) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4n) * 4;
+    const size_t grp = i / per_group4;
+    const float* mean_g = mean + grp * C;
+    const float* invstd_g = invstd + grp * C;
+    const float* sums_g = sums + grp * 2 * C;
     const f32x4 xv = x[i], yv = y[i], gv = dy[i];
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float is = invstd[c + k];
-      const float xh = (xv[k] - mean[c + k]) * is;
+      const float is = invstd_g[c + k];
+      const float xh = (xv[k] - mean_g[c + k]) * is;
       const float dz = gv[k] * act_grad_from_out(yv[k], act, slope);
       const float g = gamma ? gamma[c + k] : 1.f;
-      o[k] = g * is * (dz - sums[c + k] * invM - xh * sums[C + c + k] * invM);
+      o[k] = g * is * (dz - sums_g[c + k] * invM - xh * sums_g[C + c + k] * invM);
     }
     dx[i] = o;
   }
+}
+
+// InstanceNorm affine gradients: dgamma[c] = sum_g sums[g][C+c], dbeta[c] = sum_g sums[g][c]
+__global__ void group_sum_kernel(const float* __restrict__ sums, int G, int C, float* __restrict__ dgamma,
+                                 float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int g = 0; g < G; ++g) { s1 += sums[(size_t)g * 2 * C + c]; s2 += sums[(size_t)g * 2 * C + C + c]; }
+  if (dgamma) dgamma[c] = s2;
+  if (dbeta) dbeta[c] = s1;
 }
 
 // used by conv_igemm.hip for the bias gradient
@@ -227,60 +257,91 @@ int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, h
 
 using namespace iprgan;
 
+static int norm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float* save_mean, float* save_invstd, float* ws, int G, int M, int C,
+                    float eps, float momentum, int use_running, int act, float slope, hipStream_t st) {
+  IPR_CHECK(C % 4 == 0, "norm_fwd: C=%d must be a multiple of 4", C);
+  IPR_CHECK(M > 0 && G > 0, "norm_fwd: empty input");
+  if (use_running) {
+    IPR_CHECK(running_mean && running_var && G == 1, "norm_fwd: eval mode needs running stats");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, running_mean,
+                       running_var, eps, C, save_mean, save_invstd);
+  } else {
+    const ColGeom g = col_geom(M, C);
+    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.NB, g.gy, G), dim3(256), 0, st, x, nullptr, nullptr,
+                       nullptr, nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f);
+    IPR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, x, g.NB, M, C,
+                       eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  }
+  IPR_LAUNCH_CHECK();
+  const size_t n4 = (size_t)G * M * C / 4;
+  const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)x, (f32x4*)y, gamma,
+                     beta, save_mean, save_invstd, n4, C / 4, (size_t)M * C / 4, act, slope);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+static int norm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+                    const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+                    float* ws, int G, int M, int C, int act, float slope, hipStream_t st) {
+  IPR_CHECK(C % 4 == 0, "norm_bwd: C=%d must be a multiple of 4", C);
+  const ColGeom g = col_geom(M, C);
+  float* sums = ws + (size_t)G * g.NB * 2 * C;
+  hipLaunchKernelGGL(colreduce_kernel<2>, dim3(g.NB, g.gy, G), dim3(256), 0, st, x, y, dy, save_mean,
+                     save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope);
+  IPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, g.NB, C, sums,
+                     G == 1 ? dgamma : nullptr, G == 1 ? dbeta : nullptr);
+  IPR_LAUNCH_CHECK();
+  if (G > 1 && (dgamma || dbeta)) {
+    hipLaunchKernelGGL(group_sum_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, G, C, dgamma, dbeta);
+    IPR_LAUNCH_CHECK();
+  }
+  const size_t n4 = (size_t)G * M * C / 4;
+  const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)x, (const f32x4*)y,
+                     (const f32x4*)dy, (f32x4*)dx, gamma, save_mean, save_invstd, sums, n4, C / 4, C,
+                     (size_t)M * C / 4, 1.0f / (float)M, act, slope);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" {
 
 size_t iprgan_bn_ws_floats(int M, int C) {
   const ColGeom g = col_geom(M, C);
   return (size_t)g.NB * 2 * C + 2 * (size_t)C;
 }
+size_t iprgan_instnorm_ws_floats(int B, int HW, int C) {
+  const ColGeom g = col_geom(HW, C);
+  return (size_t)B * ((size_t)g.NB * 2 * C + 2 * (size_t)C);
+}
 
 int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                   float* running_var, float* save_mean, float* save_invstd, float* ws, int M, int C,
                   float eps, float momentum, int use_running, int act, float slope, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  IPR_CHECK(C % 4 == 0, "bn_fwd: C=%d must be a multiple of 4", C);
-  IPR_CHECK(M > 0, "bn_fwd: empty batch");
-  if (use_running) {
-    IPR_CHECK(running_mean && running_var, "bn_fwd: eval mode needs running stats");
-    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, running_mean,
-                       running_var, eps, C, save_mean, save_invstd);
-  } else {
-    const ColGeom g = col_geom(M, C);
-    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.NB, g.gy), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
-                       nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f);
-    IPR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, st, ws, x, g.NB, M, C, eps,
-                       momentum, running_mean, running_var, save_mean, save_invstd);
-  }
-  IPR_LAUNCH_CHECK();
-  const size_t n4 = (size_t)M * C / 4;
-  const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)x, (f32x4*)y, gamma,
-                     beta, save_mean, save_invstd, n4, C / 4, act, slope);
-  IPR_LAUNCH_CHECK();
-  return 0;
+  return norm_fwd(x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, 1, M, C, eps,
+                  momentum, use_running, act, slope, (hipStream_t)stream);
 }
-
 int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                   float* dbeta, float* ws, int M, int C, int act, float slope, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  IPR_CHECK(C % 4 == 0, "bn_bwd: C=%d must be a multiple of 4", C);
-  const ColGeom g = col_geom(M, C);
-  float* sums = ws + (size_t)g.NB * 2 * C;
-  hipLaunchKernelGGL(colreduce_kernel<2>, dim3(g.NB, g.gy), dim3(256), 0, st, x, y, dy, save_mean,
-                     save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope);
-  IPR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, st, ws, g.NB, C, sums, dgamma,
-                     dbeta);
-  IPR_LAUNCH_CHECK();
-  const size_t n4 = (size_t)M * C / 4;
-  const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)x, (const f32x4*)y,
-                     (const f32x4*)dy, (f32x4*)dx, gamma, save_mean, save_invstd, sums, n4, C / 4, C,
-                     1.0f / (float)M, act, slope);
-  IPR_LAUNCH_CHECK();
-  return 0;
+  return norm_bwd(x, y, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta, ws, 1, M, C, act, slope,
+                  (hipStream_t)stream);
+}
+int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
+                        float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,
+                        void* stream) {
+  return norm_fwd(x, y, gamma, beta, nullptr, nullptr, save_mean, save_invstd, ws, B, HW, C, eps, 0.f, 0, act,
+                  slope, (hipStream_t)stream);
+}
+int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+                        const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                        float* dbeta, float* ws, int B, int HW, int C, int act, float slope, void* stream) {
+  return norm_bwd(x, y, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta, ws, B, HW, C, act, slope,
+                  (hipStream_t)stream);
 }
 
 }  // extern "C"

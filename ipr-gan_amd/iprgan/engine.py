@@ -269,6 +269,98 @@ class GemvHead(Op):
         return (dx.view(st['xshape']) if dx is not None else None), grads
 
 
+class InstanceNorm(Op):
+    """InstanceNorm2d (affine or not, never tracks running stats) + optional activation."""
+
+    def __init__(self, module, act=L.ACT_NONE, slope=0.0):
+        self.m, self.act, self.slope = module, act, slope
+
+    @property
+    def params(self):
+        return (self.m.weight, self.m.bias) if self.m.weight is not None else ()
+
+    def forward(self, x, st, train):
+        y, mean, invstd = ops.instnorm_fwd(x, self.m.weight, self.m.bias, self.m.eps, self.act, self.slope)
+        st.update(x=x, y=y, mean=mean, invstd=invstd)
+        return y
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        dx, dg, db = ops.instnorm_bwd(st['x'], st['y'], dy, self.m.weight, st['mean'], st['invstd'],
+                                      self.act, self.slope)
+        return dx, ([dg, db] if self.m.weight is not None else [])
+
+
+class PReLU(Op):
+    """nn.PReLU() with a single learnable slope."""
+
+    def __init__(self, module):
+        self.m = module
+
+    @property
+    def params(self):
+        return (self.m.weight,)
+
+    def forward(self, x, st, train):
+        st['x'] = x
+        return ops.prelu_fwd(x, self.m.weight)
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        dx, dalpha = ops.prelu_bwd(st['x'], dy.contiguous(), self.m.weight)
+        return dx, [dalpha]
+
+
+class PixelShuffle2(Op):
+    def forward(self, x, st, train):
+        return ops.pixel_shuffle2(x)
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        return ops.pixel_shuffle2(dy.contiguous(), inverse=True), []
+
+
+class MaxPool2(Op):
+    def forward(self, x, st, train):
+        st['x'] = x
+        return ops.maxpool2_fwd(x)
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        return ops.maxpool2_bwd(st['x'], dy.contiguous()), []
+
+
+class SkipStart(Op):
+    """Marks the input of a residual branch: y = x + f(x) is [SkipStart, f..., SkipEnd]."""
+
+    def forward(self, x, st, train):
+        st['ctx']['skips'].append(x)
+        return x
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        g = st['ctx']['skip_grads'].pop()
+        return ops.add(dy, g), []
+
+
+class SkipEnd(Op):
+    def forward(self, x, st, train):
+        return ops.add(x, st['ctx']['skips'].pop())
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        st['ctx']['skip_grads'].append(dy)
+        return dy, []
+
+
+class Squeeze(Op):
+    """`.squeeze()` of a [B,1,1,C4>=1] logit map to [B] (networks/discriminator_96.py:24-25) or
+    NHWC [B,H,W,1(+pad)] -> NCHW [B,1,H,W] handled by ToNCHW; this op only flattens B x 1 x 1."""
+
+    def forward(self, x, st, train):
+        st['shape'] = tuple(x.shape)
+        B = x.shape[0]
+        return ops.nhwc_to_nchw(x, 1).view(B)
+
+    def backward(self, dy, st, need_dx, need_w, prev_act):
+        B = st['shape'][0]
+        return ops.nchw_to_nhwc(dy.contiguous().view(B, 1, 1, 1)), []
+
+
 class Chain:
     """A sequential network plan.  ``ops`` run in order; parameters are collected in op order."""
 
@@ -294,8 +386,9 @@ class ChainFn(torch.autograd.Function):
         h = x.detach()
         if h.dtype != torch.float32:
             raise RuntimeError('iprgan networks take float32 inputs')
+        shared = {'skips': [], 'skip_grads': []}
         for op in chain.ops:
-            st = {}
+            st = {'ctx': shared}
             h = op.forward(h, st, train)
             stash.append(st)
         ctx.chain, ctx.stash = chain, stash

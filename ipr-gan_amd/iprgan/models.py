@@ -7,6 +7,8 @@ One process drives ONE GPU: ``device`` keeps the reference's list-of-devices sig
 """
 from abc import ABC, abstractmethod
 from collections import OrderedDict
+from contextlib import contextmanager
+from itertools import chain
 
 import torch
 
@@ -15,7 +17,7 @@ from . import networks, optim, tools
 from .parallel import GradReducer, Replica, broadcast_module
 from .tools import loss_value
 
-__all__ = ['Model', 'Wrapper', 'DCGAN', 'WhiteBoxWrapper']
+__all__ = ['Model', 'Wrapper', 'DCGAN', 'SRGAN', 'CycleGAN', 'ImagePool', 'WhiteBoxWrapper']
 
 
 class Model(ABC):
@@ -55,6 +57,27 @@ def _fetch(scalars):
     keys = list(scalars)
     vals = torch.stack([scalars[k].detach().reshape(()) for k in keys]).tolist()
     return dict(zip(keys, vals))
+
+
+@contextmanager
+def _no_param_grads(*nets):
+    """Run a discriminator pass whose PARAMETER gradients nobody consumes (the generator update): the
+    reference computes and discards them (its next ``optD.zero_grad()`` precedes the next D backward);
+    skipping them leaves every result identical and saves the weight-gradient GEMMs."""
+    params = [p for n in nets for p in n.parameters() if p.requires_grad]
+    for p in params:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p in params:
+            p.requires_grad_(True)
+
+
+def _step(opt, reducer):
+    reducer.reduce()
+    reducer.wait()
+    opt.step()
 
 
 class DCGAN(Model):
@@ -104,16 +127,8 @@ class DCGAN(Model):
 
     def forward_g(self, data):
         self.generated = data['fake_sample']
-        # D's parameter gradients from this pass are never consumed (optD.zero_grad() precedes the
-        # next D backward), so only the data gradient is computed: identical results, fewer FLOPs.
-        d_params = [p for p in self.D.parameters() if p.requires_grad]
-        for p in d_params:
-            p.requires_grad_(False)
-        try:
+        with _no_param_grads(self.D):
             self.gen_logits = self.D(self.generated)
-        finally:
-            for p in d_params:
-                p.requires_grad_(True)
 
     def get_metrics(self):
         return _fetch({'D/Sum': self.LossD, 'D/Real': self.LossR, 'D/Fake': self.LossF,
@@ -137,6 +152,231 @@ class DCGAN(Model):
             self.reduceG.reduce()
             self.reduceG.wait()
             self.optG.step()
+
+
+class SRGAN(Model):
+    """models/srgan.py:7-107 - BCE-with-logits adversarial terms, VGG19-feature MSE content loss
+    (inputs fed raw in [0,1], no ImageNet normalisation), pixel MSE in the pre-training phase."""
+
+    def __init__(self, config, device=[torch.device('cpu'), ]):
+        super().__init__()
+        self.device = device
+        dev = device[0]
+        self.G = Replica(getattr(networks, config.G)(), dev)
+        self.D = Replica(getattr(networks, config.D)(), dev)
+        self.V = Replica(getattr(networks, config.V)(), dev)
+        self.G.train()
+        self.D.train()
+        self.V.eval()
+        for net in (self.G, self.D, self.V):
+            broadcast_module(net)
+        opt_fn = getattr(optim, config.opt)
+        opt_param = config.opt_param.to_dict()
+        self.optG = opt_fn(self.G.parameters(), **opt_param)
+        self.optD = opt_fn(self.D.parameters(), **opt_param)
+        self.reduceG = GradReducer(list(self.G.parameters()))
+        self.reduceD = GradReducer(list(self.D.parameters()))
+        self._modules['G'] = self.G
+        self._modules['D'] = self.D
+        self._modules['optG'] = self.optG
+        self._modules['optD'] = self.optD
+
+    def _dev(self, t):
+        return t.to(self.device[0], non_blocking=True)
+
+    def compute_d_loss(self):
+        self.LossR = loss_value(L.LOSS_BCE_ONES, self.real_logits)
+        self.LossF = loss_value(L.LOSS_BCE_ZEROS, self.fake_logits)
+        self.LossD = self.LossR + self.LossF
+
+    def compute_g_loss(self):
+        if self.pretrain:
+            self.LossG = loss_value(L.LOSS_MSE, self.super_res, self.high_res)
+        else:
+            self.LossA = loss_value(L.LOSS_BCE_ONES, self.gen_logits)
+            sr_feat = self.V(self.super_res)
+            with torch.no_grad():
+                hr_feat = self.V(self.high_res)
+            self.LossX = loss_value(L.LOSS_MSE, sr_feat, hr_feat)
+            self.LossG = self.LossX + 1e-3 * self.LossA
+
+    def forward_d(self, data):
+        self.high_res = self._dev(data['high_res'])
+        self.super_res = data['super_res']
+        self.real_logits = self.D(self.high_res)
+        self.fake_logits = self.D(self.super_res.detach())
+
+    def forward_g(self, data):
+        self.low_res = self._dev(data['low_res'])
+        self.high_res = self._dev(data['high_res'])
+        self.pretrain = data['pretrain']
+        self.super_res = self.G(self.low_res)
+        if not self.pretrain:
+            with _no_param_grads(self.D):
+                self.gen_logits = self.D(self.super_res)
+
+    def get_metrics(self):
+        if self.pretrain:
+            v = _fetch({'G/MSE': self.LossG})
+            return {'G/MSE': v['G/MSE'], 'G/Sum': v['G/MSE']}
+        return _fetch({'D/Sum': self.LossD, 'D/Real': self.LossR, 'D/Fake': self.LossF,
+                       'G/Sum': self.LossG, 'G/Adv': self.LossA, 'G/Con': self.LossX})
+
+    def update_d(self, data):
+        self.forward_d(data)
+        self.compute_d_loss()
+        self.optD.zero_grad()
+        self.LossD.backward()
+        _step(self.optD, self.reduceD)
+
+    def update_g(self, data, update=True):
+        self.forward_g(data)
+        self.compute_g_loss()
+        if update:
+            self.optG.zero_grad()
+            self.LossG.backward()
+            _step(self.optG, self.reduceG)
+
+
+class ImagePool(torch.nn.Module):
+    """models/util.py:5-35 - history of generated images; swap decisions use torch's CPU RNG exactly as
+    the reference (torch.rand / torch.randperm), the buffers live on the model's device."""
+
+    def __init__(self, pool_size):
+        super().__init__()
+        self.pool_size = pool_size
+        if self.pool_size > 0:
+            self.register_buffer('images', torch.tensor([]))
+            self.register_buffer('counts', torch.zeros([]))
+
+    def load_state_dict(self, *args, **kwargs):
+        self.images = torch.empty_like(args[0]['images'])
+        super().load_state_dict(*args, **kwargs)
+
+    def __call__(self, images):
+        if self.pool_size <= 0:
+            return images.detach()
+        if self.counts < self.pool_size:
+            self.images = torch.cat([self.images.to(images.device), images.detach()], dim=0)[:self.pool_size, ...]
+            self.counts += images.size(0)
+            return images.detach()
+        images = images.detach()
+        prob = torch.rand(images.size(0)) > 0.5
+        index = torch.randperm(self.pool_size)[:images.size(0)]
+        pool_images = self.images[index[prob]].clone()
+        self.images[index[prob]] = images[prob].detach()
+        images[prob] = pool_images
+        return images.detach()
+
+
+class CycleGAN(Model):
+    """models/cyclegan.py:10-165 - LSGAN (MSE) adversarial terms, L1 cycle and identity terms,
+    linearly decaying learning rate, image history pools."""
+
+    def __init__(self, config, device=[torch.device('cpu'), ]):
+        super().__init__()
+        self.device = device
+        dev = device[0]
+        fn_g, fn_d = getattr(networks, config.G), getattr(networks, config.D)
+        self.GA, self.GB = Replica(fn_g(), dev), Replica(fn_g(), dev)
+        self.DA, self.DB = Replica(fn_d(), dev), Replica(fn_d(), dev)
+        self.poolA, self.poolB = ImagePool(config.pool_size), ImagePool(config.pool_size)
+        for net in (self.GA, self.GB, self.DA, self.DB):
+            net.train()
+            broadcast_module(net)
+        self.lambda_A, self.lambda_B, self.lambda_idt = config.lambda_A, config.lambda_B, config.lambda_idt
+
+        opt_fn = getattr(optim, config.opt)
+        opt_param = config.opt_param.to_dict()
+        self.optG = opt_fn(chain(self.GA.parameters(), self.GB.parameters()), **opt_param)
+        self.optD = opt_fn(chain(self.DA.parameters(), self.DB.parameters()), **opt_param)
+        self.reduceG = GradReducer(list(chain(self.GA.parameters(), self.GB.parameters())))
+        self.reduceD = GradReducer(list(chain(self.DA.parameters(), self.DB.parameters())))
+
+        half_epoch = config.epoch // 2
+        linear_lr = lambda e: 1.0 - max(0, e - half_epoch) / half_epoch
+        self.schedulerG = optim.lr_scheduler.LambdaLR(self.optG, lr_lambda=linear_lr)
+        self.schedulerD = optim.lr_scheduler.LambdaLR(self.optD, lr_lambda=linear_lr)
+
+        for k, v in (('GA', self.GA), ('GB', self.GB), ('DA', self.DA), ('DB', self.DB),
+                     ('optG', self.optG), ('optD', self.optD), ('schG', self.schedulerG),
+                     ('schD', self.schedulerD), ('poolA', self.poolA), ('poolB', self.poolB)):
+            self._modules[k] = v
+
+    def _dev(self, t):
+        return t.to(self.device[0], non_blocking=True)
+
+    def get_metrics(self):
+        m = _fetch({'G/A': self.LossGA, 'G/B': self.LossGB, 'G/CycA': self.LossCycA, 'G/CycB': self.LossCycB,
+                    'G/IdtA': self.LossIdtA.to(self.device[0]), 'G/IdtB': self.LossIdtB.to(self.device[0]),
+                    'G/Sum': self.LossG, 'D/RealA': self.LossDRA, 'D/FakeA': self.LossDFA, 'D/SumA': self.LossDA,
+                    'D/RealB': self.LossDRB, 'D/FakeB': self.LossDFB, 'D/SumB': self.LossDB})
+        m['LR'] = self.optG.param_groups[0]['lr']
+        return m
+
+    def forward_g(self, data):
+        self.real_A = self._dev(data['real_A'])
+        self.real_B = self._dev(data['real_B'])
+        self.fake_B = self.GA(self.real_A)
+        self.fake_A = self.GB(self.real_B)
+        self.rec_A = self.GB(self.fake_B)
+        self.rec_B = self.GA(self.fake_A)
+        self.idt_A = self.GA(self.real_B)
+        self.idt_B = self.GB(self.real_A)
+        with _no_param_grads(self.DA, self.DB):
+            self.GA_logits = self.DA(self.fake_B)
+            self.GB_logits = self.DB(self.fake_A)
+
+    def forward_d(self, data):
+        self.real_A = self._dev(data['real_A'])
+        self.real_B = self._dev(data['real_B'])
+        self.fake_A = self.poolA(data['fake_A'])
+        self.fake_B = self.poolB(data['fake_B'])
+        self.RA_logits = self.DB(self.real_A)
+        self.FA_logits = self.DB(self.fake_A.detach())
+        self.RB_logits = self.DA(self.real_B)
+        self.FB_logits = self.DA(self.fake_B.detach())
+
+    def compute_g_loss(self):
+        self.LossGA = loss_value(L.LOSS_MSE_ONES, self.GA_logits)
+        self.LossGB = loss_value(L.LOSS_MSE_ONES, self.GB_logits)
+        self.LossCycA = loss_value(L.LOSS_L1, self.rec_A, self.real_A) * self.lambda_A
+        self.LossCycB = loss_value(L.LOSS_L1, self.rec_B, self.real_B) * self.lambda_B
+        self.LossG = self.LossGA + self.LossGB + self.LossCycA + self.LossCycB
+        if self.lambda_idt > 0:
+            self.LossIdtA = loss_value(L.LOSS_L1, self.idt_A, self.real_B) * self.lambda_B
+            self.LossIdtB = loss_value(L.LOSS_L1, self.idt_B, self.real_A) * self.lambda_A
+            self.LossG = self.LossG + self.lambda_idt * (self.LossIdtA + self.LossIdtB)
+        else:
+            self.LossIdtA = self.LossIdtB = torch.zeros([])
+
+    def compute_d_loss(self):
+        self.LossDRA = loss_value(L.LOSS_MSE_ONES, self.RB_logits)
+        self.LossDFA = loss_value(L.LOSS_MSE_ZEROS, self.FB_logits)
+        self.LossDA = (self.LossDRA + self.LossDFA) * 0.5
+        self.LossDRB = loss_value(L.LOSS_MSE_ONES, self.RA_logits)
+        self.LossDFB = loss_value(L.LOSS_MSE_ZEROS, self.FA_logits)
+        self.LossDB = (self.LossDRB + self.LossDFB) * 0.5
+
+    def update_lr(self):
+        self.schedulerG.step()
+        self.schedulerD.step()
+
+    def update_g(self, data, update=True):
+        self.forward_g(data)
+        self.compute_g_loss()
+        if update:
+            self.optG.zero_grad()
+            self.LossG.backward()
+            _step(self.optG, self.reduceG)
+
+    def update_d(self, data):
+        self.forward_d(data)
+        self.compute_d_loss()
+        self.optD.zero_grad()
+        self.LossDA.backward()
+        self.LossDB.backward()
+        _step(self.optD, self.reduceD)
 
 
 class Wrapper(Model):

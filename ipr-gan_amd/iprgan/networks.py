@@ -17,7 +17,9 @@ from . import engine as E
 from .ops import ConvSpec
 
 __all__ = ['ConvGenerator', 'ConvGenerator32', 'ConvGenerator64',
-           'SNDiscriminator', 'SNDiscriminator32', 'SNDiscriminator64', 'Flatten']
+           'SNDiscriminator', 'SNDiscriminator32', 'SNDiscriminator64', 'Flatten',
+           'SRResNet', 'Discriminator96', 'VGG19Feature',
+           'ResnetGenerator', 'ResnetBlock', 'Resnet6Blocks', 'Resnet9Blocks', 'ConvDiscriminator']
 
 
 class _HipNet(nn.Module):
@@ -128,3 +130,247 @@ def SNDiscriminator32():
 
 def SNDiscriminator64():
     return SNDiscriminator(md=8)
+
+
+# ------------------------------------------------------------------------------------------------
+# SRGAN generator: reference networks/sr_resnet.py:3-45
+# ------------------------------------------------------------------------------------------------
+def _kaiming(conv, a):
+    nn.init.kaiming_normal_(conv.weight.data, a=a, mode='fan_in')
+    conv.bias.data.zero_()
+    return conv
+
+
+def _sr_unit(cin, cout, k, pad, norm=False, prelu=False):
+    """conv [+BN] [+PReLU] as one Sequential; kaiming_normal(a=.25 with an activation, else 1)."""
+    mods = [nn.Conv2d(cin, cout, k, 1, pad)]
+    if norm:
+        mods.append(nn.BatchNorm2d(cout))
+    if prelu:
+        mods.append(nn.PReLU())
+    _kaiming(mods[0], 0.25 if prelu else 1.0)
+    return nn.Sequential(*mods)
+
+
+class _Residual(nn.Module):
+    def __init__(self, block):
+        super().__init__()
+        self.block = block
+
+    def forward(self, x):                   # never used by the engine
+        return x + self.block(x)
+
+
+class SRResNet(nn.Sequential, _HipNet):
+    def __init__(self, n_block=16):
+        trunk = [_Residual(nn.Sequential(_sr_unit(64, 64, 3, 1, norm=True, prelu=True),
+                                         _sr_unit(64, 64, 3, 1, norm=True)))
+                 for _ in range(n_block)]
+        trunk.append(_sr_unit(64, 64, 3, 1, norm=True))
+        head = _sr_unit(3, 64, 9, 4, prelu=True)
+        body = _Residual(nn.Sequential(*trunk))
+        ups = []
+        for _ in range(2):
+            ups.append(nn.Sequential(_sr_unit(64, 256, 3, 1), nn.PixelShuffle(2), nn.PReLU()))
+        tail = _sr_unit(64, 3, 9, 4)
+        nn.Sequential.__init__(self, head, body, *ups, tail)
+        self.n_block = n_block
+
+    def _unit_ops(self, unit, cin, cout, k, pad):
+        ops_ = [E.Conv(ConvSpec(cin, cout, k, 1, pad), unit[0])]
+        for m in list(unit)[1:]:
+            ops_.append(E.BatchNorm(m) if isinstance(m, nn.BatchNorm2d) else E.PReLU(m))
+        return ops_
+
+    def _build_chain(self):
+        plan = [E.ToNHWC(3)] + self._unit_ops(self[0], 3, 64, 9, 4)
+        plan.append(E.SkipStart())
+        trunk = self[1].block
+        for i in range(self.n_block):
+            plan.append(E.SkipStart())
+            plan += self._unit_ops(trunk[i].block[0], 64, 64, 3, 1)
+            plan += self._unit_ops(trunk[i].block[1], 64, 64, 3, 1)
+            plan.append(E.SkipEnd())
+        plan += self._unit_ops(trunk[self.n_block], 64, 64, 3, 1)
+        plan.append(E.SkipEnd())
+        for up in (self[2], self[3]):
+            plan += self._unit_ops(up[0], 64, 256, 3, 1)
+            plan += [E.PixelShuffle2(), E.PReLU(up[2])]
+        plan += self._unit_ops(self[4], 64, 3, 9, 4)
+        plan.append(E.ToNCHW(3))
+        return E.Chain(plan)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# SRGAN discriminator: reference networks/discriminator_96.py:3-35
+# ------------------------------------------------------------------------------------------------
+class Discriminator96(nn.Sequential, _HipNet):
+    PLAN = ((64, 64, 2), (64, 128, 1), (128, 128, 2), (128, 256, 1), (256, 256, 2), (256, 512, 1), (512, 512, 2))
+    SLOPE = 0.2
+
+    def __init__(self):
+        mods = [nn.Conv2d(3, 64, 3, 1, 1), nn.LeakyReLU(self.SLOPE, True)]
+        for cin, cout, s in self.PLAN:
+            blk = nn.Sequential(nn.Conv2d(cin, cout, 3, s, 1), nn.BatchNorm2d(cout), nn.LeakyReLU(self.SLOPE, True))
+            _kaiming(blk[0], 0.2)
+            mods.append(blk)
+        mods += [nn.Conv2d(512, 1024, 6, 1, 0), nn.LeakyReLU(self.SLOPE, True), nn.Conv2d(1024, 1, 1, 1, 0)]
+        nn.Sequential.__init__(self, *mods)
+
+    def _build_chain(self):
+        lr = dict(act=L.ACT_LRELU, slope=self.SLOPE)
+        plan = [E.ToNHWC(3), E.Conv(ConvSpec(3, 64, 3, 1, 1, **lr), self[0])]
+        for i, (cin, cout, s) in enumerate(self.PLAN):
+            blk = self[2 + i]
+            plan.append(E.Conv(ConvSpec(cin, cout, 3, s, 1), blk[0]))
+            plan.append(E.BatchNorm(blk[1], **lr))
+        plan.append(E.Conv(ConvSpec(512, 1024, 6, 1, 0, **lr), self[9]))
+        plan.append(E.Conv(ConvSpec(1024, 1, 1, 1, 0), self[11]))
+        plan.append(E.Squeeze())
+        return E.Chain(plan)
+
+    def forward(self, x):
+        return self.run(x).squeeze()
+
+
+# ------------------------------------------------------------------------------------------------
+# VGG19 feature extractor: reference networks/vgg.py:5-40 (architecture = torchvision vgg19 cfg "E";
+# pretrained weights cannot be downloaded here: random init unless a state_dict is loaded)
+# ------------------------------------------------------------------------------------------------
+class VGG19Feature(_HipNet):
+    CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M')
+
+    def __init__(self, layer='relu5_4'):
+        super().__init__()
+        names, mods, cin, blk, idx = [], [], 3, 1, 1
+        for v in self.CFG:
+            if v == 'M':
+                names.append(f'pool{blk}')
+                mods.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                blk, idx = blk + 1, 1
+            else:
+                names += [f'conv{blk}_{idx}', f'relu{blk}_{idx}']
+                mods += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin, idx = v, idx + 1
+        self.net = nn.Sequential(*mods[:names.index(layer) + 1])
+        self.net.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def _build_chain(self):
+        plan = [E.ToNHWC(3)]
+        mods = list(self.net)
+        i, cin = 0, 3
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Conv2d):
+                fused = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                plan.append(E.Conv(ConvSpec(cin, m.out_channels, 3, 1, 1, act=L.ACT_RELU if fused else L.ACT_NONE), m))
+                cin = m.out_channels
+                i += 2 if fused else 1
+            elif isinstance(m, nn.MaxPool2d):
+                plan.append(E.MaxPool2())
+                i += 1
+            else:
+                raise RuntimeError(f'unexpected module {m} in VGG19Feature')
+        plan.append(E.ToNCHW(cin))
+        return E.Chain(plan)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# CycleGAN generator: reference networks/resnet_generator.py:3-59
+# ------------------------------------------------------------------------------------------------
+class ResnetBlock(nn.Module):
+    def __init__(self, channel):
+        super().__init__()
+        seq = []
+        for last in (False, True):
+            seq += [nn.ReflectionPad2d(1), nn.Conv2d(channel, channel, 3, 1, 0, bias=True),
+                    nn.InstanceNorm2d(channel, affine=True)]
+            if not last:
+                seq.append(nn.ReLU(True))
+        self.block = nn.Sequential(*seq)
+
+    def forward(self, x):                   # never used by the engine
+        return x + self.block(x)
+
+
+class ResnetGenerator(nn.Sequential, _HipNet):
+    def __init__(self, n_block):
+        mods = [nn.ReflectionPad2d(3), nn.Conv2d(3, 64, 7, 1, 0), nn.InstanceNorm2d(64, affine=True), nn.ReLU(True)]
+        for c in (64, 128):
+            mods += [nn.Conv2d(c, 2 * c, 3, 2, 1), nn.InstanceNorm2d(2 * c, affine=True), nn.ReLU(True)]
+        mods += [ResnetBlock(256) for _ in range(n_block)]
+        for c in (256, 128):
+            mods += [nn.ConvTranspose2d(c, c // 2, 3, 2, 1, output_padding=1),
+                     nn.InstanceNorm2d(c // 2, affine=True), nn.ReLU(True)]
+        mods += [nn.ReflectionPad2d(3), nn.Conv2d(64, 3, 7, 1, 0), nn.Tanh()]
+        nn.Sequential.__init__(self, *mods)
+        self.n_block = n_block
+
+    def _build_chain(self):
+        R = L.PAD_REFLECT
+        plan = [E.ToNHWC(3),
+                E.Conv(ConvSpec(3, 64, 7, 1, 3, pad_mode=R), self[1]), E.InstanceNorm(self[2], act=L.ACT_RELU)]
+        i = 4
+        for c in (64, 128):
+            plan += [E.Conv(ConvSpec(c, 2 * c, 3, 2, 1), self[i]), E.InstanceNorm(self[i + 1], act=L.ACT_RELU)]
+            i += 3
+        for _ in range(self.n_block):
+            b = self[i].block
+            plan += [E.SkipStart(),
+                     E.Conv(ConvSpec(256, 256, 3, 1, 1, pad_mode=R), b[1]), E.InstanceNorm(b[2], act=L.ACT_RELU),
+                     E.Conv(ConvSpec(256, 256, 3, 1, 1, pad_mode=R), b[5]), E.InstanceNorm(b[6]),
+                     E.SkipEnd()]
+            i += 1
+        for c in (256, 128):
+            plan += [E.Conv(ConvSpec(c, c // 2, 3, 2, 1, outpad=1, transposed=True), self[i]),
+                     E.InstanceNorm(self[i + 1], act=L.ACT_RELU)]
+            i += 3
+        plan += [E.Conv(ConvSpec(64, 3, 7, 1, 3, pad_mode=R, act=L.ACT_TANH), self[i + 1]), E.ToNCHW(3)]
+        return E.Chain(plan)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+def Resnet9Blocks():
+    return ResnetGenerator(n_block=9)
+
+
+def Resnet6Blocks():
+    return ResnetGenerator(n_block=6)
+
+
+# ------------------------------------------------------------------------------------------------
+# CycleGAN PatchGAN discriminator: reference networks/conv_discriminator.py:3-22
+# ------------------------------------------------------------------------------------------------
+class ConvDiscriminator(nn.Sequential, _HipNet):
+    SLOPE = 0.2
+
+    def __init__(self):
+        act = lambda: nn.LeakyReLU(self.SLOPE, True)
+        nn.Sequential.__init__(
+            self,
+            nn.Conv2d(3, 64, 4, 2, 1), act(),
+            nn.Conv2d(64, 128, 4, 2, 1), nn.InstanceNorm2d(128), act(),
+            nn.Conv2d(128, 256, 4, 2, 1), nn.InstanceNorm2d(256), act(),
+            nn.Conv2d(256, 512, 4, 1, 1), nn.InstanceNorm2d(512), act(),
+            nn.Conv2d(512, 1, 4, 1, 1))
+
+    def _build_chain(self):
+        lr = dict(act=L.ACT_LRELU, slope=self.SLOPE)
+        plan = [E.ToNHWC(3), E.Conv(ConvSpec(3, 64, 4, 2, 1, **lr), self[0])]
+        for idx, cin, cout, s in ((2, 64, 128, 2), (5, 128, 256, 2), (8, 256, 512, 1)):
+            plan += [E.Conv(ConvSpec(cin, cout, 4, s, 1), self[idx]), E.InstanceNorm(self[idx + 1], **lr)]
+        plan += [E.Conv(ConvSpec(512, 1, 4, 1, 1), self[11]), E.ToNCHW(1)]
+        return E.Chain(plan)
+
+    def forward(self, x):
+        return self.run(x)

@@ -92,7 +92,9 @@ def conv_fwd(spec, d, x, wfwd, bias):
 
 def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0):
     dx = empty((d.B, d.H, d.W, c4(spec.cin)), dy)
-    call('iprgan_conv_bwd_data', C.byref(d), ptr(dy), ptr(wbwd), ptr(dx), ptr(prev_out), prev_act,
+    nws = query('iprgan_conv_bwd_data_ws_floats', C.byref(d))
+    ws = empty((nws,), dy) if nws else None
+    call('iprgan_conv_bwd_data', C.byref(d), ptr(dy), ptr(wbwd), ptr(dx), ptr(ws), ptr(prev_out), prev_act,
          float(prev_slope), stream())
     return dx
 
@@ -215,3 +217,73 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_
     call('iprgan_adam_step', L.ptr_table(params), L.ptr_table(grads), L.ptr_table(exp_avg),
          L.ptr_table(exp_avg_sq), sizes, n, float(lr), float(beta1), float(beta2), float(eps),
          float(weight_decay), int(step), stream())
+
+
+# ---- instance norm / PReLU / pixel shuffle / max pool / residual add ---------------------------------
+def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0):
+    B, H, W, C_ = x.shape
+    y = torch.empty_like(x)
+    mean, invstd = empty((B, C_), x), empty((B, C_), x)
+    ws = empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
+    call('iprgan_instnorm_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(ws),
+         B, H * W, C_, float(eps), act, float(slope), stream())
+    return y, mean, invstd
+
+
+def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0):
+    B, H, W, C_ = x.shape
+    dx = torch.empty_like(x)
+    dgamma = empty((C_,), x) if gamma is not None else None
+    dbeta = empty((C_,), x) if gamma is not None else None
+    ws = empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
+    call('iprgan_instnorm_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
+         ptr(dgamma), ptr(dbeta), ptr(ws), B, H * W, C_, act, float(slope), stream())
+    return dx, dgamma, dbeta
+
+
+def prelu_fwd(x, alpha):
+    y = torch.empty_like(x)
+    call('iprgan_prelu_fwd', ptr(x), ptr(alpha), ptr(y), x.numel(), stream())
+    return y
+
+
+def prelu_bwd(x, dy, alpha):
+    dx = torch.empty_like(x)
+    dalpha = empty((1,), x)
+    ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
+    call('iprgan_prelu_bwd', ptr(x), ptr(dy), ptr(alpha), ptr(dx), ptr(dalpha), ptr(ws), x.numel(), stream())
+    return dx, dalpha
+
+
+def pixel_shuffle2(x, inverse=False):
+    """forward: [B,H,W,4C] -> [B,2H,2W,C]; inverse: [B,2H,2W,C] -> [B,H,W,4C]."""
+    if not inverse:
+        B, H, W, C4_ = x.shape
+        Cc = C4_ // 4
+        y = empty((B, 2 * H, 2 * W, Cc), x)
+    else:
+        B, H2, W2, Cc = x.shape
+        H, W = H2 // 2, W2 // 2
+        y = empty((B, H, W, 4 * Cc), x)
+    call('iprgan_pixel_shuffle2', ptr(x), ptr(y), B, H, W, Cc, 1 if inverse else 0, stream())
+    return y
+
+
+def maxpool2_fwd(x):
+    B, H, W, C_ = x.shape
+    y = empty((B, H // 2, W // 2, C_), x)
+    call('iprgan_maxpool2_fwd', ptr(x), ptr(y), B, H, W, C_, stream())
+    return y
+
+
+def maxpool2_bwd(x, dy):
+    B, H, W, C_ = x.shape
+    dx = torch.empty_like(x)
+    call('iprgan_maxpool2_bwd', ptr(x), ptr(dy), ptr(dx), B, H, W, C_, stream())
+    return dx
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    call('iprgan_add', ptr(a), ptr(b), ptr(out), a.numel(), stream())
+    return out

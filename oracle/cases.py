@@ -136,3 +136,85 @@ def run_sign_case(networks, SignLossModel, make_cfg, name, string='EXAMPLE A', s
     res['ber_corrupt'] = np.float64(float(slm.compute_ber(net)))
     res['loss_corrupt'] = np.float64(float(slm(net).detach()))
     return res
+
+
+def _capture(model, res, tag, nets, opts, moments=True):
+    sd = model.state_dict()
+    for net in nets:
+        for k, v in sd[net].items():
+            leaf = k.rsplit('.', 1)[-1]
+            v = v.detach().cpu()
+            if leaf in BUFFER_LEAVES or v.numel() <= 512:
+                res[f'{tag}/{net}/{k}'] = v.numpy().copy()
+            else:
+                recipe.pack_summary(f'{tag}/{net}/{k}', v, res)
+    if moments:
+        for opt in opts:
+            st = sd[opt]['state']
+            for idx in sorted(st):
+                recipe.pack_summary(f'{tag}/{opt}/{idx}/exp_avg', st[idx]['exp_avg'].cpu(), res)
+
+
+SRGAN_CFG = {'G': 'SRResNet', 'D': 'Discriminator96', 'V': 'VGG19Feature', 'opt': 'Adam',
+             'opt_param': {'lr': 1.0e-4}, 'type': 'SRGAN'}
+
+
+def run_srgan_steps(make_cfg, models, device, batch=2, seed=41):
+    """One pre-training step (pixel MSE) then one GAN-phase G step and D step, in the order of
+    experiments/image_super_resolution.py:84-113, with the white-box wrapper on G."""
+    model = models.SRGAN(make_cfg(SRGAN_CFG), device=device)
+    recipe.fill(model.G.module, seed)
+    recipe.fill(model.D.module, seed + 1)
+    recipe.fill(model.V.module, seed + 2)
+    for n in (model.G, model.D, model.V):
+        n.to(device[0])
+    model = models.WhiteBoxWrapper(model, make_cfg(WBOX_CFG))
+    res = {}
+    lr = recipe.tensor(seed, 100, (batch, 3, 24, 24), dist='uniform')
+    hr = recipe.tensor(seed, 101, (batch, 3, 96, 96), dist='uniform')
+    model.update_g({'low_res': lr, 'high_res': hr, 'pretrain': True, 'inhibit_bbox': True})
+    for k, v in model.get_metrics().items():
+        res[f'step0/metric/{k}'] = np.float64(v)
+    res['step0/super_res'] = model.super_res.detach().cpu().numpy()
+    _capture(model, res, 'step0', ('G',), ('optG',))
+    lr = recipe.tensor(seed, 102, (batch, 3, 24, 24), dist='uniform')
+    hr = recipe.tensor(seed, 103, (batch, 3, 96, 96), dist='uniform')
+    model.update_g({'low_res': lr, 'high_res': hr, 'pretrain': False})
+    model.update_d({'high_res': model.high_res, 'super_res': model.super_res})
+    for k, v in model.get_metrics().items():
+        res[f'step1/metric/{k}'] = np.float64(v)
+    _capture(model, res, 'final', ('G', 'D'), ('optG', 'optD'))
+    res['final/ber'] = np.float64(float(model.loss_model.compute_ber(model.G)))
+    return res
+
+
+CYCLEGAN_CFG = {'G': 'Resnet6Blocks', 'D': 'ConvDiscriminator', 'opt': 'Adam',
+                'opt_param': {'lr': 2.0e-4, 'betas': [0.5, 0.999]}, 'type': 'CycleGAN', 'pool_size': 50,
+                'lambda_A': 10.0, 'lambda_B': 10.0, 'lambda_idt': 0.5, 'epoch': 200}
+
+
+def run_cyclegan_steps(make_cfg, models, device, n_steps=2, batch=1, size=32, seed=51):
+    """G step then D step per iteration (experiments/image_translation.py:90-112), white-box on GB."""
+    model = models.CycleGAN(make_cfg(CYCLEGAN_CFG), device=device)
+    for i, n in enumerate((model.GA, model.GB, model.DA, model.DB)):
+        recipe.fill(n.module, seed + i)
+        n.to(device[0])
+    wcfg = dict(WBOX_CFG)
+    wcfg['target'] = 'GB'                            # image_translation.py:83
+    model = models.WhiteBoxWrapper(model, make_cfg(wcfg))
+    res = {}
+    for s in range(n_steps):
+        a = torch.tanh(recipe.tensor(seed, 200 + s, (batch, 3, size, size)))
+        b = torch.tanh(recipe.tensor(seed, 300 + s, (batch, 3, size, size)))
+        model.update_g({'real_A': a, 'real_B': b})
+        model.update_d({'real_A': model.real_A, 'real_B': model.real_B,
+                        'fake_A': model.fake_A.detach(), 'fake_B': model.fake_B.detach()})
+        for k, v in model.get_metrics().items():
+            res[f'step{s}/metric/{k}'] = np.float64(v)
+        if s == 0:
+            res['step0/fake_B'] = model.fake_B.detach().cpu().numpy()
+            _capture(model, res, 'step0', ('GA', 'GB', 'DA', 'DB'), ('optG', 'optD'))
+    _capture(model, res, 'final', ('GA', 'GB', 'DA', 'DB'), (), moments=False)
+    res['final/poolA/images'] = model.state_dict()['poolA']['images'].detach().cpu().numpy()
+    res['final/ber'] = np.float64(float(model.loss_model.compute_ber(model.GB)))
+    return res

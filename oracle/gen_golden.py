@@ -38,6 +38,8 @@ def main():
     dev = [torch.device('cpu')]
     save('dcgan_steps_wbox', cases.run_dcgan_steps(ref_loader.Config, models, dev, wbox=True))
     save('dcgan_steps_plain', cases.run_dcgan_steps(ref_loader.Config, models, dev, n_steps=2, wbox=False))
+    save('srgan_steps_wbox', cases.run_srgan_steps(ref_loader.Config, models, dev))
+    save('cyclegan_steps_wbox', cases.run_cyclegan_steps(ref_loader.Config, models, dev))
 
 
 if __name__ == '__main__':

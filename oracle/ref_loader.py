@@ -40,6 +40,10 @@ def load():
         for k, v in vars(mod).items():
             if not k.startswith('__'):
                 setattr(networks, k, v)
+    # networks/vgg.py needs torchvision (absent): the architecture is restated in oracle/nets.py and
+    # injected under the reference's name so that the REAL models.SRGAN can be constructed.
+    from . import nets as _oracle_nets
+    networks.VGG19Feature = _oracle_nets.VGG19Feature
     tools = types.ModuleType('tools')
     sm = _load('_ref_tools_sign_model', 'tools/sign_model.py')
     tools.SignLossModel = sm.SignLossModel

@@ -14,7 +14,7 @@ from test_oracle_golden import compare
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 5e-4, 5e-5
-HIP_NETS = ['ConvGenerator64', 'ConvGenerator32', 'SNDiscriminator64', 'SNDiscriminator32']
+HIP_NETS = list(cases.NET_CASES)
 
 
 @pytest.fixture(scope='module')
@@ -124,3 +124,31 @@ def test_checkpoint_roundtrip_with_oracle(dev):
     m.load_state_dict(o.state_dict(), strict=True)
     for k, v in m.state_dict()['G'].items():
         assert torch.equal(v.cpu(), cpu_sd['G'][k]), k
+
+
+def test_srgan_steps_vs_reference_golden(golden, dev):
+    """SRResNet + Discriminator96 + VGG19 features (restated cfg-E, recipe weights): one pre-training
+    step and one GAN-phase G/D step.  (VGG pretrained weights are unpinned - unavailable offline.)"""
+    from iprgan import Config, models
+    res = cases.run_srgan_steps(Config, models, [dev])
+    compare(res, golden('srgan_steps_wbox'), policy=step_policy(2, lr=1e-4))
+
+
+def test_cyclegan_steps_vs_reference_golden(golden, dev):
+    from iprgan import Config, models
+    res = cases.run_cyclegan_steps(Config, models, [dev])
+    compare(res, golden('cyclegan_steps_wbox'), policy=step_policy(2))
+
+
+def test_vgg_features_vs_oracle(dev):
+    from iprgan import networks
+    a, b = nets.VGG19Feature(), networks.VGG19Feature()
+    recipe.fill(a, 7); recipe.fill(b, 7)
+    b.to(dev)
+    x = recipe.tensor(7, 1, (2, 3, 32, 32), dist='uniform').requires_grad_()
+    xd = x.detach().to(dev).requires_grad_()
+    ya, yb = a(x), b(xd)
+    np.testing.assert_allclose(yb.detach().cpu().numpy(), ya.detach().numpy(), rtol=RTOL, atol=ATOL)
+    g = recipe.tensor(7, 2, tuple(ya.shape))
+    ya.backward(g); yb.backward(g.to(dev))
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), x.grad.numpy(), rtol=2e-3, atol=1e-5)

@@ -281,3 +281,77 @@ def test_cpu_tensor_is_refused(dev):
         ops.loss_fwd(0, torch.zeros(4))
     with pytest.raises(RuntimeError):
         networks.ConvGenerator32()(torch.zeros(2, 128))
+
+
+REFLECT_CONVS = [(64, 64, 3, 1, 1, 8, 9, 2), (3, 32, 7, 1, 3, 12, 10, 2), (64, 3, 7, 1, 3, 9, 9, 1), (256, 256, 3, 1, 1, 6, 6, 2)]
+
+
+@pytest.mark.parametrize('cfg', REFLECT_CONVS, ids=lambda c: '-'.join(map(str, c)))
+def test_reflect_pad_conv(dev, cfg):
+    """ReflectionPad2d(p) + Conv2d(k, pad=0) folded into the gather (resnet_generator.py:6-7,41-49)."""
+    from iprgan import ops
+    cin, cout, k, s, p, H, W, B = cfg
+    x, w, b = rnd(B, cin, H, W, seed=1), rnd(cout, cin, k, k, seed=2, scale=(cin * k * k) ** -0.5), rnd(cout, seed=3)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.conv2d(F.pad(xr, (p, p, p, p), mode='reflect'), wr, br, stride=s)
+    g = rnd(*yr.shape, seed=4)
+    yr.backward(g)
+    spec = ops.ConvSpec(cin, cout, k, s, p, pad_mode=1)
+    d = spec.desc(B, H, W)
+    xd = to_nhwc(x).to(dev)
+    wf, wb = ops.conv_prep(spec, d, w.to(dev), None, True, True)
+    y = ops.conv_fwd(spec, d, xd, wf, b.to(dev))
+    close(from_nhwc(y.cpu(), cout), yr, what='reflect fwd')
+    gd = to_nhwc(g).to(dev)
+    dw, db = ops.conv_bwd_weight(spec, d, xd, gd, w.shape, True)
+    close(dw, wr.grad, what='reflect wgrad'); close(db, br.grad, what='reflect bgrad')
+    close(from_nhwc(ops.conv_bwd_data(spec, d, gd, wb).cpu(), cin), xr.grad, what='reflect dgrad')
+
+
+@pytest.mark.parametrize('affine,act', [(True, 'relu'), (False, 'lrelu'), (True, 'none')])
+def test_instance_norm(dev, affine, act):
+    from iprgan import ops
+    B, C, H, W = 3, 64, 9, 7
+    x = rnd(B, C, H, W, seed=1) * 2 + 0.3
+    m = torch.nn.InstanceNorm2d(C, affine=affine)
+    if affine:
+        with torch.no_grad():
+            m.weight.copy_(rnd(C, seed=2) * 0.5 + 1); m.bias.copy_(rnd(C, seed=3) * 0.1)
+    xr = x.clone().requires_grad_()
+    yr = {'none': lambda t: t, 'relu': F.relu, 'lrelu': lambda t: F.leaky_relu(t, 0.1)}[act](m(xr))
+    g = rnd(B, C, H, W, seed=4)
+    yr.backward(g)
+    gam = m.weight.detach().to(dev) if affine else None
+    bet = m.bias.detach().to(dev) if affine else None
+    xd = to_nhwc(x).to(dev)
+    y, mean, invstd = ops.instnorm_fwd(xd, gam, bet, 1e-5, *ACT[act])
+    close(from_nhwc(y.cpu(), C), yr, 1e-4, 'in fwd')
+    dx, dg, db = ops.instnorm_bwd(xd, y, to_nhwc(g).to(dev), gam, mean, invstd, *ACT[act])
+    close(from_nhwc(dx.cpu(), C), xr.grad, 2e-4, 'in dx')
+    if affine:
+        close(dg, m.weight.grad, 2e-4, 'in dgamma'); close(db, m.bias.grad, 2e-4, 'in dbeta')
+
+
+def test_prelu_pixelshuffle_maxpool_add(dev):
+    from iprgan import ops
+    x = rnd(2, 16, 6, 8, seed=1)
+    a = torch.tensor([0.25])
+    xr, ar = x.clone().requires_grad_(), a.clone().requires_grad_()
+    yr = F.prelu(xr, ar)
+    g = rnd(*x.shape, seed=2)
+    yr.backward(g)
+    xd = to_nhwc(x).to(dev)
+    close(from_nhwc(ops.prelu_fwd(xd, a.to(dev)).cpu(), 16), yr, 1e-6, 'prelu')
+    dx, da = ops.prelu_bwd(xd, to_nhwc(g).to(dev), a.to(dev))
+    close(from_nhwc(dx.cpu(), 16), xr.grad, 1e-6, 'prelu dx'); close(da, ar.grad, 1e-5, 'prelu dalpha')
+    ps = F.pixel_shuffle(x, 2)
+    y = ops.pixel_shuffle2(xd)
+    assert torch.equal(from_nhwc(y.cpu(), 4), ps)
+    assert torch.equal(ops.pixel_shuffle2(y, inverse=True).cpu(), xd.cpu())
+    xr2 = x.clone().requires_grad_()
+    mp = F.max_pool2d(xr2, 2, 2)
+    g2 = rnd(*mp.shape, seed=3)
+    mp.backward(g2)
+    assert torch.equal(from_nhwc(ops.maxpool2_fwd(xd).cpu(), 16), mp.detach())
+    assert torch.equal(from_nhwc(ops.maxpool2_bwd(xd, to_nhwc(g2).to(dev)).cpu(), 16), xr2.grad)
+    assert torch.equal(ops.add(xd, xd).cpu(), (xd + xd).cpu())

@@ -79,3 +79,13 @@ def test_dcgan_steps_match_reference(wbox, golden):
     torch.manual_seed(0)
     res = cases.run_dcgan_steps(gan.Cfg, gan, gan.CPU, n_steps=3 if wbox else 2, wbox=wbox)
     compare(res, golden('dcgan_steps_wbox' if wbox else 'dcgan_steps_plain'), rtol=5e-4, atol=5e-5)
+
+
+def test_srgan_steps_match_reference(golden):
+    torch.manual_seed(0)
+    compare(cases.run_srgan_steps(gan.Cfg, gan, gan.CPU), golden('srgan_steps_wbox'), rtol=5e-4, atol=5e-5)
+
+
+def test_cyclegan_steps_match_reference(golden):
+    torch.manual_seed(0)
+    compare(cases.run_cyclegan_steps(gan.Cfg, gan, gan.CPU), golden('cyclegan_steps_wbox'), rtol=5e-4, atol=5e-5)
