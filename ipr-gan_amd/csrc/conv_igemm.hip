@@ -49,6 +49,7 @@ struct ProfScope {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Phase {
   int th, tw, ntap;
@@ -98,7 +99,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned v
 // FAST: zero padding and Cs % 32 == 0, so every 32-wide K step lies inside ONE tap: the tap walk is
 // wave-uniform (scalar registers), borders are handled by the buffer bounds check (no branches).
 // !FAST: reflect padding and/or Cs in {4,8,16} (taps change inside a K step; RGB layers).
-template <int WGM, int WGN, int WM, int WN, bool FAST>
+template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF>
 __global__ __launch_bounds__(256) void gconv_kernel(const GConvArgs a) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -259,9 +260,16 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvArgs a) {
     for (int s = 0; s < p_steps; ++s) {
       const bool more = s + 1 < p_steps;
       if (more) gload(s + 1);
-      compute(s & 1);
-      if (more) lstore((s + 1) & 1);
-      __syncthreads();
+      if (NBUF == 2) {           // double-buffered LDS: one barrier per K step, 2 blocks per CU
+        compute(s & 1);
+        if (more) lstore((s + 1) & 1);
+        __syncthreads();
+      } else {                   // single LDS buffer (half the LDS -> 3-4 blocks per CU), two barriers
+        compute(0);
+        __syncthreads();
+        if (more) lstore(0);
+        __syncthreads();
+      }
     }
   }
 
@@ -317,7 +325,7 @@ struct WGradArgs {
   double flops;
 };
 
-template <int WGM, int WGN, int WM, int WN>
+template <int WGM, int WGN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
   constexpr int BN = WGM * WM * 32;   // tile over n (P channels)  -> MFMA rows
   constexpr int BK = WGN * WN * 32;   // tile over k (tap,c)       -> MFMA cols
@@ -408,10 +416,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
     for (int kk = 0; kk < 16; ++kk) {
       const int row = 2 * kk + half;
       float af[WM], bf[WN];
+      // a wave with two tiles per side reads 8 bytes per lane: channels 2*l31, 2*l31+1 feed tiles 0 and 1
+      // (tile t owns rows/cols base + 2*i + t), halving the LDS read count; one tile per side reads 4 bytes
+      if (WM == 2) {
+        const f32x2 v = *(const f32x2*)(Pt + row * BN + wm * 64 + 2 * l31);
+        af[0] = v.x; af[WM - 1] = v.y;
+      } else {
 #pragma unroll
-      for (int i = 0; i < WM; ++i) af[i] = Pt[row * BN + (wm * WM + i) * 32 + l31];
+        for (int i = 0; i < WM; ++i) af[i] = Pt[row * BN + (wm * WM + i) * 32 + l31];
+      }
+      if (WN == 2) {
+        const f32x2 v = *(const f32x2*)(Qt + row * BK + wn * 64 + 2 * l31);
+        bf[0] = v.x; bf[WN - 1] = v.y;
+      } else {
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bf[j] = Qt[row * BK + (wn * WN + j) * 32 + l31];
+        for (int j = 0; j < WN; ++j) bf[j] = Qt[row * BK + (wn * WN + j) * 32 + l31];
+      }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -428,10 +448,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
     for (int ch = chunk_begin; ch < chunk_end; ++ch) {
       const bool more = ch + 1 < chunk_end;
       if (more) gload(ch + 1);
-      compute(buf);
-      if (more) lstore(buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
+      if (NBUF == 2) {
+        compute(buf);
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      } else {
+        compute(0);
+        __syncthreads();
+        if (more) lstore(0);
+        __syncthreads();
+      }
     }
   }
 
@@ -441,11 +468,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = n0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int ri = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int n = WM == 2 ? n0 + wm * 64 + 2 * ri + i : n0 + (wm * WM + i) * 32 + ri;
       if (n >= a.Nrows) continue;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        const int k = k0 + (wn * WN + j) * 32 + l31;
+        const int k = WN == 2 ? k0 + wn * 64 + 2 * l31 + j : k0 + (wn * WN + j) * 32 + l31;
         if (k < a.Kw) slab[(size_t)n * a.Kw + k] = acc[i][j][r];
       }
     }
@@ -581,14 +609,16 @@ static void geom_bwd_form(GConvArgs& a, int B, int OHs, int OWs, int Cred, int H
     }
 }
 
-template <int WGM, int WGN, int WM, int WN, bool FAST>
-static int launch_gconv_tf(const GConvArgs& a, hipStream_t st) {
+static int g_nbuf = getenv("IPRGAN_LDS_BUFS") ? atoi(getenv("IPRGAN_LDS_BUFS")) : 1;  // 1 = single LDS buffer (measured faster: 3-4 blocks/CU)
+
+template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF>
+static int launch_gconv_tfn(const GConvArgs& a, hipStream_t st) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   if (maxM == 0) return 0;
-  const size_t smem = 2 * (size_t)(BM + BN) * 8 * sizeof(f32x4);
-  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST>;
+  const size_t smem = NBUF * (size_t)(BM + BN) * 8 * sizeof(f32x4);
+  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST, NBUF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -599,6 +629,12 @@ static int launch_gconv_tf(const GConvArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
   IPR_LAUNCH_CHECK();
   return 0;
+}
+
+template <int WGM, int WGN, int WM, int WN, bool FAST>
+static int launch_gconv_tf(const GConvArgs& a, hipStream_t st) {
+  return g_nbuf == 1 ? launch_gconv_tfn<WGM, WGN, WM, WN, FAST, 1>(a, st)
+                     : launch_gconv_tfn<WGM, WGN, WM, WN, FAST, 2>(a, st);
 }
 
 template <int WGM, int WGN, int WM, int WN>
@@ -658,11 +694,11 @@ static WGradPlan wgrad_plan(const iprgan_conv_desc* d) {
   return p;
 }
 
-template <int WGM, int WGN, int WM, int WN>
-static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
+template <int WGM, int WGN, int WM, int WN, int NBUF>
+static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
   constexpr int BN = WGM * WM * 32, BK = WGN * WN * 32;
-  const size_t smem = 2 * (size_t)32 * (BN + BK) * sizeof(float);
-  auto kern = wgrad_kernel<WGM, WGN, WM, WN>;
+  const size_t smem = NBUF * (size_t)32 * (BN + BK) * sizeof(float);
+  auto kern = wgrad_kernel<WGM, WGN, WM, WN, NBUF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -673,6 +709,11 @@ static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
   IPR_LAUNCH_CHECK();
   return 0;
+}
+
+template <int WGM, int WGN, int WM, int WN>
+static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
+  return g_nbuf == 1 ? launch_wgrad_tn<WGM, WGN, WM, WN, 1>(a, p, st) : launch_wgrad_tn<WGM, WGN, WM, WN, 2>(a, p, st);
 }
 
 }  // namespace iprgan

@@ -193,7 +193,7 @@ CYCLEGAN_CFG = {'G': 'Resnet6Blocks', 'D': 'ConvDiscriminator', 'opt': 'Adam',
                 'lambda_A': 10.0, 'lambda_B': 10.0, 'lambda_idt': 0.5, 'epoch': 200}
 
 
-def run_cyclegan_steps(make_cfg, models, device, n_steps=2, batch=1, size=32, seed=51):
+def run_cyclegan_steps(make_cfg, models, device, n_steps=2, batch=1, size=64, seed=51):
     """G step then D step per iteration (experiments/image_translation.py:90-112), white-box on GB."""
     model = models.CycleGAN(make_cfg(CYCLEGAN_CFG), device=device)
     for i, n in enumerate((model.GA, model.GB, model.DA, model.DB)):

@@ -64,7 +64,13 @@ def step_policy(steps, lr=2e-4):
     by overall magnitude only (10 %): at batch 4 they are dominated by that feedback."""
     def policy(k):
         if k.startswith('step0/'):
-            return (1e-3, 1e-4)
+            parts = k.split('/')
+            is_weight = (len(parts) > 2 and not parts[1].startswith(('opt', 'metric'))
+                         and k.split('::')[0].rsplit('.', 1)[-1] not in cases.BUFFER_LEAVES
+                         and parts[1] not in ('fake_sample', 'super_res', 'fake_B'))
+            # weights after the first Adam step: +-lr even where the gradient is pure noise (e.g. the
+            # bias of a conv feeding a norm layer, whose true gradient is zero)
+            return (1e-3, 2 * lr + 1e-4) if is_weight else (1e-3, 1e-4)
         if k.startswith('step'):
             return (1e-2, 1e-3)
         leaf = k.rsplit('.', 1)[-1]
