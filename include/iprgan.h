@@ -136,6 +136,12 @@ size_t iprgan_sn_ws_floats(int rows, int cols);
  * in place (skipped when training==0) and writes sigma = u.(W v) to *sigma (device). eps = 1e-12. */
 int iprgan_sn_power_iter(const float* w, float* u, float* v, float* sigma, float* ws, int rows,
                          int cols, float eps, int training, void* stream);
+/* The same for n layers at once (HOST arrays of DEVICE pointers / sizes, n <= 16): sigma[l] out; u_out/v_out
+ * (optional) receive this pass's u, v copies that the backward needs. 4 launches for a whole network. */
+size_t iprgan_sn_multi_ws_floats(const int* rows, const int* cols, int n);
+int iprgan_sn_power_iter_multi(const float* const* w, float* const* u, float* const* v, float* const* u_out,
+                               float* const* v_out, float* sigma, float* ws, const int* rows, const int* cols,
+                               int n, float eps, int training, void* stream);
 /* dW_orig = (dW_sn - (sum dW_sn*W)/sigma * u v^T) / sigma   (autograd through sigma, u,v constant) */
 int iprgan_sn_bwd(const float* dwsn, const float* w, const float* u, const float* v,
                   const float* sigma, float* dw, float* ws, int rows, int cols, void* stream);

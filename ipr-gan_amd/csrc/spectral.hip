@@ -114,6 +114,106 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
   }
 }
 
+
+// ---- multi-layer form: the power iterations of ALL spectrally-normalised layers of a network depend only
+// on the weights, so one pass runs them together: 4 launches per discriminator pass instead of 4 per layer.
+#define SN_MAX_LAYERS 16
+struct SNTable {
+  const float* w[SN_MAX_LAYERS];
+  float* u[SN_MAX_LAYERS];
+  float* v[SN_MAX_LAYERS];
+  float* u_out[SN_MAX_LAYERS];      // this pass's copies (later passes overwrite u, v)
+  float* v_out[SN_MAX_LAYERS];
+  int rows[SN_MAX_LAYERS], cols[SN_MAX_LAYERS], nsplit[SN_MAX_LAYERS], rps[SN_MAX_LAYERS];
+  long long ws_off[SN_MAX_LAYERS];  // per layer: tpart [SN_MAX_RSPLIT*cols] then s [rows]
+  int n;
+};
+
+__global__ void snm_wtu_kernel(const SNTable t, float* __restrict__ ws) {
+  const int l = blockIdx.z;
+  const int cols = t.cols[l], rows = t.rows[l];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols || (int)blockIdx.y >= t.nsplit[l]) return;
+  const int r0 = blockIdx.y * t.rps[l];
+  int r1 = r0 + t.rps[l];
+  if (r1 > rows) r1 = rows;
+  const float* w = t.w[l];
+  const float* u = t.u[l];
+  float s = 0.f;
+  for (int i = r0; i < r1; ++i) s += w[(size_t)i * cols + j] * u[i];
+  ws[t.ws_off[l] + (size_t)blockIdx.y * cols + j] = s;
+}
+__global__ __launch_bounds__(1024) void snm_v_kernel(const SNTable t, float* __restrict__ ws, float eps) {
+  __shared__ float sh[16];
+  const int l = blockIdx.x;
+  const int cols = t.cols[l], nsplit = t.nsplit[l];
+  const float* tpart = ws + t.ws_off[l];
+  float ss = 0.f;
+  for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+    float a = 0.f;
+    for (int s = 0; s < nsplit; ++s) a += tpart[(size_t)s * cols + j];
+    ss += a * a;
+  }
+  const float inv = 1.f / fmaxf(sqrtf(block_sum(ss, sh)), eps);
+  float* v = t.v[l];
+  float* vo = t.v_out[l];
+  for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+    float a = 0.f;
+    for (int s = 0; s < nsplit; ++s) a += tpart[(size_t)s * cols + j];
+    a *= inv;
+    v[j] = a;
+    if (vo) vo[j] = a;
+  }
+}
+__global__ __launch_bounds__(256) void snm_wv_kernel(const SNTable t, float* __restrict__ ws) {
+  __shared__ float sh[16];
+  const int l = blockIdx.y, row = blockIdx.x;
+  const int cols = t.cols[l];
+  if (row >= t.rows[l]) return;
+  const float* wr = t.w[l] + (size_t)row * cols;
+  const float* v = t.v[l];
+  float acc = 0.f;
+  if ((cols & 3) == 0) {
+    for (int j = threadIdx.x * 4; j < cols; j += 1024) {
+      const float4 a = *(const float4*)(wr + j), b = *(const float4*)(v + j);
+      acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+  } else {
+    for (int j = threadIdx.x; j < cols; j += 256) acc += wr[j] * v[j];
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) ws[t.ws_off[l] + (size_t)SN_MAX_RSPLIT * cols + row] = acc;
+}
+__global__ __launch_bounds__(1024) void snm_u_kernel(const SNTable t, const float* __restrict__ ws, float eps,
+                                                      float* __restrict__ sigma, int training) {
+  __shared__ float sh[16];
+  const int l = blockIdx.x;
+  const int rows = t.rows[l], cols = t.cols[l];
+  const float* s = ws + t.ws_off[l] + (size_t)SN_MAX_RSPLIT * cols;
+  float* u = t.u[l];
+  float* uo = t.u_out[l];
+  float d = 0.f;
+  if (training) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) ss += s[i] * s[i];
+    const float inv = 1.f / fmaxf(sqrtf(block_sum(ss, sh)), eps);
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+      const float un = s[i] * inv;
+      u[i] = un;
+      if (uo) uo[i] = un;
+      d += un * s[i];
+    }
+  } else {
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+      d += u[i] * s[i];
+      if (uo) uo[i] = u[i];
+    }
+    if (t.v_out[l]) for (int j = threadIdx.x; j < cols; j += blockDim.x) t.v_out[l][j] = t.v[l][j];
+  }
+  d = block_sum(d, sh);
+  if (threadIdx.x == 0) sigma[l] = d;
+}
+
 }  // namespace iprgan
 
 using namespace iprgan;
@@ -146,6 +246,51 @@ int iprgan_sn_power_iter(const float* w, float* u, float* v, float* sigma, float
   hipLaunchKernelGGL(sn_wv_kernel, dim3(rows), dim3(256), 0, st, w, v, s, rows, cols);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(sn_u_final_kernel, dim3(1), dim3(1024), 0, st, s, rows, eps, u, sigma, training);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+
+size_t iprgan_sn_multi_ws_floats(const int* rows, const int* cols, int n) {
+  size_t t = 0;
+  for (int i = 0; i < n; ++i) t += (size_t)SN_MAX_RSPLIT * cols[i] + rows[i] + 16;
+  return t;
+}
+
+int iprgan_sn_power_iter_multi(const float* const* w, float* const* u, float* const* v, float* const* u_out,
+                               float* const* v_out, float* sigma, float* ws, const int* rows, const int* cols,
+                               int n, float eps, int training, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  IPR_CHECK(n >= 1 && n <= SN_MAX_LAYERS, "sn_power_iter_multi: %d layers (max %d)", n, SN_MAX_LAYERS);
+  SNTable t;
+  memset(&t, 0, sizeof(t));
+  t.n = n;
+  long long off = 0;
+  int max_cols = 0, max_rows = 0, max_split = 1;
+  for (int i = 0; i < n; ++i) {
+    t.w[i] = w[i]; t.u[i] = u[i]; t.v[i] = v[i];
+    t.u_out[i] = u_out ? u_out[i] : nullptr; t.v_out[i] = v_out ? v_out[i] : nullptr;
+    t.rows[i] = rows[i]; t.cols[i] = cols[i];
+    int ns = rows[i] / 32;
+    if (ns < 1) ns = 1;
+    if (ns > SN_MAX_RSPLIT) ns = SN_MAX_RSPLIT;
+    t.rps[i] = cdiv(rows[i], ns);
+    t.nsplit[i] = cdiv(rows[i], t.rps[i]);
+    t.ws_off[i] = off;
+    off += (long long)SN_MAX_RSPLIT * cols[i] + rows[i] + 16;
+    if (cols[i] > max_cols) max_cols = cols[i];
+    if (rows[i] > max_rows) max_rows = rows[i];
+    if (t.nsplit[i] > max_split) max_split = t.nsplit[i];
+  }
+  if (training) {
+    hipLaunchKernelGGL(snm_wtu_kernel, dim3(cdiv(max_cols, 256), max_split, n), dim3(256), 0, st, t, ws);
+    IPR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(snm_v_kernel, dim3(n), dim3(1024), 0, st, t, ws, eps);
+    IPR_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(snm_wv_kernel, dim3(max_rows, n), dim3(256), 0, st, t, ws);
+  IPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(snm_u_kernel, dim3(n), dim3(1024), 0, st, t, ws, eps, sigma, training);
   IPR_LAUNCH_CHECK();
   return 0;
 }

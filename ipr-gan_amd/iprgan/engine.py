@@ -99,8 +99,8 @@ class Conv(Op):
         sp = self.spec
         B, H, W, _ = x.shape
         d = sp.desc(B, H, W)
-        sigma = None
-        if self.sn is not None:
+        sigma = st.get('sigma')             # set by Chain's batched spectral-norm pre-pass
+        if self.sn is not None and sigma is None:
             u, v = self.sn
             sigma = ops.sn_power_iter(self.weight, u, v, train)
             st['u'], st['v'] = u.clone(), v.clone()     # this pass's u, v (later passes overwrite the buffers)
@@ -236,6 +236,10 @@ class GemvHead(Op):
         return self.m.bias
 
     @property
+    def sn(self):
+        return (self.m.weight_u, self.m.weight_v)
+
+    @property
     def u(self):
         return self.m.weight_u
 
@@ -250,8 +254,10 @@ class GemvHead(Op):
     def forward(self, x, st, train):
         B = x.shape[0]
         K = self.C * self.HW
-        sigma = ops.sn_power_iter(self.weight, self.u, self.v, train)
-        st['u'], st['v'] = self.u.clone(), self.v.clone()
+        sigma = st.get('sigma')
+        if sigma is None:
+            sigma = ops.sn_power_iter(self.weight, self.u, self.v, train)
+            st['u'], st['v'] = self.u.clone(), self.v.clone()
         wp = ops.permute_021(self.weight, self.C, self.HW, 1)
         x2 = x.view(B, K)
         y = ops.gemv_fwd(x2, wp, self.bias, sigma)
@@ -382,15 +388,20 @@ class Chain:
 class ChainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, chain, train, x, *params):
-        stash = []
         h = x.detach()
         if h.dtype != torch.float32:
             raise RuntimeError('iprgan networks take float32 inputs')
         shared = {'skips': [], 'skip_grads': []}
-        for op in chain.ops:
-            st = {'ctx': shared}
+        stash = [{'ctx': shared} for _ in chain.ops]
+        # spectral norm depends on the weights only: run every layer's power iteration up front, together
+        sn_idx = [i for i, op in enumerate(chain.ops) if getattr(op, 'sn', None) is not None]
+        if sn_idx:
+            ws_, us_, vs_ = zip(*[(chain.ops[i].weight,) + tuple(chain.ops[i].sn) for i in sn_idx])
+            sig, uo, vo = ops.sn_power_iter_multi(list(ws_), list(us_), list(vs_), train)
+            for k, i in enumerate(sn_idx):
+                stash[i].update(sigma=sig[k:k + 1], u=uo[k], v=vo[k])
+        for op, st in zip(chain.ops, stash):
             h = op.forward(h, st, train)
-            stash.append(st)
         ctx.chain, ctx.stash = chain, stash
         return h
 

@@ -14,6 +14,10 @@ def c4(c):
     return (c + 3) & ~3
 
 
+def _int_table(sizes):
+    return (C.c_int * len(sizes))(*sizes)
+
+
 def empty(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
@@ -160,6 +164,23 @@ def sn_power_iter(w_orig, u, v, training, eps=1e-12):
     return sigma
 
 
+def sn_power_iter_multi(weights, us, vs, training, eps=1e-12):
+    """One power iteration for every (weight_orig, u, v) triple in 4 launches.  Returns (sigmas [n] device
+    tensor, u copies, v copies): the copies are this pass's vectors for its backward."""
+    n = len(weights)
+    rows = [w.shape[0] for w in weights]
+    cols = [w.numel() // w.shape[0] for w in weights]
+    sig = empty((n,), weights[0])
+    u_out = [torch.empty_like(u) for u in us]
+    v_out = [torch.empty_like(v) for v in vs]
+    r, c = _int_table(rows), _int_table(cols)
+    ws = empty((query('iprgan_sn_multi_ws_floats', r, c, n),), weights[0])
+    call('iprgan_sn_power_iter_multi', L.ptr_table(weights), L.ptr_table(us), L.ptr_table(vs),
+         L.ptr_table(u_out), L.ptr_table(v_out), ptr(sig), ptr(ws), r, c, n, float(eps),
+         1 if training else 0, stream())
+    return sig, u_out, v_out
+
+
 def sn_bwd(dwsn, w_orig, u, v, sigma):
     rows = w_orig.shape[0]
     cols = w_orig.numel() // rows
@@ -185,8 +206,6 @@ def loss_bwd(kind, x, y, gscale):
 
 
 # ---- sign loss ------------------------------------------------------------------------------------
-def _int_table(sizes):
-    return (C.c_int * len(sizes))(*sizes)
 
 
 def sign_loss_fwd(gammas, signs, gamma0):
