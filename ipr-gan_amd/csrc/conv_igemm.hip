@@ -726,8 +726,9 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
 struct WGradPlan {
   int N, Cq, Ps, Qs, ntap, Kw, Nrows, bn, bk, tiles, nsplit, cps, M;
 };
-static WGradPlan wgrad_plan(const iprgan_conv_desc* d) {
-  WGradPlan p;
+// cand: 0 = 128x128 tiles, 1 = 64x64, 2 = 128x64, each x {768, 1536, 384} target blocks (cand / 3 selects)
+#define WGRAD_NCAND 9
+static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   const Shape s = out_shape(d);
   // P = grid-aligned tensor (Conv2d: dy [OH,OW,Cout]; ConvT: x [H,W,Cin]); Q = gathered tensor
   p.N = d->transposed ? d->Cin : d->Cout;
@@ -737,19 +738,44 @@ static WGradPlan wgrad_plan(const iprgan_conv_desc* d) {
   const int PH = d->transposed ? d->H : s.OH, PW = d->transposed ? d->W : s.OW;
   p.M = d->B * PH * PW;
   const int K = p.ntap * p.Qs;
-  p.bn = p.N >= 128 ? 128 : (p.N > 32 ? 64 : 32);
-  p.bk = (p.bn == 32) ? 128 : (K >= 128 && p.bn == 128 ? 128 : 64);
-  if (p.bn == 64) p.bk = 64;
+  const int shape = cand % 3, target = cand / 3 == 0 ? 768 : (cand / 3 == 1 ? 1536 : 384);
+  if (p.N <= 32) {
+    if (shape != 0) return false;
+    p.bn = 32; p.bk = 128;
+  } else if (shape == 0) {
+    if (p.N < 128 || K < 128) return false;
+    p.bn = 128; p.bk = 128;
+  } else if (shape == 1) {
+    p.bn = 64; p.bk = 64;
+  } else {
+    if (p.N < 128) return false;
+    p.bn = 128; p.bk = 64;
+  }
   p.Kw = rup(K, p.bk);
   p.Nrows = rup(p.N, p.bn);
   p.tiles = (p.Kw / p.bk) * (p.Nrows / p.bn);
   const int chunks = cdiv(p.M, 32);
-  int want = cdiv(768, p.tiles);
+  int want = cdiv(target, p.tiles);
   if (want < 1) want = 1;
   if (want > chunks) want = chunks;
   p.cps = cdiv(chunks, want);
   p.nsplit = cdiv(chunks, p.cps);
+  return true;
+}
+static WGradPlan wgrad_plan(const iprgan_conv_desc* d) {       // the un-tuned default
+  WGradPlan p;
+  if (!wgrad_plan_c(d, 0, p)) wgrad_plan_c(d, 1, p);
   return p;
+}
+static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that fits every candidate
+  size_t m = 0;
+  for (int c = 0; c < WGRAD_NCAND; ++c) {
+    WGradPlan p;
+    if (!wgrad_plan_c(d, c, p)) continue;
+    const size_t n = (size_t)p.nsplit * p.Nrows * p.Kw;
+    if (n > m) m = n;
+  }
+  return m;
 }
 
 template <int WGM, int WGN, int WM, int WN, int NBUF>
@@ -862,44 +888,43 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
 }
 
 size_t iprgan_conv_wgrad_ws_floats(const iprgan_conv_desc* d) {
-  const WGradPlan p = wgrad_plan(d);
   const Shape s = out_shape(d);
-  return (size_t)p.nsplit * p.Nrows * p.Kw + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout));
+  return wgrad_slab_floats(d) + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout));
 }
 
 int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const float* dy, float* dw,
                            float* db, float* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const WGradPlan p = wgrad_plan(d);
   const Shape s = out_shape(d);
-  WGradArgs a;
-  memset(&a, 0, sizeof(a));
-  a.P = d->transposed ? x : dy;
-  a.Q = d->transposed ? dy : x;
-  a.ws = ws;
-  a.Ps = p.Ps; a.Pvalid = p.Ps;
-  a.QH = d->transposed ? s.OH : d->H; a.QW = d->transposed ? s.OW : d->W;
-  a.Qs = p.Qs; a.c4n = p.Qs / 4; a.d_c4n = make_fastdiv(a.c4n);
-  a.PH = d->transposed ? d->H : s.OH; a.PW = d->transposed ? d->W : s.OW;
-  a.M = p.M;
-  a.d_pw = make_fastdiv(a.PW); a.d_plane = make_fastdiv(a.PH * a.PW); a.d_tw = make_fastdiv(d->KW);
-  a.isy = a.isx = d->stride; a.pad = d->pad; a.tw = d->KW; a.ntap = p.ntap;
-  a.pad_mode = d->pad_mode;
-  a.Kw = p.Kw; a.Nrows = p.Nrows; a.chunks_per_split = p.cps;
-  {
+  auto run = [&](int cand) -> int {
+    WGradPlan p;
+    if (!wgrad_plan_c(d, cand, p)) return -1;
+    WGradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.P = d->transposed ? x : dy;
+    a.Q = d->transposed ? dy : x;
+    a.ws = ws;
+    a.Ps = p.Ps; a.Pvalid = p.Ps;
+    a.QH = d->transposed ? s.OH : d->H; a.QW = d->transposed ? s.OW : d->W;
+    a.Qs = p.Qs; a.c4n = p.Qs / 4; a.d_c4n = make_fastdiv(a.c4n);
+    a.PH = d->transposed ? d->H : s.OH; a.PW = d->transposed ? d->W : s.OW;
+    a.M = p.M;
+    a.d_pw = make_fastdiv(a.PW); a.d_plane = make_fastdiv(a.PH * a.PW); a.d_tw = make_fastdiv(d->KW);
+    a.isy = a.isx = d->stride; a.pad = d->pad; a.tw = d->KW; a.ntap = p.ntap;
+    a.pad_mode = d->pad_mode;
+    a.Kw = p.Kw; a.Nrows = p.Nrows; a.chunks_per_split = p.cps;
     const unsigned long long pb = (unsigned long long)a.M * a.Ps * 4ull;
     const unsigned long long qb = (unsigned long long)d->B * a.QH * a.QW * a.Qs * 4ull;
     IPR_CHECK(pb < 0x7fffffffull && qb < 0x7fffffffull, "conv_bwd_weight: tensor larger than 2 GiB");
     a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
-  }
-  a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
-  int rc;
-  if (p.bn == 128 && p.bk == 128) rc = launch_wgrad_t<2, 2, 2, 2>(a, p, st);
-  else if (p.bn == 64) rc = launch_wgrad_t<2, 2, 1, 1>(a, p, st);
-  else if (p.bn == 128) rc = launch_wgrad_t<2, 2, 2, 1>(a, p, st);
-  else rc = launch_wgrad_t<1, 4, 1, 1>(a, p, st);     // bn == 32, bk == 128
-  if (rc) return rc;
-  {
+    a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW
+                            : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
+    int rc;
+    if (p.bn == 128 && p.bk == 128) rc = launch_wgrad_t<2, 2, 2, 2>(a, p, st);
+    else if (p.bn == 64) rc = launch_wgrad_t<2, 2, 1, 1>(a, p, st);
+    else if (p.bn == 128) rc = launch_wgrad_t<2, 2, 2, 1>(a, p, st);
+    else rc = launch_wgrad_t<1, 4, 1, 1>(a, p, st);     // bn == 32, bk == 128
+    if (rc) return rc;
     const long long total = (long long)p.N * p.ntap * p.Qs;
     IPR_CHECK(total < (1ll << 31), "conv_bwd_weight: weight too large");
     const long long sn = (long long)p.Cq * p.ntap, sc = p.ntap;
@@ -907,10 +932,50 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
                        p.nsplit, p.Nrows, p.Kw, p.N, p.Cq, p.Qs, p.ntap, make_fastdiv(p.Qs),
                        make_fastdiv(p.ntap * p.Qs), sn, sc);
     IPR_LAUNCH_CHECK();
+    return 0;
+  };
+  int cand = 0;
+  {
+    WGradPlan p0;
+    if (!wgrad_plan_c(d, 0, p0)) cand = 1;
+  }
+  if (g_autotune) {     // same scheme as the forward/backward-data tiles: time every candidate once per geometry
+    TuneKey key = {{d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->outpad,
+                    d->transposed, d->pad_mode, -7, 0, 0, 0}};
+    auto it = g_tune.find(key);
+    if (it != g_tune.end()) {
+      cand = it->second;
+    } else {
+      const bool prof_was = g_prof_on;
+      g_prof_on = false;
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      float best_ms = 1e30f;
+      for (int c = 0; c < WGRAD_NCAND; ++c) {
+        const int rc = run(c);
+        if (rc == -1) continue;
+        if (rc) { g_prof_on = prof_was; return rc; }
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < 3; ++r) run(c);
+        (void)hipEventRecord(e1, st);
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+        if (ms < best_ms) { best_ms = ms; cand = c; }
+      }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      g_prof_on = prof_was;
+      g_tune[key] = cand;
+    }
+  }
+  {
+    const int rc = run(cand);
+    if (rc) return rc;
   }
   if (db) {
     const int Cs = c4(d->Cout), M = d->B * s.OH * s.OW;
-    float* part = ws + (size_t)p.nsplit * p.Nrows * p.Kw;
+    float* part = ws + wgrad_slab_floats(d);
     const int rc2 = colsum_launch(dy, db, part, M, Cs, d->Cout, st);
     if (rc2) return rc2;
   }
