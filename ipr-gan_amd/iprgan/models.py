@@ -17,7 +17,8 @@ from . import networks, optim, tools
 from .parallel import GradReducer, Replica, broadcast_module
 from .tools import loss_value
 
-__all__ = ['Model', 'Wrapper', 'DCGAN', 'SRGAN', 'CycleGAN', 'ImagePool', 'WhiteBoxWrapper']
+__all__ = ['Model', 'Wrapper', 'DCGAN', 'SRGAN', 'CycleGAN', 'ImagePool', 'WhiteBoxWrapper',
+           'DisableBatchNormStats']
 
 
 class Model(ABC):
@@ -138,20 +139,18 @@ class DCGAN(Model):
         self.forward_d(data)
         self.compute_d_loss()
         self.optD.zero_grad()
+        self.reduceD.arm()
         self.LossD.backward()
-        self.reduceD.reduce()
-        self.reduceD.wait()
-        self.optD.step()
+        _step(self.optD, self.reduceD)
 
     def update_g(self, data, update=True):
         self.forward_g(data)
         self.compute_g_loss()
         if update:
             self.optG.zero_grad()
+            self.reduceG.arm()
             self.LossG.backward()
-            self.reduceG.reduce()
-            self.reduceG.wait()
-            self.optG.step()
+            _step(self.optG, self.reduceG)
 
 
 class SRGAN(Model):
@@ -226,6 +225,7 @@ class SRGAN(Model):
         self.forward_d(data)
         self.compute_d_loss()
         self.optD.zero_grad()
+        self.reduceD.arm()
         self.LossD.backward()
         _step(self.optD, self.reduceD)
 
@@ -234,6 +234,7 @@ class SRGAN(Model):
         self.compute_g_loss()
         if update:
             self.optG.zero_grad()
+            self.reduceG.arm()
             self.LossG.backward()
             _step(self.optG, self.reduceG)
 
@@ -367,6 +368,7 @@ class CycleGAN(Model):
         self.compute_g_loss()
         if update:
             self.optG.zero_grad()
+            self.reduceG.arm()
             self.LossG.backward()
             _step(self.optG, self.reduceG)
 
@@ -374,9 +376,29 @@ class CycleGAN(Model):
         self.forward_d(data)
         self.compute_d_loss()
         self.optD.zero_grad()
+        self.reduceD.arm()
         self.LossDA.backward()
         self.LossDB.backward()
         _step(self.optD, self.reduceD)
+
+
+class DisableBatchNormStats(object):
+    """models/util.py:55-69 - inside the block every BatchNorm2d of ``model`` normalises with batch
+    statistics and leaves its running statistics untouched (used by the black-box watermark pass)."""
+
+    def __init__(self, model):
+        self.model, self.cache = model, {}
+
+    def __enter__(self):
+        for name, m in self.model.named_modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                self.cache[name] = m.track_running_stats
+                m.track_running_stats = False
+
+    def __exit__(self, *args):
+        for name, m in self.model.named_modules():
+            if name in self.cache:
+                m.track_running_stats = self.cache[name]
 
 
 class Wrapper(Model):
@@ -443,9 +465,7 @@ class WhiteBoxWrapper(Wrapper):
         if update:
             self.model.optG.zero_grad()
             loss = self.LossG + self.Lambda * self.LossW + self.LossS
-            loss.backward()
             red = self.model.reduceG
-            if red is not None:
-                red.reduce()
-                red.wait()
-            self.model.optG.step()
+            red.arm()
+            loss.backward()
+            _step(self.model.optG, red)

@@ -28,23 +28,40 @@ def _worker(rank, world, port, out):
     from iprgan.parallel import GradReducer, broadcast_module
     torch.manual_seed(100 + rank)                              # ranks start different on purpose
     net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.BatchNorm1d(7), torch.nn.Linear(7, 3))
+    frozen = torch.nn.Parameter(torch.ones(4))                 # a parameter that gets no gradient
     broadcast_module(net)
     flat0 = torch.cat([t.flatten().float() for t in list(net.parameters()) + list(net.buffers())])
-    params = list(net.parameters())
-    for i, p in enumerate(params):
-        p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
-    params[1].grad = None                                      # a parameter without gradient on this step
-    red = GradReducer(params)
+    params = list(net.parameters()) + [frozen]
+    x = torch.randn(6, 5)                                      # each rank its own shard of the batch
+
+    def backward():
+        for p in params:
+            p.grad = None
+        net(x).square().mean().backward()
+
+    backward()
+    want = []
+    for p in params:                                           # expected: mean over ranks of the local grads
+        g = torch.zeros_like(p) if p.grad is None else p.grad.clone()
+        dist.all_reduce(g)
+        want.append(g / world)
+    red = GradReducer(params, bucket_mb=0.0001)                # tiny buckets -> several buckets, hook path
+    red.arm()
+    backward()                                                 # hooks launch the bucket reductions
     red.reduce()
     red.wait()
-    mean = sum(range(1, world + 1)) / world
-    ok = all(torch.allclose(p.grad, torch.full_like(p, mean * (i + 1))) for i, p in enumerate(params) if i != 1)
-    ok = ok and bool((params[1].grad == 0).all())
+    ok = all(torch.allclose(p.grad, w, atol=1e-7) for p, w in zip(params, want))
+    nb = len(red.buckets)
+    red.arm()                                                  # a second step reuses the buckets
+    backward()
+    red.reduce()
+    red.wait()
+    ok = ok and all(torch.allclose(p.grad, w, atol=1e-7) for p, w in zip(params, want))
     gathered = [torch.zeros_like(flat0) for _ in range(world)]
     dist.all_gather(gathered, flat0)
     same = all(torch.equal(gathered[0], g) for g in gathered)
     if rank == 0:
-        torch.save({'ok': ok, 'same': same}, out)
+        torch.save({'ok': ok, 'same': same, 'buckets': nb}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,6 +72,7 @@ def test_grad_bucket_allreduce_and_broadcast_world2(tmp_path):
     res = torch.load(out)
     assert res['ok'], 'averaged gradients wrong'
     assert res['same'], 'replicas differ after broadcast'
+    assert res['buckets'] > 1
 
 
 def test_world1_is_noop():
@@ -62,5 +80,5 @@ def test_world1_is_noop():
     p = torch.nn.Parameter(torch.ones(3))
     p.grad = torch.full_like(p, 2.0)
     r = GradReducer([p])
-    r.reduce(); r.wait()
+    r.arm(); r.reduce(); r.wait()
     assert torch.equal(p.grad, torch.full_like(p, 2.0))
