@@ -28,7 +28,8 @@ static ProfSlot g_slots[] = {
     {"gconv_kernel<64x64>", 0, 0, 0},   {"gconv_kernel<128x32>", 0, 0, 0},
     {"wgrad_kernel<128x128>", 0, 0, 0}, {"wgrad_kernel<128x64>", 0, 0, 0},
     {"wgrad_kernel<64x64>", 0, 0, 0},   {"wgrad_kernel<32x128>", 0, 0, 0},
-    {"gconv_kernel<64x128>", 0, 0, 0},
+    {"gconv_kernel<64x128>", 0, 0, 0},  {"gconv_kernel<128x128,8w>", 0, 0, 0},
+    {"gconv_kernel<128x64,8w>", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; };
@@ -102,10 +103,11 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned v
 // wave-uniform (scalar registers), borders are handled by the buffer bounds check (no branches).
 // !FAST: reflect padding and/or Cs in {4,8,16} (taps change inside a K step; RGB layers).
 template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK>
-__global__ __launch_bounds__(256) void gconv_kernel(const GConvArgs a) {
+__global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+  constexpr int NT = WGM * WGN * 64;            // threads: one wave per (32*WM)x(32*WN) sub-tile
   constexpr int CH = BK / 4;                    // 16-byte chunks per tile row (K step = BK floats)
-  constexpr int RP = 256 / CH;                  // tile rows loaded per pass of the 256 threads
+  constexpr int RP = NT / CH;                   // tile rows loaded per pass of the block
   constexpr int RA = BM / RP, RB = BN / RP;
   constexpr int TILE4 = (BM + BN) * CH;         // 16-byte chunks per stage buffer
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
@@ -637,8 +639,8 @@ static int launch_gconv_tfnk(const GConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.nphase);
-  ProfScope prof(st, BM == 128 ? (BN == 128 ? 0 : (BN == 64 ? 1 : 3)) : (BN == 128 ? 8 : 2), a.flops);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  ProfScope prof(st, WGM * WGN == 8 ? (BN == 128 ? 9 : 10) : BM == 128 ? (BN == 128 ? 0 : (BN == 64 ? 1 : 3)) : (BN == 128 ? 8 : 2), a.flops);
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), smem, st, a);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -680,6 +682,8 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
       case 0: return launch_gconv_t<2, 2, 2, 2>(a, st);
       case 1: return launch_gconv_t<2, 2, 2, 1>(a, st);
       case 3: return launch_gconv_t<2, 2, 1, 2>(a, st);
+      case 4: return launch_gconv_t<2, 4, 2, 1>(a, st);      // 128x128, 8 waves of 64x32
+      case 5: return launch_gconv_t<4, 2, 1, 1>(a, st);      // 128x64, 8 waves of 32x32
       default: return launch_gconv_t<2, 2, 1, 1>(a, st);
     }
   };
@@ -704,8 +708,8 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   (void)hipEventCreate(&e1);
   float best_ms = 1e30f;
   int best = tile;
-  for (int cand = 0; cand < 4; ++cand) {
-    if ((cand == 0 || cand == 3) && N < 128) continue;
+  for (int cand = 0; cand < 6; ++cand) {
+    if ((cand == 0 || cand == 3 || cand == 4) && N < 128) continue;
     int rc = run(cand);                       // warm-up (also sets the LDS attribute)
     if (rc) { g_prof_on = prof_was; return rc; }
     (void)hipEventRecord(e0, st);
@@ -719,6 +723,9 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   (void)hipEventDestroy(e1);
   g_prof_on = prof_was;
   g_tune[key] = best;
+  if (getenv("IPRGAN_TUNE_LOG"))
+    fprintf(stderr, "[iprgan tune] gconv B%d in %dx%dx%d out %dx%dx%d taps %dx%d phases %d -> tile %d (%.1f us)\n", a.B,
+            a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.ph[0].th, a.ph[0].tw, a.nphase, best, best_ms * 1000.f / 3);
   return run(best);
 }
 
