@@ -62,13 +62,16 @@ size_t iprgan_conv_wgrad_ws_floats(const iprgan_conv_desc* d);
  * wfwd / wbwd (either may be NULL): tap-major operands for forward and for backward-data. */
 int iprgan_conv_weight_prep(const iprgan_conv_desc* d, const float* w, const float* inv_scale,
                             float* wfwd, float* wbwd, void* stream);
-/* y = act(conv(x, w) + bias); bias may be NULL (length Cout). */
+/* y = act(conv(x, w) + bias); bias may be NULL (length Cout).  ws: optional workspace of
+ * iprgan_conv_fwd_ws_floats(d) floats (non-zero only for layers with <= 4 output channels, which then run as
+ * one dense 1x1 GEMM over tap planes + a gather instead of a 3/32-full MFMA tile); NULL = generic kernel. */
+size_t iprgan_conv_fwd_ws_floats(const iprgan_conv_desc* d);
 int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd, const float* bias,
-                    float* y, void* stream);
+                    float* y, float* ws, void* stream);
 /* dx = conv_bwd_data(dy, w) [* act'(x_out_prev)]: if prev_out != NULL the result is multiplied by the
  * derivative of activation prev_act evaluated from the saved OUTPUT prev_out of the previous layer
  * (same shape as dx), i.e. the previous layer's activation backward is fused into this epilogue. */
-size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d);   /* non-zero only for reflect padding */
+size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d);   /* reflect padding, or <= 4 input channels */
 int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
                          const float* prev_out, int prev_act, float prev_slope, void* stream);
 /* dw (PyTorch layout, overwritten) = conv_bwd_weight(x, dy); db (optional, length Cout) = sum dy.

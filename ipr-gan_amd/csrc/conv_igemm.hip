@@ -80,6 +80,9 @@ struct GConvArgs {
   float aux_slope;
   unsigned in_bytes, wt_bytes;
   int linear_out;
+  int planar_M;        // > 0: store output channel n at plane n>>2 (tap-planar T of the small-N path)
+  float* ws;           // host-side only: workspace for the small-N path (may be null)
+  size_t ws_floats;
   int nphase;
   Phase ph[4];
   double flops;   // algorithmic 2*MAC of this launch (host-side bookkeeping only)
@@ -307,11 +310,76 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
         float v = acc[i][j][r];
         if (a.bias && n < a.N) v += a.bias[n];
         v = act_apply(v, a.act, a.slope);
-        const size_t idx = opix * a.Ns + n;
+        const size_t idx = a.planar_M ? ((size_t)(n >> 2) * a.planar_M + opix) * 4 + (n & 3) : opix * a.Ns + n;
         if (a.aux) v *= act_grad_from_out(a.aux[idx], a.aux_act, a.aux_slope);
         a.out[idx] = v;
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tiny-Cout convolutions (RGB heads: 64->3 k3/k7/k9, and the data gradient of RGB stems): on the MFMA tile
+// the 3 output channels would use 3 of 32 columns.  Instead:  T[tap][pix][n] = sum_c in[pix][c] W[n][tap][c]
+// is ONE dense 1x1 GEMM with N' = taps*4 columns (full MFMA tiles), and out[pix][n] = sum_tap T[tap][pix+tap][n]
+// is a coalesced gather over tap planes (HBM-bound).  Stride-1 forward- or backward-form geometries only.
+// ------------------------------------------------------------------------------------------
+__global__ void smalln_weight_kernel(const float* __restrict__ wt, float* __restrict__ w2, int Kp, int Cs,
+                                     int ntap, int tw, int wbase, int wsy, int wsx, int rows_alloc) {
+  const int total = rows_alloc * Cs;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % Cs, r = i / Cs;
+    const int t = r >> 2, n = r & 3;
+    float v = 0.f;
+    if (t < ntap) {
+      const int ty = t / tw, tx = t - ty * tw;
+      v = wt[(size_t)n * Kp + (size_t)(wbase + ty * wsy + tx * wsx) * Cs + c];
+    }
+    w2[i] = v;
+  }
+}
+
+struct TapGatherArgs {
+  const float* T;
+  const float* bias;
+  const float* aux;
+  float* out;
+  int B, IH, IW, OH, OW, N;
+  int th, tw, dy0, dx0, dys, dxs;
+  int pad_mode, act, aux_act;
+  float slope, aux_slope;
+  long long plane;     // floats per tap plane = B*IH*IW*4
+};
+__global__ void tap_gather_kernel(const TapGatherArgs a) {
+  const long long total = (long long)a.B * a.OH * a.OW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % a.OW);
+    const long long t1 = i / a.OW;
+    const int y = (int)(t1 % a.OH);
+    const long long b = t1 / a.OH;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int ty = 0; ty < a.th; ++ty) {
+      int sy = y + a.dy0 + ty * a.dys;
+      if (a.pad_mode == IPRGAN_PAD_REFLECT) sy = reflect_idx(sy, a.IH);
+      else if ((unsigned)sy >= (unsigned)a.IH) continue;
+      for (int tx = 0; tx < a.tw; ++tx) {
+        int sx = x + a.dx0 + tx * a.dxs;
+        if (a.pad_mode == IPRGAN_PAD_REFLECT) sx = reflect_idx(sx, a.IW);
+        else if ((unsigned)sx >= (unsigned)a.IW) continue;
+        s += *(const f32x4*)(a.T + (size_t)(ty * a.tw + tx) * a.plane + ((b * a.IH + sy) * a.IW + sx) * 4);
+      }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float v = s[n];
+      if (a.bias && n < a.N) v += a.bias[n];
+      v = act_apply(v, a.act, a.slope);
+      if (a.aux) v *= act_grad_from_out(a.aux[i * 4 + n], a.aux_act, a.aux_slope);
+      o[n] = n < a.N ? v : 0.f;
+    }
+    *(f32x4*)(a.out + i * 4) = o;
   }
 }
 
@@ -623,6 +691,7 @@ struct TuneKey {
 };
 static std::map<TuneKey, int> g_tune;
 static int g_autotune = getenv("IPRGAN_AUTOTUNE") ? atoi(getenv("IPRGAN_AUTOTUNE")) : 1;
+static int g_smalln = getenv("IPRGAN_SMALLN") ? atoi(getenv("IPRGAN_SMALLN")) : 1;
 static int g_nbuf = getenv("IPRGAN_LDS_BUFS") ? atoi(getenv("IPRGAN_LDS_BUFS")) : 1;  // 1 = single LDS buffer (measured faster: 3-4 blocks/CU)
 
 template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK>
@@ -663,6 +732,45 @@ static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
   return fast ? launch_gconv_tf<WGM, WGN, WM, WN, true>(a, st) : launch_gconv_tf<WGM, WGN, WM, WN, false>(a, st);
 }
 
+static int launch_gconv(const GConvArgs& ain, hipStream_t st);
+
+static bool smalln_eligible(const GConvArgs& a) {
+  return g_smalln && a.Ns == 4 && a.nphase == 1 && a.isy == 1 && a.isx == 1 && a.osy == 1 && a.osx == 1 &&
+         (a.Cs % 32) == 0 && a.ph[0].ntap >= 2 && !a.planar_M;
+}
+static size_t smalln_ws_floats(const GConvArgs& a) {
+  return (size_t)rup(a.ph[0].ntap * 4, 128) * a.Cs + (size_t)a.ph[0].ntap * a.B * a.IH * a.IW * 4;
+}
+static int launch_smalln(const GConvArgs& a, hipStream_t st) {
+  const Phase& p = a.ph[0];
+  const int ntap = p.ntap, rows = rup(ntap * 4, 128);
+  float* w2 = a.ws;
+  float* T = a.ws + (size_t)rows * a.Cs;
+  hipLaunchKernelGGL(smalln_weight_kernel, dim3(cdiv(rows * a.Cs, 256)), dim3(256), 0, st, a.wt, w2, a.Kp, a.Cs,
+                     ntap, p.tw, p.wbase, p.wsy, p.wsx, rows);
+  IPR_LAUNCH_CHECK();
+  GConvArgs g;
+  memset(&g, 0, sizeof(g));
+  geom_forward_form(g, a.B, a.IH, a.IW, a.Cs, a.IH, a.IW, ntap * 4, 1, 1, 1, 0);
+  g.in = a.in; g.wt = w2; g.out = T;
+  g.planar_M = a.B * a.IH * a.IW;
+  g.flops = a.flops;                       // the algorithmic FLOPs of the convolution are accounted here
+  int rc = launch_gconv(g, st);
+  if (rc) return rc;
+  TapGatherArgs t;
+  memset(&t, 0, sizeof(t));
+  t.T = T; t.bias = a.bias; t.aux = a.aux; t.out = a.out;
+  t.B = a.B; t.IH = a.IH; t.IW = a.IW; t.OH = a.OH; t.OW = a.OW; t.N = a.N;
+  t.th = p.th; t.tw = p.tw; t.dy0 = p.dy0; t.dx0 = p.dx0; t.dys = p.dys; t.dxs = p.dxs;
+  t.pad_mode = a.pad_mode; t.act = a.act; t.slope = a.slope; t.aux_act = a.aux_act; t.aux_slope = a.aux_slope;
+  t.plane = (long long)a.B * a.IH * a.IW * 4;
+  const long long total = (long long)a.B * a.OH * a.OW;
+  hipLaunchKernelGGL(tap_gather_kernel, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)),
+                     dim3(256), 0, st, t);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
 static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   GConvArgs a = ain;
   {
@@ -673,6 +781,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
     a.linear_out = (a.nphase == 1 && a.osy == 1 && a.osx == 1 && a.ph[0].ooy == 0 && a.ph[0].oox == 0) ? 1 : 0;
   }
   IPR_CHECK(a.nphase >= 1 && a.nphase <= 4, "conv: stride %d unsupported (max 2)", a.osy);
+  if (smalln_eligible(a) && a.ws && a.ws_floats >= smalln_ws_floats(a)) return launch_smalln(a, st);
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   const int N = a.Ns;
@@ -844,8 +953,21 @@ int iprgan_conv_weight_prep(const iprgan_conv_desc* d, const float* w, const flo
   return 0;
 }
 
+static size_t smalln_ws_for(const iprgan_conv_desc* d, bool fwd) {
+  // forward of a layer with <= 4 output channels, or backward-data of a layer with <= 4 input channels
+  const int n_out = fwd ? d->Cout : d->Cin, c_red = fwd ? d->Cin : d->Cout;
+  if (!g_smalln || n_out > 4 || d->stride != 1 || (c4(c_red) % 32) != 0 || d->KH * d->KW < 2) return 0;
+  const Shape s = out_shape(d);
+  // source image of the gather: fwd of Conv2d / bwd of ConvT read x-shaped [H,W]; the other two read y-shaped
+  const bool src_is_in = fwd;
+  const long long pix = (long long)d->B * (src_is_in ? (long long)d->H * d->W : (long long)s.OH * s.OW);
+  const int ntap = d->KH * d->KW;
+  return (size_t)rup(ntap * 4, 128) * c4(c_red) + (size_t)ntap * pix * 4;
+}
+size_t iprgan_conv_fwd_ws_floats(const iprgan_conv_desc* d) { return smalln_ws_for(d, true); }
+
 int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd, const float* bias,
-                    float* y, void* stream) {
+                    float* y, float* ws, void* stream) {
   IPR_CHECK(d->stride >= 1 && d->stride <= 2, "conv_fwd: stride %d unsupported", d->stride);
   GConvArgs a;
   memset(&a, 0, sizeof(a));
@@ -860,11 +982,12 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
   a.in = x; a.wt = wfwd; a.bias = bias; a.out = y; a.aux = nullptr;
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = d->act; a.slope = d->slope;
+  a.ws = ws; a.ws_floats = ws ? iprgan_conv_fwd_ws_floats(d) : 0;
   return launch_gconv(a, (hipStream_t)stream);
 }
 
 size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d) {
-  if (d->pad_mode != IPRGAN_PAD_REFLECT) return 0;
+  if (d->pad_mode != IPRGAN_PAD_REFLECT) return smalln_ws_for(d, false);
   return (size_t)d->B * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * c4(d->Cin);
 }
 
@@ -888,7 +1011,7 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
   a.in = dy; a.wt = wbwd; a.bias = nullptr; a.out = reflect ? ws : dx;
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = IPRGAN_ACT_NONE; a.slope = 0.f;
-  if (!reflect) { a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; }
+  if (!reflect) { a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.ws = ws; a.ws_floats = ws ? smalln_ws_for(d, false) : 0; }
   const int rc = launch_gconv(a, (hipStream_t)stream);
   if (rc || !reflect) return rc;
   return iprgan_reflect_fold(ws, dx, prev_out, prev_act, prev_slope, d->B, d->H, d->W, c4(d->Cin), d->pad, stream);

@@ -90,7 +90,9 @@ def conv_prep(spec, d, w, sigma=None, fwd=True, bwd=False):
 def conv_fwd(spec, d, x, wfwd, bias):
     OH, OW = spec.out_hw(d.H, d.W)
     y = empty((d.B, OH, OW, c4(spec.cout)), x)
-    call('iprgan_conv_fwd', C.byref(d), ptr(x), ptr(wfwd), ptr(bias), ptr(y), stream())
+    nws = query('iprgan_conv_fwd_ws_floats', C.byref(d))
+    ws = empty((nws,), x) if nws else None
+    call('iprgan_conv_fwd', C.byref(d), ptr(x), ptr(wfwd), ptr(bias), ptr(y), ptr(ws), stream())
     return y
 
 
