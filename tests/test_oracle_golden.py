@@ -28,7 +28,8 @@ def compare(res, ref, rtol=RTOL, atol=ATOL, policy=None):
             assert np.array_equal(a, b), k
         else:
             r, t = tol(k)[:2]
-            np.testing.assert_allclose(a, b, rtol=r, atol=t, err_msg=k)
+            np.testing.assert_allclose(a, b, rtol=r, atol=t + 2e-5 * float(np.abs(b).max() if b.size else 0.0),
+                                       err_msg=k)
     for p in sorted(summ):
         pol = tol(p)
         if len(pol) == 3:          # (rtol, atol, 'scale'): only the overall magnitude is comparable
@@ -42,7 +43,8 @@ def compare(res, ref, rtol=RTOL, atol=ATOL, policy=None):
             if f in ('sum', 'asum'):      # element-wise slack accumulates like a random walk in the sums
                 at = t * np.sqrt(n_est) + r * float(ref[f'{p}::asum']) * (1.0 if f == 'sum' else 0.0)
             else:
-                at = t
+                # entries far below the tensor's own scale carry that scale's rounding noise
+                at = t + 2e-5 * float(np.abs(b).max())
             np.testing.assert_allclose(a, b, rtol=r, atol=at, err_msg=f'{p}::{f}')
 
 
