@@ -148,6 +148,11 @@ int iprgan_sn_power_iter_multi(const float* const* w, float* const* u, float* co
 /* dW_orig = (dW_sn - (sum dW_sn*W)/sigma * u v^T) / sigma   (autograd through sigma, u,v constant) */
 int iprgan_sn_bwd(const float* dwsn, const float* w, const float* u, const float* v,
                   const float* sigma, float* dw, float* ws, int rows, int cols, void* stream);
+/* n layers at once (HOST arrays of DEVICE pointers; sigma[l] points at that layer's device scalar);
+ * ws >= 64*16 floats. */
+int iprgan_sn_bwd_multi(const float* const* dwsn, const float* const* w, const float* const* u,
+                        const float* const* v, const float* const* sigma, float* const* dw, float* ws,
+                        const int* rows, const int* cols, int n, void* stream);
 
 /* ---- losses (models/dcgan.py:33-40, srgan.py:36-59, cyclegan.py:122-142) ------------------ */
 enum { IPRGAN_LOSS_HINGE_REAL = 0,   /* mean(relu(1-x)) */

@@ -214,6 +214,47 @@ __global__ __launch_bounds__(1024) void snm_u_kernel(const SNTable t, const floa
   if (threadIdx.x == 0) sigma[l] = d;
 }
 
+// ---- multi-layer backward: dW_orig = (dWsn - (sum dWsn*W)/sigma * u v^T)/sigma for n layers in 2 launches
+struct SNBwdTable {
+  const float* dwsn[SN_MAX_LAYERS];
+  const float* w[SN_MAX_LAYERS];
+  const float* u[SN_MAX_LAYERS];
+  const float* v[SN_MAX_LAYERS];
+  const float* sigma[SN_MAX_LAYERS];
+  float* dw[SN_MAX_LAYERS];
+  int rows[SN_MAX_LAYERS], cols[SN_MAX_LAYERS];
+};
+#define SNB_BLOCKS 64
+__global__ __launch_bounds__(256) void snm_dot_kernel(const SNBwdTable t, float* __restrict__ part) {
+  __shared__ float sh[16];
+  const int l = blockIdx.y;
+  const size_t n = (size_t)t.rows[l] * t.cols[l];
+  const float* a = t.dwsn[l];
+  const float* b = t.w[l];
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s += a[i] * b[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[l * SNB_BLOCKS + blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void snm_bwd_apply_kernel(const SNBwdTable t, const float* __restrict__ part) {
+  const int l = blockIdx.y;
+  float dot = 0.f;
+  for (int i = 0; i < SNB_BLOCKS; ++i) dot += part[l * SNB_BLOCKS + i];
+  const float sg = *t.sigma[l];
+  const float coef = dot / sg;
+  const int cols = t.cols[l];
+  const size_t n = (size_t)t.rows[l] * cols;
+  const float* dwsn = t.dwsn[l];
+  const float* u = t.u[l];
+  const float* v = t.v[l];
+  float* dw = t.dw[l];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+    dw[i] = (dwsn[i] - coef * u[r] * v[c]) / sg;
+  }
+}
+
 }  // namespace iprgan
 
 using namespace iprgan;
@@ -291,6 +332,29 @@ int iprgan_sn_power_iter_multi(const float* const* w, float* const* u, float* co
   hipLaunchKernelGGL(snm_wv_kernel, dim3(max_rows, n), dim3(256), 0, st, t, ws);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(snm_u_kernel, dim3(n), dim3(1024), 0, st, t, ws, eps, sigma, training);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+
+int iprgan_sn_bwd_multi(const float* const* dwsn, const float* const* w, const float* const* u,
+                        const float* const* v, const float* const* sigma, float* const* dw, float* ws,
+                        const int* rows, const int* cols, int n, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  IPR_CHECK(n >= 1 && n <= SN_MAX_LAYERS, "sn_bwd_multi: %d layers (max %d)", n, SN_MAX_LAYERS);
+  SNBwdTable t;
+  memset(&t, 0, sizeof(t));
+  size_t maxn = 0;
+  for (int i = 0; i < n; ++i) {
+    t.dwsn[i] = dwsn[i]; t.w[i] = w[i]; t.u[i] = u[i]; t.v[i] = v[i]; t.sigma[i] = sigma[i]; t.dw[i] = dw[i];
+    t.rows[i] = rows[i]; t.cols[i] = cols[i];
+    const size_t e = (size_t)rows[i] * cols[i];
+    if (e > maxn) maxn = e;
+  }
+  hipLaunchKernelGGL(snm_dot_kernel, dim3(SNB_BLOCKS, n), dim3(256), 0, st, t, ws);
+  IPR_LAUNCH_CHECK();
+  const int bx = (int)(cdivz(maxn, 1024) < 512 ? cdivz(maxn, 1024) : 512);
+  hipLaunchKernelGGL(snm_bwd_apply_kernel, dim3(bx > 0 ? bx : 1, n), dim3(256), 0, st, t, ws);
   IPR_LAUNCH_CHECK();
   return 0;
 }

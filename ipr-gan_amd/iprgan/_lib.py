@@ -65,6 +65,7 @@ SIGNATURES = {
     'iprgan_sn_multi_ws_floats': (_Z, [_P, _P, _I]),
     'iprgan_sn_power_iter_multi': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _P]),
     'iprgan_sn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'iprgan_sn_bwd_multi': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'iprgan_loss_ws_floats': (_Z, [_Z]),
     'iprgan_loss_fwd': (_I, [_I, _P, _P, _P, _P, _Z, _P]),
     'iprgan_loss_bwd': (_I, [_I, _P, _P, _P, _P, _Z, _P]),

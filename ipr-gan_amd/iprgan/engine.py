@@ -117,7 +117,7 @@ class Conv(Op):
         if need_w:
             dw, db = ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, self.bias is not None)
             if self.sn is not None:
-                dw = ops.sn_bwd(dw, self.weight, st['u'], st['v'], sigma)
+                st['dwsn'] = dw             # spectral-norm backward of all layers is batched by ChainFn.backward
             grads = [dw] + ([db] if self.bias is not None else [])
         dx = None
         if need_dx:
@@ -271,7 +271,8 @@ class GemvHead(Op):
         grads = []
         if need_w:
             dwsn = ops.permute_021(dwp, self.HW, self.C, 1).view(1, -1)
-            grads = [ops.sn_bwd(dwsn, self.weight, st['u'], st['v'], st['sigma']), db]
+            st['dwsn'] = dwsn
+            grads = [dwsn, db]
         return (dx.view(st['xshape']) if dx is not None else None), grads
 
 
@@ -437,6 +438,14 @@ class ChainFn(torch.autograd.Function):
                 stash[i - 1]['dy_is_preact'] = True
             g, pg = op.backward(g, st, need_dx, op_need_w[i], fuse)
             grads_per_op[i] = pg
+        # batched spectral-norm backward: dW_orig from dW_sn for every SN layer that produced a gradient
+        sn_i = [i for i in range(len(ops_list)) if grads_per_op[i] and 'dwsn' in stash[i]]
+        if sn_i:
+            dws = ops.sn_bwd_multi([stash[i]['dwsn'] for i in sn_i], [ops_list[i].weight for i in sn_i],
+                                   [stash[i]['u'] for i in sn_i], [stash[i]['v'] for i in sn_i],
+                                   [stash[i]['sigma'] for i in sn_i])
+            for i, dw in zip(sn_i, dws):
+                grads_per_op[i][0] = dw.view_as(ops_list[i].weight)
         out = []
         pi = 0
         for i, op in enumerate(ops_list):

@@ -193,6 +193,18 @@ def sn_bwd(dwsn, w_orig, u, v, sigma):
     return dw
 
 
+def sn_bwd_multi(dwsns, weights, us, vs, sigmas):
+    """Spectral-norm backward of several layers in two launches; returns the list of dW_orig."""
+    n = len(weights)
+    rows = [w.shape[0] for w in weights]
+    cols = [w.numel() // w.shape[0] for w in weights]
+    dws = [torch.empty_like(w) for w in weights]
+    ws = empty((64 * 16,), weights[0])
+    call('iprgan_sn_bwd_multi', L.ptr_table(dwsns), L.ptr_table(weights), L.ptr_table(us), L.ptr_table(vs),
+         L.ptr_table(sigmas), L.ptr_table(dws), ptr(ws), _int_table(rows), _int_table(cols), n, stream())
+    return dws
+
+
 # ---- losses ---------------------------------------------------------------------------------------
 def loss_fwd(kind, x, y=None):
     out = empty((), x)
