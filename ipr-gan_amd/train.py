@@ -1,0 +1,209 @@
+"""Thin training driver with the reference's command line and config files:
+
+    python ipr-gan_amd/train.py -c <reference YAML>            (reference: train.py:10-49, README.md:36)
+    python -m torch.distributed.run --nproc-per-node 8 ipr-gan_amd/train.py -c <yaml>     (one process per GPU)
+
+It reproduces ``Experiment.start/train/checkpoint`` (experiments/base.py:70-82 and the three ``train()``
+bodies, image_generation.py:86-101, image_super_resolution.py:84-113, image_translation.py:90-112) on the
+HIP engine, writes ``checkpoint.pt`` in the reference layout (resumable both ways) and a metrics JSONL.
+Out of scope: real datasets (no data on the box: synthetic batches of the configured
+shapes instead), TensorBoard, FID/IS/PSNR evaluation, the black-box watermark wrapper (section 8f "next").
+"""
+import argparse
+import json
+import math
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from iprgan import Config, models  # noqa: E402
+
+
+class SyntheticLoader:
+    """Infinite ``next()``-able loader (datasets/util.py:3-15) producing batches of the configured shapes and
+    value ranges: DCGAN images in [-1,1] (datasets/img_datasets.py:12-17), SRGAN (lr, hr) in [0,1]
+    (datasets/sr_datasets.py:27-33), CycleGAN unaligned pairs in [-1,1]."""
+
+    def __init__(self, kind, bsz, size, n_samples=10000):
+        self.kind, self.bsz, self.size, self.n = kind, bsz, size, n_samples
+
+    def __len__(self):
+        return self.n
+
+    def __next__(self):
+        b, s = self.bsz, self.size
+        if self.kind == 'generation':
+            return torch.tanh(torch.randn(b, 3, s, s)), torch.zeros(b, dtype=torch.long)
+        if self.kind == 'super_resolution':
+            return torch.rand(b, 3, 24, 24), torch.rand(b, 3, 96, 96)
+        return torch.tanh(torch.randn(b, 3, s, s)), torch.tanh(torch.randn(b, 3, s, s))
+
+
+class Experiment:
+    KINDS = {'ImageGeneration': 'generation', 'ImageSuperResolution': 'super_resolution',
+             'ImageTranslation': 'translation'}
+
+    def __init__(self, config):
+        self.config = config
+        self.kind = self.KINDS[config.experiment]
+        self.rank = int(os.environ.get('RANK', 0))
+        self.world = int(os.environ.get('WORLD_SIZE', 1))
+        os.makedirs(config.log.path, exist_ok=True)
+        if self.rank == 0:
+            with open(os.path.join(config.log.path, 'config.yaml'), 'w') as f:
+                f.write(config.to_yaml())                      # dumped BEFORE the mutations below (base.py:15-19)
+        self.init_step = 1
+        self.configure_device()
+        self.configure_dataset()
+        self.configure_model()
+        self.configure_protection()
+
+    def configure_device(self):
+        """base.py:24-43, one process per GPU: the per-process batch stays hparam.bsz (the reference's
+        DataParallel scatters bsz*ngpu over ngpu devices), iteration counts are divided by the world size."""
+        if not torch.cuda.is_available():
+            raise SystemExit('the HIP engine needs a GPU')
+        local = int(os.environ.get('LOCAL_RANK', 0))
+        torch.cuda.set_device(local)
+        self.device = [torch.device('cuda', local)]
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('nccl', device_id=self.device[0])
+        hp = self.config.hparam
+        if 'pretrain_iter' in hp.to_dict():
+            hp.pretrain_iter //= self.world
+        hp.iteration //= self.world
+
+    def configure_dataset(self):
+        ds, hp = self.config.dataset, self.config.hparam
+        size = ds.get('size', None) or ds.get('crop', None) or 96
+        self.data_loader = SyntheticLoader(self.kind, hp.bsz, size)
+        if self.kind == 'translation':                          # iteration / log.freq are given in epochs
+            n = math.ceil(len(self.data_loader) / hp.bsz)       # image_translation.py:38-40
+            hp.iteration *= n
+            self.config.log.freq *= n
+
+    def configure_model(self):
+        mc = self.config.model
+        if self.kind == 'translation':
+            mc.epoch = self.config.hparam.iteration // self.config.log.freq     # image_translation.py:44
+        self.model = getattr(models, mc.type)(mc, device=self.device)
+
+    def configure_protection(self):
+        wm = self.config.get('protection', None)
+        self.wbox = False
+        if not wm:
+            return
+        if wm.get('bbox', None):
+            raise NotImplementedError('black-box watermark (BlackBoxWrapper + SSIM) is not part of this engine yet')
+        wbox = wm.get('wbox', None)
+        if wbox:
+            wbox['target'] = 'GB' if self.kind == 'translation' else 'G'         # image_translation.py:83
+            self.model = models.WhiteBoxWrapper(self.model, wbox)
+            self.wbox = True
+
+    # ---- one iteration: the three reference train() bodies -------------------------------------------------
+    def train(self):
+        hp, m = self.config.hparam, self.model
+        d_iter, g_iter = hp.get('d_iter', 1), hp.get('g_iter', 1)
+        if self.kind == 'generation':
+            for _ in range(d_iter):
+                x, _ = next(self.data_loader)
+                m.update_d({'real_sample': x, 'latent': torch.randn(x.size(0), 128)})
+            for _ in range(g_iter):
+                m.update_g({'fake_sample': m.fake_sample})
+        elif self.kind == 'super_resolution':
+            pre = hp.get('pretrain_iter', 0)
+            if self._step == pre + hp.iteration // 2 and pre > 0:
+                m.optG.param_groups[0]['lr'] *= 0.1
+                m.optD.param_groups[0]['lr'] *= 0.1
+            if self._step <= pre:
+                lr, hr = next(self.data_loader)
+                m.update_g({'low_res': lr, 'high_res': hr, 'pretrain': True, 'inhibit_bbox': True})
+            else:
+                for _ in range(g_iter):
+                    lr, hr = next(self.data_loader)
+                    m.update_g({'low_res': lr, 'high_res': hr, 'pretrain': False})
+                for _ in range(d_iter):
+                    m.update_d({'high_res': m.high_res, 'super_res': m.super_res})
+        else:
+            if self._step % self.config.log.freq == 1 and self._step > 1:
+                m.update_lr()
+            for _ in range(g_iter):
+                a, b = next(self.data_loader)
+                m.update_g({'real_A': a, 'real_B': b})
+            for _ in range(d_iter):
+                m.update_d({'real_A': m.real_A, 'real_B': m.real_B,
+                            'fake_A': m.fake_A.detach(), 'fake_B': m.fake_B.detach()})
+
+    def checkpoint(self, metrics_every=1):
+        path = os.path.join(self.config.log.path, 'checkpoint.pt')
+        if self._step == 'end':
+            if self.rank == 0:
+                sd = self.model.state_dict()
+                sd['step'] = 'END'
+                torch.save(sd, path)
+            return
+        if self._step % metrics_every == 0:
+            metrics = self.model.get_metrics()
+            if self.rank == 0:
+                with open(os.path.join(self.config.log.path, 'metrics.jsonl'), 'a') as f:
+                    f.write(json.dumps({'step': self._step, **metrics}) + '\n')
+        if self._step % self.config.log.freq == 0 and self.rank == 0:
+            sd = self.model.state_dict()
+            sd['step'] = self._step
+            torch.save(sd, path)
+
+    def load_state_dict(self, state_dict, strict=False):
+        self.model.load_state_dict(state_dict, strict=strict)
+        if state_dict['step'] == 'END':
+            self.init_step = self.config.hparam.get('pretrain_iter', 0) + self.config.hparam.iteration
+        else:
+            self.init_step = state_dict['step'] + 1
+
+    def start(self, max_steps=None, metrics_every=1):
+        total = self.config.hparam.get('pretrain_iter', 0) + self.config.hparam.iteration
+        last = total if max_steps is None else min(total, self.init_step + max_steps - 1)
+        for step in range(self.init_step, last + 1):
+            self._step = step
+            self.train()
+            self.checkpoint(metrics_every)
+        if last >= total:
+            self._step = 'end'
+            self.checkpoint()
+        if self.wbox and self.rank == 0:
+            target = getattr(self.model, 'GB' if self.kind == 'translation' else 'G')
+            ber = float(self.model.loss_model.compute_ber(target))
+            with open(os.path.join(self.config.log.path, 'metrics.json'), 'w') as f:
+                json.dump({'BER': ber}, f)
+        return last
+
+
+def main():
+    ap = argparse.ArgumentParser(description='Training script (HIP engine)')
+    ap.add_argument('-c', '--config', required=True, help='path to a reference config file')
+    ap.add_argument('--max-steps', type=int, default=None, help='stop after this many iterations (smoke runs)')
+    ap.add_argument('--log-path', default=None, help='override log.path')
+    args = ap.parse_args()
+    config = Config.parse(args.config)
+    if args.log_path:
+        config.log.path = args.log_path
+    torch.manual_seed(config.seed)                              # train.py:43-47
+    np.random.seed(config.seed)
+    random.seed(config.seed)
+    exp = Experiment(config)
+    ckpt = os.path.join(config.log.path, 'checkpoint.pt')
+    if os.path.exists(ckpt):                                    # train.py:26-31 auto-resume
+        exp.load_state_dict(torch.load(ckpt, map_location=exp.device[0]))
+    exp.start(max_steps=args.max_steps)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, 'ipr-gan_amd'))
 import torch  # noqa: E402
 from iprgan import ops  # noqa: E402
 
-B = 128
+B = int(os.environ.get("CONV_BENCH_B", "128"))
 LAYERS = [  # name, cin, cout, k, s, p, transposed, H
     ('D.conv0 3->64 k3', 3, 64, 3, 1, 1, False, 64),
     ('D.conv1 64->64 k4s2', 64, 64, 4, 2, 1, False, 64),

@@ -1,0 +1,32 @@
+"""GPU: the thin train.py driver runs a reference-format YAML, checkpoints in the reference layout and resumes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_driver_checkpoint_and_resume(tmp_path):
+    cfg = os.path.join(ROOT, 'tests', 'configs', 'dcgan-wbox-tiny.yaml')
+    log = str(tmp_path / 'log')
+    cmd = [sys.executable, os.path.join(PKG, 'train.py'), '-c', cfg, '--log-path', log]
+    subprocess.run(cmd + ['--max-steps', '3'], check=True, timeout=600)
+    sd = torch.load(os.path.join(log, 'checkpoint.pt'), map_location='cpu')
+    assert sd['step'] == 2 and list(sd) == ['G', 'D', 'optG', 'optD', 'sign', 'step']
+    assert 'module.convs.0.1.weight' in sd['G'] and 'module.net.0.0.weight_orig' in sd['D']
+    subprocess.run(cmd, check=True, timeout=600)               # auto-resume at step 3, runs to the end
+    sd = torch.load(os.path.join(log, 'checkpoint.pt'), map_location='cpu')
+    assert sd['step'] == 'END'
+    steps = [json.loads(l)['step'] for l in open(os.path.join(log, 'metrics.jsonl'))]
+    assert steps == [1, 2, 3, 3, 4]                             # step 3 ran twice: before and after the resume
+    assert json.load(open(os.path.join(log, 'metrics.json')))['BER'] == 0.0
+    # the checkpoint loads into the CPU oracle (reference layout)
+    from oracle import cases, gan
+    o = gan.WhiteBoxWrapper(gan.DCGAN(gan.Cfg(cases.DCGAN_CFG)), gan.Cfg(cases.WBOX_CFG))
+    o.load_state_dict({k: v for k, v in sd.items() if k != 'step'}, strict=True)
