@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libiprgan_hip.so')
+LIB_PATH = os.environ.get('IPRGAN_LIB', os.path.join(_HERE, 'libiprgan_hip.so'))   # override: A/B builds
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
