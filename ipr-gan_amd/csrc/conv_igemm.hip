@@ -572,19 +572,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
     }
   }
 
+  // slab store: quad transpose (see gconv epilogue) so that every lane writes 16 contiguous bytes
   const int half = lane >> 5, l31 = lane & 31;
+  const int qp = lane & 3, q4 = (l31 >> 2);
   float* slab = a.ws + (size_t)split * a.Nrows * a.Kw;
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ri = (r & 3) + 8 * (r >> 2) + 4 * half;
+    for (int g = 0; g < 4; ++g) {
+      const int ri = 8 * g + 4 * half + qp;
       const int n = WM == 2 ? n0 + wm * 64 + 2 * ri + i : n0 + (wm * WM + i) * 32 + ri;
-      if (n >= a.Nrows) continue;
+      float t[WN][4];
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        const int k = WN == 2 ? k0 + wn * 64 + 2 * l31 + j : k0 + (wn * WN + j) * 32 + l31;
-        if (k < a.Kw) slab[(size_t)n * a.Kw + k] = acc[i][j][r];
+        t[j][0] = acc[i][j][4 * g]; t[j][1] = acc[i][j][4 * g + 1]; t[j][2] = acc[i][j][4 * g + 2]; t[j][3] = acc[i][j][4 * g + 3];
+        quad_transpose(t[j][0], t[j][1], t[j][2], t[j][3], qp);
+      }
+      if (n >= a.Nrows) continue;
+      float* row = slab + (size_t)n * a.Kw;
+      if (WN == 2) {          // tile tn owns columns base + 2*col + tn: interleave the two tiles -> 8 contiguous floats
+        const int k = k0 + wn * 64 + 8 * q4;
+        if (k < a.Kw) {
+          const f32x4 v0 = {t[0][0], t[WN - 1][0], t[0][1], t[WN - 1][1]};
+          const f32x4 v1 = {t[0][2], t[WN - 1][2], t[0][3], t[WN - 1][3]};
+          *(f32x4*)(row + k) = v0;
+          *(f32x4*)(row + k + 4) = v1;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int k = k0 + (wn * WN + j) * 32 + 4 * q4;
+          if (k < a.Kw) {
+            const f32x4 v = {t[j][0], t[j][1], t[j][2], t[j][3]};
+            *(f32x4*)(row + k) = v;
+          }
+        }
       }
     }
 }
