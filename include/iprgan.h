@@ -62,6 +62,11 @@ size_t iprgan_conv_wgrad_ws_floats(const iprgan_conv_desc* d);
  * wfwd / wbwd (either may be NULL): tap-major operands for forward and for backward-data. */
 int iprgan_conv_weight_prep(const iprgan_conv_desc* d, const float* w, const float* inv_scale,
                             float* wfwd, float* wbwd, void* stream);
+/* The same for n layers in one launch: descs[n] (only Cin/Cout/KH/KW/transposed are read); w / inv_scale /
+ * wfwd / wbwd are HOST arrays of n DEVICE pointers (entries, or whole arrays, may be NULL). */
+int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* const* w,
+                                  const float* const* inv_scale, float* const* wfwd, float* const* wbwd, int n,
+                                  void* stream);
 /* y = act(conv(x, w) + bias); bias may be NULL (length Cout).  ws: optional workspace of
  * iprgan_conv_fwd_ws_floats(d) floats (non-zero only for layers with <= 4 output channels, which then run as
  * one dense 1x1 GEMM over tap planes + a gather instead of a 3/32-full MFMA tile); NULL = generic kernel. */

@@ -664,6 +664,38 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __r
   }
 }
 
+
+// all layers of a network in one launch: blockIdx.y = table entry
+#define PREP_MAX 32
+struct PrepEntry {
+  const float* w;
+  const float* inv_scale;
+  float* dst;
+  int rows_alloc, Kp, Drow, Dcol, Cs, ntap, row_is_d0;
+};
+struct PrepTable {
+  PrepEntry e[PREP_MAX];
+};
+__global__ void weight_prep_multi_kernel(const PrepTable t) {
+  const PrepEntry e = t.e[blockIdx.y];
+  const float sc = e.inv_scale ? *e.inv_scale : 1.f;
+  const long long total = (long long)e.rows_alloc * e.Kp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % e.Kp);
+    const int r = (int)(i / e.Kp);
+    const int tap = k / e.Cs, c = k - tap * e.Cs;
+    float v = 0.f;
+    if (r < e.Drow && tap < e.ntap && c < e.Dcol) {
+      const long long src = e.row_is_d0 ? ((long long)r * e.Dcol + c) * e.ntap + tap
+                                        : ((long long)c * e.Drow + r) * e.ntap + tap;
+      v = e.w[src];
+      if (e.inv_scale) v = v / sc;
+    }
+    e.dst[i] = v;
+  }
+}
+
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
                                float* __restrict__ dz, size_t n, int act, float slope) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
@@ -1021,6 +1053,42 @@ static size_t smalln_ws_for(const iprgan_conv_desc* d, bool fwd) {
   return (size_t)rup(ntap * 4, 128) * c4(c_red) + (size_t)ntap * pix * 4;
 }
 size_t iprgan_conv_fwd_ws_floats(const iprgan_conv_desc* d) { return smalln_ws_for(d, true); }
+
+
+int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* const* w,
+                                  const float* const* inv_scale, float* const* wfwd, float* const* wbwd, int n,
+                                  void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  PrepTable t;
+  int cnt = 0;
+  long long maxtotal = 0;
+  auto flush = [&]() -> int {
+    if (!cnt) return 0;
+    const int bx = (int)((maxtotal + 255) / 256 < 1024 ? (maxtotal + 255) / 256 : 1024);
+    hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(bx, cnt), dim3(256), 0, st, t);
+    IPR_LAUNCH_CHECK();
+    cnt = 0; maxtotal = 0;
+    return 0;
+  };
+  for (int l = 0; l < n; ++l) {
+    const iprgan_conv_desc* d = descs + l;
+    const int ntap = d->KH * d->KW;
+    for (int which = 0; which < 2; ++which) {
+      float* dst = which == 0 ? (wfwd ? wfwd[l] : nullptr) : (wbwd ? wbwd[l] : nullptr);
+      if (!dst) continue;
+      const int rows = which == 0 ? d->Cout : d->Cin, red = which == 0 ? d->Cin : d->Cout;
+      PrepEntry& e = t.e[cnt++];
+      e.w = w[l]; e.inv_scale = inv_scale ? inv_scale[l] : nullptr; e.dst = dst;
+      e.Cs = c4(red); e.Kp = rup(ntap * e.Cs, 32); e.rows_alloc = rup(rows, 128);
+      e.Drow = rows; e.Dcol = red; e.ntap = ntap;
+      e.row_is_d0 = ((which == 0) != (d->transposed != 0)) ? 1 : 0;
+      const long long total = (long long)e.rows_alloc * e.Kp;
+      if (total > maxtotal) maxtotal = total;
+      if (cnt == PREP_MAX) { const int rc = flush(); if (rc) return rc; }
+    }
+  }
+  return flush();
+}
 
 int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd, const float* bias,
                     float* y, float* ws, void* stream) {

@@ -39,6 +39,7 @@ SIGNATURES = {
     'iprgan_conv_wbwd_floats': (_Z, [_D]),
     'iprgan_conv_wgrad_ws_floats': (_Z, [_D]),
     'iprgan_conv_weight_prep': (_I, [_D, _P, _P, _P, _P, _P]),
+    'iprgan_conv_weight_prep_multi': (_I, [_P, _P, _P, _P, _P, _I, _P]),
     'iprgan_conv_fwd_ws_floats': (_Z, [_D]),
     'iprgan_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P]),
     'iprgan_conv_bwd_data_ws_floats': (_Z, [_D]),

@@ -11,8 +11,12 @@ optimizers keep working, SURVEY.md section 8b "State/ownership").
 """
 import torch
 
+import os
+
 from . import _lib as L
 from . import ops
+
+_BATCH_PREP = os.environ.get('IPRGAN_BATCH_PREP', '1') != '0'
 
 
 class Op:
@@ -104,7 +108,9 @@ class Conv(Op):
             u, v = self.sn
             sigma = ops.sn_power_iter(self.weight, u, v, train)
             st['u'], st['v'] = u.clone(), v.clone()     # this pass's u, v (later passes overwrite the buffers)
-        wf, _ = ops.conv_prep(sp, d, self.weight, sigma, fwd=True, bwd=False)
+        wf = st.pop('wf', None)             # set by Chain's batched weight-prep pre-pass
+        if wf is None:
+            wf, _ = ops.conv_prep(sp, d, self.weight, sigma, fwd=True, bwd=False)
         y = ops.conv_fwd(sp, d, x, wf, self.bias)
         st.update(x=x, y=y, d=d, sigma=sigma)
         return y
@@ -121,7 +127,9 @@ class Conv(Op):
             grads = [dw] + ([db] if self.bias is not None else [])
         dx = None
         if need_dx:
-            _, wb = ops.conv_prep(sp, d, self.weight, sigma, fwd=False, bwd=True)
+            wb = st.pop('wb', None)
+            if wb is None:
+                _, wb = ops.conv_prep(sp, d, self.weight, sigma, fwd=False, bwd=True)
             if prev_act is not None:
                 dx = ops.conv_bwd_data(sp, d, dy, wb, st['x'], prev_act[0], prev_act[1])
             else:
@@ -401,6 +409,13 @@ class ChainFn(torch.autograd.Function):
             sig, uo, vo = ops.sn_power_iter_multi(list(ws_), list(us_), list(vs_), train)
             for k, i in enumerate(sn_idx):
                 stash[i].update(sigma=sig[k:k + 1], u=uo[k], v=vo[k])
+        # ... and every conv layer's forward operand (tap-major copy, divided by sigma) in one launch
+        cv = [i for i, op in enumerate(chain.ops) if isinstance(op, Conv)] if _BATCH_PREP else []
+        if cv:
+            wfs = ops.conv_prep_multi([chain.ops[i].spec for i in cv], [chain.ops[i].weight for i in cv],
+                                      [stash[i].get('sigma') for i in cv])
+            for i, wf in zip(cv, wfs):
+                stash[i]['wf'] = wf
         for op, st in zip(chain.ops, stash):
             h = op.forward(h, st, train)
         ctx.chain, ctx.stash = chain, stash
@@ -425,6 +440,13 @@ class ChainFn(torch.autograd.Function):
                 first_needed = i
             pi += n
         grads_per_op = [None] * len(ops_list)
+        if first_needed is not None and _BATCH_PREP:        # backward-data operands of every conv that must produce dx: one launch
+            cv = [i for i, op in enumerate(ops_list) if isinstance(op, Conv) and (i > first_needed or (need_x and i == 0))]
+            if cv:
+                wbs = ops.conv_prep_multi([ops_list[i].spec for i in cv], [ops_list[i].weight for i in cv],
+                                          [stash[i].get('sigma') for i in cv], bwd=True)
+                for i, wb in zip(cv, wbs):
+                    stash[i]['wb'] = wb
         g = dy.contiguous()
         for i in range(len(ops_list) - 1, -1, -1):
             op, st = ops_list[i], stash[i]

@@ -87,6 +87,20 @@ def conv_prep(spec, d, w, sigma=None, fwd=True, bwd=False):
     return wf, wb
 
 
+def conv_prep_multi(specs, weights, sigmas, bwd=False):
+    """Prepared operands (forward ones, or backward-data ones with bwd=True) of several layers in one launch.
+    sigmas[i] is that layer's device scalar or None."""
+    n = len(specs)
+    descs = (ConvDesc * n)(*[sp.desc(1, 1, 1) for sp in specs])
+    q = 'iprgan_conv_wbwd_floats' if bwd else 'iprgan_conv_wfwd_floats'
+    outs = [empty((query(q, C.byref(descs[i])),), weights[i]) for i in range(n)]
+    sig = (C.c_void_p * n)(*[ptr(s) for s in sigmas])
+    tab = L.ptr_table(outs)
+    call('iprgan_conv_weight_prep_multi', descs, L.ptr_table(weights), sig, None if bwd else tab,
+         tab if bwd else None, n, stream())
+    return outs
+
+
 def conv_fwd(spec, d, x, wfwd, bias):
     OH, OW = spec.out_hw(d.H, d.W)
     y = empty((d.B, OH, OW, c4(spec.cout)), x)
