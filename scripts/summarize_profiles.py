@@ -1,0 +1,55 @@
+"""Turn rocprofv3 CSVs (gpurun_out/prof/<tag>_*.csv) into the committed summaries under profiles/:
+  <out>_bench_kernel_stats.csv   copy of <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats)
+  <out>_pmc_traffic.json         HBM bytes per launch per kernel from the FETCH_SIZE / WRITE_SIZE passes
+Kernel names are mapped to the names bench.py reports (iprgan_prof_get).  FETCH_SIZE is doubled as
+MI355X_MICROARCH.md prescribes for gfx950 (128-B requests of 16-B/lane streams are tallied at 64 B).
+usage: python scripts/summarize_profiles.py <prof_dir> <tag> <out_prefix>"""
+import collections
+import csv
+import json
+import re
+import shutil
+import sys
+
+
+def short(k):
+    m = re.match(r'void iprgan::gconv_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)>', k)
+    if m:
+        wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
+        return f'gconv_kernel<{wgm * wm * 32}x{wgn * wn * 32}' + (',8w>' if wgm * wgn == 8 else '>')
+    m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>', k)
+    if m:
+        wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
+        return f'wgrad_kernel<{wgm * wm * 32}x{wgn * wn * 32}>'
+    return k.split('(')[0].replace('void ', '').replace('iprgan::', '')
+
+
+def agg(path, cname):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == cname:
+            d[short(r['Kernel_Name'])][0] += 1
+            d[short(r['Kernel_Name'])][1] += float(r['Counter_Value'])
+    return d
+
+
+def main():
+    prof, tag, out = sys.argv[1:4]
+    shutil.copy(f'{prof}/{tag}_kernel_stats.csv', f'{out}_bench_kernel_stats.csv')
+    f, w = agg(f'{prof}/{tag}_fetch_counter_collection.csv', 'FETCH_SIZE'), agg(f'{prof}/{tag}_write_counter_collection.csv', 'WRITE_SIZE')
+    res = {'_how': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (with --kernel-trace only) over '
+                   '`bench.py --steps 3 --warmup 12` (autotuning launches happen in the first warm-up step and are a minority of the '
+                   'samples); counter unit KiB; FETCH_SIZE x2 (gfx950 correction, checked on bn_apply whose byte count is known); '
+                   'averages over all launches of a kernel name (layers of different sizes share kernels).',
+           'kernels': {}}
+    for k in sorted(f):
+        n, wn = f[k][0], max(1, w[k][0])
+        fb, wb = 2 * f[k][1] / n * 1024, w[k][1] / wn * 1024
+        res['kernels'][k] = {'launches_sampled': n, 'fetch_bytes_per_launch': round(fb), 'write_bytes_per_launch': round(wb),
+                             'hbm_bytes_per_launch': round(fb + wb)}
+    json.dump(res, open(f'{out}_pmc_traffic.json', 'w'), indent=1)
+    print('wrote', f'{out}_pmc_traffic.json', len(res['kernels']), 'kernels')
+
+
+if __name__ == '__main__':
+    main()

@@ -181,3 +181,28 @@ def test_vgg_features_vs_oracle(dev):
     g = recipe.tensor(7, 2, tuple(ya.shape))
     ya.backward(g); yb.backward(g.to(dev))
     np.testing.assert_allclose(xd.grad.cpu().numpy(), x.grad.numpy(), rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize('which', ['G128', 'D128'])
+def test_dcgan128_networks_vs_oracle(which, dev):
+    """BASELINE config 5 uses the 128x128 variants ConvGenerator(mg=16) / SNDiscriminator(md=16) (no factory in
+    the reference); fp32 forward + backward against the live oracle at batch 2."""
+    from iprgan import networks
+    if which == 'G128':
+        a, b, x = nets.ConvGenerator(mg=16), networks.ConvGenerator(mg=16), recipe.tensor(9, 1, (2, 128))
+    else:
+        a, b = nets.SNDiscriminator(md=16), networks.SNDiscriminator(md=16)
+        x = torch.tanh(recipe.tensor(9, 2, (2, 3, 128, 128)))
+    recipe.fill(a, 9); recipe.fill(b, 9)
+    b.to(dev)
+    a.train(); b.train()
+    xa, xb = x.clone().requires_grad_(), x.clone().to(dev).requires_grad_()
+    ya, yb = a(xa), b(xb)
+    np.testing.assert_allclose(yb.detach().cpu().numpy(), ya.detach().numpy(), rtol=RTOL, atol=ATOL)
+    g = recipe.tensor(9, 3, tuple(ya.shape))
+    ya.backward(g); yb.backward(g.to(dev))
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        ga, gb = pa.grad.numpy(), pb.grad.cpu().numpy()
+        # 3e-4 of the tensor's scale: batch-2 BatchNorm / spectral-norm chains amplify summation-order noise
+        tol = 1e-3 if k.endswith('.bias') else 3e-4 * float(np.abs(ga).max()) + ATOL
+        np.testing.assert_allclose(gb, ga, rtol=2e-3, atol=tol, err_msg=k)
