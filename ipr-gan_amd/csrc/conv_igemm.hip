@@ -29,7 +29,7 @@ static ProfSlot g_slots[] = {
     {"wgrad_kernel<128x128>", 0, 0, 0}, {"wgrad_kernel<128x64>", 0, 0, 0},
     {"wgrad_kernel<64x64>", 0, 0, 0},   {"wgrad_kernel<32x128>", 0, 0, 0},
     {"gconv_kernel<64x128>", 0, 0, 0},  {"gconv_kernel<128x128,8w>", 0, 0, 0},
-    {"gconv_kernel<128x64,8w>", 0, 0, 0},
+    {"gconv_kernel<128x64,8w>", 0, 0, 0}, {"wgrad_kernel<128x128,8w>", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; };
@@ -436,11 +436,12 @@ struct WGradArgs {
 };
 
 template <int WGM, int WGN, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
+__global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a) {
   constexpr int BN = WGM * WM * 32;   // tile over n (P channels)  -> MFMA rows
   constexpr int BK = WGN * WN * 32;   // tile over k (tap,c)       -> MFMA cols
   constexpr int CP = BN / 4, CQ = BK / 4;          // 16-B chunks per tile row
-  constexpr int RPP = 256 / CP, RPQ = 256 / CQ;    // rows per pass
+  constexpr int NT = WGM * WGN * 64;               // threads: one wave per (32*WM)x(32*WN) sub-tile
+  constexpr int RPP = NT / CP, RPQ = NT / CQ;      // rows per pass
   constexpr int NP = 32 / RPP, NQ = 32 / RPQ;      // passes per 32-row chunk
   constexpr int STAGE = 32 * (BN + BK);            // floats per stage
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
@@ -928,10 +929,10 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
 
 // ---- backward-weight ------------------------------------------------------------------------
 struct WGradPlan {
-  int N, Cq, Ps, Qs, ntap, Kw, Nrows, bn, bk, tiles, nsplit, cps, M;
+  int N, Cq, Ps, Qs, ntap, Kw, Nrows, bn, bk, tiles, nsplit, cps, M, w8;
 };
 // cand: 0 = 128x128 tiles, 1 = 64x64, 2 = 128x64, each x {768, 1536, 384} target blocks (cand / 3 selects)
-#define WGRAD_NCAND 9
+#define WGRAD_NCAND 12
 static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   const Shape s = out_shape(d);
   // P = grid-aligned tensor (Conv2d: dy [OH,OW,Cout]; ConvT: x [H,W,Cin]); Q = gathered tensor
@@ -942,7 +943,12 @@ static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   const int PH = d->transposed ? d->H : s.OH, PW = d->transposed ? d->W : s.OW;
   p.M = d->B * PH * PW;
   const int K = p.ntap * p.Qs;
-  const int shape = cand % 3, target = cand / 3 == 0 ? 768 : (cand / 3 == 1 ? 1536 : 384);
+  // candidates 0..8: shape = cand % 3 x target blocks {768, 1536, 384}; 9..11: 128x128 tile on 8 waves
+  const int shape = cand >= 9 ? 0 : cand % 3;
+  const int tsel = cand >= 9 ? cand - 9 : cand / 3;
+  const int target = tsel == 0 ? 768 : (tsel == 1 ? 1536 : 384);
+  p.w8 = cand >= 9 ? 1 : 0;
+  if (p.w8 && (p.N < 128 || K < 128)) return false;
   if (p.N <= 32) {
     if (shape != 0) return false;
     p.bn = 32; p.bk = 128;
@@ -993,8 +999,8 @@ static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t s
     attr_set = true;
   }
   dim3 grid(p.Kw / BK, p.Nrows / BN, p.nsplit);
-  ProfScope prof(st, BN == 128 ? (BK == 128 ? 4 : 5) : (BN == 64 ? 6 : 7), a.flops);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  ProfScope prof(st, WGM * WGN == 8 ? 11 : BN == 128 ? (BK == 128 ? 4 : 5) : (BN == 64 ? 6 : 7), a.flops);
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), smem, st, a);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -1174,7 +1180,8 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW
                             : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
     int rc;
-    if (p.bn == 128 && p.bk == 128) rc = launch_wgrad_t<2, 2, 2, 2>(a, p, st);
+    if (p.w8) rc = launch_wgrad_t<2, 4, 2, 1>(a, p, st);        // 128x128, 8 waves of 64x32
+    else if (p.bn == 128 && p.bk == 128) rc = launch_wgrad_t<2, 2, 2, 2>(a, p, st);
     else if (p.bn == 64) rc = launch_wgrad_t<2, 2, 1, 1>(a, p, st);
     else if (p.bn == 128) rc = launch_wgrad_t<2, 2, 2, 1>(a, p, st);
     else rc = launch_wgrad_t<1, 4, 1, 1>(a, p, st);     // bn == 32, bk == 128

@@ -20,7 +20,7 @@ def short(k):
     m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>', k)
     if m:
         wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
-        return f'wgrad_kernel<{wgm * wm * 32}x{wgn * wn * 32}>'
+        return f'wgrad_kernel<{wgm * wm * 32}x{wgn * wn * 32}' + (',8w>' if wgm * wgn == 8 else '>')
     return k.split('(')[0].replace('void ', '').replace('iprgan::', '')
 
 
