@@ -779,6 +779,7 @@ struct TuneKey {
   bool operator<(const TuneKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
 };
 static std::map<TuneKey, int> g_tune;
+static int g_force_tile = -1, g_force_wgrad = -1;     // test hook: iprgan_debug_force_tiles
 static int g_autotune = getenv("IPRGAN_AUTOTUNE") ? atoi(getenv("IPRGAN_AUTOTUNE")) : 1;
 static int g_smalln = getenv("IPRGAN_SMALLN") ? atoi(getenv("IPRGAN_SMALLN")) : 1;
 static int g_nbuf = getenv("IPRGAN_LDS_BUFS") ? atoi(getenv("IPRGAN_LDS_BUFS")) : 1;  // 1 = single LDS buffer (measured faster: 3-4 blocks/CU)
@@ -890,6 +891,10 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   int tile = 2;
   if (N >= 128 && blocks(128, 128) >= 384) tile = 0;
   else if (blocks(128, 64) >= 384) tile = 1;
+  if (g_force_tile >= 0) {
+    if ((g_force_tile == 0 || g_force_tile == 3 || g_force_tile == 4) && N < 128) return run(2);
+    return run(g_force_tile);
+  }
   if (!g_autotune) return run(tile);
 
   // autotune (the reference trains with cudnn.benchmark = True, train.py:44-45): the first launch of a new
@@ -1200,7 +1205,10 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     WGradPlan p0;
     if (!wgrad_plan_c(d, 0, p0)) cand = 1;
   }
-  if (g_autotune) {     // same scheme as the forward/backward-data tiles: time every candidate once per geometry
+  if (g_force_wgrad >= 0) {
+    WGradPlan pf;
+    if (wgrad_plan_c(d, g_force_wgrad, pf)) cand = g_force_wgrad;
+  } else if (g_autotune) {     // same scheme as the forward/backward-data tiles: time every candidate once per geometry
     TuneKey key = {{d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->outpad,
                     d->transposed, d->pad_mode, -7, 0, 0, 0}};
     auto it = g_tune.find(key);
@@ -1240,6 +1248,12 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     const int rc2 = colsum_launch(dy, db, part, M, Cs, d->Cout, st);
     if (rc2) return rc2;
   }
+  return 0;
+}
+
+int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand) {
+  g_force_tile = gconv_tile;
+  g_force_wgrad = wgrad_cand;
   return 0;
 }
 

@@ -74,6 +74,7 @@ SIGNATURES = {
     'iprgan_sign_loss_bwd': (_I, [_P, _P, _P, _P, _I, _F, _P, _P]),
     'iprgan_sign_ber': (_I, [_P, _P, _P, _I, _P, _P]),
     'iprgan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
+    'iprgan_debug_force_tiles': (_I, [_I, _I]),
     'iprgan_prof_enable': (_I, [_I]),
     'iprgan_prof_collect': (_I, []),
     'iprgan_prof_num_kernels': (_I, []),

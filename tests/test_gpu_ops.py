@@ -355,3 +355,56 @@ def test_prelu_pixelshuffle_maxpool_add(dev):
     assert torch.equal(from_nhwc(ops.maxpool2_fwd(xd).cpu(), 16), mp.detach())
     assert torch.equal(from_nhwc(ops.maxpool2_bwd(xd, to_nhwc(g2).to(dev)).cpu(), 16), xr2.grad)
     assert torch.equal(ops.add(xd, xd).cpu(), (xd + xd).cpu())
+
+
+TILE_SHAPES = [(256, 512, 3, 1, 1, False, 16, 2), (64, 64, 4, 2, 1, False, 16, 3), (128, 64, 4, 2, 1, True, 8, 2),
+               (64, 128, 3, 1, 1, False, 9, 1)]
+
+
+@pytest.mark.parametrize('tile', range(6))
+def test_every_gconv_tile_variant(dev, tile):
+    """The autotuner picks ONE tile per geometry; this forces each of the six forward/backward-data tile
+    variants in turn (including shapes with few rows) so that none ships untested."""
+    from iprgan import _lib, ops
+    try:
+        _lib.call('iprgan_debug_force_tiles', tile, -1)
+        for cin, cout, k, s, p, tr, H, B in TILE_SHAPES:
+            x = rnd(B, cin, H, H, seed=1)
+            wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+            w = rnd(*wshape, seed=2, scale=(cin * k * k) ** -0.5)
+            xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+            yr = F.conv_transpose2d(xr, wr, None, stride=s, padding=p) if tr else F.conv2d(xr, wr, None, stride=s, padding=p)
+            g = rnd(*yr.shape, seed=3)
+            yr.backward(g)
+            spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr)
+            d = spec.desc(B, H, H)
+            wf, wb = ops.conv_prep(spec, d, w.to(dev), None, True, True)
+            y = ops.conv_fwd(spec, d, to_nhwc(x).to(dev), wf, None)
+            close(from_nhwc(y.cpu(), cout), yr, what=f'tile {tile} fwd {cin}->{cout}')
+            dx = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb)
+            close(from_nhwc(dx.cpu(), cin), xr.grad, what=f'tile {tile} dgrad {cin}->{cout}')
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
+
+
+@pytest.mark.parametrize('cand', range(12))
+def test_every_wgrad_candidate(dev, cand):
+    from iprgan import _lib, ops
+    try:
+        _lib.call('iprgan_debug_force_tiles', -1, cand)
+        for cin, cout, k, s, p, tr, H, B in TILE_SHAPES:
+            x = rnd(B, cin, H, H, seed=1)
+            wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+            w = rnd(*wshape, seed=2, scale=0.05)
+            xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+            br = torch.zeros(cout, requires_grad=True)
+            yr = F.conv_transpose2d(xr, wr, br, stride=s, padding=p) if tr else F.conv2d(xr, wr, br, stride=s, padding=p)
+            g = rnd(*yr.shape, seed=3)
+            yr.backward(g)
+            spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr)
+            d = spec.desc(B, H, H)
+            dw, db = ops.conv_bwd_weight(spec, d, to_nhwc(x).to(dev), to_nhwc(g).to(dev), wshape, True)
+            close(dw, wr.grad, what=f'cand {cand} wgrad {cin}->{cout}')
+            close(db, br.grad, what=f'cand {cand} bgrad')
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
