@@ -90,11 +90,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU path)')
+    ndev = torch.cuda.device_count()
+    if local >= ndev and os.environ.get('IPRGAN_SHARE_DEVICE') == '1':
+        local = local % ndev            # test-only: several ranks on one GPU (needs IPRGAN_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        backend = os.environ.get('IPRGAN_DIST_BACKEND', 'nccl')     # nccl = RCCL over xGMI
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from iprgan import _lib
