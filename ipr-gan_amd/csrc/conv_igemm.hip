@@ -122,6 +122,16 @@ __device__ __forceinline__ void quad_transpose(float& a0, float& a1, float& a2, 
   a1 = o2 ? t0 : b1; a3 = o2 ? b3 : t1;
 }
 
+// The dispatcher hands workgroup i (x fastest) to XCD i % 8, each with its own 4 MB L2.  Blocks remap their
+// id so that every XCD owns one contiguous run of logical tiles: neighbours in that order (which share
+// operand rows) then hit the same L2 instead of fetching the rows once per XCD.
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned total) {
+  constexpr unsigned X = 8;
+  const unsigned per = total / X, rem = total % X;      // XCD x owns per + (x < rem) tiles
+  const unsigned x = id % X, j = id / X;
+  return x * per + (x < rem ? x : rem) + j;
+}
+
 // FAST: zero padding and Cs % 32 == 0, so every 32-wide K step lies inside ONE tap: the tap walk is
 // wave-uniform (scalar registers), borders are handled by the buffer bounds check (no branches).
 // !FAST: reflect padding and/or Cs in {4,8,16} (taps change inside a K step; RGB layers).
@@ -135,9 +145,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   constexpr int TILE4 = (BM + BN) * CH;         // 16-byte chunks per stage buffer
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
 
-  const int pz = blockIdx.z;
+  // logical tile order (see xcd_remap): n tiles fastest, then the sub-pixel phases, then m tiles, so the
+  // blocks that read the same input rows run together on one XCD and share its L2
+  const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                gridDim.x * gridDim.y * gridDim.z);
+  const unsigned lq = lt / gridDim.y;
+  const int pz = (int)(lq % gridDim.z);
   const int pM = a.ph[pz].M;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = (int)(lq / gridDim.z) * BM, n0 = (int)(lt % gridDim.y) * BN;
   if (m0 >= pM) return;
   // phase constants into scalars once (the K loop must not re-read the kernel arguments)
   const int p_ntap = a.ph[pz].ntap, p_tw = a.ph[pz].tw, p_steps = (a.ph[pz].steps * 32 + BK - 1) / BK;
@@ -432,10 +447,12 @@ struct WGradArgs {
   int Kw, Nrows;             // slab row length / rows
   int chunks_per_split;
   unsigned p_bytes, q_bytes;
+  int dx32, dy32;            // 32 rows of m = db32 images + dy32 rows + dx32 pixels (mixed radix of PH x PW)
+  unsigned bstep0, bstep1;   // byte step of the image base for db32 / db32+1 images
   double flops;
 };
 
-template <int WGM, int WGN, int WM, int WN, int NBUF>
+template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT>
 __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a) {
   constexpr int BN = WGM * WM * 32;   // tile over n (P channels)  -> MFMA rows
   constexpr int BK = WGN * WN * 32;   // tile over k (tap,c)       -> MFMA cols
@@ -447,6 +464,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
   float* ldsf = (float*)lds;
 
+  // (no xcd_remap here: keeping the blocks of one split on one XCD cuts the L2 miss traffic 4x but measured
+  //  2-3 % slower - the blocks of a split then queue on the same L2 channels)
   const int k0 = blockIdx.x * BK, n0 = blockIdx.y * BN, split = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -480,35 +499,59 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
 
   const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.P, 0, a.p_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)a.Q, 0, a.q_bytes, 0x00020000);
-  const int M = a.M, PW = a.PW, QH = a.QH, QW = a.QW, Qs = a.Qs, Ps = a.Ps, isy = a.isy, isx = a.isx;
-  const FastDiv d_plane = a.d_plane, d_pw = a.d_pw;
-  const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
-  const unsigned pcol = (unsigned)(n0 + cp * 4) * 4u, qcol = (unsigned)c4 * 16u;
+  const int M = a.M, PW = a.PW, PH = a.PH, QH = a.QH, QW = a.QW, isy = a.isy, isx = a.isx;
+  const int Qs4 = a.Qs * 4, dx32 = a.dx32, dy32 = a.dy32;
+  const unsigned pstep = 32u * (unsigned)a.Ps * 4u, bstep0 = a.bstep0, bstep1 = a.bstep1;
 
-  auto gload = [&](int ch) {
-    const int mb = ch * 32;
+  // Running state of this thread's rows, advanced by 32 rows of m per chunk with adds and selects only.
+  // The integer work of the loader competes with the MFMAs for issue slots (the waves of a block are
+  // in the same phase between barriers), so there are no divisions and only 24-bit (full-rate) multiplies
+  // in the loop: pixel (y, x) and the image base are carried, taps and borders are applied per load.
+  // A thread whose channel chunk is outside the tensor carries OOB_OFFSET in its base (rows past M of P
+  // fall outside the buffer by themselves: p_bytes = M * Ps * 4).
+  unsigned po[NP], qb[NQ];
+  int qm[NQ], qy[NQ], qx[NQ];
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    po[i] = pvalid ? (unsigned)((chunk_begin * 32 + rp + RPP * i) * a.Ps) * 4u + (unsigned)(n0 + cp * 4) * 4u
+                   : OOB_OFFSET;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int m = chunk_begin * 32 + rq + RPQ * i;
+    const int b = fdiv(m, a.d_plane);
+    const int rem = m - b * plane;
+    qy[i] = fdiv(rem, a.d_pw);
+    qx[i] = rem - qy[i] * PW;
+    qm[i] = m;
+    qb[i] = (unsigned)b * (unsigned)(QH * QW) * (unsigned)Qs4 + (qvalid ? (unsigned)c4 * 16u : OOB_OFFSET);
+  }
+
+  auto gload = [&]() {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int m = mb + rp + RPP * i;
-      const bool ok = pvalid && m < M;
-      rP[i] = buf_load4(rs_p, ok ? (unsigned)(m * Ps) * 4u + pcol : OOB_OFFSET);
+      rP[i] = buf_load4(rs_p, po[i]);
+      po[i] += pstep;
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int m = mb + rq + RPQ * i;
-      const int b = fdiv(m, d_plane);
-      const int rem = m - b * plane;
-      const int y = fdiv(rem, d_pw);
-      const int x = rem - y * PW;
-      int iy = y * isy + dy, ix = x * isx + dx;
-      bool ok = qvalid && m < M;
-      if (reflect) {
+      int iy = __mul24(qy[i], isy) + dy, ix = __mul24(qx[i], isx) + dx;
+      bool ok = qm[i] < M;
+      if (REFLECT) {
         iy = reflect_idx(iy, QH);
         ix = reflect_idx(ix, QW);
       } else {
         ok = ok && (unsigned)iy < (unsigned)QH && (unsigned)ix < (unsigned)QW;
       }
-      rQ[i] = buf_load4(rs_q, ok ? (unsigned)(((b * QH + iy) * QW + ix) * Qs) * 4u + qcol : OOB_OFFSET);
+      const unsigned off = qb[i] + (unsigned)__mul24(__mul24(iy, QW) + ix, Qs4);
+      rQ[i] = buf_load4(rs_q, ok ? off : OOB_OFFSET);
+      int x = qx[i] + dx32, y = qy[i] + dy32;
+      const bool cx = x >= PW;
+      x -= cx ? PW : 0;
+      y += cx ? 1 : 0;
+      const bool cy = y >= PH;
+      y -= cy ? PH : 0;
+      qb[i] += cy ? bstep1 : bstep0;
+      qx[i] = x; qy[i] = y; qm[i] += 32;
     }
   };
   auto lstore = [&](int buf) {
@@ -552,13 +595,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
   };
 
   if (chunk_begin < chunk_end) {
-    gload(chunk_begin);
+    gload();
     lstore(0);
     __syncthreads();
     int buf = 0;
     for (int ch = chunk_begin; ch < chunk_end; ++ch) {
       const bool more = ch + 1 < chunk_end;
-      if (more) gload(ch + 1);
+      if (more) gload();
       if (NBUF == 2) {
         compute(buf);
         if (more) lstore(buf ^ 1);
@@ -993,11 +1036,11 @@ static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that
   return m;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF>
+template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT>
 static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
   constexpr int BN = WGM * WM * 32, BK = WGN * WN * 32;
   const size_t smem = NBUF * (size_t)32 * (BN + BK) * sizeof(float);
-  auto kern = wgrad_kernel<WGM, WGN, WM, WN, NBUF>;
+  auto kern = wgrad_kernel<WGM, WGN, WM, WN, NBUF, REFLECT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1012,7 +1055,11 @@ static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t s
 
 template <int WGM, int WGN, int WM, int WN>
 static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
-  return g_nbuf == 1 ? launch_wgrad_tn<WGM, WGN, WM, WN, 1>(a, p, st) : launch_wgrad_tn<WGM, WGN, WM, WN, 2>(a, p, st);
+  if (a.pad_mode == IPRGAN_PAD_REFLECT)
+    return g_nbuf == 1 ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true>(a, p, st)
+                       : launch_wgrad_tn<WGM, WGN, WM, WN, 2, true>(a, p, st);
+  return g_nbuf == 1 ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, false>(a, p, st)
+                     : launch_wgrad_tn<WGM, WGN, WM, WN, 2, false>(a, p, st);
 }
 
 }  // namespace iprgan
@@ -1182,6 +1229,14 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     const unsigned long long qb = (unsigned long long)d->B * a.QH * a.QW * a.Qs * 4ull;
     IPR_CHECK(pb < 0x7fffffffull && qb < 0x7fffffffull, "conv_bwd_weight: tensor larger than 2 GiB");
     a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
+    IPR_CHECK(a.QH * (long long)a.QW < (1 << 24) && a.PH * (long long)a.PW < (1 << 24),
+              "conv_bwd_weight: image larger than 2^24 pixels");
+    {
+      const int plane = a.PH * a.PW, db = 32 / plane, r = 32 % plane;
+      a.dy32 = r / a.PW; a.dx32 = r % a.PW;
+      const unsigned img = (unsigned)a.QH * a.QW * a.Qs * 4u;
+      a.bstep0 = (unsigned)db * img; a.bstep1 = (unsigned)(db + 1) * img;
+    }
     a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW
                             : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
     int rc;
