@@ -17,7 +17,7 @@ def short(k):
     if m:
         wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
         return f'gconv_kernel<{wgm * wm * 32}x{wgn * wn * 32}' + (',8w>' if wgm * wgn == 8 else '>')
-    m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>', k)
+    m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>', k)
     if m:
         wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
         return f'wgrad_kernel<{wgm * wm * 32}x{wgn * wn * 32}' + (',8w>' if wgm * wgn == 8 else '>')
