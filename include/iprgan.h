@@ -203,7 +203,7 @@ int iprgan_prof_collect(void);
 int iprgan_prof_num_kernels(void);
 int iprgan_prof_get(int i, char* name, int name_len, long long* launches, double* ms, double* flops);
 
-/* test hook: force one tile configuration (gconv 0..5, wgrad candidate 0..11; -1 = autotune / heuristic) so that
+/* test hook: force one tile configuration (gconv 0..5, wgrad candidate 0..19 = 4 * block target + tile shape; -1 = autotune / heuristic) so that
  * the parity tests can exercise every variant, not only the one the autotuner picks. */
 int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand);
 

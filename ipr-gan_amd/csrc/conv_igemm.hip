@@ -904,6 +904,49 @@ static int launch_smalln(const GConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+// Times candidates 0..ncand-1 on the caller's stream and returns the fastest.  run(c) returns 0 on success,
+// -1 if c does not apply to this geometry (skipped), anything else is an error (returned through *err).
+// Two passes: 3 launches of every candidate, then 10 launches of those within 8 % of the best - with ~20
+// candidates a single short timing picks a noise winner often enough to cost 1-2 % of a step.
+template <class Run>
+static int tune_pick(int ncand, Run run, hipStream_t st, int fallback, float* best_us, int* err) {
+  *err = 0;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  std::vector<float> ms(ncand, -1.f);
+  auto time_one = [&](int c, int reps) -> float {
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < reps; ++r) run(c);
+    (void)hipEventRecord(e1, st);
+    float t = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) return -1.f;
+    return t / reps;
+  };
+  float best = 1e30f;
+  int pick = fallback;
+  for (int c = 0; c < ncand && !*err; ++c) {
+    const int rc = run(c);                    // warm-up (also sets the LDS attribute)
+    if (rc == -1) continue;
+    if (rc) { *err = rc; break; }
+    ms[c] = time_one(c, 3);
+    if (ms[c] >= 0.f && ms[c] < best) { best = ms[c]; pick = c; }
+  }
+  if (!*err && best < 1e30f) {
+    const float cut = best * 1.08f;
+    best = 1e30f;
+    for (int c = 0; c < ncand; ++c) {
+      if (ms[c] < 0.f || ms[c] > cut) continue;
+      const float t = time_one(c, 10);
+      if (t >= 0.f && t < best) { best = t; pick = c; }
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (best_us) *best_us = best * 1000.f;
+  return pick;
+}
+
 static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   GConvArgs a = ain;
   {
@@ -949,29 +992,18 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   if (it != g_tune.end()) return run(it->second);
   const bool prof_was = g_prof_on;
   g_prof_on = false;
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  float best_ms = 1e30f;
-  int best = tile;
-  for (int cand = 0; cand < 6; ++cand) {
-    if ((cand == 0 || cand == 3 || cand == 4) && N < 128) continue;
-    int rc = run(cand);                       // warm-up (also sets the LDS attribute)
-    if (rc) { g_prof_on = prof_was; return rc; }
-    (void)hipEventRecord(e0, st);
-    for (int r = 0; r < 3; ++r) run(cand);
-    (void)hipEventRecord(e1, st);
-    float ms = 0.f;
-    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
-    if (ms < best_ms) { best_ms = ms; best = cand; }
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  float best_us = 0.f;
+  int err = 0;
+  const int best = tune_pick(6, [&](int cand) -> int {
+    if ((cand == 0 || cand == 3 || cand == 4) && N < 128) return -1;
+    return run(cand);
+  }, st, tile, &best_us, &err);
   g_prof_on = prof_was;
+  if (err) return err;
   g_tune[key] = best;
   if (getenv("IPRGAN_TUNE_LOG"))
     fprintf(stderr, "[iprgan tune] gconv B%d in %dx%dx%d out %dx%dx%d taps %dx%d phases %d -> tile %d (%.1f us)\n", a.B,
-            a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.ph[0].th, a.ph[0].tw, a.nphase, best, best_ms * 1000.f / 3);
+            a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.ph[0].th, a.ph[0].tw, a.nphase, best, best_us);
   return run(best);
 }
 
@@ -979,8 +1011,15 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
 struct WGradPlan {
   int N, Cq, Ps, Qs, ntap, Kw, Nrows, bn, bk, tiles, nsplit, cps, M, w8;
 };
-// cand: 0 = 128x128 tiles, 1 = 64x64, 2 = 128x64, each x {768, 1536, 384} target blocks (cand / 3 selects)
-#define WGRAD_NCAND 12
+// cand = 4 * target + shape.  shape: 0 = 128x128 tiles, 1 = 64x64, 2 = 128x64, 3 = 128x128 on 8 waves;
+// target blocks {768, 1536, 3072, 6144, 384}.  768 blocks are ONE round of 3 blocks per CU: the blocks start
+// together and stay in lockstep (loader phases aligned between barriers, nothing else to run meanwhile), so on
+// long reductions more, shorter splits win (north-star shape: 113 -> 129 TFLOP/s at 3072) until the slab
+// traffic of the extra splits costs more.
+#define WGRAD_NSHAPE 4
+#define WGRAD_NTARGET 5
+#define WGRAD_NCAND (WGRAD_NSHAPE * WGRAD_NTARGET)
+#define WGRAD_MAX_SLAB_FLOATS ((size_t)128 << 20)      // candidates needing more than 512 MB of slabs are skipped
 static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   const Shape s = out_shape(d);
   // P = grid-aligned tensor (Conv2d: dy [OH,OW,Cout]; ConvT: x [H,W,Cin]); Q = gathered tensor
@@ -991,11 +1030,11 @@ static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   const int PH = d->transposed ? d->H : s.OH, PW = d->transposed ? d->W : s.OW;
   p.M = d->B * PH * PW;
   const int K = p.ntap * p.Qs;
-  // candidates 0..8: shape = cand % 3 x target blocks {768, 1536, 384}; 9..11: 128x128 tile on 8 waves
-  const int shape = cand >= 9 ? 0 : cand % 3;
-  const int tsel = cand >= 9 ? cand - 9 : cand / 3;
-  const int target = tsel == 0 ? 768 : (tsel == 1 ? 1536 : 384);
-  p.w8 = cand >= 9 ? 1 : 0;
+  static const int targets[WGRAD_NTARGET] = {768, 1536, 3072, 6144, 384};
+  if (cand < 0 || cand >= WGRAD_NCAND) return false;
+  const int shape = (cand % WGRAD_NSHAPE) == 3 ? 0 : cand % WGRAD_NSHAPE;
+  const int target = targets[cand / WGRAD_NSHAPE];
+  p.w8 = (cand % WGRAD_NSHAPE) == 3 ? 1 : 0;
   if (p.w8 && (p.N < 128 || K < 128)) return false;
   if (p.N <= 32) {
     if (shape != 0) return false;
@@ -1018,6 +1057,7 @@ static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   if (want > chunks) want = chunks;
   p.cps = cdiv(chunks, want);
   p.nsplit = cdiv(chunks, p.cps);
+  if (cand >= WGRAD_NSHAPE && (size_t)p.nsplit * p.Nrows * p.Kw > WGRAD_MAX_SLAB_FLOATS) return false;
   return true;
 }
 static WGradPlan wgrad_plan(const iprgan_conv_desc* d) {       // the un-tuned default
@@ -1272,24 +1312,14 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     } else {
       const bool prof_was = g_prof_on;
       g_prof_on = false;
-      hipEvent_t e0, e1;
-      (void)hipEventCreate(&e0);
-      (void)hipEventCreate(&e1);
-      float best_ms = 1e30f;
-      for (int c = 0; c < WGRAD_NCAND; ++c) {
-        const int rc = run(c);
-        if (rc == -1) continue;
-        if (rc) { g_prof_on = prof_was; return rc; }
-        (void)hipEventRecord(e0, st);
-        for (int r = 0; r < 3; ++r) run(c);
-        (void)hipEventRecord(e1, st);
-        float ms = 0.f;
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
-        if (ms < best_ms) { best_ms = ms; cand = c; }
-      }
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
+      float best_us = 0.f;
+      int err = 0;
+      cand = tune_pick(WGRAD_NCAND, run, st, cand, &best_us, &err);
       g_prof_on = prof_was;
+      if (err) return err;
+      if (getenv("IPRGAN_TUNE_LOG"))
+        fprintf(stderr, "[iprgan tune] wgrad B%d %dx%d %d->%d k%d s%d t%d -> cand %d (%.1f us)\n", d->B, d->H, d->W,
+                d->Cin, d->Cout, d->KH, d->stride, d->transposed, cand, best_us);
       g_tune[key] = cand;
     }
   }

@@ -25,6 +25,10 @@ LAYERS = [  # name, cin, cout, k, s, p, transposed, H
     ('G.up2 128->64 T k4s2', 128, 64, 4, 2, 1, True, 32),
     ('G.out 64->3 T k3', 64, 3, 3, 1, 1, True, 64),
     ('NS 256->256 k3 @64 B64', 256, 256, 3, 1, 1, False, 64),
+    # SURVEY section 8(d) microbench: the 3x3 convs Resnet9Blocks executes on a 64x3x256x256 batch
+    ('NS(i) 64->128 k3s2 @256 B64', 64, 128, 3, 2, 1, False, 256),
+    ('NS(ii) 128->256 k3s2 @128 B64', 128, 256, 3, 2, 1, False, 128),
+    ('NS(iii) 256->256 k3 reflect @64 B64', 256, 256, 3, 1, 1, False, 64),
 ]
 
 
@@ -48,7 +52,7 @@ def main():
         if only and only not in name:
             continue
         b = 64 if name.startswith('NS') else B
-        spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr)
+        spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr, pad_mode=1 if 'reflect' in name else 0)
         d = spec.desc(b, H, H)
         OH, OW = spec.out_hw(H, H)
         x = torch.randn(b, H, H, ops.c4(cin), device=dev)
@@ -56,6 +60,7 @@ def main():
         wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
         w = torch.randn(*wshape, device=dev) * 0.05
         wf, wb = ops.conv_prep(spec, d, w, None, True, True)
+        del w
         flops = 2.0 * b * (H * H if tr else OH * OW) * cin * cout * k * k
         t_f = timeit(lambda: ops.conv_fwd(spec, d, x, wf, None))
         t_d = timeit(lambda: ops.conv_bwd_data(spec, d, dy, wb))

@@ -387,7 +387,7 @@ def test_every_gconv_tile_variant(dev, tile):
         _lib.call('iprgan_debug_force_tiles', -1, -1)
 
 
-@pytest.mark.parametrize('cand', range(12))
+@pytest.mark.parametrize('cand', range(20))
 def test_every_wgrad_candidate(dev, cand):
     from iprgan import _lib, ops
     try:
