@@ -1012,10 +1012,9 @@ struct WGradPlan {
   int N, Cq, Ps, Qs, ntap, Kw, Nrows, bn, bk, tiles, nsplit, cps, M, w8;
 };
 // cand = 4 * target + shape.  shape: 0 = 128x128 tiles, 1 = 64x64, 2 = 128x64, 3 = 128x128 on 8 waves;
-// target blocks {768, 1536, 3072, 6144, 384}.  768 blocks are ONE round of 3 blocks per CU: the blocks start
-// together and stay in lockstep (loader phases aligned between barriers, nothing else to run meanwhile), so on
-// long reductions more, shorter splits win (north-star shape: 113 -> 129 TFLOP/s at 3072) until the slab
-// traffic of the extra splits costs more.
+// target blocks {768, 1536, 3072, 6144, 384}.  768 blocks are ONE round of 3 blocks per CU; on long reductions
+// more, shorter splits balance better across CUs (north-star shape: 113 -> 129 TFLOP/s at 3072) until the slab
+// traffic of the extra splits costs more.  (Starting the blocks of a round out of phase with s_sleep did nothing.)
 #define WGRAD_NSHAPE 4
 #define WGRAD_NTARGET 5
 #define WGRAD_NCAND (WGRAD_NSHAPE * WGRAD_NTARGET)
