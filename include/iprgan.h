@@ -24,7 +24,8 @@ extern "C" {
 
 #define IPRGAN_VERSION 100
 
-enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3 };
+enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
+       IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
 enum { IPRGAN_PAD_ZERO = 0, IPRGAN_PAD_REFLECT = 1 };
 
 /* One 2-D convolution / transposed convolution layer.
@@ -166,13 +167,29 @@ enum { IPRGAN_LOSS_HINGE_REAL = 0,   /* mean(relu(1-x)) */
        IPRGAN_LOSS_BCE_ONES = 3,     /* BCE-with-logits vs 1 */
        IPRGAN_LOSS_BCE_ZEROS = 4,    /* BCE-with-logits vs 0 */
        IPRGAN_LOSS_MSE_ONES = 5, IPRGAN_LOSS_MSE_ZEROS = 6,
-       IPRGAN_LOSS_MSE = 7, IPRGAN_LOSS_L1 = 8 };  /* two-input forms use y */
+       IPRGAN_LOSS_MSE = 7, IPRGAN_LOSS_L1 = 8,    /* two-input forms use y */
+       /* VAE terms (models/vae.py:36-48), used with iprgan_loss_sum_* (sum * scale, scale = 1/batch): */
+       IPRGAN_LOSS_BCE_PM1 = 9,      /* F.binary_cross_entropy((x+1)/2, (y+1)/2): logs clamped at -100 like ATen */
+       IPRGAN_LOSS_KL_MEAN = 10,     /* x^2 / 2                      (x = mean)   */
+       IPRGAN_LOSS_KL_LOGVAR = 11 }; /* (exp(x) - 1 - x) / 2         (x = logvar) */
 size_t iprgan_loss_ws_floats(size_t n);
 int iprgan_loss_fwd(int kind, const float* x, const float* y, float* loss, float* ws, size_t n,
                     void* stream);
 /* dx = (*gscale) * dloss/dx ; gscale is a device scalar (upstream gradient), may be NULL (=1). */
 int iprgan_loss_bwd(int kind, const float* x, const float* y, const float* gscale, float* dx,
                     size_t n, void* stream);
+/* same kernels with an explicit reduction: loss = scale * sum_i term_i (reduction='sum' / N, models/vae.py:41-47) */
+int iprgan_loss_sum_fwd(int kind, const float* x, const float* y, float* loss, float* ws, size_t n,
+                        float scale, void* stream);
+int iprgan_loss_sum_bwd(int kind, const float* x, const float* y, const float* gscale, float* dx,
+                        size_t n, float scale, void* stream);
+
+/* ---- VAE reparameterisation (networks/encoder.py:24-28): z = eps * exp(logvar/2) + mean ---- */
+int iprgan_reparam_fwd(const float* mean, const float* logvar, const float* eps, float* z, size_t n,
+                       void* stream);
+/* dmean = dz ; dlogvar = dz * eps * exp(logvar/2) / 2 */
+int iprgan_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmean,
+                       float* dlogvar, size_t n, void* stream);
 
 /* ---- sign-loss watermark (tools/sign_model.py:42-60) --------------------------------------- */
 /* gammas/signs/dgammas: HOST arrays of nlayer DEVICE pointers, sizes: HOST array of channel counts.

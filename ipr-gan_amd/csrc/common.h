@@ -82,6 +82,7 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     case IPRGAN_ACT_RELU: return v > 0.f ? v : 0.f;
     case IPRGAN_ACT_LRELU: return v > 0.f ? v : v * slope;
     case IPRGAN_ACT_TANH: return tanhf(v);
+    case IPRGAN_ACT_SIGMOID_PM1: return (1.f / (1.f + expf(-v))) * 2.f - 1.f;
     default: return v;
   }
 }
@@ -91,6 +92,7 @@ __device__ __forceinline__ float act_grad_from_out(float o, int act, float slope
     case IPRGAN_ACT_RELU: return o > 0.f ? 1.f : 0.f;
     case IPRGAN_ACT_LRELU: return o > 0.f ? 1.f : slope;
     case IPRGAN_ACT_TANH: return 1.f - o * o;
+    case IPRGAN_ACT_SIGMOID_PM1: return (1.f + o) * (1.f - o) * 0.5f;     // 2 s (1 - s), s = (o + 1) / 2
     default: return 1.f;
   }
 }

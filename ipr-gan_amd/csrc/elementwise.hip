@@ -124,6 +124,12 @@ __device__ __forceinline__ float loss_term(int kind, float x, float y) {
     case IPRGAN_LOSS_MSE_ONES: return (x - 1.f) * (x - 1.f);
     case IPRGAN_LOSS_MSE_ZEROS: return x * x;
     case IPRGAN_LOSS_MSE: return (x - y) * (x - y);
+    case IPRGAN_LOSS_BCE_PM1: {       // ATen binary_cross_entropy: (t - 1) * max(log(1 - p), -100) - t * max(log p, -100)
+      const float p = (x + 1.f) / 2.f, t = (y + 1.f) / 2.f;
+      return (t - 1.f) * fmaxf(logf(1.f - p), -100.f) - t * fmaxf(logf(p), -100.f);
+    }
+    case IPRGAN_LOSS_KL_MEAN: return x * x / 2.f;
+    case IPRGAN_LOSS_KL_LOGVAR: return (expf(x) - 1.f - x) / 2.f;
     default: return fabsf(x - y);
   }
 }
@@ -137,6 +143,12 @@ __device__ __forceinline__ float loss_grad(int kind, float x, float y) {
     case IPRGAN_LOSS_MSE_ONES: return 2.f * (x - 1.f);
     case IPRGAN_LOSS_MSE_ZEROS: return 2.f * x;
     case IPRGAN_LOSS_MSE: return 2.f * (x - y);
+    case IPRGAN_LOSS_BCE_PM1: {       // ATen backward: (p - t) / max((1 - p) p, 1e-12); dp/dx = 1/2
+      const float p = (x + 1.f) / 2.f, t = (y + 1.f) / 2.f;
+      return (p - t) / fmaxf((1.f - p) * p, 1e-12f) * 0.5f;
+    }
+    case IPRGAN_LOSS_KL_MEAN: return x;
+    case IPRGAN_LOSS_KL_LOGVAR: return (expf(x) - 1.f) / 2.f;
     default: { const float d = x - y; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
   }
 }
@@ -166,6 +178,21 @@ __global__ void loss_bwd_kernel(int kind, const float* __restrict__ x, const flo
     dx[i] = g * loss_grad(kind, x[i], y ? y[i] : 0.f);
 }
 
+// ---- VAE reparameterisation (networks/encoder.py:24-28): std = exp(logvar * 0.5); z = eps * std + mean ----
+__global__ void reparam_fwd_kernel(const float* __restrict__ mean, const float* __restrict__ logvar,
+                                   const float* __restrict__ eps, float* __restrict__ z, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    z[i] = eps[i] * expf(logvar[i] * 0.5f) + mean[i];
+}
+__global__ void reparam_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ logvar,
+                                   const float* __restrict__ eps, float* __restrict__ dmean,
+                                   float* __restrict__ dlogvar, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float g = dz[i];
+    dmean[i] = g;
+    dlogvar[i] = g * eps[i] * expf(logvar[i] * 0.5f) * 0.5f;
+  }
+}
 
 // ---- PReLU with ONE learnable slope (nn.PReLU(), networks/sr_resnet.py:7,14,43) ---------------------
 __global__ void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
@@ -523,26 +550,57 @@ int iprgan_reflect_fold(const float* dxp, float* dx, const float* prev_out, int 
   return 0;
 }
 
+static bool loss_needs_y(int kind) {
+  return kind == IPRGAN_LOSS_MSE || kind == IPRGAN_LOSS_L1 || kind == IPRGAN_LOSS_BCE_PM1;
+}
 size_t iprgan_loss_ws_floats(size_t n) { (void)n; return LOSS_BLOCKS; }
-int iprgan_loss_fwd(int kind, const float* x, const float* y, float* loss, float* ws, size_t n,
-                    void* stream) {
+int iprgan_loss_sum_fwd(int kind, const float* x, const float* y, float* loss, float* ws, size_t n,
+                        float scale, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  IPR_CHECK(kind >= 0 && kind <= IPRGAN_LOSS_L1, "loss_fwd: bad kind %d", kind);
+  IPR_CHECK(kind >= 0 && kind <= IPRGAN_LOSS_KL_LOGVAR, "loss_fwd: bad kind %d", kind);
   IPR_CHECK(n > 0, "loss_fwd: empty input");
-  IPR_CHECK(kind < IPRGAN_LOSS_MSE || y, "loss_fwd: kind %d needs a second input", kind);
+  IPR_CHECK(!loss_needs_y(kind) || y, "loss_fwd: kind %d needs a second input", kind);
   const int nb = grid_for(n, LOSS_BLOCKS);
   hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, st, kind, x, y, ws, n);
   IPR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, ws, nb, 1.0f / (float)n, loss);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, ws, nb, scale, loss);
   IPR_LAUNCH_CHECK();
   return 0;
 }
-int iprgan_loss_bwd(int kind, const float* x, const float* y, const float* gscale, float* dx, size_t n,
-                    void* stream) {
-  IPR_CHECK(kind >= 0 && kind <= IPRGAN_LOSS_L1, "loss_bwd: bad kind %d", kind);
+int iprgan_loss_sum_bwd(int kind, const float* x, const float* y, const float* gscale, float* dx, size_t n,
+                        float scale, void* stream) {
+  IPR_CHECK(kind >= 0 && kind <= IPRGAN_LOSS_KL_LOGVAR, "loss_bwd: bad kind %d", kind);
+  IPR_CHECK(!loss_needs_y(kind) || y, "loss_bwd: kind %d needs a second input", kind);
   if (!n) return 0;
   hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, kind, x, y,
-                     gscale, dx, n, 1.0f / (float)n);
+                     gscale, dx, n, scale);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_loss_fwd(int kind, const float* x, const float* y, float* loss, float* ws, size_t n,
+                    void* stream) {
+  IPR_CHECK(n > 0, "loss_fwd: empty input");
+  return iprgan_loss_sum_fwd(kind, x, y, loss, ws, n, 1.0f / (float)n, stream);
+}
+int iprgan_loss_bwd(int kind, const float* x, const float* y, const float* gscale, float* dx, size_t n,
+                    void* stream) {
+  if (!n) return 0;
+  return iprgan_loss_sum_bwd(kind, x, y, gscale, dx, n, 1.0f / (float)n, stream);
+}
+
+int iprgan_reparam_fwd(const float* mean, const float* logvar, const float* eps, float* z, size_t n,
+                       void* stream) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, mean,
+                     logvar, eps, z, n);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmean, float* dlogvar,
+                       size_t n, void* stream) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, dz,
+                     logvar, eps, dmean, dlogvar, n);
   IPR_LAUNCH_CHECK();
   return 0;
 }

@@ -12,10 +12,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('IPRGAN_LIB', os.path.join(_HERE, 'libiprgan_hip.so'))   # override: A/B builds
 
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID_PM1 = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 (LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_NEG_MEAN, LOSS_BCE_ONES, LOSS_BCE_ZEROS,
- LOSS_MSE_ONES, LOSS_MSE_ZEROS, LOSS_MSE, LOSS_L1) = range(9)
+ LOSS_MSE_ONES, LOSS_MSE_ZEROS, LOSS_MSE, LOSS_L1, LOSS_BCE_PM1, LOSS_KL_MEAN, LOSS_KL_LOGVAR) = range(12)
 
 
 class ConvDesc(C.Structure):
@@ -70,6 +70,10 @@ SIGNATURES = {
     'iprgan_loss_ws_floats': (_Z, [_Z]),
     'iprgan_loss_fwd': (_I, [_I, _P, _P, _P, _P, _Z, _P]),
     'iprgan_loss_bwd': (_I, [_I, _P, _P, _P, _P, _Z, _P]),
+    'iprgan_loss_sum_fwd': (_I, [_I, _P, _P, _P, _P, _Z, _F, _P]),
+    'iprgan_loss_sum_bwd': (_I, [_I, _P, _P, _P, _P, _Z, _F, _P]),
+    'iprgan_reparam_fwd': (_I, [_P, _P, _P, _P, _Z, _P]),
+    'iprgan_reparam_bwd': (_I, [_P, _P, _P, _P, _P, _Z, _P]),
     'iprgan_sign_loss_fwd': (_I, [_P, _P, _P, _I, _F, _P, _P]),
     'iprgan_sign_loss_bwd': (_I, [_P, _P, _P, _P, _I, _F, _P, _P]),
     'iprgan_sign_ber': (_I, [_P, _P, _P, _I, _P, _P]),

@@ -15,9 +15,9 @@ import torch
 from . import _lib as L
 from . import networks, optim, tools
 from .parallel import GradReducer, Replica, broadcast_module
-from .tools import loss_value
+from .tools import loss_sum, loss_value
 
-__all__ = ['Model', 'Wrapper', 'DCGAN', 'SRGAN', 'CycleGAN', 'ImagePool', 'WhiteBoxWrapper',
+__all__ = ['Model', 'Wrapper', 'DCGAN', 'SRGAN', 'CycleGAN', 'VAE', 'ImagePool', 'WhiteBoxWrapper',
            'DisableBatchNormStats']
 
 
@@ -145,6 +145,62 @@ class DCGAN(Model):
 
     def update_g(self, data, update=True):
         self.forward_g(data)
+        self.compute_g_loss()
+        if update:
+            self.optG.zero_grad()
+            self.reduceG.arm()
+            self.LossG.backward()
+            _step(self.optG, self.reduceG)
+
+
+class VAE(Model):
+    """models/vae.py:9-74 - encoder ``D`` + decoder ``G`` trained by ONE optimizer on KL + BCE reconstruction
+    (both summed over elements and divided by the batch size); ``update_d`` only runs the forward pass."""
+
+    def __init__(self, config, device=[torch.device('cpu'), ]):
+        super().__init__()
+        self.device = device
+        dev = device[0]
+        self.G = Replica(getattr(networks, config.G)(), dev)
+        self.D = Replica(getattr(networks, config.D)(), dev)
+        self.G.train()
+        self.D.train()
+        broadcast_module(self.G)
+        broadcast_module(self.D)
+
+        opt_fn = getattr(optim, config.opt)
+        params = list(chain(self.G.parameters(), self.D.parameters()))
+        self.optG = opt_fn(params, **config.opt_param.to_dict())
+        self.reduceG = GradReducer(params)
+
+        self._modules['G'] = self.G
+        self._modules['D'] = self.D
+        self._modules['opt'] = self.optG
+
+    def compute_d_loss(self): pass
+
+    def compute_g_loss(self):
+        inv_n = 1.0 / self.mean.size(0)
+        self.kl_loss = (loss_sum(L.LOSS_KL_MEAN, self.mean, None, inv_n)
+                        + loss_sum(L.LOSS_KL_LOGVAR, self.logvar, None, inv_n))
+        self.reconstruct = loss_sum(L.LOSS_BCE_PM1, self.fake_sample, self.real_sample, inv_n)
+        self.LossG = self.kl_loss + self.reconstruct
+
+    def forward_d(self, data):
+        self.real_sample = data['real_sample'].to(self.device[0], non_blocking=True)
+        self.latent, (self.mean, self.logvar) = self.D(self.real_sample)
+        self.fake_sample = self.G(self.latent)
+        self.generated = self.fake_sample
+
+    def forward_g(self, data): pass
+
+    def get_metrics(self):
+        return _fetch({'G/KL': self.kl_loss, 'G/R': self.reconstruct, 'G/Sum': self.LossG})
+
+    def update_d(self, data):
+        self.forward_d(data)
+
+    def update_g(self, data, update=True):
         self.compute_g_loss()
         if update:
             self.optG.zero_grad()

@@ -14,12 +14,13 @@ from torch.nn.utils import spectral_norm
 
 from . import _lib as L
 from . import engine as E
-from .ops import ConvSpec
+from .ops import ConvSpec, reparam_bwd as ops_reparam_bwd, reparam_fwd as ops_reparam_fwd
 
 __all__ = ['ConvGenerator', 'ConvGenerator32', 'ConvGenerator64',
            'SNDiscriminator', 'SNDiscriminator32', 'SNDiscriminator64', 'Flatten',
            'SRResNet', 'Discriminator96', 'VGG19Feature',
-           'ResnetGenerator', 'ResnetBlock', 'Resnet6Blocks', 'Resnet9Blocks', 'ConvDiscriminator']
+           'ResnetGenerator', 'ResnetBlock', 'Resnet6Blocks', 'Resnet9Blocks', 'ConvDiscriminator',
+           'Encoder32', 'Decoder32']
 
 
 class _HipNet(nn.Module):
@@ -374,3 +375,91 @@ class ConvDiscriminator(nn.Sequential, _HipNet):
 
     def forward(self, x):
         return self.run(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# VAE on 32x32 images: reference networks/encoder.py:4-30 and networks/decoder.py:3-33
+# ------------------------------------------------------------------------------------------------
+class _ReparamFn(torch.autograd.Function):
+    """z = eps * exp(logvar / 2) + mean (networks/encoder.py:24-28)."""
+
+    @staticmethod
+    def forward(ctx, mean, logvar, eps):
+        m, lv = mean.detach().contiguous(), logvar.detach().contiguous()
+        ctx.save_for_backward(lv, eps)
+        return ops_reparam_fwd(m, lv, eps)
+
+    @staticmethod
+    def backward(ctx, dz):
+        lv, eps = ctx.saved_tensors
+        dmean, dlogvar = ops_reparam_bwd(dz.contiguous(), lv, eps)
+        return dmean, dlogvar, None
+
+
+class Encoder32(_HipNet):
+    """image -> (z, (mean, logvar)).  ``eps_fn(shape, device)``, when set, supplies the N(0,1) draw of the
+    reparameterisation (parity tests replay the reference's draw); otherwise ``torch.randn`` on the device."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = nn.Sequential(
+            nn.Conv2d(3, 32, 3, 2, 1), nn.BatchNorm2d(32, affine=True), nn.ReLU(inplace=True),
+            nn.Conv2d(32, 64, 3, 2, 1), nn.BatchNorm2d(64, affine=True), nn.ReLU(inplace=True),
+            nn.Conv2d(64, 128, 3, 2, 1))
+        self.q_mean = nn.Linear(2048, 128)
+        self.q_logvar = nn.Linear(2048, 128)
+        self.__dict__['eps_fn'] = None
+
+    def _build_chain(self):
+        e = self.encoder
+        body = E.Chain([E.ToNHWC(3),
+                        E.Conv(ConvSpec(3, 32, 3, 2, 1), e[0]), E.BatchNorm(e[1], act=L.ACT_RELU),
+                        E.Conv(ConvSpec(32, 64, 3, 2, 1), e[3]), E.BatchNorm(e[4], act=L.ACT_RELU),
+                        E.Conv(ConvSpec(64, 128, 3, 2, 1), e[6]),
+                        E.ToNCHW(128), E.View((2048,))])         # q.flatten(start_dim=1) in NCHW order
+        heads = [E.Chain([E.LinearNHWC(m, 128, 1, act=L.ACT_NONE)]) for m in (self.q_mean, self.q_logvar)]
+        return body, heads
+
+    def forward(self, x):
+        body, heads = self.chain()
+        q = body(x, self.training)
+        mean, logvar = heads[0](q, self.training), heads[1](q, self.training)
+        fn = self.__dict__.get('eps_fn')
+        eps = fn(tuple(mean.shape), mean.device) if fn is not None else torch.randn(mean.shape, device=mean.device)
+        z = _ReparamFn.apply(mean, logvar, eps.to(mean.device, torch.float32).contiguous())
+        return z, (mean, logvar)
+
+
+class Decoder32(nn.Sequential, _HipNet):
+    """z -> image in [-1,1].  Module indices (state_dict keys 0., 2., 3., 5., 6., 8.) follow the reference."""
+
+    class Reshape(nn.Module):
+        def __init__(self, *shape):
+            super().__init__()
+            self.shape = shape
+
+        def forward(self, x):
+            return x.view(-1, *self.shape)
+
+    class Normalize(nn.Module):
+        def forward(self, x):
+            return x * 2 - 1
+
+    def __init__(self):
+        nn.Sequential.__init__(
+            self,
+            nn.Linear(128, 2048), Decoder32.Reshape(128, 4, 4),
+            nn.ConvTranspose2d(128, 64, 4, 2, 1), nn.BatchNorm2d(64, affine=True), nn.ReLU(inplace=True),
+            nn.ConvTranspose2d(64, 32, 4, 2, 1), nn.BatchNorm2d(32, affine=True), nn.ReLU(inplace=True),
+            nn.ConvTranspose2d(32, 3, 4, 2, 1), nn.Sigmoid(), Decoder32.Normalize())
+
+    def _build_chain(self):
+        T = dict(transposed=True)
+        return E.Chain([E.LinearNHWC(self[0], 128, 16, act=L.ACT_NONE), E.View((4, 4, 128)),
+                        E.Conv(ConvSpec(128, 64, 4, 2, 1, **T), self[2]), E.BatchNorm(self[3], act=L.ACT_RELU),
+                        E.Conv(ConvSpec(64, 32, 4, 2, 1, **T), self[5]), E.BatchNorm(self[6], act=L.ACT_RELU),
+                        E.Conv(ConvSpec(32, 3, 4, 2, 1, act=L.ACT_SIGMOID_PM1, **T), self[8]),   # Sigmoid + x*2-1
+                        E.ToNCHW(3)])
+
+    def forward(self, z):
+        return self.run(z)

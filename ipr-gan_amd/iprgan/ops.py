@@ -233,6 +233,33 @@ def loss_bwd(kind, x, y, gscale):
     return dx
 
 
+def loss_sum_fwd(kind, x, y, scale):
+    """scale * sum(term): the reduction='sum' / N losses of models/vae.py:36-48."""
+    out = empty((), x)
+    ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
+    call('iprgan_loss_sum_fwd', kind, ptr(x), ptr(y), ptr(out), ptr(ws), x.numel(), float(scale), stream())
+    return out
+
+
+def loss_sum_bwd(kind, x, y, gscale, scale):
+    dx = torch.empty_like(x)
+    call('iprgan_loss_sum_bwd', kind, ptr(x), ptr(y), ptr(gscale), ptr(dx), x.numel(), float(scale), stream())
+    return dx
+
+
+# ---- VAE reparameterisation -----------------------------------------------------------------------
+def reparam_fwd(mean, logvar, eps):
+    z = torch.empty_like(mean)
+    call('iprgan_reparam_fwd', ptr(mean), ptr(logvar), ptr(eps), ptr(z), mean.numel(), stream())
+    return z
+
+
+def reparam_bwd(dz, logvar, eps):
+    dmean, dlogvar = torch.empty_like(dz), torch.empty_like(dz)
+    call('iprgan_reparam_bwd', ptr(dz), ptr(logvar), ptr(eps), ptr(dmean), ptr(dlogvar), dz.numel(), stream())
+    return dmean, dlogvar
+
+
 # ---- sign loss ------------------------------------------------------------------------------------
 
 

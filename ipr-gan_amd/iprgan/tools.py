@@ -103,6 +103,24 @@ class _LossFn(torch.autograd.Function):
         return None, ops.loss_bwd(ctx.kind, ctx.x, ctx.y, gout.contiguous()), None
 
 
+class _LossSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, scale, x, y):
+        xd = x.detach().contiguous()
+        yd = None if y is None else y.detach().contiguous()
+        ctx.kind, ctx.scale, ctx.x, ctx.y = kind, scale, xd, yd
+        return ops.loss_sum_fwd(kind, xd, yd, scale)
+
+    @staticmethod
+    def backward(ctx, gout):
+        return None, None, ops.loss_sum_bwd(ctx.kind, ctx.x, ctx.y, gout.contiguous(), ctx.scale), None
+
+
+def loss_sum(kind, x, y=None, scale=1.0):
+    """``scale * sum(term)`` (reduction='sum' / N of models/vae.py:36-48); gradient flows to ``x`` only."""
+    return _LossSumFn.apply(kind, float(scale), x, y)
+
+
 def loss_value(kind, x, y=None):
     """Mean-reduced loss of ``kind`` (include/iprgan.h IPRGAN_LOSS_*); gradient flows to ``x`` only."""
     return _LossFn.apply(kind, x, y)

@@ -21,7 +21,18 @@ NET_CASES = {
     'Discriminator96':   ('Discriminator96', {}, (2, 3, 96, 96), 16),
     'Resnet6Blocks':     ('Resnet6Blocks', {}, (1, 3, 32, 32), 17),
     'ConvDiscriminator': ('ConvDiscriminator', {}, (1, 3, 64, 64), 18),
+    'Decoder32':         ('Decoder32', {}, (3, 128), 19),
+    'Encoder32':         ('Encoder32', {}, (3, 3, 32, 32), 20),      # returns (z, (mean, logvar)); eps replayed
 }
+
+
+def replay_eps(net):
+    """The reference draws the VAE's eps with torch.randn_like on the CPU generator (networks/encoder.py:26);
+    an implementation exposing ``eps_fn`` (the HIP Encoder32) is pointed at the same CPU stream so that
+    ``torch.manual_seed`` replays the identical draw on every side."""
+    if 'eps_fn' in getattr(net, '__dict__', {}):
+        net.__dict__['eps_fn'] = lambda shape, device: torch.randn(shape)
+
 
 BUFFER_LEAVES = ('running_mean', 'running_var', 'num_batches_tracked', 'weight_u', 'weight_v')
 
@@ -37,7 +48,11 @@ def run_net_case(networks, name, device='cpu'):
     if len(xshape) == 4:
         x = torch.tanh(x)
     x.requires_grad_(True)
+    replay_eps(net)
+    torch.manual_seed(seed)
     out = net(x)
+    if isinstance(out, tuple):                  # Encoder32
+        out = torch.cat([out[0], out[1][0], out[1][1]], dim=1)
     r = recipe.tensor(seed, 1001, tuple(out.shape)).to(device)
     loss = (out * r).sum()
     loss.backward()
@@ -153,6 +168,41 @@ def _capture(model, res, tag, nets, opts, moments=True):
             st = sd[opt]['state']
             for idx in sorted(st):
                 recipe.pack_summary(f'{tag}/{opt}/{idx}/exp_avg', st[idx]['exp_avg'].cpu(), res)
+
+
+VAE_CFG = {'G': 'Decoder32', 'D': 'Encoder32', 'opt': 'Adam',
+           'opt_param': {'lr': 3.0e-5, 'weight_decay': 1.0e-6}, 'type': 'VAE'}      # configs/VAE/*/vae-cifar10-a.yaml
+
+
+def run_vae_steps(make_cfg, models, device, n_steps=3, batch=4, seed=61, wbox=True):
+    """VAE steps in the order of experiments/image_generation.py:86-101: update_d (forward only, models/vae.py:66-67)
+    then update_g (loss, backward, ONE Adam over decoder + encoder), white-box sign loss on the decoder's BN."""
+    model = models.VAE(make_cfg(VAE_CFG), device=device)
+    recipe.fill(model.G.module, seed)
+    recipe.fill(model.D.module, seed + 1)
+    model.G.to(device[0])
+    model.D.to(device[0])
+    replay_eps(model.D.module)
+    if wbox:
+        model = models.WhiteBoxWrapper(model, make_cfg(WBOX_CFG))
+    res = {}
+    for s in range(n_steps):
+        x = torch.tanh(recipe.tensor(seed, 2000 + s, (batch, 3, 32, 32)))
+        torch.manual_seed(7000 + s)
+        model.update_d({'real_sample': x, 'latent': None})
+        model.update_g({'fake_sample': model.fake_sample})
+        for k, v in model.get_metrics().items():
+            res[f'step{s}/metric/{k}'] = np.float64(float(v.detach()) if torch.is_tensor(v) else float(v))
+        if s == 0:
+            res['step0/fake_sample'] = model.fake_sample.detach().cpu().numpy()
+            res['step0/latent'] = model.latent.detach().cpu().numpy()
+            _capture(model, res, 'step0', (), ('opt',))
+    _capture(model, res, 'final', ('G', 'D'), ('opt',))
+    if wbox:
+        for k, v in model.state_dict()['sign'].items():
+            res[f'final/sign/{k}'] = v.detach().cpu().numpy()
+        res['final/ber'] = np.float64(float(model.loss_model.compute_ber(model.G)))
+    return res
 
 
 SRGAN_CFG = {'G': 'SRResNet', 'D': 'Discriminator96', 'V': 'VGG19Feature', 'opt': 'Adam',

@@ -135,6 +135,51 @@ class DCGAN(Model):
             self.optG.step()
 
 
+class VAE(Model):
+    """models/vae.py:9-74: one Adam over decoder G and encoder D; loss = KL + BCE, both sum / batch."""
+
+    def __init__(self, config, device=CPU, networks=_nets):
+        super().__init__()
+        self.device = device
+        self.G = _wrap(getattr(networks, config.G)(), device)
+        self.D = _wrap(getattr(networks, config.D)(), device)
+        self.G.train()
+        self.D.train()
+        make = getattr(optim, config.opt)
+        self.optG = make(chain(self.G.parameters(), self.D.parameters()), **config.opt_param.to_dict())
+        self._modules.update(G=self.G, D=self.D, opt=self.optG)
+
+    def forward_d(self, data):                   # vae.py:50-55
+        self.real_sample = data['real_sample']
+        self.latent, (self.mean, self.logvar) = self.D(self.real_sample)
+        self.fake_sample = self.G(self.latent)
+        self.generated = self.fake_sample
+
+    def compute_d_loss(self): pass
+
+    def forward_g(self, data): pass
+
+    def compute_g_loss(self):                    # vae.py:36-48
+        n = self.mean.size(0)
+        self.kl_loss = ((self.mean ** 2 + self.logvar.exp() - 1 - self.logvar) / 2).sum() / n
+        self.reconstruct = F.binary_cross_entropy((self.fake_sample + 1.) / 2., (self.real_sample + 1.) / 2.,
+                                                  reduction='sum') / n
+        self.LossG = self.kl_loss + self.reconstruct
+
+    def get_metrics(self):                       # vae.py:59-64 (tensors there; floats here like the other models)
+        return {'G/KL': self.kl_loss.item(), 'G/R': self.reconstruct.item(), 'G/Sum': self.LossG.item()}
+
+    def update_d(self, data):                    # vae.py:66-67
+        self.forward_d(data)
+
+    def update_g(self, data, update=True):       # vae.py:69-75
+        self.compute_g_loss()
+        if update:
+            self.optG.zero_grad()
+            self.LossG.backward()
+            self.optG.step()
+
+
 class SRGAN(Model):
     """models/srgan.py:7-107."""
 

@@ -40,6 +40,7 @@ def main():
     save('dcgan_steps_plain', cases.run_dcgan_steps(ref_loader.Config, models, dev, n_steps=2, wbox=False))
     save('srgan_steps_wbox', cases.run_srgan_steps(ref_loader.Config, models, dev))
     save('cyclegan_steps_wbox', cases.run_cyclegan_steps(ref_loader.Config, models, dev))
+    save('vae_steps_wbox', cases.run_vae_steps(ref_loader.Config, models, dev))
 
 
 if __name__ == '__main__':

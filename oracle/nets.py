@@ -237,3 +237,51 @@ class ConvDiscriminator(nn.Sequential):
             nn.Conv2d(128, 256, 4, 2, 1), nn.InstanceNorm2d(256), nn.LeakyReLU(0.2, True),
             nn.Conv2d(256, 512, 4, 1, 1), nn.InstanceNorm2d(512), nn.LeakyReLU(0.2, True),
             nn.Conv2d(512, 1, 4, 1, 1))
+
+
+# --------------------------------------------------------------------------
+# VAE encoder / decoder on 32x32 (reference networks/encoder.py:4-30, networks/decoder.py:3-33)
+# --------------------------------------------------------------------------
+class Encoder32(nn.Module):
+    """3x Conv k3s2p1 (BN+ReLU after the first two) -> flatten(2048) -> two Linear(2048,128) heads;
+    z = eps * exp(logvar/2) + mean with eps = randn_like (encoder.py:20-30)."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = _seq(nn.Conv2d(3, 32, 3, 2, 1), nn.BatchNorm2d(32, affine=True), nn.ReLU(inplace=True),
+                            nn.Conv2d(32, 64, 3, 2, 1), nn.BatchNorm2d(64, affine=True), nn.ReLU(inplace=True),
+                            nn.Conv2d(64, 128, 3, 2, 1))
+        self.q_mean = nn.Linear(2048, 128)
+        self.q_logvar = nn.Linear(2048, 128)
+
+    def forward(self, x):
+        q = self.encoder(x).flatten(start_dim=1)
+        mean, logvar = self.q_mean(q), self.q_logvar(q)
+        std = torch.exp(logvar * 0.5)
+        eps = torch.randn_like(std)
+        return eps * std + mean, (mean, logvar)
+
+
+class _Reshape(nn.Module):
+    def __init__(self, *shape):
+        super().__init__()
+        self.shape = shape
+
+    def forward(self, x):                       # decoder.py:5-11
+        return x.view(-1, *self.shape)
+
+
+class _PlusMinusOne(nn.Module):
+    def forward(self, x):                       # decoder.py:13-15
+        return x * 2 - 1
+
+
+class Decoder32(nn.Sequential):
+    """Linear(128,2048) -> (128,4,4) -> 2x[ConvT k4s2p1, BN, ReLU] -> ConvT k4s2p1 -> Sigmoid -> x*2-1
+    (decoder.py:17-33)."""
+
+    def __init__(self):
+        super().__init__(nn.Linear(128, 2048), _Reshape(128, 4, 4),
+                         nn.ConvTranspose2d(128, 64, 4, 2, 1), nn.BatchNorm2d(64, affine=True), nn.ReLU(inplace=True),
+                         nn.ConvTranspose2d(64, 32, 4, 2, 1), nn.BatchNorm2d(32, affine=True), nn.ReLU(inplace=True),
+                         nn.ConvTranspose2d(32, 3, 4, 2, 1), nn.Sigmoid(), _PlusMinusOne())

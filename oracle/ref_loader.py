@@ -35,7 +35,7 @@ def load():
         return m.networks, m.tools, m.models
     networks = types.ModuleType('networks')
     for f in ('conv_generator', 'sn_discriminator', 'conv_discriminator', 'sr_resnet',
-              'discriminator_96', 'resnet_generator'):
+              'discriminator_96', 'resnet_generator', 'encoder', 'decoder'):
         mod = _load(f'_ref_net_{f}', f'networks/{f}.py')
         for k, v in vars(mod).items():
             if not k.startswith('__'):

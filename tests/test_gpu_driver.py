@@ -30,3 +30,19 @@ def test_train_driver_checkpoint_and_resume(tmp_path):
     from oracle import cases, gan
     o = gan.WhiteBoxWrapper(gan.DCGAN(gan.Cfg(cases.DCGAN_CFG)), gan.Cfg(cases.WBOX_CFG))
     o.load_state_dict({k: v for k, v in sd.items() if k != 'step'}, strict=True)
+
+
+def test_train_driver_vae(tmp_path):
+    """configs/VAE/*: same ImageGeneration experiment, models.VAE with one optimizer stored under 'opt'."""
+    cfg = os.path.join(ROOT, 'tests', 'configs', 'vae-wbox-tiny.yaml')
+    log = str(tmp_path / 'log')
+    subprocess.run([sys.executable, os.path.join(PKG, 'train.py'), '-c', cfg, '--log-path', log], check=True, timeout=600)
+    sd = torch.load(os.path.join(log, 'checkpoint.pt'), map_location='cpu')
+    assert sd['step'] == 'END' and list(sd) == ['G', 'D', 'opt', 'sign', 'step']
+    assert 'module.3.weight' in sd['G'] and 'module.q_logvar.bias' in sd['D']
+    rows = [json.loads(l) for l in open(os.path.join(log, 'metrics.jsonl'))]
+    assert [r['step'] for r in rows] == [1, 2, 3] and all(r['G/KL'] > 0 and r['G/R'] > 0 for r in rows)
+    assert json.load(open(os.path.join(log, 'metrics.json')))['BER'] == 0.0
+    from oracle import cases, gan
+    o = gan.WhiteBoxWrapper(gan.VAE(gan.Cfg(cases.VAE_CFG)), gan.Cfg(cases.WBOX_CFG))
+    o.load_state_dict({k: v for k, v in sd.items() if k != 'step'}, strict=True)

@@ -169,6 +169,20 @@ def test_cyclegan_steps_vs_reference_golden(golden, dev):
     compare(res, golden('cyclegan_steps_wbox'), policy=policy)
 
 
+def test_vae_steps_vs_reference_golden(golden, dev):
+    """VAE (Encoder32 + Decoder32, KL + BCE/N, one Adam with weight decay, sign loss on the decoder) against the
+    real reference's three steps; the reparameterisation noise is the reference's own CPU draw."""
+    from iprgan import Config, models
+    res = cases.run_vae_steps(Config, models, [dev])
+    base = step_policy(3, lr=3e-5)
+
+    def policy(k):
+        if k.startswith('step') and '/metric/' in k:
+            return (1e-3, 1e-3)            # losses are O(1e3) sums over 3x32x32 pixels / batch
+        return base(k)
+    compare(res, golden('vae_steps_wbox'), policy=policy)
+
+
 def test_vgg_features_vs_oracle(dev):
     from iprgan import networks
     a, b = nets.VGG19Feature(), networks.VGG19Feature()

@@ -232,6 +232,44 @@ def test_losses(dev, kind, n):
     close(xd.grad, x.grad, 1e-5, 'loss grad')
 
 
+@pytest.mark.parametrize('n', [5, 4 * 3 * 32 * 32])
+def test_vae_losses_and_reparam(dev, n):
+    """models/vae.py:36-48 (KL and BCE, sum / N with ATen's log clamp) and networks/encoder.py:24-28."""
+    from iprgan import _lib as L, ops, tools
+    N = 4
+    x = torch.tanh(rnd(n, seed=1) * 3)
+    x[:2] = torch.tensor([1.0, -1.0])[:min(2, n)]          # p = 1 and p = 0: the clamped-log / 1e-12 branches
+    x = x.requires_grad_()
+    t = torch.tanh(rnd(n, seed=2))
+    ref = F.binary_cross_entropy((x + 1.) / 2., (t + 1.) / 2., reduction='sum') / N
+    (ref * 0.7).backward()
+    xd = x.detach().to(dev).requires_grad_()
+    out = tools.loss_sum(L.LOSS_BCE_PM1, xd, t.to(dev), 1.0 / N)
+    (out * 0.7).backward()
+    close(out, ref, 1e-5, 'bce')
+    # the gradient at exactly p in {0, 1} is (p - t) / 1e-12 in ATen and here: compare the finite entries tightly
+    close(xd.grad[2:], x.grad[2:], 1e-5, 'bce grad')
+    assert torch.equal(torch.isfinite(xd.grad.cpu()), torch.isfinite(x.grad))
+    m, lv = rnd(n, seed=3).requires_grad_(), (rnd(n, seed=4) * 0.5).requires_grad_()
+    ref = ((m ** 2 + lv.exp() - 1 - lv) / 2).sum() / N
+    ref.backward()
+    md, lvd = m.detach().to(dev).requires_grad_(), lv.detach().to(dev).requires_grad_()
+    out = tools.loss_sum(L.LOSS_KL_MEAN, md, None, 1.0 / N) + tools.loss_sum(L.LOSS_KL_LOGVAR, lvd, None, 1.0 / N)
+    out.backward()
+    close(out, ref, 1e-5, 'kl')
+    close(md.grad, m.grad, 1e-6, 'kl dmean')
+    close(lvd.grad, lv.grad, 1e-5, 'kl dlogvar')
+    eps, g = rnd(n, seed=5), rnd(n, seed=6)
+    m2, lv2 = m.detach().clone().requires_grad_(), lv.detach().clone().requires_grad_()
+    z = eps * torch.exp(lv2 * 0.5) + m2
+    z.backward(g)
+    zd = ops.reparam_fwd(m.detach().to(dev), lv.detach().to(dev), eps.to(dev))
+    dm, dlv = ops.reparam_bwd(g.to(dev), lv.detach().to(dev), eps.to(dev))
+    close(zd, z, 1e-6, 'reparam')
+    close(dm, m2.grad, 1e-6, 'reparam dmean')
+    close(dlv, lv2.grad, 1e-6, 'reparam dlogvar')
+
+
 def test_sign_loss_and_ber_exact(dev):
     from iprgan import ops
     g = np.random.default_rng(5)

@@ -91,3 +91,9 @@ def test_srgan_steps_match_reference(golden):
 def test_cyclegan_steps_match_reference(golden):
     torch.manual_seed(0)
     compare(cases.run_cyclegan_steps(gan.Cfg, gan, gan.CPU), golden('cyclegan_steps_wbox'), rtol=5e-4, atol=5e-5)
+
+
+def test_vae_steps_match_reference(golden):
+    """Encoder32 / Decoder32 / models.VAE: KL + BCE, one Adam with weight decay over both
+    nets, sign loss on the decoder's BatchNorm; eps of the reparameterisation replayed from the CPU generator."""
+    compare(cases.run_vae_steps(gan.Cfg, gan, gan.CPU), golden('vae_steps_wbox'), rtol=5e-4, atol=5e-5)
