@@ -183,6 +183,29 @@ def test_vae_steps_vs_reference_golden(golden, dev):
     compare(res, golden('vae_steps_wbox'), policy=policy)
 
 
+def test_watermark_survives_training_and_attacks_count_exactly(dev):
+    """BER stays 0 through training steps on the engine; the sign-flip (sign_flip.py:59-75) and
+    prune (prune.py:46-57) attacks then change it to exactly the flipped / zeroed fraction (int64 count kernel)."""
+    from iprgan import Config, attacks, models
+    m = models.WhiteBoxWrapper(models.DCGAN(Config(cases.DCGAN_CFG), device=[dev]), Config(cases.WBOX_CFG))
+    for s in range(3):
+        m.update_d({'real_sample': torch.tanh(recipe.tensor(3, s, (8, 3, 64, 64))), 'latent': recipe.tensor(4, s, (8, 128))})
+        m.update_g({'fake_sample': m.fake_sample})
+    assert float(m.loss_model.compute_ber(m.G)) == 0.0
+    attacks.sign_flip_(m.G.module, 20, generator=torch.Generator().manual_seed(1))
+    assert float(m.loss_model.compute_ber(m.G)) == float(np.float32(int(448 * 20 / 100)) / np.float32(448))
+    attacks.sign_flip_(m.G.module, 100)
+    sd = m.G.module.state_dict()
+    attacks.prune_(sd, 50)
+    zeroed = sum(int((w == 0).sum()) for w in attacks.norm_scales(m.G.module))
+    flipped = 448 - int(448 * 20 / 100)
+    signs = torch.cat([b.flatten() for b in m.loss_model.buffers()]).cpu()
+    gam = torch.cat([w.detach().flatten() for w in attacks.norm_scales(m.G.module)]).cpu()
+    wrong = int((gam.sign() != signs).sum())
+    assert wrong >= max(zeroed, 1) and wrong <= flipped + zeroed
+    assert float(m.loss_model.compute_ber(m.G)) == float(np.float32(wrong) / np.float32(448))
+
+
 def test_vgg_features_vs_oracle(dev):
     from iprgan import networks
     a, b = nets.VGG19Feature(), networks.VGG19Feature()

@@ -9,7 +9,7 @@ from oracle import cases, gan, nets, recipe, sign
 
 def test_product_networks_mirror_reference_state_dict():
     from iprgan import networks
-    for name in ('ConvGenerator32', 'ConvGenerator64', 'SNDiscriminator32', 'SNDiscriminator64'):
+    for name in ('ConvGenerator32', 'ConvGenerator64', 'SNDiscriminator32', 'SNDiscriminator64', 'Encoder32', 'Decoder32'):
         a, b = getattr(nets, name)(), getattr(networks, name)()
         sa, sb = a.state_dict(), b.state_dict()
         assert list(sa) == list(sb), name
@@ -75,3 +75,34 @@ def test_adam_state_dict_layout_is_torch_compatible():
     ref.step()
     mine.load_state_dict(ref.state_dict())                      # a torch.optim.Adam checkpoint loads
     assert set(mine.state_dict()['state'][0]) >= {'step', 'exp_avg', 'exp_avg_sq'}
+
+
+def test_removal_attacks_and_ber_counts():
+    """sign_flip.py:59-75 / prune.py:46-57 restated as library functions: after flipping k of n scales the
+    bit-error rate is exactly k/n; pruning zeroes scales (sign 0 counts as an error) below a global percentile."""
+    from iprgan import attacks
+    net = nets.ConvGenerator64()
+    recipe.fill(net, 3)
+    model = sign.SignLossModel(net, gan.Cfg({'gamma_0': 0.1, 'string': 'EXAMPLE A'}))
+    assert float(model.compute_ber(net)) == 0.0
+    g = torch.Generator().manual_seed(7)
+    mask = attacks.sign_flip_(net, 30, generator=g)
+    n = sum(w.numel() for w in attacks.norm_scales(net))
+    assert n == 448 and int((mask < 0).sum()) == int(448 * 30 / 100)
+    assert float(model.compute_ber(net)) == float(np.float32(134) / np.float32(448))      # fp32 ratio of exact counts
+    attacks.sign_flip_(net, 100)                                # flip everything: previous flips come back
+    assert float(model.compute_ber(net)) == float(np.float32(448 - 134) / np.float32(448))
+    # prune: threshold is the percentile over ALL state_dict entries, like the script
+    net2 = nets.ConvGenerator64()
+    recipe.fill(net2, 3)
+    model2 = sign.SignLossModel(net2, gan.Cfg({'gamma_0': 0.1, 'string': 'EXAMPLE A'}))
+    sd = net2.state_dict()
+    flat = np.concatenate([v.abs().double().numpy().ravel() for v in sd.values()])
+    thr = attacks.prune_(sd, 40)
+    assert thr == float(np.percentile(flat, 40))
+    zeroed = sum(int((w == 0).sum()) for w in attacks.norm_scales(net2))
+    assert float(model2.compute_ber(net2)) == float(np.float32(zeroed) / np.float32(448))
+    # p-value of tools/phash_pvalue.py:34-37: identical hashes -> 2^-256, complementary -> 1
+    h = np.random.default_rng(0).integers(0, 2, (3, 256)).astype(bool)
+    p = attacks.matching_p_value(h, np.stack([h[0], ~h[1], h[2] ^ (np.arange(256) < 128)]))
+    assert p[0] < 1e-30 and p[1] == 1.0 and abs(float(p[2]) - 0.5249) < 1e-3
