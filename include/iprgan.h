@@ -191,6 +191,19 @@ int iprgan_reparam_fwd(const float* mean, const float* logvar, const float* eps,
 int iprgan_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmean,
                        float* dlogvar, size_t n, void* stream);
 
+/* ---- SSIM loss of the black-box objective (tools/loss.py:82-85 -> third-party pytorch-msssim 0.2.1 `ssim`,
+ * restated: 11-tap Gaussian sigma 1.5 valid window per channel, C1 = 0.01^2, C2 = 0.03^2, data_range 1).
+ * x, y: `planes` = B*C contiguous H x W images (NCHW tensors); denorm != 0 applies (v+1)/2 to both first
+ * (tools/loss.py:15-18).  loss = 1 - mean SSIM.  gmaps (iprgan_ssim_gmap_floats, may be NULL when no gradient
+ * is needed) receives the per-window sensitivities the backward pass consumes; ws: iprgan_ssim_ws_floats.
+ * Only x receives a gradient (the wrapper detaches y, models/wrappers.py:50-52). */
+size_t iprgan_ssim_ws_floats(int planes, int H, int W);
+size_t iprgan_ssim_gmap_floats(int planes, int H, int W);
+int iprgan_ssim_fwd(const float* x, const float* y, float* loss, float* gmaps, float* ws, int planes, int H,
+                    int W, int denorm, void* stream);
+int iprgan_ssim_bwd(const float* x, const float* y, const float* gmaps, const float* gscale, float* dx,
+                    int planes, int H, int W, int denorm, void* stream);
+
 /* ---- sign-loss watermark (tools/sign_model.py:42-60) --------------------------------------- */
 /* gammas/signs/dgammas: HOST arrays of nlayer DEVICE pointers, sizes: HOST array of channel counts.
  * loss = sum_l mean(relu(gamma0 - gamma_l*sign_l)).  Pointer tables are copied into the launch. */

@@ -73,6 +73,10 @@ SIGNATURES = {
     'iprgan_loss_sum_fwd': (_I, [_I, _P, _P, _P, _P, _Z, _F, _P]),
     'iprgan_loss_sum_bwd': (_I, [_I, _P, _P, _P, _P, _Z, _F, _P]),
     'iprgan_reparam_fwd': (_I, [_P, _P, _P, _P, _Z, _P]),
+    'iprgan_ssim_ws_floats': (_Z, [_I, _I, _I]),
+    'iprgan_ssim_gmap_floats': (_Z, [_I, _I, _I]),
+    'iprgan_ssim_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'iprgan_ssim_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'iprgan_reparam_bwd': (_I, [_P, _P, _P, _P, _P, _Z, _P]),
     'iprgan_sign_loss_fwd': (_I, [_P, _P, _P, _I, _F, _P, _P]),
     'iprgan_sign_loss_bwd': (_I, [_P, _P, _P, _P, _I, _F, _P, _P]),

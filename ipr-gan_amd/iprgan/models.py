@@ -17,8 +17,8 @@ from . import networks, optim, tools
 from .parallel import GradReducer, Replica, broadcast_module
 from .tools import loss_sum, loss_value
 
-__all__ = ['Model', 'Wrapper', 'DCGAN', 'SRGAN', 'CycleGAN', 'VAE', 'ImagePool', 'WhiteBoxWrapper',
-           'DisableBatchNormStats']
+__all__ = ['Model', 'Wrapper', 'DCGAN', 'SRGAN', 'CycleGAN', 'VAE', 'ImagePool', 'BlackBoxWrapper',
+           'WhiteBoxWrapper', 'DisableBatchNormStats']
 
 
 class Model(ABC):
@@ -480,6 +480,65 @@ class Wrapper(Model):
 
     def update_d(self, data):
         self.model.update_d(data)
+
+
+class BlackBoxWrapper(Wrapper):
+    """models/wrappers.py:7-74 - trigger-set watermark: the target generator must map the transformed input
+    ``fn_inp(x)`` to the watermarked output ``fn_out(G(x))``; adds ``lambda * loss_fn(G(fn_inp(x)), fn_out(y))``
+    (a second generator forward/backward per step, batch statistics only) to the G objective."""
+
+    def __init__(self, model, config):
+        super().__init__(model, config)
+        self.configure()
+
+    def configure(self):
+        normalized = self.config.normalized
+        dev = self.device[0]
+        make = lambda c: Replica(getattr(tools, c.type)(c, normalized=normalized), dev)
+        self.fn_inp = make(self.config.fn_inp)
+        self.fn_out = make(self.config.fn_out)
+        self.Lambda = self.config['lambda']
+        self.loss_fn = getattr(tools, self.config.loss_fn)(normalized=normalized)
+        self._modules = self.model._modules
+        self._modules['fn_inp'] = self.fn_inp
+        self._modules['fn_out'] = self.fn_out
+
+    def compute_g_loss(self):
+        self.LossG = self.model.LossG
+        self.LossW = torch.zeros_like(self.LossG) if self.inhibit else self.loss_fn(self.Gxwm, self.ywm)
+
+    def forward_g(self, data):
+        self.inhibit = data.get('inhibit_bbox', False)
+        if self.inhibit:
+            return
+        x = getattr(self.model, self.config.input_var)
+        y = getattr(self.model, self.config.output_var)
+        with torch.no_grad():
+            self.xwm = self.fn_inp(x.detach())
+            self.ywm = self.fn_out(y.detach())
+        G = getattr(self.model, self.config.target)
+        with DisableBatchNormStats(G):
+            self.Gxwm = G(self.xwm)
+
+    def get_metrics(self):
+        metrics = self.model.get_metrics()
+        if not self.inhibit:
+            w = self.LossW.item()
+            metrics[f'P/{self.config.loss_fn.upper()}'] = w
+            metrics['G/Sum'] += self.Lambda * w
+        return metrics
+
+    def update_g(self, data, update=True):
+        self.model.update_g(data, update=False)
+        self.forward_g(data)
+        self.compute_g_loss()
+        if update:
+            self.model.optG.zero_grad()
+            loss = self.LossG + self.Lambda * self.LossW
+            red = self.model.reduceG
+            red.arm()
+            loss.backward()
+            _step(self.model.optG, red)
 
 
 class WhiteBoxWrapper(Wrapper):

@@ -247,6 +247,26 @@ def loss_sum_bwd(kind, x, y, gscale, scale):
     return dx
 
 
+# ---- SSIM loss (black-box watermark objective) --------------------------------------------------------
+def ssim_fwd(x, y, denorm, want_grad):
+    """x, y: contiguous NCHW fp32.  Returns (loss = 1 - mean SSIM, gmaps for the backward pass or None)."""
+    B, Cc, H, W = x.shape
+    planes = B * Cc
+    out = empty((), x)
+    ws = empty((query('iprgan_ssim_ws_floats', planes, H, W),), x)
+    gm = empty((query('iprgan_ssim_gmap_floats', planes, H, W),), x) if want_grad else None
+    call('iprgan_ssim_fwd', ptr(x), ptr(y), ptr(out), ptr(gm), ptr(ws), planes, H, W, int(bool(denorm)), stream())
+    return out, gm
+
+
+def ssim_bwd(x, y, gmaps, gscale, denorm):
+    B, Cc, H, W = x.shape
+    dx = torch.empty_like(x)
+    call('iprgan_ssim_bwd', ptr(x), ptr(y), ptr(gmaps), ptr(gscale), ptr(dx), B * Cc, H, W, int(bool(denorm)),
+         stream())
+    return dx
+
+
 # ---- VAE reparameterisation -----------------------------------------------------------------------
 def reparam_fwd(mean, logvar, eps):
     z = torch.empty_like(mean)

@@ -1,5 +1,6 @@
 """Watermark tooling on the hot path: the sign-loss regulariser and image losses, with the reference's
 names and call signatures (tools/sign_model.py:6-60, tools/loss.py:10-20,72-76) on HIP kernels."""
+import math
 import random
 
 import torch
@@ -8,7 +9,8 @@ import torch.nn as nn
 from . import _lib as L
 from . import ops
 
-__all__ = ['BitGenerator', 'SignLossModel', 'Loss', 'l1', 'mse', 'loss_value']
+__all__ = ['BitGenerator', 'SignLossModel', 'Loss', 'l1', 'mse', 'ssim', 'ms_ssim', 'loss_value', 'loss_sum',
+           'TransformDist', 'RandomBitMask', 'TransformVar', 'RandomNoisePatch', 'PasteWatermark']
 
 _NORMS = (nn.BatchNorm2d, nn.InstanceNorm2d)
 
@@ -146,3 +148,173 @@ def l1(normalized=False):
 
 def mse(normalized=False):
     return Loss(L.LOSS_MSE, normalized=normalized)
+
+
+class _SSIMFn(torch.autograd.Function):
+    """1 - mean SSIM (include/iprgan.h iprgan_ssim_*); the gradient flows to ``x`` only."""
+
+    @staticmethod
+    def forward(ctx, x, y, denorm):
+        xd, yd = x.detach().contiguous(), y.detach().contiguous()
+        want = x.requires_grad
+        out, gm = ops.ssim_fwd(xd, yd, denorm, want)
+        ctx.x, ctx.y, ctx.gm, ctx.denorm = xd, yd, gm, denorm
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        return ops.ssim_bwd(ctx.x, ctx.y, ctx.gm, gout.contiguous(), ctx.denorm), None, None
+
+
+class _SSIMLoss(object):
+    """tools/loss.py:82-85: ``Loss(lambda x, y: 1 - SSIM(data_range=1)(x, y), normalized)``; the (x+1)/2
+    de-normalisation of tools/loss.py:15-18 happens inside the kernel."""
+
+    def __init__(self, normalized=False):
+        self.denorm = normalized
+
+    def __call__(self, x, y):
+        return _SSIMFn.apply(x, y, bool(self.denorm))
+
+
+def ssim(normalized=False):
+    return _SSIMLoss(normalized=normalized)
+
+
+def ms_ssim(normalized=False):
+    raise NotImplementedError('ms_ssim (tools/loss.py:78-80) is not used by any reference config and is not built')
+
+
+# ---- black-box trigger / target transforms (tools/transform_dist.py, random_bitmask.py, transform_var.py,
+# ---- random_noise_patch.py, paste_watermark.py).  Tiny host-side tensor edits outside the hot path: plain
+# ---- torch ops on whatever device the tensors live on.
+class TransformDist(nn.Module):
+    """z -> sqrt(2 pi) * Phi(z) (tools/transform_dist.py:5-14)."""
+
+    def __init__(self, config=None, **kwargs):
+        super().__init__()
+
+    def forward(self, z):
+        return 0.5 * (1 + torch.erf(z / math.sqrt(2))) * math.sqrt(2 * math.pi)
+
+    def reset(self): pass
+
+
+class RandomBitMask(nn.Module):
+    """Overwrites ``n_bit`` randomly chosen latent coordinates with ``constant`` (tools/random_bitmask.py:4-29)."""
+
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.n, self.c, self.z_dim = config.n_bit, config.constant, config.z_dim
+        self.reset()
+
+    @torch.no_grad()
+    def forward(self, z):
+        return z.clone().scatter_(1, self._mask.repeat(z.size(0), 1), self.c)
+
+    def reset(self):
+        mask = torch.randperm(self.z_dim)[:self.n].unsqueeze(0)
+        if hasattr(self, '_mask'):
+            mask = mask.to(self._mask.device)
+        self.register_buffer('_mask', mask)
+
+    @property
+    def mask(self):
+        return self._mask
+
+    @mask.setter
+    def mask(self, mask):
+        self._mask = mask
+
+
+class TransformVar(nn.Module):
+    """z * (1 - a) + a * w with a ~ Bernoulli(0.25), w = exp(|N(0,1)|) (tools/transform_var.py:5-16)."""
+
+    def __init__(self, config=None, **kwargs):
+        super().__init__()
+        self.register_buffer('w', torch.ones(1, 128))
+        self.register_buffer('a', torch.ones(1, 128))
+        self.reset()
+
+    def forward(self, z):
+        return z * (1 - self.a) + self.a * self.w
+
+    def reset(self):
+        dev = self.w.device
+        self.w = torch.exp(torch.randn_like(self.w).abs())
+        self.a = (torch.rand(1, 128) < 0.25).float().to(dev)
+
+
+class _Patch(nn.Module):
+    """Shared body of RandomNoisePatch / PasteWatermark: paste ``fg`` where ``bg`` is 0 into one image corner
+    (random_noise_patch.py:33-53, paste_watermark.py:42-60)."""
+
+    def _place(self, config, normalized):
+        self.position = config.get('position', 'tl')
+        assert self.position in ('tl', 'tr', 'bl', 'br'), 'invalid position'
+        if normalized:                              # TF.normalize(fg, [0.5]*3, [0.5]*3)
+            self.fg = (self.fg - 0.5) / 0.5
+        y, x = self.position
+        s = config.size
+        self.y = (None, s) if y == 't' else (-s, None)
+        self.x = (None, s) if x == 'l' else (-s, None)
+
+    @torch.no_grad()
+    def forward(self, x):
+        (hi, hj), (wi, wj) = self.y, self.x
+        y = x.clone()
+        y[..., hi:hj, wi:wj] *= self.bg
+        y[..., hi:hj, wi:wj] += (1 - self.bg) * self.fg
+        return y
+
+    @torch.no_grad()
+    def apply_mask(self, x):
+        (hi, hj), (wi, wj) = self.y, self.x
+        y = torch.ones_like(x[..., hi:hj, wi:wj])
+        y *= self.bg
+        y += (1 - self.bg) * x[..., hi:hj, wi:wj]
+        return y
+
+
+class RandomNoisePatch(_Patch):
+    """Uniform-noise square in a corner (tools/random_noise_patch.py:6-53)."""
+
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.config, self.normalized = config, kwargs.get('normalized', False)
+        self.reset()
+
+    def reset(self):
+        size = (self.config.size,) * 2
+        dev = self.fg.device if hasattr(self, 'fg') else torch.device('cpu')
+        fg = torch.rand(3, *size)
+        self.register_buffer('bg', torch.zeros(1, 1, *size))
+        self.register_buffer('fg', fg.view(1, 3, *size))
+        self._place(self.config, self.normalized)
+        self.to(dev)
+
+
+class PasteWatermark(_Patch):
+    """Logo from an RGBA image file, composited on white, resized to ``size`` (tools/paste_watermark.py:6-40);
+    PIL only (the reference goes through torchvision's PIL wrappers ``TF.resize`` / ``TF.to_tensor``)."""
+
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.config, self.normalized = config, kwargs.get('normalized', False)
+        import numpy as np
+        from PIL import Image
+        size = (config.size,) * 2
+        tmp = Image.open(config.watermark).convert('RGBA').resize(size, Image.BILINEAR)
+        img = Image.new('RGBA', size, 'white')
+        img.paste(tmp, (0, 0), mask=tmp)
+        to_tensor = lambda im: torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255
+        fg = to_tensor(img.convert('RGB'))
+        if config.opaque:
+            bg = torch.zeros_like(fg[0:1])
+        else:
+            mask = Image.new('RGBA', size, (0,) * 4)
+            mask.paste(tmp, (0, 0), mask=tmp)
+            bg = (to_tensor(mask)[3:] == 0).float()
+        self.register_buffer('bg', bg.view(1, 1, *size))
+        self.register_buffer('fg', fg.view(1, 3, *size))
+        self._place(config, self.normalized)

@@ -7,7 +7,7 @@ It reproduces ``Experiment.start/train/checkpoint`` (experiments/base.py:70-82 a
 bodies, image_generation.py:86-101, image_super_resolution.py:84-113, image_translation.py:90-112) on the
 HIP engine, writes ``checkpoint.pt`` in the reference layout (resumable both ways) and a metrics JSONL.
 Out of scope: real datasets (no data on the box: synthetic batches of the configured
-shapes instead), TensorBoard, FID/IS/PSNR evaluation, the black-box watermark wrapper (section 8f "next").
+shapes instead), TensorBoard, FID/IS/PSNR evaluation.
 """
 import argparse
 import json
@@ -99,8 +99,13 @@ class Experiment:
         self.wbox = False
         if not wm:
             return
-        if wm.get('bbox', None):
-            raise NotImplementedError('black-box watermark (BlackBoxWrapper + SSIM) is not part of this engine yet')
+        bbox = wm.get('bbox', None)
+        if bbox:                                                # image_generation.py:60-68, image_super_resolution.py:59-66,
+            bbox['normalized'], bbox['input_var'], bbox['output_var'], bbox['target'] = {      # image_translation.py:65-72
+                'generation': (True, 'latent', 'generated', 'G'),
+                'super_resolution': (False, 'low_res', 'super_res', 'G'),
+                'translation': (True, 'real_B', 'fake_A', 'GB')}[self.kind]
+            self.model = models.BlackBoxWrapper(self.model, bbox)
         wbox = wm.get('wbox', None)
         if wbox:
             wbox['target'] = 'GB' if self.kind == 'translation' else 'G'         # image_translation.py:83

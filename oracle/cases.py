@@ -170,6 +170,57 @@ def _capture(model, res, tag, nets, opts, moments=True):
                 recipe.pack_summary(f'{tag}/{opt}/{idx}/exp_avg', st[idx]['exp_avg'].cpu(), res)
 
 
+BBOX_CFG = {'fn_inp': {'type': 'TransformDist'}, 'fn_out': {'type': 'RandomNoisePatch', 'size': 16},
+            'lambda': 1.0, 'loss_fn': 'ssim',
+            # set by ImageGeneration.configure_protection (experiments/image_generation.py:63-67)
+            'normalized': True, 'input_var': 'latent', 'output_var': 'generated', 'target': 'G'}
+
+
+def run_bbox_transforms(tools, make_cfg):
+    """Known answers of the trigger transforms (tools/transform_dist.py, random_bitmask.py, transform_var.py):
+    seeded construction, fixed latent batch."""
+    z = recipe.tensor(71, 1, (5, 128))
+    res = {'dist': tools.TransformDist(make_cfg({}))(z).numpy()}
+    torch.manual_seed(72)
+    m = tools.RandomBitMask(make_cfg({'n_bit': 10, 'constant': -10.0, 'z_dim': 128}))
+    res['bitmask/mask'] = m._mask.numpy().astype(np.int64)
+    res['bitmask/out'] = m(z).numpy()
+    torch.manual_seed(73)
+    v = tools.TransformVar(make_cfg({}))
+    res['var/w'], res['var/a'], res['var/out'] = v.w.numpy(), v.a.numpy(), v(z).numpy()
+    return res
+
+
+def run_dcgan_complete_steps(make_cfg, models, device, n_steps=2, batch=4, seed=81):
+    """The 'complete' protection (configs/DCGAN/complete/*.yaml): BlackBoxWrapper (TransformDist trigger ->
+    noise-patch target, SSIM) inside WhiteBoxWrapper, in the order of experiments/image_generation.py:56-101."""
+    model = models.DCGAN(make_cfg(DCGAN_CFG), device=device)
+    recipe.fill(model.G.module, seed)
+    recipe.fill(model.D.module, seed + 1)
+    model.G.to(device[0])
+    model.D.to(device[0])
+    torch.manual_seed(seed)                         # RandomNoisePatch draws its patch at construction
+    model = models.BlackBoxWrapper(model, make_cfg(BBOX_CFG))
+    model = models.WhiteBoxWrapper(model, make_cfg(WBOX_CFG))
+    res = {}
+    for s in range(n_steps):
+        x = torch.tanh(recipe.tensor(seed, 2000 + s, (batch, 3, 64, 64)))
+        z = recipe.tensor(seed, 3000 + s, (batch, 128))
+        model.update_d({'real_sample': x, 'latent': z})
+        model.update_g({'fake_sample': model.fake_sample})
+        for k, v in model.get_metrics().items():
+            res[f'step{s}/metric/{k}'] = np.float64(v)
+        if s == 0:
+            res['step0/fake_sample'] = model.fake_sample.detach().cpu().numpy()
+            res['step0/xwm'] = model.xwm.detach().cpu().numpy()
+            res['step0/ywm'] = model.ywm.detach().cpu().numpy()
+            res['step0/Gxwm'] = model.Gxwm.detach().cpu().numpy()
+            _capture(model, res, 'step0', ('G',), ('optG', 'optD'))
+    _capture(model, res, 'final', ('G', 'D', 'fn_out'), ('optG', 'optD'))
+    res['final/ber'] = np.float64(float(model.loss_model.compute_ber(model.G)))
+    return res
+
+
 VAE_CFG = {'G': 'Decoder32', 'D': 'Encoder32', 'opt': 'Adam',
            'opt_param': {'lr': 3.0e-5, 'weight_decay': 1.0e-6}, 'type': 'VAE'}      # configs/VAE/*/vae-cifar10-a.yaml
 

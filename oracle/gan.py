@@ -13,6 +13,7 @@ from torch import optim
 from torch.nn import DataParallel
 
 from . import nets as _nets
+from . import bbox as _bbox
 from .sign import SignLossModel
 
 
@@ -418,3 +419,82 @@ class WhiteBoxWrapper:
             m['P/SignLoss'] = self.LossS.item()
             m['G/Sum'] += self.LossS.item()
         return m
+
+
+class _NoBNStats:
+    """models/util.py:55-69."""
+
+    def __init__(self, net):
+        self.net, self.saved = net, {}
+
+    def __enter__(self):
+        for n, m in self.net.named_modules():
+            if isinstance(m, nn.BatchNorm2d):
+                self.saved[n] = m.track_running_stats
+                m.track_running_stats = False
+
+    def __exit__(self, *a):
+        for n, m in self.net.named_modules():
+            if n in self.saved:
+                m.track_running_stats = self.saved[n]
+
+
+class BlackBoxWrapper:
+    """models/wrappers.py:7-74 + Wrapper base (models/base.py:46-79)."""
+
+    def __init__(self, model, config, tools=_bbox):
+        self.model, self.config = model, config
+        norm = config.normalized
+        self.fn_inp = _wrap(getattr(tools, config.fn_inp.type)(config.fn_inp, normalized=norm), model.device)
+        self.fn_out = _wrap(getattr(tools, config.fn_out.type)(config.fn_out, normalized=norm), model.device)
+        self.Lambda = config['lambda']
+        self.loss_fn = getattr(tools, config.loss_fn)(normalized=norm)
+        self._modules = model._modules
+        self._modules['fn_inp'] = self.fn_inp
+        self._modules['fn_out'] = self.fn_out
+
+    def __getattr__(self, key):                  # base.py:60-67: unknown attributes resolve to None
+        model = self.__dict__.get('model')
+        return getattr(model, key, None) if model is not None else None
+
+    def state_dict(self):
+        return Model.state_dict(self)
+
+    def load_state_dict(self, sd, strict=False):
+        return Model.load_state_dict(self, sd, strict)
+
+    def update_d(self, data):
+        self.model.update_d(data)
+
+    def forward_g(self, data):                   # wrappers.py:43-56
+        self.inhibit = data.get('inhibit_bbox', False)
+        if self.inhibit:
+            return
+        x = getattr(self.model, self.config.input_var)
+        y = getattr(self.model, self.config.output_var)
+        with torch.no_grad():
+            self.xwm = self.fn_inp(x.detach())
+            self.ywm = self.fn_out(y.detach())
+        G = getattr(self.model, self.config.target)
+        with _NoBNStats(G):
+            self.Gxwm = G(self.xwm)
+
+    def compute_g_loss(self):                    # wrappers.py:36-41
+        self.LossG = self.model.LossG
+        self.LossW = torch.zeros_like(self.LossG) if self.inhibit else self.loss_fn(self.Gxwm, self.ywm)
+
+    def get_metrics(self):                       # wrappers.py:58-63
+        m = self.model.get_metrics()
+        if not self.inhibit:
+            m[f'P/{self.config.loss_fn.upper()}'] = self.LossW.item()
+            m['G/Sum'] += self.Lambda * self.LossW.item()
+        return m
+
+    def update_g(self, data, update=True):       # wrappers.py:65-74
+        self.model.update_g(data, update=False)
+        self.forward_g(data)
+        self.compute_g_loss()
+        if update:
+            self.model.optG.zero_grad()
+            (self.LossG + self.Lambda * self.LossW).backward()
+            self.model.optG.step()

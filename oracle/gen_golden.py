@@ -41,6 +41,8 @@ def main():
     save('srgan_steps_wbox', cases.run_srgan_steps(ref_loader.Config, models, dev))
     save('cyclegan_steps_wbox', cases.run_cyclegan_steps(ref_loader.Config, models, dev))
     save('vae_steps_wbox', cases.run_vae_steps(ref_loader.Config, models, dev))
+    save('bbox_transforms', cases.run_bbox_transforms(tools, ref_loader.Config))
+    save('dcgan_steps_complete', cases.run_dcgan_complete_steps(ref_loader.Config, models, dev))
 
 
 if __name__ == '__main__':

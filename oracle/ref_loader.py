@@ -48,6 +48,15 @@ def load():
     sm = _load('_ref_tools_sign_model', 'tools/sign_model.py')
     tools.SignLossModel = sm.SignLossModel
     tools.BitGenerator = sm.BitGenerator
+    # black-box pieces: the torch-only transforms are the reference's own; the ones that import torchvision /
+    # pytorch_msssim (absent) are the restatements of oracle/bbox.py, injected under the reference's names so
+    # that the REAL models.BlackBoxWrapper choreography (models/wrappers.py:7-74) can run.
+    for f, cls in (('transform_dist', 'TransformDist'), ('random_bitmask', 'RandomBitMask'),
+                   ('transform_var', 'TransformVar')):
+        setattr(tools, cls, getattr(_load(f'_ref_tools_{f}', f'tools/{f}.py'), cls))
+    from . import bbox as _oracle_bbox
+    for name in ('RandomNoisePatch', 'PasteWatermark', 'ssim', 'l1', 'mse'):
+        setattr(tools, name, getattr(_oracle_bbox, name))
     saved = {k: sys.modules.get(k) for k in ('networks', 'tools', 'models')}
     sys.modules['networks'] = networks
     sys.modules['tools'] = tools

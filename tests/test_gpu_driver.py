@@ -46,3 +46,16 @@ def test_train_driver_vae(tmp_path):
     from oracle import cases, gan
     o = gan.WhiteBoxWrapper(gan.VAE(gan.Cfg(cases.VAE_CFG)), gan.Cfg(cases.WBOX_CFG))
     o.load_state_dict({k: v for k, v in sd.items() if k != 'step'}, strict=True)
+
+
+def test_train_driver_complete_protection(tmp_path):
+    """configs/DCGAN/complete: black-box (trigger set + SSIM) and white-box (sign loss) wrappers together."""
+    cfg = os.path.join(ROOT, 'tests', 'configs', 'dcgan-complete-tiny.yaml')
+    log = str(tmp_path / 'log')
+    subprocess.run([sys.executable, os.path.join(PKG, 'train.py'), '-c', cfg, '--log-path', log], check=True, timeout=600)
+    sd = torch.load(os.path.join(log, 'checkpoint.pt'), map_location='cpu')
+    assert list(sd) == ['G', 'D', 'optG', 'optD', 'fn_inp', 'fn_out', 'sign', 'step'] and sd['step'] == 'END'
+    assert list(sd['fn_out']) == ['module.bg', 'module.fg']
+    rows = [json.loads(l) for l in open(os.path.join(log, 'metrics.jsonl'))]
+    assert len(rows) == 3 and all(0.0 < r['P/SSIM'] <= 1.0 and 'P/SignLoss' in r for r in rows)
+    assert json.load(open(os.path.join(log, 'metrics.json')))['BER'] == 0.0

@@ -183,6 +183,14 @@ def test_vae_steps_vs_reference_golden(golden, dev):
     compare(res, golden('vae_steps_wbox'), policy=policy)
 
 
+def test_dcgan_complete_protection_steps_vs_reference_golden(golden, dev):
+    """configs/DCGAN/complete: BlackBoxWrapper (TransformDist trigger, noise-patch target, HIP SSIM kernel, second G
+    pass on batch statistics) inside WhiteBoxWrapper, against the REAL wrappers' run (SSIM / patch leaves restated)."""
+    from iprgan import Config, models
+    res = cases.run_dcgan_complete_steps(Config, models, [dev])
+    compare(res, golden('dcgan_steps_complete'), policy=step_policy(2))
+
+
 def test_watermark_survives_training_and_attacks_count_exactly(dev):
     """BER stays 0 through training steps on the engine; the sign-flip (sign_flip.py:59-75) and
     prune (prune.py:46-57) attacks then change it to exactly the flipped / zeroed fraction (int64 count kernel)."""

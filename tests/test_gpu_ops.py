@@ -270,6 +270,30 @@ def test_vae_losses_and_reparam(dev, n):
     close(dlv, lv2.grad, 1e-6, 'reparam dlogvar')
 
 
+@pytest.mark.parametrize('shape', [(2, 3, 32, 32), (1, 3, 11, 11), (3, 1, 37, 53), (2, 3, 64, 64)])
+@pytest.mark.parametrize('denorm', [False, True])
+def test_ssim_loss_vs_oracle(dev, shape, denorm):
+    """iprgan_ssim_fwd/bwd against the CPU restatement of pytorch-msssim's ssim (oracle/ssim.py, parity unpinned):
+    loss to 1e-5, gradient to 2e-4 of its max; ragged sizes cover partial tiles; SSIM(x, x) = 1."""
+    from iprgan import tools
+    from oracle import ssim as ossim
+    g = torch.Generator().manual_seed(sum(shape))
+    x, y = torch.rand(*shape, generator=g), torch.rand(*shape, generator=g)
+    y = 0.7 * y + 0.3 * x                                  # correlated, like a generated image and its target
+    if denorm:
+        x, y = x * 2 - 1, y * 2 - 1
+    xr = x.clone().requires_grad_()
+    ref = ossim.ssim_loss(normalized=denorm)(xr, y)
+    (ref * 1.3).backward()
+    xd = x.to(dev).requires_grad_()
+    out = tools.ssim(normalized=denorm)(xd, y.to(dev))
+    (out * 1.3).backward()
+    assert abs(float(out.detach()) - float(ref.detach())) < 1e-5, (float(out.detach()), float(ref.detach()))
+    close(xd.grad, xr.grad, 2e-4, 'ssim grad')
+    same = tools.ssim(normalized=denorm)(x.to(dev), x.to(dev))
+    assert abs(float(same)) < 1e-6
+
+
 def test_sign_loss_and_ber_exact(dev):
     from iprgan import ops
     g = np.random.default_rng(5)

@@ -106,3 +106,38 @@ def test_removal_attacks_and_ber_counts():
     h = np.random.default_rng(0).integers(0, 2, (3, 256)).astype(bool)
     p = attacks.matching_p_value(h, np.stack([h[0], ~h[1], h[2] ^ (np.arange(256) < 128)]))
     assert p[0] < 1e-30 and p[1] == 1.0 and abs(float(p[2]) - 0.5249) < 1e-3
+
+
+def test_product_bbox_transforms_match_reference(golden):
+    """iprgan.tools trigger transforms (host-side torch ops) against the reference's own classes."""
+    from iprgan import Config, tools
+    from test_oracle_golden import compare
+    compare(cases.run_bbox_transforms(tools, Config), golden('bbox_transforms'), rtol=1e-6, atol=1e-7)
+
+
+def test_paste_watermark_and_noise_patch(tmp_path):
+    """PasteWatermark / RandomNoisePatch (parity unpinned: torchvision + the reference's PNGs are absent):
+    product vs oracle restatement on a synthetic RGBA logo, all four corners, opaque and transparent."""
+    from PIL import Image
+    from iprgan import Config, tools
+    from oracle import bbox
+    rgba = np.zeros((24, 24, 4), dtype=np.uint8)
+    rgba[4:20, 6:18] = (200, 30, 60, 255)
+    rgba[8:12, 8:12, 3] = 128
+    path = str(tmp_path / 'logo.png')
+    Image.fromarray(rgba, 'RGBA').save(path)
+    x = torch.tanh(recipe.tensor(5, 1, (2, 3, 32, 32)))
+    for pos in ('tl', 'tr', 'bl', 'br'):
+        for opaque in (True, False):
+            cfg = {'size': 16, 'opaque': opaque, 'watermark': path, 'position': pos}
+            a = tools.PasteWatermark(Config(cfg), normalized=True)
+            b = bbox.PasteWatermark(gan.Cfg(cfg), normalized=True)
+            assert torch.equal(a.fg, b.fg) and torch.equal(a.bg, b.bg)
+            assert torch.equal(a(x), b(x))
+            assert not torch.equal(a(x), x)
+            assert torch.equal(a.apply_mask(x) * 0 + 1, torch.ones(2, 3, 16, 16))
+        torch.manual_seed(3)
+        a = tools.RandomNoisePatch(Config({'size': 8, 'position': pos}), normalized=False)
+        torch.manual_seed(3)
+        b = bbox.RandomNoisePatch(gan.Cfg({'size': 8, 'position': pos}), normalized=False)
+        assert torch.equal(a(x), b(x)) and list(a.state_dict()) == ['bg', 'fg']

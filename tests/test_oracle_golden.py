@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import cases, gan, nets, recipe, sign
+from oracle import bbox, cases, gan, nets, recipe, sign, ssim
 
 RTOL, ATOL = 2e-4, 2e-5      # same torch CPU kernels; slack only for thread-count dependent summation order
 
@@ -97,3 +97,28 @@ def test_vae_steps_match_reference(golden):
     """Encoder32 / Decoder32 / models.VAE: KL + BCE, one Adam with weight decay over both
     nets, sign loss on the decoder's BatchNorm; eps of the reparameterisation replayed from the CPU generator."""
     compare(cases.run_vae_steps(gan.Cfg, gan, gan.CPU), golden('vae_steps_wbox'), rtol=5e-4, atol=5e-5)
+
+
+def test_bbox_transforms_match_reference(golden):
+    """TransformDist / RandomBitMask / TransformVar restatements vs the reference's own classes (seeded)."""
+    compare(cases.run_bbox_transforms(bbox, gan.Cfg), golden('bbox_transforms'), rtol=1e-6, atol=1e-7)
+
+
+def test_dcgan_complete_steps_match_reference(golden):
+    """BlackBoxWrapper inside WhiteBoxWrapper: the restated choreography vs the REAL models/wrappers.py run
+    (with the same restated SSIM / noise-patch leaves injected: those two are parity-unpinned, oracle/bbox.py)."""
+    compare(cases.run_dcgan_complete_steps(gan.Cfg, gan, gan.CPU), golden('dcgan_steps_complete'), rtol=5e-4, atol=5e-5)
+
+
+def test_ssim_restatement_known_answers():
+    """pytorch-msssim is absent (parity unpinned): closed forms the published algorithm must satisfy."""
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.rand(2, 3, 40, 33, generator=g), torch.rand(2, 3, 40, 33, generator=g)
+    assert abs(float(ssim.ssim(x, x)) - 1.0) < 1e-6
+    assert float(ssim.ssim(x, y)) == float(ssim.ssim(y, x))
+    c, d = torch.full((1, 3, 16, 16), 0.3), torch.full((1, 3, 16, 16), 0.6)
+    # constant images: zero variance and covariance -> luminance term only
+    assert abs(float(ssim.ssim(c, d)) - (2 * 0.3 * 0.6 + 1e-4) / (0.09 + 0.36 + 1e-4)) < 2e-5
+    assert abs(float(ssim.gauss_1d().sum()) - 1.0) < 1e-6 and ssim.gauss_1d().numel() == 11
+    lossn = ssim.ssim_loss(normalized=True)(x * 2 - 1, y * 2 - 1)
+    assert abs(float(lossn) - (1 - float(ssim.ssim(x, y)))) < 1e-5
