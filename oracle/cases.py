@@ -260,15 +260,30 @@ SRGAN_CFG = {'G': 'SRResNet', 'D': 'Discriminator96', 'V': 'VGG19Feature', 'opt'
              'opt_param': {'lr': 1.0e-4}, 'type': 'SRGAN'}
 
 
-def run_srgan_steps(make_cfg, models, device, batch=2, seed=41):
+def bbox_cfg(kind, watermark, inp_size, out_size):
+    """protection.bbox of configs/{SRGAN,CycleGAN}/complete/*.yaml + the keys the experiments add
+    (image_super_resolution.py:62-65, image_translation.py:68-71)."""
+    extra = {'super_resolution': (False, 'low_res', 'super_res', 'G'),
+             'translation': (True, 'real_B', 'fake_A', 'GB')}[kind]
+    return {'fn_inp': {'type': 'RandomNoisePatch', 'size': inp_size},
+            'fn_out': {'type': 'PasteWatermark', 'size': out_size, 'opaque': True, 'watermark': watermark},
+            'lambda': 1.0, 'loss_fn': 'ssim',
+            'normalized': extra[0], 'input_var': extra[1], 'output_var': extra[2], 'target': extra[3]}
+
+
+def run_srgan_steps(make_cfg, models, device, batch=2, seed=41, bbox=None):
     """One pre-training step (pixel MSE) then one GAN-phase G step and D step, in the order of
-    experiments/image_super_resolution.py:84-113, with the white-box wrapper on G."""
+    experiments/image_super_resolution.py:84-113, with the white-box wrapper on G (and, when ``bbox`` is
+    given, the black-box wrapper inside it as in configs/SRGAN/complete)."""
     model = models.SRGAN(make_cfg(SRGAN_CFG), device=device)
     recipe.fill(model.G.module, seed)
     recipe.fill(model.D.module, seed + 1)
     recipe.fill(model.V.module, seed + 2)
     for n in (model.G, model.D, model.V):
         n.to(device[0])
+    if bbox:
+        torch.manual_seed(seed)
+        model = models.BlackBoxWrapper(model, make_cfg(bbox))
     model = models.WhiteBoxWrapper(model, make_cfg(WBOX_CFG))
     res = {}
     lr = recipe.tensor(seed, 100, (batch, 3, 24, 24), dist='uniform')
@@ -294,12 +309,16 @@ CYCLEGAN_CFG = {'G': 'Resnet6Blocks', 'D': 'ConvDiscriminator', 'opt': 'Adam',
                 'lambda_A': 10.0, 'lambda_B': 10.0, 'lambda_idt': 0.5, 'epoch': 200}
 
 
-def run_cyclegan_steps(make_cfg, models, device, n_steps=2, batch=1, size=64, seed=51):
-    """G step then D step per iteration (experiments/image_translation.py:90-112), white-box on GB."""
+def run_cyclegan_steps(make_cfg, models, device, n_steps=2, batch=1, size=64, seed=51, bbox=None):
+    """G step then D step per iteration (experiments/image_translation.py:90-112), white-box on GB
+    (black-box inside it when ``bbox`` is given, configs/CycleGAN/complete)."""
     model = models.CycleGAN(make_cfg(CYCLEGAN_CFG), device=device)
     for i, n in enumerate((model.GA, model.GB, model.DA, model.DB)):
         recipe.fill(n.module, seed + i)
         n.to(device[0])
+    if bbox:
+        torch.manual_seed(seed)
+        model = models.BlackBoxWrapper(model, make_cfg(bbox))
     wcfg = dict(WBOX_CFG)
     wcfg['target'] = 'GB'                            # image_translation.py:83
     model = models.WhiteBoxWrapper(model, make_cfg(wcfg))

@@ -191,6 +191,53 @@ def test_dcgan_complete_protection_steps_vs_reference_golden(golden, dev):
     compare(res, golden('dcgan_steps_complete'), policy=step_policy(2))
 
 
+class _Ref:
+    """dict with the npz interface ``compare`` expects."""
+
+    def __init__(self, d):
+        self.d, self.files = d, list(d)
+
+    def __getitem__(self, k):
+        return np.asarray(self.d[k])
+
+
+def _logo(tmp_path):
+    from PIL import Image
+    rgba = np.zeros((40, 40, 4), dtype=np.uint8)
+    rgba[6:34, 10:30] = (220, 40, 90, 255)
+    rgba[14:22, 14:26] = (20, 200, 120, 255)
+    path = str(tmp_path / 'logo.png')
+    Image.fromarray(rgba, 'RGBA').save(path)
+    return path
+
+
+def test_srgan_complete_protection_vs_oracle(dev, tmp_path):
+    """configs/SRGAN/complete: noise patch on the low-res input, logo on the detached super-res target, SSIM at 96x96,
+    bbox inhibited during pre-training (image_super_resolution.py:96).  Checked against the CPU oracle run live."""
+    from iprgan import Config, models
+    bb = cases.bbox_cfg('super_resolution', _logo(tmp_path), 12, 48)
+    res = cases.run_srgan_steps(Config, models, [dev], bbox=bb)
+    ref = cases.run_srgan_steps(gan.Cfg, gan, gan.CPU, bbox=bb)
+    assert 'step1/metric/P/SSIM' in ref and 'step0/metric/P/SSIM' not in ref
+    compare(res, _Ref(ref), policy=step_policy(2, lr=1e-4))
+
+
+def test_cyclegan_complete_protection_vs_oracle(dev, tmp_path):
+    """configs/CycleGAN/complete: trigger on real_B, target fake_A, generator GB (InstanceNorm only)."""
+    from iprgan import Config, models
+    bb = cases.bbox_cfg('translation', _logo(tmp_path), 16, 16)
+    res = cases.run_cyclegan_steps(Config, models, [dev], n_steps=1, bbox=bb)
+    ref = cases.run_cyclegan_steps(gan.Cfg, gan, gan.CPU, n_steps=1, bbox=bb)
+    assert 'step0/metric/P/SSIM' in ref
+    base = step_policy(1)
+
+    def policy(k):
+        if k.startswith(('step0/optD', 'step0/optG')):       # see test_cyclegan_steps_vs_reference_golden
+            return (0.1, 1e-3, 'scale')
+        return base(k)
+    compare(res, _Ref(ref), policy=policy)
+
+
 def test_watermark_survives_training_and_attacks_count_exactly(dev):
     """BER stays 0 through training steps on the engine; the sign-flip (sign_flip.py:59-75) and
     prune (prune.py:46-57) attacks then change it to exactly the flipped / zeroed fraction (int64 count kernel)."""
