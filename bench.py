@@ -35,6 +35,7 @@ import torch.distributed as dist  # noqa: E402
 
 BATCH = 128
 PEAK_FP32_MFMA = 157.3e12
+PEAK_BF16_MFMA = 2500e12          # dense bf16 MFMA (MI355X_MICROARCH.md); only used with --math bf16
 DCGAN_CFG = {'G': 'ConvGenerator64', 'D': 'SNDiscriminator64', 'opt': 'Adam',
              'opt_param': {'lr': 2.0e-4, 'betas': [0.5, 0.999]}, 'type': 'DCGAN'}
 WBOX_CFG = {'gamma_0': 0.1, 'string': 'EXAMPLE A', 'target': 'G'}
@@ -83,6 +84,9 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--math', choices=['fp32', 'bf16'], default='fp32',
+                    help="conv math mode; the headline metric is fp32 (the reference's precision). 'bf16' = bf16 MFMA "
+                         "tiles with fp32 accumulation / tensors / master weights, reported with dtype bf16")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -105,6 +109,7 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from iprgan import _lib
+    _lib.set_math(args.math)
     torch.manual_seed(1234 + rank)
     model = build_model(device)
     pool = 8                                      # synthetic batches resident in HBM, cycled
@@ -154,19 +159,23 @@ def main():
             pass
         if dom:
             ach = dom['flops'] / (dom['ms'] * 1e-3)
+            peak = PEAK_BF16_MFMA if 'bf16' in dom['name'] else PEAK_FP32_MFMA
             roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(ach / 1e12, 2),
-                    'peak': round(PEAK_FP32_MFMA / 1e12, 1), 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_FP32_MFMA, 4), 'traffic': traffic,
+                    'peak': round(peak / 1e12, 1), 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak, 4), 'traffic': traffic,
                     'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2)}
         conv_ms = sum(k['ms'] for k in kernels)
         conv_flops = sum(k['flops'] for k in kernels)
         out = {
             'metric': 'imgs/sec G+D step (DCGAN-64 bs128)', 'value': round(value, 1), 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.math == 'fp32' else 'bf16',
             'data': 'synthetic',
             'config': {'workload': 'DCGAN-64 (ConvGenerator64 + SNDiscriminator64) + sign-loss white-box '
-                                   'watermark, G+D step, batch 128 per GPU, fp32, Adam',
+                                   'watermark, G+D step, batch 128 per GPU, ' +
+                                   ('fp32' if args.math == 'fp32' else 'bf16 MFMA tiles (fp32 accumulate, fp32 tensors)') +
+                                   ', Adam',
                        'global_batch': BATCH * world, 'parallelism': f'dp{world}'},
             'roofline': roof,
             'conv_kernels': {'device_ms_per_step': round(conv_ms / args.steps, 3),

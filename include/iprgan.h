@@ -233,6 +233,15 @@ int iprgan_prof_collect(void);
 int iprgan_prof_num_kernels(void);
 int iprgan_prof_get(int i, char* name, int name_len, long long* launches, double* ms, double* flops);
 
+/* ---- math mode of the conv family (process-wide).  FP32 (default): v_mfma_f32_32x32x2_f32 on fp32 tiles.
+ * BF16 (BASELINE config "DCGAN 128x128 bs256 bf16"): tensors and master weights stay fp32 in HBM, tiles are
+ * rounded to bf16 (nearest-even) when staged into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation; layers with fewer than 32 (padded) input channels keep the fp32 kernel.  Norms, losses, spectral
+ * norm and Adam are fp32 in both modes. */
+enum { IPRGAN_MATH_FP32 = 0, IPRGAN_MATH_BF16 = 1 };
+int iprgan_set_math_mode(int mode);
+int iprgan_get_math_mode(void);
+
 /* test hook: force one tile configuration (gconv 0..5, wgrad candidate 0..19 = 4 * block target + tile shape; -1 = autotune / heuristic) so that
  * the parity tests can exercise every variant, not only the one the autotuner picks. */
 int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand);

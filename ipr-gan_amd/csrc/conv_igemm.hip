@@ -30,6 +30,7 @@ static ProfSlot g_slots[] = {
     {"wgrad_kernel<64x64>", 0, 0, 0},   {"wgrad_kernel<32x128>", 0, 0, 0},
     {"gconv_kernel<64x128>", 0, 0, 0},  {"gconv_kernel<128x128,8w>", 0, 0, 0},
     {"gconv_kernel<128x64,8w>", 0, 0, 0}, {"wgrad_kernel<128x128,8w>", 0, 0, 0},
+    {"gconv_bf16_kernel", 0, 0, 0},     {"wgrad_bf16_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; };
@@ -53,6 +54,12 @@ struct ProfScope {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 f) {      // round-to-nearest-even (v_cvt_pk_bf16_f32)
+  const bf16x4 v = {(__bf16)f.x, (__bf16)f.y, (__bf16)f.z, (__bf16)f.w};
+  return v;
+}
 
 struct Phase {
   int th, tw, ntap;
@@ -135,14 +142,22 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned total) {
 // FAST: zero padding and Cs % 32 == 0, so every 32-wide K step lies inside ONE tap: the tap walk is
 // wave-uniform (scalar registers), borders are handled by the buffer bounds check (no branches).
 // !FAST: reflect padding and/or Cs in {4,8,16} (taps change inside a K step; RGB layers).
-template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK>
+// BF16 (math mode 1, BASELINE config "DCGAN 128x128 bf16"): tensors stay fp32 in HBM (fp32 master weights and
+// activations); the tiles are rounded to bf16 on their way into LDS and multiplied by v_mfma_f32_32x32x16_bf16
+// with fp32 accumulation - 16x the fp32 MFMA rate, half the LDS bytes, the same loader and epilogue.  An LDS row
+// is then 32 k x 2 B = 64 B = four 16-byte chunks of 8 consecutive k; lane half h of MFMA kk reads chunk
+// 2 kk + h; chunk c of row r sits at c ^ ((r >> 2) & 3), which makes the 16-lane groups of ds_read_b128 hit 16
+// distinct slots of the 256-B bank line (4 rows).
+template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a) {
+  static_assert(!BF16 || BK == 32, "the bf16 tile is written for 32-deep K steps");
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;            // threads: one wave per (32*WM)x(32*WN) sub-tile
   constexpr int CH = BK / 4;                    // 16-byte chunks per tile row (K step = BK floats)
   constexpr int RP = NT / CH;                   // tile rows loaded per pass of the block
   constexpr int RA = BM / RP, RB = BN / RP;
-  constexpr int TILE4 = (BM + BN) * CH;         // 16-byte chunks per stage buffer
+  constexpr int CHB = BK / 8;                   // bf16 mode: 16-byte chunks per tile row
+  constexpr int TILE4 = (BM + BN) * (BF16 ? CHB : CH);         // 16-byte chunks per stage buffer
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
 
   // logical tile order (see xcd_remap): n tiles fastest, then the sub-pixel phases, then m tiles, so the
@@ -256,6 +271,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
     }
   };
   auto lstore = [&](int buf) {
+    if (BF16) {                  // this thread's 4 floats are half of 16-byte chunk (chunk >> 1)
+      bf16x4* A8 = (bf16x4*)(lds + buf * TILE4);
+      bf16x4* B8 = A8 + BM * CHB * 2;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int r = lrow + RP * i;
+        A8[(r * CHB + ((chunk >> 1) ^ ((r >> 2) & 3))) * 2 + (chunk & 1)] = to_bf16x4(ra[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int r = lrow + RP * i;
+        B8[(r * CHB + ((chunk >> 1) ^ ((r >> 2) & 3))) * 2 + (chunk & 1)] = to_bf16x4(rb[i]);
+      }
+      return;
+    }
     f32x4* A4 = lds + buf * TILE4;
     f32x4* B4 = A4 + BM * CH;
 #pragma unroll
@@ -270,9 +300,34 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
     }
   };
   auto compute = [&](int buf) {
+    const int half = lane >> 5, l31 = lane & 31;
+    if (BF16) {
+      const bf16x8* A16 = (const bf16x8*)(lds + buf * TILE4);
+      const bf16x8* B16 = A16 + BM * CHB;
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 af[WM], bf[WN];
+        const int c = 2 * kk + half;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          const int r = (wm * WM + i) * 32 + l31;
+          af[i] = A16[r * CHB + (c ^ ((r >> 2) & 3))];
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int r = (wn * WN + j) * 32 + l31;
+          bf[j] = B16[r * CHB + (c ^ ((r >> 2) & 3))];
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
     const f32x4* A4 = lds + buf * TILE4;
     const f32x4* B4 = A4 + BM * CH;
-    const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int kq = 0; kq < BK / 8; ++kq) {
       f32x4 af[WM], bf[WN];
@@ -452,8 +507,28 @@ struct WGradArgs {
   double flops;
 };
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT>
+// BF16 (math mode 1; 128x128 tiles only, so both LDS images have 256-byte rows): the chunk rows are rounded to
+// bf16 on the way into LDS, stored row-major [m][n] / [m][k] exactly as they arrive, and consumed along m - the
+// MFMA's K dimension - through ds_read_b64_tr_b16 (the CDNA4 transposing read: a 16-lane group fetches a 4-row x
+// 16-column block and every lane receives one column).  Two such reads give a lane its 8 consecutive m for
+// v_mfma_f32_32x32x16_bf16.  16-byte chunk ch of row r sits at ch ^ (((r & 3) << 2) | ((r >> 2) & 3)): conflict-free
+// for the 8-byte stores and for the transposed reads (cdna_hip_programming.md T10, image (b)).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned wg_bf16_off(int row, int ch) {
+  return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+__device__ __forceinline__ bf16x8 wg_tr_read8(const char* base, unsigned off0, unsigned off1) {
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + off1));
+  union { s16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = lo; u.h[1] = hi;
+  return u.v;
+}
+
+template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a) {
+  static_assert(!BF16 || (WGM * WM == 4 && WGN * WN == 4), "the bf16 wgrad image is written for 128x128 tiles");
   constexpr int BN = WGM * WM * 32;   // tile over n (P channels)  -> MFMA rows
   constexpr int BK = WGN * WN * 32;   // tile over k (tap,c)       -> MFMA cols
   constexpr int CP = BN / 4, CQ = BK / 4;          // 16-B chunks per tile row
@@ -555,6 +630,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
     }
   };
   auto lstore = [&](int buf) {
+    if (BF16) {               // stage = two [32][128] bf16 images of 8 KB
+      char* Pb = (char*)lds + buf * 16384;
+      char* Qb = Pb + 8192;
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        *(bf16x4*)(Pb + wg_bf16_off(rp + RPP * i, cp >> 1) + 8 * (cp & 1)) = to_bf16x4(rP[i]);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+        *(bf16x4*)(Qb + wg_bf16_off(rq + RPQ * i, cq >> 1) + 8 * (cq & 1)) = to_bf16x4(rQ[i]);
+      return;
+    }
     float* Pt = ldsf + buf * STAGE;
     float* Qt = Pt + 32 * BN;
 #pragma unroll
@@ -563,9 +649,36 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
     for (int i = 0; i < NQ; ++i) *(f32x4*)(Qt + (rq + RPQ * i) * BK + cq * 4) = rQ[i];
   };
   auto compute = [&](int buf) {
+    const int half = lane >> 5, l31 = lane & 31;
+    if (BF16) {
+      const char* Pb = (const char*)lds + buf * 16384;
+      const char* Qb = Pb + 8192;
+      // 16-lane group: lane 4q+p addresses row r0+q, columns 4p..4p+3 of the group's 16 columns
+      const int gq = (lane & 15) >> 2, gp = lane & 3, gcol = (lane >> 4) & 1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int r0 = 16 * kk + 8 * half + gq;            // rows r0 (first read) and r0 + 4 (second read)
+        bf16x8 af[WM], bf[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          const int ch = (wm * WM + i) * 4 + 2 * gcol + (gp >> 1);
+          af[i] = wg_tr_read8(Pb, wg_bf16_off(r0, ch) + 8 * (gp & 1), wg_bf16_off(r0 + 4, ch) + 8 * (gp & 1));
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int ch = (wn * WN + j) * 4 + 2 * gcol + (gp >> 1);
+          bf[j] = wg_tr_read8(Qb, wg_bf16_off(r0, ch) + 8 * (gp & 1), wg_bf16_off(r0 + 4, ch) + 8 * (gp & 1));
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
     const float* Pt = ldsf + buf * STAGE;
     const float* Qt = Pt + 32 * BN;
-    const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       const int row = 2 * kk + half;
@@ -625,7 +738,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int ri = 8 * g + 4 * half + qp;
-      const int n = WM == 2 ? n0 + wm * 64 + 2 * ri + i : n0 + (wm * WM + i) * 32 + ri;
+      const int n = (WM == 2 && !BF16) ? n0 + wm * 64 + 2 * ri + i : n0 + (wm * WM + i) * 32 + ri;
       float t[WN][4];
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
@@ -634,7 +747,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
       }
       if (n >= a.Nrows) continue;
       float* row = slab + (size_t)n * a.Kw;
-      if (WN == 2) {          // tile tn owns columns base + 2*col + tn: interleave the two tiles -> 8 contiguous floats
+      if (WN == 2 && !BF16) {  // tile tn owns columns base + 2*col + tn: interleave the two tiles -> 8 contiguous floats
         const int k = k0 + wn * 64 + 8 * q4;
         if (k < a.Kw) {
           const f32x4 v0 = {t[0][0], t[WN - 1][0], t[0][1], t[WN - 1][1]};
@@ -825,23 +938,24 @@ static std::map<TuneKey, int> g_tune;
 static int g_force_tile = -1, g_force_wgrad = -1;     // test hook: iprgan_debug_force_tiles
 static int g_autotune = getenv("IPRGAN_AUTOTUNE") ? atoi(getenv("IPRGAN_AUTOTUNE")) : 1;
 static int g_smalln = getenv("IPRGAN_SMALLN") ? atoi(getenv("IPRGAN_SMALLN")) : 1;
+static int g_math = IPRGAN_MATH_FP32;                 // iprgan_set_math_mode
 static int g_nbuf = getenv("IPRGAN_LDS_BUFS") ? atoi(getenv("IPRGAN_LDS_BUFS")) : 1;  // 1 = single LDS buffer (measured faster: 3-4 blocks/CU)
 
-template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK>
+template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false>
 static int launch_gconv_tfnk(const GConvArgs& a, hipStream_t st) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   if (maxM == 0) return 0;
-  const size_t smem = NBUF * (size_t)(BM + BN) * (BK / 4) * sizeof(f32x4);
-  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST, NBUF, BK>;
+  const size_t smem = NBUF * (size_t)(BM + BN) * (BF16 ? BK / 8 : BK / 4) * sizeof(f32x4);
+  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST, NBUF, BK, BF16>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.nphase);
-  ProfScope prof(st, WGM * WGN == 8 ? (BN == 128 ? 9 : 10) : BM == 128 ? (BN == 128 ? 0 : (BN == 64 ? 1 : 3)) : (BN == 128 ? 8 : 2), a.flops);
+  ProfScope prof(st, BF16 ? 12 : WGM * WGN == 8 ? (BN == 128 ? 9 : 10) : BM == 128 ? (BN == 128 ? 0 : (BN == 64 ? 1 : 3)) : (BN == 128 ? 8 : 2), a.flops);
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), smem, st, a);
   IPR_LAUNCH_CHECK();
   return 0;
@@ -862,6 +976,8 @@ static int launch_gconv_tf(const GConvArgs& a, hipStream_t st) {
 template <int WGM, int WGN, int WM, int WN>
 static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
   const bool fast = (a.Cs % 32) == 0;
+  // bf16 math: layers whose K step lies in one tap (C4 % 32 == 0); RGB stems / heads keep the fp32 kernel
+  if (g_math == IPRGAN_MATH_BF16 && fast) return launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true>(a, st);
   return fast ? launch_gconv_tf<WGM, WGN, WM, WN, true>(a, st) : launch_gconv_tf<WGM, WGN, WM, WN, false>(a, st);
 }
 
@@ -987,7 +1103,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   // geometry times every tile on the caller's stream and keeps the fastest.  Tiles only change the summation
   // order, results stay within fp32 rounding of each other.
   TuneKey key = {{a.B, a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.isy, a.osy, a.nphase, a.ph[0].th, a.ph[0].tw,
-                  a.ph[0].ohg, a.ph[0].owg, a.pad_mode, a.Kp}};
+                  a.ph[0].ohg, a.ph[0].owg, a.pad_mode + 16 * g_math, a.Kp}};
   auto it = g_tune.find(key);
   if (it != g_tune.end()) return run(it->second);
   const bool prof_was = g_prof_on;
@@ -1075,18 +1191,18 @@ static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that
   return m;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT>
+template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = false>
 static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
   constexpr int BN = WGM * WM * 32, BK = WGN * WN * 32;
-  const size_t smem = NBUF * (size_t)32 * (BN + BK) * sizeof(float);
-  auto kern = wgrad_kernel<WGM, WGN, WM, WN, NBUF, REFLECT>;
+  const size_t smem = NBUF * (size_t)32 * (BN + BK) * (BF16 ? 2 : sizeof(float));
+  auto kern = wgrad_kernel<WGM, WGN, WM, WN, NBUF, REFLECT, BF16>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   dim3 grid(p.Kw / BK, p.Nrows / BN, p.nsplit);
-  ProfScope prof(st, WGM * WGN == 8 ? 11 : BN == 128 ? (BK == 128 ? 4 : 5) : (BN == 64 ? 6 : 7), a.flops);
+  ProfScope prof(st, BF16 ? 13 : WGM * WGN == 8 ? 11 : BN == 128 ? (BK == 128 ? 4 : 5) : (BN == 64 ? 6 : 7), a.flops);
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), smem, st, a);
   IPR_LAUNCH_CHECK();
   return 0;
@@ -1094,6 +1210,11 @@ static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t s
 
 template <int WGM, int WGN, int WM, int WN>
 static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
+  if constexpr (WGM * WM == 4 && WGN * WN == 4) {       // bf16 math: the 128x128 tiles (4 and 8 waves)
+    if (g_math == IPRGAN_MATH_BF16)
+      return a.pad_mode == IPRGAN_PAD_REFLECT ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true, true>(a, p, st)
+                                              : launch_wgrad_tn<WGM, WGN, WM, WN, 1, false, true>(a, p, st);
+  }
   if (a.pad_mode == IPRGAN_PAD_REFLECT)
     return g_nbuf == 1 ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true>(a, p, st)
                        : launch_wgrad_tn<WGM, WGN, WM, WN, 2, true>(a, p, st);
@@ -1304,7 +1425,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     if (wgrad_plan_c(d, g_force_wgrad, pf)) cand = g_force_wgrad;
   } else if (g_autotune) {     // same scheme as the forward/backward-data tiles: time every candidate once per geometry
     TuneKey key = {{d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->outpad,
-                    d->transposed, d->pad_mode, -7, 0, 0, 0}};
+                    d->transposed, d->pad_mode, -7, g_math, 0, 0}};
     auto it = g_tune.find(key);
     if (it != g_tune.end()) {
       cand = it->second;
@@ -1334,6 +1455,13 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   }
   return 0;
 }
+
+int iprgan_set_math_mode(int mode) {
+  IPR_CHECK(mode == IPRGAN_MATH_FP32 || mode == IPRGAN_MATH_BF16, "set_math_mode: unknown mode %d", mode);
+  g_math = mode;
+  return 0;
+}
+int iprgan_get_math_mode(void) { return g_math; }
 
 int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand) {
   g_force_tile = gconv_tile;

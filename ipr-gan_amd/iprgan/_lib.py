@@ -83,6 +83,8 @@ SIGNATURES = {
     'iprgan_sign_ber': (_I, [_P, _P, _P, _I, _P, _P]),
     'iprgan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
     'iprgan_debug_force_tiles': (_I, [_I, _I]),
+    'iprgan_set_math_mode': (_I, [_I]),
+    'iprgan_get_math_mode': (_I, []),
     'iprgan_prof_enable': (_I, [_I]),
     'iprgan_prof_collect': (_I, []),
     'iprgan_prof_num_kernels': (_I, []),
@@ -159,3 +161,16 @@ def prof_results():
         call('iprgan_prof_get', i, name, 96, C.byref(n), C.byref(ms), C.byref(fl))
         out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value))
     return out
+
+
+MATH_MODES = {'fp32': 0, 'bf16': 1}
+
+
+def set_math(mode):
+    """Process-wide math mode of the conv family (include/iprgan.h: iprgan_set_math_mode): 'fp32' (default) or
+    'bf16' (bf16 MFMA tiles, fp32 accumulation, fp32 tensors and master weights in HBM)."""
+    call('iprgan_set_math_mode', MATH_MODES[mode] if isinstance(mode, str) else int(mode))
+
+
+def get_math():
+    return {v: k for k, v in MATH_MODES.items()}[load().iprgan_get_math_mode()]

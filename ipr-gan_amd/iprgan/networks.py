@@ -16,8 +16,8 @@ from . import _lib as L
 from . import engine as E
 from .ops import ConvSpec, reparam_bwd as ops_reparam_bwd, reparam_fwd as ops_reparam_fwd
 
-__all__ = ['ConvGenerator', 'ConvGenerator32', 'ConvGenerator64',
-           'SNDiscriminator', 'SNDiscriminator32', 'SNDiscriminator64', 'Flatten',
+__all__ = ['ConvGenerator', 'ConvGenerator32', 'ConvGenerator64', 'ConvGenerator128',
+           'SNDiscriminator', 'SNDiscriminator32', 'SNDiscriminator64', 'SNDiscriminator128', 'Flatten',
            'SRResNet', 'Discriminator96', 'VGG19Feature',
            'ResnetGenerator', 'ResnetBlock', 'Resnet6Blocks', 'Resnet9Blocks', 'ConvDiscriminator',
            'Encoder32', 'Decoder32']
@@ -82,6 +82,11 @@ def ConvGenerator64():
     return ConvGenerator(mg=8)
 
 
+def ConvGenerator128():
+    """Not in the reference (BASELINE config 5 'DCGAN 128x128': SURVEY section 8a constructs ConvGenerator(mg=16))."""
+    return ConvGenerator(mg=16)
+
+
 # ------------------------------------------------------------------------------------------------
 # DCGAN spectral-norm discriminator: reference networks/sn_discriminator.py:4-38
 # ------------------------------------------------------------------------------------------------
@@ -131,6 +136,11 @@ def SNDiscriminator32():
 
 def SNDiscriminator64():
     return SNDiscriminator(md=8)
+
+
+def SNDiscriminator128():
+    """Not in the reference (BASELINE config 5): SNDiscriminator(md=16)."""
+    return SNDiscriminator(md=16)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -46,6 +46,8 @@ def timeit(fn, n=10):
 
 def main():
     dev = torch.device('cuda:0')
+    from iprgan import _lib
+    _lib.set_math(os.environ.get('CONV_BENCH_MATH', 'fp32'))
     only = sys.argv[1] if len(sys.argv) > 1 else None
     rows = []
     for name, cin, cout, k, s, p, tr, H in LAYERS:

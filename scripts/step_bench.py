@@ -1,6 +1,7 @@
 """Secondary configs of BASELINE.json (not the headline metric): SRGAN GAN-phase step (24->96, batch 64,
-VGG19 features with random weights) and CycleGAN step (Resnet9Blocks + ConvDiscriminator, 256x256, batch 8),
-both with the sign-loss wrapper, on one GPU.  Prints one JSON line per config."""
+VGG19 features with random weights), CycleGAN step (Resnet9Blocks + ConvDiscriminator, 256x256, batch 8) and the
+DCGAN step in bf16 math (64x64 batch 128, and BASELINE config 5: 128x128 batch 256), all with the sign-loss
+wrapper, on one GPU.  Prints one JSON line per config."""
 import json
 import os
 import sys
@@ -55,8 +56,36 @@ def cyclegan(B=8, S=256):
                       'pairs_per_s': round(B / dt, 2), 'algorithmic_tflops': round(1884.6 * B / dt / 1e3, 1)}), flush=True)
 
 
+def dcgan(size, B, math):
+    from iprgan import _lib
+    _lib.set_math(math)
+    try:
+        m = models.DCGAN(Config({'G': f'ConvGenerator{size}', 'D': f'SNDiscriminator{size}', 'opt': 'Adam',
+                                 'opt_param': {'lr': 2e-4, 'betas': [0.5, 0.999]}}), device=[dev])
+        m = models.WhiteBoxWrapper(m, Config(dict(WBOX, target='G')))
+        x, z = torch.tanh(torch.randn(B, 3, size, size, device=dev)), torch.randn(B, 128, device=dev)
+
+        def step():
+            m.update_d({'real_sample': x, 'latent': z})
+            m.update_g({'fake_sample': m.fake_sample})
+        dt = timed(step, 6, 20)
+        gflop_img = 9.443 if size == 64 else 37.77            # 3 F_G + 8 F_D
+        metrics = m.get_metrics()
+        print(json.dumps({'config': f'DCGAN-{size} + sign loss B={B} {math} math (fp32 tensors / master weights)',
+                          'ms_per_step': round(dt * 1e3, 2), 'img_per_s': round(B / dt, 1),
+                          'algorithmic_tflops': round(gflop_img * B / dt / 1e3, 1),
+                          'finite': all(v == v and abs(v) < 1e9 for v in metrics.values()),
+                          'ber': float(m.loss_model.compute_ber(m.G))}), flush=True)
+    finally:
+        _lib.set_math('fp32')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['srgan', 'cyclegan']
+    which = sys.argv[1:] or ['srgan', 'cyclegan', 'dcgan']
+    if 'dcgan' in which:
+        dcgan(64, 128, 'bf16')
+        dcgan(128, 256, 'fp32')
+        dcgan(128, 256, 'bf16')
     if 'srgan' in which:
         srgan()
     if 'cyclegan' in which:

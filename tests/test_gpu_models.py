@@ -341,3 +341,26 @@ def test_conv_linearity_at_full_size(dev):
         wg = lambda xx, gg: ops.conv_bwd_weight(spec, d, xx, gg, w.shape, False)[0]
         lhs, rhs = wg(x1, 0.5 * g1 - 2.0 * g2), 0.5 * wg(x1, g1) - 2.0 * wg(x1, g2)
         assert float((lhs - rhs).abs().max()) <= 5e-5 * float(rhs.abs().max())
+
+
+def test_dcgan_bf16_math_vs_reference_golden(golden, dev):
+    """BASELINE config 5 asks for bf16 MFMA conv tiles: IPRGAN_MATH_BF16 rounds the conv operands to bf16 in LDS
+    (fp32 accumulation, fp32 tensors / master weights / norms / Adam).  Tolerance: operand rounding is 2^-9
+    relative per element, so after three training steps the losses must agree with the fp32 reference to 3e-2
+    absolute (they are O(1)), the generated images to 3 % in L2, and the sign bits / BER exactly."""
+    from iprgan import Config, _lib, models
+    ref = golden('dcgan_steps_wbox')
+    try:
+        _lib.set_math('bf16')
+        res = cases.run_dcgan_steps(Config, models, [dev], n_steps=3, wbox=True)
+    finally:
+        _lib.set_math('fp32')
+    for k in ref.files:
+        if '/metric/' in k:
+            assert abs(float(res[k]) - float(ref[k])) < 3e-2, (k, float(res[k]), float(ref[k]))
+    a, b = res['step0/fake_sample'].astype(np.float64), ref['step0/fake_sample'].astype(np.float64)
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 3e-2
+    assert float(res['final/ber']) == 0.0
+    for k in ref.files:
+        if k.startswith('final/sign/'):
+            assert np.array_equal(res[k], ref[k]), k

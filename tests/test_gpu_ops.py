@@ -470,3 +470,46 @@ def test_every_wgrad_candidate(dev, cand):
             close(db, br.grad, what=f'cand {cand} bgrad')
     finally:
         _lib.call('iprgan_debug_force_tiles', -1, -1)
+
+
+BF16_SHAPES = [  # cin, cout, k, s, p, transposed, H, B
+    (64, 128, 3, 1, 1, False, 16, 4), (128, 64, 4, 2, 1, False, 16, 4), (256, 128, 4, 2, 1, True, 8, 4),
+    (32, 96, 3, 1, 1, False, 9, 3), (64, 64, 3, 2, 1, False, 17, 2)]
+
+
+@pytest.mark.parametrize('shape', BF16_SHAPES)
+def test_conv_bf16_math_mode(dev, shape):
+    """IPRGAN_MATH_BF16: operands rounded to bf16 (nearest-even) in LDS, fp32 accumulation.  Checked two ways:
+    (1) against fp32 torch on inputs that are ALREADY bf16-representable - then the products are exact and only the
+    summation order differs (2e-4 of max, like the fp32 kernels); (2) against fp32 torch on generic inputs within
+    the bf16 rounding bound 2^-8 * sqrt(2) relative to max|x| max|w| sqrt(K)."""
+    from iprgan import _lib, ops
+    cin, cout, k, s, p, tr, H, B = shape
+    spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr)
+    d = spec.desc(B, H, H)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    conv = (lambda x, w: F.conv_transpose2d(x, w, None, stride=s, padding=p)) if tr else \
+           (lambda x, w: F.conv2d(x, w, None, stride=s, padding=p))
+    try:
+        _lib.set_math('bf16')
+        assert _lib.get_math() == 'bf16'
+        for exact in (True, False):
+            x, w = rnd(B, cin, H, H, seed=1), rnd(*wshape, seed=2, scale=0.05)
+            if exact:
+                x, w = x.bfloat16().float(), w.bfloat16().float()
+            xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+            yr = conv(xr, wr)
+            g = rnd(*yr.shape, seed=3)
+            if exact:
+                g = g.bfloat16().float()
+            yr.backward(g)
+            wf, wb = ops.conv_prep(spec, d, w.to(dev), None, True, True)
+            y = ops.conv_fwd(spec, d, to_nhwc(x).to(dev), wf, None)
+            dx = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb)
+            dw, _ = ops.conv_bwd_weight(spec, d, to_nhwc(x).to(dev), to_nhwc(g).to(dev), wshape, False)
+            tol = 2e-4 if exact else 2e-2
+            close(from_nhwc(y.cpu(), cout), yr, tol, f'bf16 fwd exact={exact}')
+            close(from_nhwc(dx.cpu(), cin), xr.grad, tol, f'bf16 dgrad exact={exact}')
+            close(dw, wr.grad, tol, f'bf16 wgrad exact={exact}')
+    finally:
+        _lib.set_math('fp32')
