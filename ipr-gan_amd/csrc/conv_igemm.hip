@@ -499,6 +499,7 @@ struct WGradArgs {
   FastDiv d_c4n, d_pw, d_plane, d_tw;
   int PH, PW, M;
   int isy, isx, pad, tw, ntap, pad_mode;
+  int flip;                  // +1: Q pixel = P pixel * stride + (tap - pad);  -1 (swapped roles): P pixel - (tap - pad)
   int Kw, Nrows;             // slab row length / rows
   int chunks_per_split;
   unsigned p_bytes, q_bytes;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
   const int c4 = q - t * a.c4n;
   const bool qvalid = t < a.ntap;
   const int ty = fdiv(t, a.d_tw), tx = t - ty * a.tw;
-  const int dy = ty - a.pad, dx = tx - a.pad;
+  const int dy = (ty - a.pad) * a.flip, dx = (tx - a.pad) * a.flip;
   const bool pvalid = (n0 + cp * 4) < a.Pvalid;
   const int plane = a.PH * a.PW;
 
@@ -766,6 +767,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
         }
       }
     }
+}
+
+// x[B][H][W][C4] -> xp[B][H+2p][W+2p][C4] with ReflectionPad2d borders (only for the swapped-role wgrad of the
+// reflect-padded RGB heads, see WGeom)
+__global__ void reflect_pad_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ xp, int B, int H, int W,
+                                   int C4n, int pad) {
+  const int HP = H + 2 * pad, WP = W + 2 * pad;
+  const size_t total = (size_t)B * HP * WP * C4n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4n);
+    size_t r = i / C4n;
+    const int xq = (int)(r % WP); r /= WP;
+    const int yq = (int)(r % HP);
+    const int b = (int)(r / HP);
+    const int sy = reflect_idx(yq - pad, H), sx = reflect_idx(xq - pad, W);
+    xp[i] = x[(((size_t)b * H + sy) * W + sx) * C4n + c];
+  }
 }
 
 // sum the split slabs in fixed order and scatter into PyTorch weight layout.
@@ -1151,15 +1169,49 @@ struct WGradPlan {
 #define WGRAD_NTARGET 5
 #define WGRAD_NCAND (WGRAD_NSHAPE * WGRAD_NTARGET)
 #define WGRAD_MAX_SLAB_FLOATS ((size_t)128 << 20)      // candidates needing more than 512 MB of slabs are skipped
-static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
+// Roles of the two tensors.  P is walked on its own pixel grid (the GEMM's reduction index m), Q is gathered
+// around it tap by tap; the slab is [P channel][(tap, Q channel)].
+//   Conv2d          : P = dy on the output grid, Q = x at  o * stride + (tap - pad)
+//   ConvTranspose2d : P = x  on the input grid,  Q = dy at i * stride + (tap - pad)
+//   Conv2d, swapped : P = x  on the input grid,  Q = dy at i - (tap - pad)          (stride 1 only)
+// The swapped form serves layers with a handful of output channels (RGB heads 64->3 k7/k9, patch logits
+// 512->1): with P = dy the MFMA tile has 3 useful rows of 32; swapped, the 4-padded output channels sit in the K
+// dimension (3 useful of 4) and the rows are the 64+ input channels.  With ReflectionPad2d the input is first
+// copied into its padded form (reflect_pad_kernel) and the layer becomes a pad-0 convolution of that image.
+struct WGeom {
+  int N, Cq, PH, PW, QH, QW, pad, flip, swap, padded;
+};
+static WGeom wgrad_geom(const iprgan_conv_desc* d) {
   const Shape s = out_shape(d);
-  // P = grid-aligned tensor (Conv2d: dy [OH,OW,Cout]; ConvT: x [H,W,Cin]); Q = gathered tensor
-  p.N = d->transposed ? d->Cin : d->Cout;
-  p.Cq = d->transposed ? d->Cout : d->Cin;
+  WGeom g;
+  memset(&g, 0, sizeof(g));
+  g.flip = 1; g.pad = d->pad;
+  if (d->transposed) {
+    g.N = d->Cin; g.Cq = d->Cout; g.PH = d->H; g.PW = d->W; g.QH = s.OH; g.QW = s.OW;
+  } else if (d->stride == 1 && d->Cout <= 16 && d->Cin >= 32) {
+    g.swap = 1; g.flip = -1;
+    g.padded = d->pad_mode == IPRGAN_PAD_REFLECT && d->pad > 0;
+    g.N = d->Cin; g.Cq = d->Cout; g.QH = s.OH; g.QW = s.OW;
+    g.PH = d->H + (g.padded ? 2 * d->pad : 0); g.PW = d->W + (g.padded ? 2 * d->pad : 0);
+    if (g.padded) g.pad = 0;
+  } else {
+    g.N = d->Cout; g.Cq = d->Cin; g.PH = s.OH; g.PW = s.OW; g.QH = d->H; g.QW = d->W;
+  }
+  return g;
+}
+static size_t rup4(size_t n) { return (n + 3) & ~(size_t)3; }
+static size_t wgrad_padded_floats(const iprgan_conv_desc* d) {
+  const WGeom g = wgrad_geom(d);
+  return g.padded ? (size_t)d->B * g.PH * g.PW * c4(d->Cin) : 0;
+}
+
+static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
+  const WGeom g = wgrad_geom(d);
+  p.N = g.N;
+  p.Cq = g.Cq;
   p.Ps = c4(p.N); p.Qs = c4(p.Cq);
   p.ntap = d->KH * d->KW;
-  const int PH = d->transposed ? d->H : s.OH, PW = d->transposed ? d->W : s.OW;
-  p.M = d->B * PH * PW;
+  p.M = d->B * g.PH * g.PW;
   const int K = p.ntap * p.Qs;
   static const int targets[WGRAD_NTARGET] = {768, 1536, 3072, 6144, 384};
   if (cand < 0 || cand >= WGRAD_NCAND) return false;
@@ -1377,29 +1429,39 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
 
 size_t iprgan_conv_wgrad_ws_floats(const iprgan_conv_desc* d) {
   const Shape s = out_shape(d);
-  return wgrad_slab_floats(d) + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout));
+  return rup4(wgrad_slab_floats(d) + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout))) + wgrad_padded_floats(d);
 }
 
 int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const float* dy, float* dw,
                            float* db, float* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const Shape s = out_shape(d);
+  const WGeom g = wgrad_geom(d);
+  const float* xin = x;
+  if (g.padded) {             // reflect-padded copy of x behind the slabs and the bias partials
+    float* xp = ws + rup4(wgrad_slab_floats(d) + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout)));
+    const size_t n4 = wgrad_padded_floats(d) / 4;
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256)),
+                       dim3(256), 0, st, (const f32x4*)x, (f32x4*)xp, d->B, d->H, d->W, c4(d->Cin) / 4, d->pad);
+    IPR_LAUNCH_CHECK();
+    xin = xp;
+  }
   auto run = [&](int cand) -> int {
     WGradPlan p;
     if (!wgrad_plan_c(d, cand, p)) return -1;
     WGradArgs a;
     memset(&a, 0, sizeof(a));
-    a.P = d->transposed ? x : dy;
-    a.Q = d->transposed ? dy : x;
+    a.P = (d->transposed || g.swap) ? xin : dy;
+    a.Q = (d->transposed || g.swap) ? dy : xin;
     a.ws = ws;
     a.Ps = p.Ps; a.Pvalid = p.Ps;
-    a.QH = d->transposed ? s.OH : d->H; a.QW = d->transposed ? s.OW : d->W;
+    a.QH = g.QH; a.QW = g.QW;
     a.Qs = p.Qs; a.c4n = p.Qs / 4; a.d_c4n = make_fastdiv(a.c4n);
-    a.PH = d->transposed ? d->H : s.OH; a.PW = d->transposed ? d->W : s.OW;
+    a.PH = g.PH; a.PW = g.PW;
     a.M = p.M;
     a.d_pw = make_fastdiv(a.PW); a.d_plane = make_fastdiv(a.PH * a.PW); a.d_tw = make_fastdiv(d->KW);
-    a.isy = a.isx = d->stride; a.pad = d->pad; a.tw = d->KW; a.ntap = p.ntap;
-    a.pad_mode = d->pad_mode;
+    a.isy = a.isx = d->stride; a.pad = g.pad; a.tw = d->KW; a.ntap = p.ntap; a.flip = g.flip;
+    a.pad_mode = g.swap ? IPRGAN_PAD_ZERO : d->pad_mode;      // swapped + reflect runs on the padded copy
     a.Kw = p.Kw; a.Nrows = p.Nrows; a.chunks_per_split = p.cps;
     const unsigned long long pb = (unsigned long long)a.M * a.Ps * 4ull;
     const unsigned long long qb = (unsigned long long)d->B * a.QH * a.QW * a.Qs * 4ull;
@@ -1424,7 +1486,9 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     if (rc) return rc;
     const long long total = (long long)p.N * p.ntap * p.Qs;
     IPR_CHECK(total < (1ll << 31), "conv_bwd_weight: weight too large");
-    const long long sn = (long long)p.Cq * p.ntap, sc = p.ntap;
+    // dw[row * sn + qchannel * sc + tap]: Conv2d [Cout][Cin][taps], ConvTranspose2d [Cin][Cout][taps];
+    // swapped roles: rows are Cin and the Q channel is Cout of a Conv2d weight
+    const long long sn = g.swap ? p.ntap : (long long)p.Cq * p.ntap, sc = g.swap ? (long long)p.N * p.ntap : p.ntap;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, ws, dw,
                        p.nsplit, p.Nrows, p.Kw, p.N, p.Cq, p.Qs, p.ntap, make_fastdiv(p.Qs),
                        make_fastdiv(p.ntap * p.Qs), sn, sc);

@@ -67,6 +67,12 @@ CONVS = [
     (256, 512, 3, 1, 1, 0, False, 8, 8, 2, 'lrelu'),
     (128, 128, 1, 1, 0, 0, False, 5, 5, 2, 'none'),        # 1x1
     (512, 64, 6, 1, 0, 0, False, 6, 6, 3, 'lrelu'),        # D96 "FC" conv
+    # few output channels, stride 1: backward-weight runs with swapped roles (P = x, Q = dy, negated taps)
+    (64, 3, 9, 1, 4, 0, False, 12, 12, 2, 'none'),         # SRGAN head
+    (64, 3, 7, 1, 3, 0, False, 13, 11, 2, 'tanh'),         # ragged
+    (512, 1, 4, 1, 1, 0, False, 9, 9, 2, 'none'),          # PatchGAN logits
+    (64, 16, 3, 1, 1, 0, False, 10, 10, 3, 'none'),
+    (1024, 1, 1, 1, 0, 0, False, 1, 1, 5, 'none'),         # D96 last 1x1 on a 1x1 map
 ]
 ACT = {'none': (0, 0.0), 'relu': (1, 0.0), 'lrelu': (2, 0.1), 'tanh': (3, 0.0)}
 
@@ -345,7 +351,8 @@ def test_cpu_tensor_is_refused(dev):
         networks.ConvGenerator32()(torch.zeros(2, 128))
 
 
-REFLECT_CONVS = [(64, 64, 3, 1, 1, 8, 9, 2), (3, 32, 7, 1, 3, 12, 10, 2), (64, 3, 7, 1, 3, 9, 9, 1), (256, 256, 3, 1, 1, 6, 6, 2)]
+REFLECT_CONVS = [(64, 64, 3, 1, 1, 8, 9, 2), (3, 32, 7, 1, 3, 12, 10, 2), (64, 3, 7, 1, 3, 9, 9, 1), (256, 256, 3, 1, 1, 6, 6, 2),
+                 (64, 3, 7, 1, 3, 14, 11, 2)]         # RGB head, ragged: swapped-role wgrad on the reflect-padded copy
 
 
 @pytest.mark.parametrize('cfg', REFLECT_CONVS, ids=lambda c: '-'.join(map(str, c)))
