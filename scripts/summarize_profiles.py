@@ -13,12 +13,16 @@ import sys
 
 
 def short(k):
-    m = re.match(r'void iprgan::gconv_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)>', k)
+    m = re.match(r'void iprgan::gconv_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)(?:, (true|false))?>', k)
     if m:
+        if m.group(8) == 'true':
+            return 'gconv_bf16_kernel'
         wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
         return f'gconv_kernel<{wgm * wm * 32}x{wgn * wn * 32}' + (',8w>' if wgm * wgn == 8 else '>')
-    m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>', k)
+    m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?>', k)
     if m:
+        if m.group(7) == 'true':
+            return 'wgrad_bf16_kernel'
         wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
         return f'wgrad_kernel<{wgm * wm * 32}x{wgn * wn * 32}' + (',8w>' if wgm * wgn == 8 else '>')
     return k.split('(')[0].replace('void ', '').replace('iprgan::', '')
