@@ -35,6 +35,7 @@ import torch.distributed as dist  # noqa: E402
 
 BATCH = 128
 PEAK_FP32_MFMA = 157.3e12
+PROF_EVERY = 4
 PEAK_BF16_MFMA = 2500e12          # dense bf16 MFMA (MI355X_MICROARCH.md); only used with --math bf16
 DCGAN_CFG = {'G': 'ConvGenerator64', 'D': 'SNDiscriminator64', 'opt': 'Adam',
              'opt_param': {'lr': 2.0e-4, 'betas': [0.5, 0.999]}, 'type': 'DCGAN'}
@@ -127,14 +128,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    _lib.prof_enable(True)
+    # Per-kernel HIP events ride on the conv-family dispatches of every PROF_EVERY-th step of the timed region
+    # (all steps when K < 2 * PROF_EVERY): timing every launch costs ~0.3 ms of a 12.5 ms step in completion-signal
+    # handling, and the headline value should not pay for its own instrumentation.
+    every = PROF_EVERY if args.steps >= 2 * PROF_EVERY else 1
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        _lib.prof_enable(i % every == 0)
         step(model, xs[i % pool], zs[i % pool])
     fence()
     elapsed = time.perf_counter() - t0
     _lib.prof_enable(False)
+    prof_steps = len(range(0, args.steps, every))
     log(f'timed {args.steps} steps in {elapsed:.3f}s')
     kernels = [k for k in _lib.prof_results() if k['launches']]
     metrics = model.get_metrics()
@@ -178,7 +184,7 @@ def main():
                                    ', Adam',
                        'global_batch': BATCH * world, 'parallelism': f'dp{world}'},
             'roofline': roof,
-            'conv_kernels': {'device_ms_per_step': round(conv_ms / args.steps, 3),
+            'conv_kernels': {'device_ms_per_step': round(conv_ms / prof_steps, 3), 'steps_sampled': prof_steps,
                              'tflops': round(conv_flops / max(conv_ms, 1e-9) / 1e9, 2),
                              'mfma_util_pct': round(100 * conv_flops / max(conv_ms, 1e-9) / 1e9 / 157.3, 1),
                              'by_kernel': [{'name': k['name'], 'launches': k['launches'],
