@@ -978,6 +978,35 @@ struct TuneKey {
   bool operator<(const TuneKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
 };
 static std::map<TuneKey, int> g_tune;
+// IPRGAN_TUNE_CACHE=<file>: tuning decisions are appended to the file and read back by later processes, which
+// then launch no tuning trials (start-up time; and a profiler run sees only the launches of the step itself).
+static bool g_tune_loaded = false;
+static void tune_load() {
+  if (g_tune_loaded) return;
+  g_tune_loaded = true;
+  const char* path = getenv("IPRGAN_TUNE_CACHE");
+  FILE* f = path ? fopen(path, "r") : nullptr;
+  if (!f) return;
+  TuneKey k;
+  int v;
+  for (;;) {
+    int n = 0;
+    for (int i = 0; i < 16; ++i) n += fscanf(f, "%d", &k.v[i]);
+    n += fscanf(f, "%d", &v);
+    if (n != 17) break;
+    g_tune[k] = v;
+  }
+  fclose(f);
+}
+static void tune_store(const TuneKey& k, int v) {
+  g_tune[k] = v;
+  const char* path = getenv("IPRGAN_TUNE_CACHE");
+  FILE* f = path ? fopen(path, "a") : nullptr;
+  if (!f) return;
+  for (int i = 0; i < 16; ++i) fprintf(f, "%d ", k.v[i]);
+  fprintf(f, "%d\n", v);
+  fclose(f);
+}
 static int g_force_tile = -1, g_force_wgrad = -1;     // test hook: iprgan_debug_force_tiles
 static int g_autotune = getenv("IPRGAN_AUTOTUNE") ? atoi(getenv("IPRGAN_AUTOTUNE")) : 1;
 static int g_smalln = getenv("IPRGAN_SMALLN") ? atoi(getenv("IPRGAN_SMALLN")) : 1;
@@ -1148,6 +1177,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   // order, results stay within fp32 rounding of each other.
   TuneKey key = {{a.B, a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.isy, a.osy, a.nphase, a.ph[0].th, a.ph[0].tw,
                   a.ph[0].ohg, a.ph[0].owg, a.pad_mode + 16 * g_math, a.Kp}};
+  tune_load();
   auto it = g_tune.find(key);
   if (it != g_tune.end()) return run(it->second);
   const bool prof_was = g_prof_on;
@@ -1160,7 +1190,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   }, st, tile, &best_us, &err);
   g_prof_on = prof_was;
   if (err) return err;
-  g_tune[key] = best;
+  tune_store(key, best);
   if (getenv("IPRGAN_TUNE_LOG"))
     fprintf(stderr, "[iprgan tune] gconv B%d in %dx%dx%d out %dx%dx%d taps %dx%d phases %d -> tile %d (%.1f us)\n", a.B,
             a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.ph[0].th, a.ph[0].tw, a.nphase, best, best_us);
@@ -1516,6 +1546,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   } else if (g_autotune) {     // same scheme as the forward/backward-data tiles: time every candidate once per geometry
     TuneKey key = {{d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->outpad,
                     d->transposed, d->pad_mode, -7, g_math, 0, 0}};
+    tune_load();
     auto it = g_tune.find(key);
     if (it != g_tune.end()) {
       cand = it->second;
@@ -1530,7 +1561,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
       if (getenv("IPRGAN_TUNE_LOG"))
         fprintf(stderr, "[iprgan tune] wgrad B%d %dx%d %d->%d k%d s%d t%d -> cand %d (%.1f us)\n", d->B, d->H, d->W,
                 d->Cin, d->Cout, d->KH, d->stride, d->transposed, cand, best_us);
-      g_tune[key] = cand;
+      tune_store(key, cand);
     }
   }
   {

@@ -12,6 +12,11 @@ cd $R
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -3 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+# one un-profiled pass records the autotuner's choices; the profiler runs replay them (IPRGAN_TUNE_CACHE), so their
+# per-kernel averages contain the launches of the training step only, like the bench line's own HIP-event figures
+export IPRGAN_TUNE_CACHE=$O/tune_cache.txt
+rm -f $IPRGAN_TUNE_CACHE
+timeout 300 python bench.py --steps 8 --warmup 4 --no-cpu-baseline > /dev/null 2> $O/tune_pass.err
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o $TAG --output-format csv -- python3 $R/bench.py --steps 20 --warmup 8 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/prof_bench.err
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof -o ${TAG}_fetch --output-format csv -- python3 $R/bench.py --steps 4 --warmup 8 --no-cpu-baseline > /dev/null 2> $O/prof_fetch.err
