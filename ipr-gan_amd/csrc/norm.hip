@@ -166,11 +166,12 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean,
 __global__ void bn_apply_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ mean, const float* __restrict__ invstd,
-                                size_t n4, int C4n, size_t per_group4, int act, float slope) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4n) * 4;
-    const size_t go = (i / per_group4) * (size_t)C4n * 4;     // group offset into mean/invstd
+                                unsigned n4, int C4n, FastDiv d_c4n, FastDiv d_group4, int act, float slope) {
+  // 32-bit indices and multiply-shift division: the first version's 64-bit % and / per element made this
+  // streaming kernel instruction-bound (2.2 TB/s)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const int c = (int)(i - fdiv(i, d_c4n) * (unsigned)C4n) * 4;
+    const size_t go = (size_t)fdiv(i, d_group4) * (size_t)C4n * 4;     // group offset into mean/invstd
     const f32x4 v = x[i];
     f32x4 o;
 #pragma unroll
@@ -204,12 +205,11 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ x, const f32x4* __
                                     const f32x4* __restrict__ dy, f32x4* __restrict__ dx,
                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ sums,
-                                    size_t n4, int C4n, int C, size_t per_group4, float invM, int act,
-                                    float slope) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4n) * 4;
-    const size_t grp = i / per_group4;
+                                    unsigned n4, int C4n, int C, FastDiv d_c4n, FastDiv d_group4, float invM,
+                                    int act, float slope) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const int c = (int)(i - fdiv(i, d_c4n) * (unsigned)C4n) * 4;
+    const size_t grp = fdiv(i, d_group4);
     const float* mean_g = mean + grp * C;
     const float* invstd_g = invstd + grp * C;
     const float* sums_g = sums + grp * 2 * C;
@@ -276,9 +276,11 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
   }
   IPR_LAUNCH_CHECK();
   const size_t n4 = (size_t)G * M * C / 4;
+  IPR_CHECK(n4 < 0x7fffffffull, "norm_fwd: tensor of %zu elements is too large", n4 * 4);
   const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)x, (f32x4*)y, gamma,
-                     beta, save_mean, save_invstd, n4, C / 4, (size_t)M * C / 4, act, slope);
+                     beta, save_mean, save_invstd, (unsigned)n4, C / 4, make_fastdiv(C / 4),
+                     make_fastdiv((uint32_t)((size_t)M * C / 4)), act, slope);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -300,10 +302,11 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
     IPR_LAUNCH_CHECK();
   }
   const size_t n4 = (size_t)G * M * C / 4;
+  IPR_CHECK(n4 < 0x7fffffffull, "norm_bwd: tensor of %zu elements is too large", n4 * 4);
   const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)x, (const f32x4*)y,
-                     (const f32x4*)dy, (f32x4*)dx, gamma, save_mean, save_invstd, sums, n4, C / 4, C,
-                     (size_t)M * C / 4, 1.0f / (float)M, act, slope);
+                     (const f32x4*)dy, (f32x4*)dx, gamma, save_mean, save_invstd, sums, (unsigned)n4, C / 4, C,
+                     make_fastdiv(C / 4), make_fastdiv((uint32_t)((size_t)M * C / 4)), 1.0f / (float)M, act, slope);
   IPR_LAUNCH_CHECK();
   return 0;
 }
