@@ -99,11 +99,24 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 __device__ __forceinline__ void final_sums(const float* __restrict__ part, int NB, int C, int c, int lane,
                                            float (*sh)[FL][64], float& s0, float& s1, bool two) {
   float a0 = 0.f, a1 = 0.f;
-  if (c < C)
-    for (int b = lane; b < NB; b += FL) {
-      a0 += part[((size_t)b * 2) * C + c];
-      if (two) a1 += part[((size_t)b * 2 + 1) * C + c];
+  if (c < C) {
+    // four independent partial sums per lane: the loads overlap instead of queueing behind one accumulator
+    float p0[4] = {0.f, 0.f, 0.f, 0.f}, p1[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = lane;
+    for (; b + 3 * FL < NB; b += 4 * FL) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p0[u] += part[((size_t)(b + u * FL) * 2) * C + c];
+        if (two) p1[u] += part[((size_t)(b + u * FL) * 2 + 1) * C + c];
+      }
     }
+    for (; b < NB; b += FL) {
+      p0[0] += part[((size_t)b * 2) * C + c];
+      if (two) p1[0] += part[((size_t)b * 2 + 1) * C + c];
+    }
+    a0 = (p0[0] + p0[1]) + (p0[2] + p0[3]);
+    a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+  }
   const int cl = threadIdx.x & 63;
   sh[0][lane][cl] = a0;
   sh[1][lane][cl] = a1;
