@@ -872,27 +872,29 @@ struct PrepEntry {
   const float* inv_scale;
   float* dst;
   int rows_alloc, Kp, Drow, Dcol, Cs, ntap, row_is_d0;
+  FastDiv d_cs;
 };
 struct PrepTable {
   PrepEntry e[PREP_MAX];
 };
+// blocks walk rows, threads walk k: no 64-bit division per element (the first version spent its time there)
 __global__ void weight_prep_multi_kernel(const PrepTable t) {
   const PrepEntry e = t.e[blockIdx.y];
   const float sc = e.inv_scale ? *e.inv_scale : 1.f;
-  const long long total = (long long)e.rows_alloc * e.Kp;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % e.Kp);
-    const int r = (int)(i / e.Kp);
-    const int tap = k / e.Cs, c = k - tap * e.Cs;
-    float v = 0.f;
-    if (r < e.Drow && tap < e.ntap && c < e.Dcol) {
-      const long long src = e.row_is_d0 ? ((long long)r * e.Dcol + c) * e.ntap + tap
-                                        : ((long long)c * e.Drow + r) * e.ntap + tap;
-      v = e.w[src];
-      if (e.inv_scale) v = v / sc;
+  const FastDiv d_cs = e.d_cs;
+  for (int r = blockIdx.x; r < e.rows_alloc; r += gridDim.x) {
+    float* out = e.dst + (size_t)r * e.Kp;
+    for (int k = threadIdx.x; k < e.Kp; k += blockDim.x) {
+      const int tap = (int)fdiv((uint32_t)k, d_cs), c = k - tap * e.Cs;
+      float v = 0.f;
+      if (r < e.Drow && tap < e.ntap && c < e.Dcol) {
+        const size_t src = e.row_is_d0 ? ((size_t)r * e.Dcol + c) * e.ntap + tap
+                                       : ((size_t)c * e.Drow + r) * e.ntap + tap;
+        v = e.w[src];
+        if (e.inv_scale) v = v / sc;
+      }
+      out[k] = v;
     }
-    e.dst[i] = v;
   }
 }
 
@@ -1387,13 +1389,12 @@ int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* co
   hipStream_t st = (hipStream_t)stream;
   PrepTable t;
   int cnt = 0;
-  long long maxtotal = 0;
+  int maxrows = 0;
   auto flush = [&]() -> int {
     if (!cnt) return 0;
-    const int bx = (int)((maxtotal + 255) / 256 < 1024 ? (maxtotal + 255) / 256 : 1024);
-    hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(bx, cnt), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(maxrows < 1024 ? maxrows : 1024, cnt), dim3(256), 0, st, t);
     IPR_LAUNCH_CHECK();
-    cnt = 0; maxtotal = 0;
+    cnt = 0; maxrows = 0;
     return 0;
   };
   for (int l = 0; l < n; ++l) {
@@ -1406,10 +1407,9 @@ int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* co
       PrepEntry& e = t.e[cnt++];
       e.w = w[l]; e.inv_scale = inv_scale ? inv_scale[l] : nullptr; e.dst = dst;
       e.Cs = c4(red); e.Kp = rup(ntap * e.Cs, 32); e.rows_alloc = rup(rows, 128);
-      e.Drow = rows; e.Dcol = red; e.ntap = ntap;
+      e.Drow = rows; e.Dcol = red; e.ntap = ntap; e.d_cs = make_fastdiv(e.Cs);
       e.row_is_d0 = ((which == 0) != (d->transposed != 0)) ? 1 : 0;
-      const long long total = (long long)e.rows_alloc * e.Kp;
-      if (total > maxtotal) maxtotal = total;
+      if (e.rows_alloc > maxrows) maxrows = e.rows_alloc;
       if (cnt == PREP_MAX) { const int rc = flush(); if (rc) return rc; }
     }
   }

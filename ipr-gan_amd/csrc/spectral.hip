@@ -139,27 +139,61 @@ __global__ void snm_wtu_kernel(const SNTable t, float* __restrict__ ws) {
   if (r1 > rows) r1 = rows;
   const float* w = t.w[l];
   const float* u = t.u[l];
-  float s = 0.f;
-  for (int i = r0; i < r1; ++i) s += w[(size_t)i * cols + j] * u[i];
-  ws[t.ws_off[l] + (size_t)blockIdx.y * cols + j] = s;
+  // four independent accumulators: the row loads overlap (one accumulator serialised them: 27 us for 12 MB)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = r0;
+  for (; i + 3 < r1; i += 4) {
+    s0 += w[(size_t)i * cols + j] * u[i];
+    s1 += w[(size_t)(i + 1) * cols + j] * u[i + 1];
+    s2 += w[(size_t)(i + 2) * cols + j] * u[i + 2];
+    s3 += w[(size_t)(i + 3) * cols + j] * u[i + 3];
+  }
+  for (; i < r1; ++i) s0 += w[(size_t)i * cols + j] * u[i];
+  ws[t.ws_off[l] + (size_t)blockIdx.y * cols + j] = (s0 + s1) + (s2 + s3);
 }
 __global__ __launch_bounds__(1024) void snm_v_kernel(const SNTable t, float* __restrict__ ws, float eps) {
   __shared__ float sh[16];
   const int l = blockIdx.x;
   const int cols = t.cols[l], nsplit = t.nsplit[l];
   const float* tpart = ws + t.ws_off[l];
-  float ss = 0.f;
-  for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+  auto colsum = [&](int j) {                    // all split partials of a column are loaded together
+    float p[SN_MAX_RSPLIT];
+#pragma unroll
+    for (int s = 0; s < SN_MAX_RSPLIT; ++s) p[s] = s < nsplit ? tpart[(size_t)s * cols + j] : 0.f;
     float a = 0.f;
-    for (int s = 0; s < nsplit; ++s) a += tpart[(size_t)s * cols + j];
+#pragma unroll
+    for (int s = 0; s < SN_MAX_RSPLIT; ++s) a += p[s];
+    return a;
+  };
+  // up to 32 columns per thread stay in registers between the norm pass and the write pass, loaded together
+  // (one block per layer: the serial column walk was the long pole, 19 us for the 32768-column head)
+  constexpr int KEEP = 32;
+  float* v = t.v[l];
+  float* vo = t.v_out[l];
+  float keep[KEEP];
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q) {
+    const int j = threadIdx.x + q * blockDim.x;
+    keep[q] = j < cols ? colsum(j) : 0.f;
+    ss += keep[q] * keep[q];
+  }
+  for (int j = threadIdx.x + KEEP * blockDim.x; j < cols; j += blockDim.x) {
+    const float a = colsum(j);
     ss += a * a;
   }
   const float inv = 1.f / fmaxf(sqrtf(block_sum(ss, sh)), eps);
-  float* v = t.v[l];
-  float* vo = t.v_out[l];
-  for (int j = threadIdx.x; j < cols; j += blockDim.x) {
-    float a = 0.f;
-    for (int s = 0; s < nsplit; ++s) a += tpart[(size_t)s * cols + j];
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q) {
+    const int j = threadIdx.x + q * blockDim.x;
+    if (j < cols) {
+      const float a = keep[q] * inv;
+      v[j] = a;
+      if (vo) vo[j] = a;
+    }
+  }
+  for (int j = threadIdx.x + KEEP * blockDim.x; j < cols; j += blockDim.x) {
+    float a = colsum(j);
     a *= inv;
     v[j] = a;
     if (vo) vo[j] = a;
@@ -232,8 +266,24 @@ __global__ __launch_bounds__(256) void snm_dot_kernel(const SNBwdTable t, float*
   const float* a = t.dwsn[l];
   const float* b = t.w[l];
   float s = 0.f;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    s += a[i] * b[i];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if ((n & 3) == 0) {          // 16-byte loads, two of each array in flight
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* a4 = (const f4*)a;
+    const f4* b4 = (const f4*)b;
+    const size_t n4 = n >> 2;
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    for (; i + stride < n4; i += 2 * stride) {
+      acc0 += a4[i] * b4[i];
+      acc1 += a4[i + stride] * b4[i + stride];
+    }
+    if (i < n4) acc0 += a4[i] * b4[i];
+    const f4 t4 = acc0 + acc1;
+    s = (t4.x + t4.y) + (t4.z + t4.w);
+  } else {
+    for (; i < n; i += stride) s += a[i] * b[i];
+  }
   s = block_sum(s, sh);
   if (threadIdx.x == 0) part[l * SNB_BLOCKS + blockIdx.x] = s;
 }
