@@ -163,6 +163,13 @@ def main():
             traffic = json.load(open(tf))['kernels'][dom['name']]['hbm_bytes_per_launch']
         except Exception:
             pass
+        util_pmc = None
+        try:          # hardware MFMA utilisation of the step's conv kernels from the committed PMC pass
+            import glob
+            uf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_mfma_util.json')))[-1]
+            util_pmc = json.load(open(uf))['all_conv']['mfma_util_pct']
+        except Exception:
+            pass
         if dom:
             ach = dom['flops'] / (dom['ms'] * 1e-3)
             peak = PEAK_BF16_MFMA if 'bf16' in dom['name'] else PEAK_FP32_MFMA
@@ -187,6 +194,7 @@ def main():
             'conv_kernels': {'device_ms_per_step': round(conv_ms / prof_steps, 3), 'steps_sampled': prof_steps,
                              'tflops': round(conv_flops / max(conv_ms, 1e-9) / 1e9, 2),
                              'mfma_util_pct': round(100 * conv_flops / max(conv_ms, 1e-9) / 1e9 / 157.3, 1),
+                             'mfma_util_pct_pmc': util_pmc,
                              'by_kernel': [{'name': k['name'], 'launches': k['launches'],
                                             'ms': round(k['ms'], 2),
                                             'tflops': round(k['flops'] / max(k['ms'], 1e-9) / 1e9, 2)}

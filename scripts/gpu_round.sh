@@ -21,6 +21,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof -o $TAG --output-format csv -- python3 $R/bench.py --steps 20 --warmup 8 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/prof_bench.err
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof -o ${TAG}_fetch --output-format csv -- python3 $R/bench.py --steps 4 --warmup 8 --no-cpu-baseline > /dev/null 2> $O/prof_fetch.err
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof -o ${TAG}_write --output-format csv -- python3 $R/bench.py --steps 4 --warmup 8 --no-cpu-baseline > /dev/null 2> $O/prof_write.err
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/prof -o ${TAG}_mfma --output-format csv -- python3 $R/bench.py --steps 4 --warmup 8 --no-cpu-baseline > /dev/null 2> $O/prof_mfma.err
 cd $R
 # the counters of THIS build first, so that the bench line's roofline.traffic (read from profiles/) matches it
 python scripts/summarize_profiles.py $O/prof $TAG $R/profiles/$TAG > /dev/null && cp $R/profiles/${TAG}_pmc_traffic.json $R/profiles/${TAG}_bench_kernel_stats.csv $O/

@@ -5,6 +5,7 @@ Kernel names are mapped to the names bench.py reports (iprgan_prof_get).  FETCH_
 MI355X_MICROARCH.md prescribes for gfx950 (128-B requests of 16-B/lane streams are tallied at 64 B).
 usage: python scripts/summarize_profiles.py <prof_dir> <tag> <out_prefix>"""
 import collections
+import os
 import csv
 import json
 import re
@@ -42,8 +43,8 @@ def main():
     shutil.copy(f'{prof}/{tag}_kernel_stats.csv', f'{out}_bench_kernel_stats.csv')
     f, w = agg(f'{prof}/{tag}_fetch_counter_collection.csv', 'FETCH_SIZE'), agg(f'{prof}/{tag}_write_counter_collection.csv', 'WRITE_SIZE')
     res = {'_how': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (with --kernel-trace only) over '
-                   '`bench.py --steps 3 --warmup 12` (autotuning launches happen in the first warm-up step and are a minority of the '
-                   'samples); counter unit KiB; FETCH_SIZE x2 (gfx950 correction, checked on bn_apply whose byte count is known); '
+                   '`bench.py --steps 4 --warmup 8` with the tile choices replayed from IPRGAN_TUNE_CACHE (no tuning launches); '
+                   'counter unit KiB; FETCH_SIZE x2 (gfx950 correction, checked on bn_apply whose byte count is known); '
                    'averages over all launches of a kernel name (layers of different sizes share kernels).',
            'kernels': {}}
     for k in sorted(f):
@@ -53,6 +54,24 @@ def main():
                              'hbm_bytes_per_launch': round(fb + wb)}
     json.dump(res, open(f'{out}_pmc_traffic.json', 'w'), indent=1)
     print('wrote', f'{out}_pmc_traffic.json', len(res['kernels']), 'kernels')
+    mf = f'{prof}/{tag}_mfma_counter_collection.csv'
+    if os.path.exists(mf):          # hardware MFMA utilisation of the conv kernels of the DCGAN step itself
+        busy, gui = agg(mf, 'SQ_VALU_MFMA_BUSY_CYCLES'), agg(mf, 'GRBM_GUI_ACTIVE')
+        util = {'_how': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over `bench.py --steps 4 '
+                        '--warmup 8` (tile choices replayed from IPRGAN_TUNE_CACHE); mfma_util_pct = SQ_VALU_MFMA_BUSY_CYCLES '
+                        '/ (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) * 100, summed over all launches of a kernel name; '
+                        '"all_conv" weighs every gconv / wgrad launch of the step by its cycles.', 'kernels': {}}
+        tb = tg = 0.0
+        for k in sorted(busy):
+            if 'gconv' not in k and 'wgrad_kernel' not in k:
+                continue
+            b, g = busy[k][1], gui[k][1]
+            tb += b
+            tg += g
+            util['kernels'][k] = {'launches_sampled': busy[k][0], 'mfma_util_pct': round(b / (g / 8 * 1024) * 100, 1)}
+        util['all_conv'] = {'mfma_util_pct': round(tb / (tg / 8 * 1024) * 100, 1)}
+        json.dump(util, open(f'{out}_mfma_util.json', 'w'), indent=1)
+        print('wrote', f'{out}_mfma_util.json', util['all_conv'])
 
 
 if __name__ == '__main__':
