@@ -146,7 +146,8 @@ def test_conv_sn_scale(dev):
     close(from_nhwc(y.cpu(), 64), F.conv2d(x, w / sigma, padding=1), what='sn-scaled conv')
 
 
-@pytest.mark.parametrize('M,C,act', [(2 * 16 * 16, 64, 'relu'), (777, 128, 'lrelu'), (5000, 256, 'none'), (3, 64, 'relu')])
+@pytest.mark.parametrize('M,C,act', [(2 * 16 * 16, 64, 'relu'), (777, 128, 'lrelu'), (5000, 256, 'none'), (3, 64, 'relu'),
+                                     (1234, 96, 'relu'), (300, 20, 'lrelu'), (4097, 512, 'none')])   # C4n not dividing 256: generic apply path
 def test_batchnorm(dev, M, C, act):
     from iprgan import ops
     x = rnd(M, C, seed=1) * 2 + 0.5
