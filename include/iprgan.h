@@ -171,7 +171,9 @@ enum { IPRGAN_LOSS_HINGE_REAL = 0,   /* mean(relu(1-x)) */
        /* VAE terms (models/vae.py:36-48), used with iprgan_loss_sum_* (sum * scale, scale = 1/batch): */
        IPRGAN_LOSS_BCE_PM1 = 9,      /* F.binary_cross_entropy((x+1)/2, (y+1)/2): logs clamped at -100 like ATen */
        IPRGAN_LOSS_KL_MEAN = 10,     /* x^2 / 2                      (x = mean)   */
-       IPRGAN_LOSS_KL_LOGVAR = 11 }; /* (exp(x) - 1 - x) / 2         (x = logvar) */
+       IPRGAN_LOSS_KL_LOGVAR = 11,   /* (exp(x) - 1 - x) / 2         (x = logvar) */
+       IPRGAN_LOSS_MSE_DENORM = 12,  /* tools/loss.py:15-18 normalized=True: MSE of ((x+1)/2, (y+1)/2) */
+       IPRGAN_LOSS_L1_DENORM = 13 }; /*                                    : L1  of ((x+1)/2, (y+1)/2) */
 size_t iprgan_loss_ws_floats(size_t n);
 int iprgan_loss_fwd(int kind, const float* x, const float* y, float* loss, float* ws, size_t n,
                     void* stream);

@@ -130,6 +130,9 @@ __device__ __forceinline__ float loss_term(int kind, float x, float y) {
     }
     case IPRGAN_LOSS_KL_MEAN: return x * x / 2.f;
     case IPRGAN_LOSS_KL_LOGVAR: return (expf(x) - 1.f - x) / 2.f;
+    // tools/loss.py:15-18 with normalized=True: both arguments go through (v + 1) / 2 first, rounded as there
+    case IPRGAN_LOSS_MSE_DENORM: { const float d = (x + 1.f) / 2.f - (y + 1.f) / 2.f; return d * d; }
+    case IPRGAN_LOSS_L1_DENORM: return fabsf((x + 1.f) / 2.f - (y + 1.f) / 2.f);
     default: return fabsf(x - y);
   }
 }
@@ -149,6 +152,11 @@ __device__ __forceinline__ float loss_grad(int kind, float x, float y) {
     }
     case IPRGAN_LOSS_KL_MEAN: return x;
     case IPRGAN_LOSS_KL_LOGVAR: return (expf(x) - 1.f) / 2.f;
+    case IPRGAN_LOSS_MSE_DENORM: return (x + 1.f) / 2.f - (y + 1.f) / 2.f;          // 2 d * dp/dx, dp/dx = 1/2
+    case IPRGAN_LOSS_L1_DENORM: {
+      const float d = (x + 1.f) / 2.f - (y + 1.f) / 2.f;
+      return d > 0.f ? 0.5f : (d < 0.f ? -0.5f : 0.f);
+    }
     default: { const float d = x - y; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
   }
 }
@@ -585,13 +593,14 @@ int iprgan_reflect_fold(const float* dxp, float* dx, const float* prev_out, int 
 }
 
 static bool loss_needs_y(int kind) {
-  return kind == IPRGAN_LOSS_MSE || kind == IPRGAN_LOSS_L1 || kind == IPRGAN_LOSS_BCE_PM1;
+  return kind == IPRGAN_LOSS_MSE || kind == IPRGAN_LOSS_L1 || kind == IPRGAN_LOSS_BCE_PM1 ||
+         kind == IPRGAN_LOSS_MSE_DENORM || kind == IPRGAN_LOSS_L1_DENORM;
 }
 size_t iprgan_loss_ws_floats(size_t n) { (void)n; return LOSS_BLOCKS; }
 int iprgan_loss_sum_fwd(int kind, const float* x, const float* y, float* loss, float* ws, size_t n,
                         float scale, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  IPR_CHECK(kind >= 0 && kind <= IPRGAN_LOSS_KL_LOGVAR, "loss_fwd: bad kind %d", kind);
+  IPR_CHECK(kind >= 0 && kind <= IPRGAN_LOSS_L1_DENORM, "loss_fwd: bad kind %d", kind);
   IPR_CHECK(n > 0, "loss_fwd: empty input");
   IPR_CHECK(!loss_needs_y(kind) || y, "loss_fwd: kind %d needs a second input", kind);
   const int nb = grid_for(n, LOSS_BLOCKS);
@@ -603,7 +612,7 @@ int iprgan_loss_sum_fwd(int kind, const float* x, const float* y, float* loss, f
 }
 int iprgan_loss_sum_bwd(int kind, const float* x, const float* y, const float* gscale, float* dx, size_t n,
                         float scale, void* stream) {
-  IPR_CHECK(kind >= 0 && kind <= IPRGAN_LOSS_KL_LOGVAR, "loss_bwd: bad kind %d", kind);
+  IPR_CHECK(kind >= 0 && kind <= IPRGAN_LOSS_L1_DENORM, "loss_bwd: bad kind %d", kind);
   IPR_CHECK(!loss_needs_y(kind) || y, "loss_bwd: kind %d needs a second input", kind);
   if (!n) return 0;
   hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, kind, x, y,

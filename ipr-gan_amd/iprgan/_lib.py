@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get('IPRGAN_LIB', os.path.join(_HERE, 'libiprgan_hip.so'))
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID_PM1 = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 (LOSS_HINGE_REAL, LOSS_HINGE_FAKE, LOSS_NEG_MEAN, LOSS_BCE_ONES, LOSS_BCE_ZEROS,
- LOSS_MSE_ONES, LOSS_MSE_ZEROS, LOSS_MSE, LOSS_L1, LOSS_BCE_PM1, LOSS_KL_MEAN, LOSS_KL_LOGVAR) = range(12)
+ LOSS_MSE_ONES, LOSS_MSE_ZEROS, LOSS_MSE, LOSS_L1, LOSS_BCE_PM1, LOSS_KL_MEAN, LOSS_KL_LOGVAR,
+ LOSS_MSE_DENORM, LOSS_L1_DENORM) = range(14)
 
 
 class ConvDesc(C.Structure):

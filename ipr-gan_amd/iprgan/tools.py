@@ -129,17 +129,17 @@ def loss_value(kind, x, y=None):
 
 
 class Loss(object):
-    """tools/loss.py:10-20: optional (x+1)/2 de-normalisation of both arguments, then fn."""
+    """tools/loss.py:10-20: optional (x+1)/2 de-normalisation of both arguments, then the mean-reduced fn.  The
+    de-normalisation runs inside the loss kernel (IPRGAN_LOSS_*_DENORM) with the reference's own rounding."""
 
     def __init__(self, kind, normalized=False):
         self.kind, self.denorm = kind, normalized
 
     def __call__(self, x, y):
-        v = loss_value(self.kind, x, y)
+        kind = self.kind
         if self.denorm:
-            # L1 scales by 1/2 and MSE by 1/4 under x -> (x+1)/2 on both arguments
-            v = v * (0.5 if self.kind == L.LOSS_L1 else 0.25)
-        return v
+            kind = {L.LOSS_L1: L.LOSS_L1_DENORM, L.LOSS_MSE: L.LOSS_MSE_DENORM}[kind]
+        return loss_value(kind, x, y)
 
 
 def l1(normalized=False):

@@ -71,11 +71,16 @@ DCGAN_CFG = {'G': 'ConvGenerator64', 'D': 'SNDiscriminator64', 'opt': 'Adam',
 WBOX_CFG = {'gamma_0': 0.1, 'string': 'EXAMPLE A', 'target': 'G'}
 
 
-def run_dcgan_steps(make_cfg, models, device, n_steps=3, batch=4, seed=21, wbox=True):
+# BASELINE config 5: the 128x128 DCGAN.  The reference has no factory for it ("construct
+# ConvGenerator(mg=16) / SNDiscriminator(md=16)"); every side registers these two names over its own classes.
+DCGAN128_CFG = dict(DCGAN_CFG, G='ConvGenerator128', D='SNDiscriminator128')
+
+
+def run_dcgan_steps(make_cfg, models, device, n_steps=3, batch=4, seed=21, wbox=True, cfg=None, size=64):
     """n G+D steps in the order of experiments/image_generation.py:86-101 (update_d on
     {real_sample, latent}, then update_g on {fake_sample: model.fake_sample}) with the
     white-box wrapper (configure_protection, image_generation.py:75-84)."""
-    model = models.DCGAN(make_cfg(DCGAN_CFG), device=device)
+    model = models.DCGAN(make_cfg(cfg or DCGAN_CFG), device=device)
     recipe.fill(model.G.module, seed)
     recipe.fill(model.D.module, seed + 1)
     model.G.to(device[0])
@@ -84,7 +89,7 @@ def run_dcgan_steps(make_cfg, models, device, n_steps=3, batch=4, seed=21, wbox=
         model = models.WhiteBoxWrapper(model, make_cfg(WBOX_CFG))
     res = {}
     for s in range(n_steps):
-        x = torch.tanh(recipe.tensor(seed, 2000 + s, (batch, 3, 64, 64)))
+        x = torch.tanh(recipe.tensor(seed, 2000 + s, (batch, 3, size, size)))
         z = recipe.tensor(seed, 3000 + s, (batch, 128))
         model.update_d({'real_sample': x, 'latent': z})
         model.update_g({'fake_sample': model.fake_sample})
@@ -309,10 +314,10 @@ CYCLEGAN_CFG = {'G': 'Resnet6Blocks', 'D': 'ConvDiscriminator', 'opt': 'Adam',
                 'lambda_A': 10.0, 'lambda_B': 10.0, 'lambda_idt': 0.5, 'epoch': 200}
 
 
-def run_cyclegan_steps(make_cfg, models, device, n_steps=2, batch=1, size=64, seed=51, bbox=None):
+def run_cyclegan_steps(make_cfg, models, device, n_steps=2, batch=1, size=64, seed=51, bbox=None, G=None):
     """G step then D step per iteration (experiments/image_translation.py:90-112), white-box on GB
     (black-box inside it when ``bbox`` is given, configs/CycleGAN/complete)."""
-    model = models.CycleGAN(make_cfg(CYCLEGAN_CFG), device=device)
+    model = models.CycleGAN(make_cfg(dict(CYCLEGAN_CFG, G=G) if G else CYCLEGAN_CFG), device=device)
     for i, n in enumerate((model.GA, model.GB, model.DA, model.DB)):
         recipe.fill(n.module, seed + i)
         n.to(device[0])
@@ -338,3 +343,72 @@ def run_cyclegan_steps(make_cfg, models, device, n_steps=2, batch=1, size=64, se
     res['final/poolA/images'] = model.state_dict()['poolA']['images'].detach().cpu().numpy()
     res['final/ber'] = np.float64(float(model.loss_model.compute_ber(model.GB)))
     return res
+
+
+def run_cyclegan_pool_steps(make_cfg, models, device, n_steps=4, batch=4, size=64, seed=53):
+    """CycleGAN at batch 4 with a SMALL history pool and a SHORT schedule so that four steps reach what the
+    two-step fixture never does: ImagePool's swap branch once ``counts >= pool_size`` (models/util.py:27-34; the
+    swap decisions are torch.rand / torch.randperm draws on the CPU generator, seeded per step here) and the
+    linear learning-rate decay of ``update_lr()`` (models/cyclegan.py:50-56,145-147: epoch 4 -> factor 1, 1, 1,
+    0.5).  At batch 4 the step-0 Adam moments are no longer dominated by single-pixel sign flips and are
+    compared tightly."""
+    cfg = dict(CYCLEGAN_CFG, pool_size=6, epoch=4)
+    model = models.CycleGAN(make_cfg(cfg), device=device)
+    for i, n in enumerate((model.GA, model.GB, model.DA, model.DB)):
+        recipe.fill(n.module, seed + i)
+        n.to(device[0])
+    wcfg = dict(WBOX_CFG)
+    wcfg['target'] = 'GB'
+    model = models.WhiteBoxWrapper(model, make_cfg(wcfg))
+    res = {}
+    for s in range(n_steps):
+        a = torch.tanh(recipe.tensor(seed, 200 + s, (batch, 3, size, size)))
+        b = torch.tanh(recipe.tensor(seed, 300 + s, (batch, 3, size, size)))
+        model.update_g({'real_A': a, 'real_B': b})
+        torch.manual_seed(900 + s)                   # ImagePool draws from the CPU generator
+        model.update_d({'real_A': model.real_A, 'real_B': model.real_B,
+                        'fake_A': model.fake_A.detach(), 'fake_B': model.fake_B.detach()})
+        for k, v in model.get_metrics().items():
+            res[f'step{s}/metric/{k}'] = np.float64(v)
+        res[f'step{s}/pool_counts'] = np.float64(float(model.state_dict()['poolA']['counts']))
+        if s == 0:
+            res['step0/fake_B'] = model.fake_B.detach().cpu().numpy()
+            _capture(model, res, 'step0', ('GA', 'GB', 'DA', 'DB'), ('optG', 'optD'))
+        model.update_lr()                            # once per epoch in image_translation.py; per step here
+    _capture(model, res, 'final', ('GA', 'GB', 'DA', 'DB'), (), moments=False)
+    sd = model.state_dict()
+    res['final/poolA/images'] = sd['poolA']['images'].detach().cpu().numpy()
+    res['final/poolB/images'] = sd['poolB']['images'].detach().cpu().numpy()
+    res['final/lr'] = np.float64(model.optG.param_groups[0]['lr'])
+    res['final/ber'] = np.float64(float(model.loss_model.compute_ber(model.GB)))
+    return res
+
+
+def vgg_layer_names_from_source(path):
+    """The ``layer_name`` list literal of the reference's networks/vgg.py:6-28, read with ``ast`` (the file cannot be
+    imported: torchvision is absent).  Only the list of names - data - is returned and stored as a fixture."""
+    import ast
+    tree = ast.parse(open(path).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and any(getattr(t, 'id', None) == 'layer_name' for t in node.targets):
+            return [ast.literal_eval(e) for e in node.value.elts]
+    raise RuntimeError('layer_name not found')
+
+
+def vgg_layer_names(net_cls):
+    """Names of an implementation's VGG19 feature stack in the reference's scheme (conv{b}_{i} / relu{b}_{i} /
+    pool{b}), derived from the MODULE TYPES of the full 'pool5' stack it builds."""
+    names, blk, idx = [], 1, 1
+    for m in net_cls(layer='pool5').net:
+        if isinstance(m, torch.nn.Conv2d):
+            assert m.kernel_size == (3, 3) and m.padding == (1, 1) and m.stride == (1, 1)
+            names.append(f'conv{blk}_{idx}')
+        elif isinstance(m, torch.nn.ReLU):
+            names.append(f'relu{blk}_{idx}')
+            idx += 1
+        elif isinstance(m, torch.nn.MaxPool2d):
+            names.append(f'pool{blk}')
+            blk, idx = blk + 1, 1
+        else:
+            raise AssertionError(f'unexpected module {m}')
+    return names

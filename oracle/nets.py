@@ -50,6 +50,10 @@ def ConvGenerator64():
     return ConvGenerator(mg=8)
 
 
+def ConvGenerator128():                         # not a reference factory: BASELINE config 5
+    return ConvGenerator(mg=16)
+
+
 # --------------------------------------------------------------------------
 # DCGAN spectral-norm discriminator (reference networks/sn_discriminator.py:4-38)
 # --------------------------------------------------------------------------
@@ -85,6 +89,10 @@ def SNDiscriminator32():
 
 def SNDiscriminator64():
     return SNDiscriminator(md=8)
+
+
+def SNDiscriminator128():                       # not a reference factory: BASELINE config 5
+    return SNDiscriminator(md=16)
 
 
 # --------------------------------------------------------------------------

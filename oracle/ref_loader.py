@@ -40,6 +40,10 @@ def load():
         for k, v in vars(mod).items():
             if not k.startswith('__'):
                 setattr(networks, k, v)
+    # BASELINE config 5 (128x128 DCGAN): the reference has the classes but no factory names; models.DCGAN looks
+    # networks up by name (models/dcgan.py:10-11), so the two names are registered over the reference's OWN classes
+    networks.ConvGenerator128 = lambda: networks.ConvGenerator(mg=16)
+    networks.SNDiscriminator128 = lambda: networks.SNDiscriminator(md=16)
     # networks/vgg.py needs torchvision (absent): the architecture is restated in oracle/nets.py and
     # injected under the reference's name so that the REAL models.SRGAN can be constructed.
     from . import nets as _oracle_nets

@@ -364,3 +364,130 @@ def test_dcgan_bf16_math_vs_reference_golden(golden, dev):
     for k in ref.files:
         if k.startswith('final/sign/'):
             assert np.array_equal(res[k], ref[k]), k
+
+
+# ---- round 2: the configs and branches the first round's fixtures did not reach -------------------------------
+
+def test_dcgan128_steps_vs_reference_golden(golden, dev):
+    """BASELINE config 5's networks (128x128, ConvGenerator(mg=16) / SNDiscriminator(md=16)) for two full G+D steps at
+    batch 8 in fp32 against the REAL reference's run (tests/golden/dcgan128_steps_wbox.npz)."""
+    from iprgan import Config, models
+    res = cases.run_dcgan_steps(Config, models, [dev], n_steps=2, batch=8, seed=91, cfg=cases.DCGAN128_CFG, size=128)
+    compare(res, golden('dcgan128_steps_wbox'), policy=step_policy(2))
+
+
+def test_dcgan128_bf16_steps_vs_reference_golden(golden, dev):
+    """The same two 128x128 steps with IPRGAN_MATH_BF16 (bf16 MFMA tiles, fp32 accumulation / master weights / norms /
+    Adam).  Tolerance as for the 64x64 bf16 test: operand rounding is 2^-9 relative per element, so the O(1) losses
+    must agree with the fp32 reference to 3e-2 absolute, the generated images to 3 % in L2, the first Adam moments of
+    every parameter (= the gradients) to 5 % in overall magnitude; sign buffers and the BER exactly."""
+    from iprgan import Config, _lib, models
+    ref = golden('dcgan128_steps_wbox')
+    try:
+        _lib.set_math('bf16')
+        res = cases.run_dcgan_steps(Config, models, [dev], n_steps=2, batch=8, seed=91, cfg=cases.DCGAN128_CFG, size=128)
+    finally:
+        _lib.set_math('fp32')
+    for k in ref.files:
+        if '/metric/' in k:
+            assert abs(float(res[k]) - float(ref[k])) < 3e-2, (k, float(res[k]), float(ref[k]))
+        if k.startswith('step0/opt') and k.endswith('::asum'):
+            a, b = float(res[k]), float(ref[k])
+            assert abs(a - b) <= 5e-2 * abs(b) + 1e-6, (k, a, b)
+    a, b = res['step0/fake_sample'].astype(np.float64), ref['step0/fake_sample'].astype(np.float64)
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 3e-2
+    assert float(res['final/ber']) == 0.0
+    for k in ref.files:
+        if k.startswith('final/sign/'):
+            assert np.array_equal(res[k], ref[k]), k
+
+
+def test_cyclegan_pool_swap_and_lr_decay_vs_reference_golden(golden, dev):
+    """Batch 4, pool of 6, 4-epoch schedule: ImagePool's swap branch (seeded CPU draws, models/util.py:27-34) and
+    update_lr() (models/cyclegan.py:145-147) against the real reference; at batch 4 the step-0 Adam moments of all
+    four networks are compared tightly (1e-3 rel + 2e-2 of the tensor's scale per element) instead of by magnitude."""
+    from iprgan import Config, models
+    ref = golden('cyclegan_pool_steps')
+    res = cases.run_cyclegan_pool_steps(Config, models, [dev])
+    assert [float(res[f'step{s}/pool_counts']) for s in range(4)] == [4.0, 8.0, 8.0, 8.0]
+    assert [float(res[f'step{s}/metric/LR']) for s in range(4)] == [2e-4, 2e-4, 2e-4, 1e-4]
+    base = step_policy(4)
+
+    def policy(k):
+        if k.startswith(('step0/optD', 'step0/optG')):
+            return (2e-2, 1e-5)
+        if k.startswith('final/pool'):
+            return (2e-2, 2e-2)
+        return base(k)
+    compare(res, ref, policy=policy)
+
+
+@pytest.mark.parametrize('normalized', [False, True])
+@pytest.mark.parametrize('name', ['l1', 'mse'])
+def test_loss_factories_vs_oracle(name, normalized, dev):
+    """tools.l1 / tools.mse (tools/loss.py:10-20,72-76): value and gradient against the restated Loss class, with and
+    without the (x+1)/2 de-normalisation of both arguments."""
+    from iprgan import tools
+    from oracle import bbox
+    x = torch.tanh(recipe.tensor(5, 1, (3, 3, 20, 24)))
+    y = torch.tanh(recipe.tensor(5, 2, (3, 3, 20, 24)))
+    y[0, 0, :2] = x[0, 0, :2]                       # exact ties: sign(0) = 0 in the L1 gradient
+    xa = x.clone().requires_grad_()
+    xb = x.clone().to(dev).requires_grad_()
+    la = getattr(bbox, name)(normalized=normalized)(xa, y)
+    lb = getattr(tools, name)(normalized=normalized)(xb, y.to(dev))
+    np.testing.assert_allclose(float(lb), float(la), rtol=2e-6)
+    la.backward(); lb.backward()
+    np.testing.assert_allclose(xb.grad.cpu().numpy(), xa.grad.numpy(), rtol=1e-6, atol=1e-10)
+
+
+def _bitwise_equal_runs(fn):
+    runs = [fn() for _ in range(2)]
+    for k in runs[0]:
+        a, b = np.asarray(runs[0][k]), np.asarray(runs[1][k])
+        assert np.array_equal(a, b), f'{k} differs between two identical runs'
+    for k, v in runs[0].items():
+        if np.asarray(v).dtype.kind == 'f':
+            assert np.all(np.isfinite(v)), k
+    return runs[0]
+
+
+def test_srgan_full_size_step_is_deterministic_and_keeps_watermark(dev):
+    """BASELINE config 3 at its full size (SRResNet 24->96, Discriminator96, VGG19 features, batch 64): one
+    pre-training step and one GAN-phase G+D step twice from the same seeds agree bit for bit (fixed-order reductions,
+    per-process tile choices), everything stays finite and the embedded signature survives (BER 0)."""
+    from iprgan import Config, models
+    r = _bitwise_equal_runs(lambda: cases.run_srgan_steps(Config, models, [dev], batch=64))
+    assert r['final/ber'] == 0.0
+    assert r['step1/metric/P/SignLoss'] >= 0.0 and r['step1/metric/G/Con'] > 0.0
+
+
+def test_cyclegan_full_size_step_is_deterministic_and_keeps_watermark(dev):
+    """BASELINE config 4 at its full per-GPU size (Resnet9Blocks + ConvDiscriminator, 256x256, batch 8): this is the
+    only test that runs nine residual blocks and the PatchGAN's odd 31x31 / 30x30 maps.  Same properties as above,
+    plus the PatchGAN logit map shape."""
+    from iprgan import Config, models, networks
+    r = _bitwise_equal_runs(lambda: cases.run_cyclegan_steps(Config, models, [dev], n_steps=1, batch=8, size=256,
+                                                             G='Resnet9Blocks'))
+    assert r['final/ber'] == 0.0 and r['step0/fake_B'].shape == (8, 3, 256, 256)
+    d = networks.ConvDiscriminator().to(dev)
+    with torch.no_grad():
+        assert tuple(d(torch.zeros(2, 3, 256, 256, device=dev)).shape) == (2, 1, 30, 30)
+
+
+@pytest.mark.parametrize('hw', [64, 256])
+def test_patchgan_odd_maps_vs_oracle(hw, dev):
+    """ConvDiscriminator on a 256x256 input runs k4 s1 p1 convolutions on 32 -> 31 -> 30 pixel maps (odd sizes: ragged
+    MFMA tiles, the InstanceNorm over 31x31 planes); forward and parameter gradients against the live oracle."""
+    from iprgan import networks
+    a, b = nets.ConvDiscriminator(), networks.ConvDiscriminator()
+    recipe.fill(a, 23); recipe.fill(b, 23)
+    b.to(dev); a.train(); b.train()
+    x = torch.tanh(recipe.tensor(23, 1, (2, 3, hw, hw)))
+    ya, yb = a(x), b(x.to(dev))
+    np.testing.assert_allclose(yb.detach().cpu().numpy(), ya.detach().numpy(), rtol=RTOL, atol=ATOL)
+    g = recipe.tensor(23, 2, tuple(ya.shape))
+    ya.backward(g); yb.backward(g.to(dev))
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        ga, gb = pa.grad.double(), pb.grad.cpu().double()
+        assert float((ga - gb).norm()) <= 2e-3 * float(ga.norm()) + 1e-5, k

@@ -521,3 +521,49 @@ def test_conv_bf16_math_mode(dev, shape):
             close(dw, wr.grad, tol, f'bf16 wgrad exact={exact}')
     finally:
         _lib.set_math('fp32')
+
+
+NORTH_STAR = [
+    # SURVEY 8d "conv microbench (north-star)": the 3x3 convs Resnet9Blocks runs on a 64x3x256x256 batch
+    # cin, cout, stride, pad_mode, H
+    (64, 128, 2, 0, 256),
+    (128, 256, 2, 0, 128),
+    (256, 256, 1, 1, 64),          # the headline shape: reflect-padded 256->256 on (64,256,64,64)
+]
+
+
+@pytest.mark.parametrize('cfg', NORTH_STAR, ids=lambda c: '-'.join(map(str, c)))
+def test_north_star_conv_shapes_full_size(dev, cfg):
+    """Forward, backward-data and backward-weight at the FULL north-star sizes (batch 64) against torch CPU.  Forward
+    and backward-data are per-image, so three images of the batch are checked against the CPU (first, middle, last:
+    tile edges at both ends of the M range); backward-weight reduces over all 64 images and is checked in full."""
+    from iprgan import ops
+    cin, cout, s, pm, H = cfg
+    B, k, p = 64, 3, 1
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (cin * k * k) ** -0.5
+    spec = ops.ConvSpec(cin, cout, k, s, p, pad_mode=pm)
+    d = spec.desc(B, H, H)
+    OH, OW = spec.out_hw(H, H)
+    gy = torch.randn(B, cout, OH, OW, generator=g)
+
+    def ref_fwd(xx):
+        return F.conv2d(F.pad(xx, (p, p, p, p), mode='reflect'), w, None, stride=s) if pm else F.conv2d(xx, w, None, stride=s, padding=p)
+
+    xd, gd = to_nhwc(x).to(dev), to_nhwc(gy).to(dev)
+    wf, wb = ops.conv_prep(spec, d, w.to(dev), None, True, True)
+    y = ops.conv_fwd(spec, d, xd, wf, None)
+    dx = ops.conv_bwd_data(spec, d, gd, wb)
+    dw, _ = ops.conv_bwd_weight(spec, d, xd, gd, w.shape, False)
+    sel = [0, B // 2, B - 1]
+    xs = x[sel].clone().requires_grad_()
+    ys = ref_fwd(xs)
+    ys.backward(gy[sel])
+    close(from_nhwc(y[sel].cpu(), cout), ys, what='fwd')
+    close(from_nhwc(dx[sel].cpu(), cin), xs.grad, what='dgrad')
+    # full backward-weight on the CPU: 2*B*OH*OW*cout*cin*9 FLOP (154-309 GFLOP), seconds on the host cores
+    wr = w.clone().requires_grad_()
+    xin = F.pad(x, (p, p, p, p), mode='reflect') if pm else x
+    dwr = torch.nn.grad.conv2d_weight(xin, w.shape, gy, stride=s, padding=0 if pm else p)
+    close(dw, dwr, what='wgrad')

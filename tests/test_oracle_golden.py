@@ -93,6 +93,35 @@ def test_cyclegan_steps_match_reference(golden):
     compare(cases.run_cyclegan_steps(gan.Cfg, gan, gan.CPU), golden('cyclegan_steps_wbox'), rtol=5e-4, atol=5e-5)
 
 
+def test_dcgan128_steps_match_reference(golden):
+    """BASELINE config 5's networks (ConvGenerator(mg=16) / SNDiscriminator(md=16), 128x128) for two G+D steps at
+    batch 8 against the real reference's run."""
+    torch.manual_seed(0)
+    res = cases.run_dcgan_steps(gan.Cfg, gan, gan.CPU, n_steps=2, batch=8, seed=91, cfg=cases.DCGAN128_CFG, size=128)
+    compare(res, golden('dcgan128_steps_wbox'), rtol=5e-4, atol=5e-5)
+
+
+def test_cyclegan_pool_and_lr_schedule_match_reference(golden):
+    """Batch 4, pool of 6, schedule of 4 epochs: the ImagePool swap branch (models/util.py:27-34) and the LambdaLR decay
+    (models/cyclegan.py:50-56,145-147) both run; the fixture's own metrics prove it."""
+    ref = golden('cyclegan_pool_steps')
+    assert [float(ref[f'step{s}/pool_counts']) for s in range(4)] == [4.0, 8.0, 8.0, 8.0]
+    assert [float(ref[f'step{s}/metric/LR']) for s in range(4)] == [2e-4, 2e-4, 2e-4, 1e-4]
+    compare(cases.run_cyclegan_pool_steps(gan.Cfg, gan, gan.CPU), ref, rtol=5e-4, atol=5e-5)
+
+
+def test_vgg_layer_order_matches_reference_name_list(golden):
+    """torchvision is absent, so VGG19[:36] is restated from the cfg-E channel list; its conv/relu/pool ORDER is pinned
+    to the reference's own ``layer_name`` list (networks/vgg.py:6-28, read with ast by oracle/gen_golden.py) - for the
+    oracle and for the product's module tree - and the default cut 'relu5_4' keeps the first 36 modules."""
+    names = [str(n) for n in golden('vgg_layer_names')['names']]
+    assert len(names) == 37 and names.index('relu5_4') + 1 == 36
+    assert cases.vgg_layer_names(nets.VGG19Feature) == names
+    from iprgan import networks
+    assert cases.vgg_layer_names(networks.VGG19Feature) == names
+    assert len(nets.VGG19Feature().net) == len(networks.VGG19Feature().net) == 36
+
+
 def test_vae_steps_match_reference(golden):
     """Encoder32 / Decoder32 / models.VAE: KL + BCE, one Adam with weight decay over both
     nets, sign loss on the decoder's BatchNorm; eps of the reparameterisation replayed from the CPU generator."""
