@@ -415,9 +415,16 @@ def test_cyclegan_pool_swap_and_lr_decay_vs_reference_golden(golden, dev):
 
     def policy(k):
         if k.startswith(('step0/optD', 'step0/optG')):
-            return (2e-2, 1e-5)
+            # element-wise: 2 % relative + 2 % of the tensor's largest sampled entry.  Measured against the live
+            # oracle on the full tensors: D moments agree to 6e-6 except where ONE LeakyReLU input of the norm-free
+            # first conv rounds to the other side of zero (one output channel of DA.conv0 moves by 0.4 % of the
+            # tensor's scale); G moments to 3-5e-3 in L2 (sign() gradient of the L1 cycle terms).  The biases of convs
+            # feeding a norm layer have a zero true gradient (1e-9 noise on both sides, under the 1e-6 floor).
+            return (2e-2, 2e-2, 'relmax')
         if k.startswith('final/pool'):
-            return (2e-2, 2e-2)
+            # images generated after up to three Adam steps (+-lr moves on noise-level gradients, see step_policy):
+            # a wrongly swapped pool slot differs by O(1), rounding drift stays below 5e-2
+            return (5e-2, 5e-2)
         return base(k)
     compare(res, ref, policy=policy)
 
@@ -490,4 +497,6 @@ def test_patchgan_odd_maps_vs_oracle(hw, dev):
     ya.backward(g); yb.backward(g.to(dev))
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         ga, gb = pa.grad.double(), pb.grad.cpu().double()
-        assert float((ga - gb).norm()) <= 2e-3 * float(ga.norm()) + 1e-5, k
+        # the bias of a conv that feeds an InstanceNorm has an exactly-zero gradient: both sides hold summation noise
+        slack = 1e-3 if (k.endswith('.bias') and k not in ('0.bias', '11.bias')) else 1e-5
+        assert float((ga - gb).norm()) <= 2e-3 * float(ga.norm()) + slack, k

@@ -32,9 +32,18 @@ def compare(res, ref, rtol=RTOL, atol=ATOL, policy=None):
                                        err_msg=k)
     for p in sorted(summ):
         pol = tol(p)
-        if len(pol) == 3:          # (rtol, atol, 'scale'): only the overall magnitude is comparable
+        if len(pol) == 3 and pol[2] == 'scale':          # (rtol, atol, 'scale'): only the overall magnitude is comparable
             a, b = float(res[f'{p}::asum']), float(ref[f'{p}::asum'])
             assert abs(a - b) <= pol[0] * abs(b) + pol[1], f'{p}::asum {a} vs {b}'
+            continue
+        if len(pol) == 3 and pol[2] == 'relmax':      # (rtol, frac, 'relmax'): absolute slack = frac * max|sample|
+            r, frac = pol[0], pol[1]
+            for f in ('head', 'samp'):
+                a, b = np.asarray(res[f'{p}::{f}']), ref[f'{p}::{f}']
+                np.testing.assert_allclose(a, b, rtol=r, atol=frac * float(np.abs(ref[f'{p}::samp']).max()) + 1e-6,
+                                           err_msg=f'{p}::{f}')
+            a, b = float(res[f'{p}::asum']), float(ref[f'{p}::asum'])
+            assert abs(a - b) <= (r + frac) * abs(b) + 1e-6 * max(1.0, abs(b) / max(1e-30, float(np.abs(ref[f'{p}::samp']).mean()))), f'{p}::asum {a} vs {b}'
             continue
         r, t = pol
         n_est = max(1.0, float(ref[f'{p}::asum']) / max(1e-12, float(np.abs(ref[f'{p}::samp']).mean())))
