@@ -206,6 +206,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        from iprgan import parallel
+        parallel.RcclTransport.destroy()
         dist.destroy_process_group()
 
 

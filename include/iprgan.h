@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 100
+#define IPRGAN_VERSION 200
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -49,7 +49,8 @@ int iprgan_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W
 int iprgan_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, void* stream);
 /* dst[b][a][k] = src[a][b][k] (NCHW-flatten <-> NHWC-flatten order of Linear weights,
  * networks/conv_generator.py:26 and sn_discriminator.py:32) */
-int iprgan_permute_021(const float* src, float* dst, int A, int Bd, int K, void* stream);
+/* beta: 0 overwrites dst, 1 accumulates (dst = beta*dst + permuted src) - see "gradient accumulation" below */
+int iprgan_permute_021(const float* src, float* dst, int A, int Bd, int K, float beta, void* stream);
 
 /* ---- convolution (replaces aten::conv2d / conv_transpose2d + their backward;
  *      networks/sn_discriminator.py:9-18, conv_generator.py:8,21, sr_resnet.py:22,
@@ -80,10 +81,12 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
 size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d);   /* reflect padding, or <= 4 input channels */
 int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
                          const float* prev_out, int prev_act, float prev_slope, void* stream);
-/* dw (PyTorch layout, overwritten) = conv_bwd_weight(x, dy); db (optional, length Cout) = sum dy.
- * ws: workspace of iprgan_conv_wgrad_ws_floats(d) floats. Deterministic (fixed-order split reduce). */
+/* dw (PyTorch layout) = beta*dw + conv_bwd_weight(x, dy); db (optional, length Cout) = beta*db + sum dy.
+ * beta = 0 overwrites; beta = 1 accumulates straight into a gradient bucket (what autograd's AccumulateGrad
+ * add plus DDP's bucket copy do in two extra passes).  ws: workspace of iprgan_conv_wgrad_ws_floats(d) floats.
+ * Deterministic (fixed-order split reduce). */
 int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const float* dy, float* dw,
-                           float* db, float* ws, void* stream);
+                           float* db, float* ws, float beta, void* stream);
 /* dz = dy * act'(out) elementwise (activation backward from the saved output), n floats. */
 int iprgan_act_bwd(const float* dy, const float* out, float* dz, size_t n, int act, float slope,
                    void* stream);
@@ -158,7 +161,7 @@ int iprgan_sn_bwd(const float* dwsn, const float* w, const float* u, const float
  * ws >= 64*16 floats. */
 int iprgan_sn_bwd_multi(const float* const* dwsn, const float* const* w, const float* const* u,
                         const float* const* v, const float* const* sigma, float* const* dw, float* ws,
-                        const int* rows, const int* cols, int n, void* stream);
+                        const int* rows, const int* cols, int n, float beta, void* stream);   /* dw = beta*dw + ... */
 
 /* ---- losses (models/dcgan.py:33-40, srgan.py:36-59, cyclegan.py:122-142) ------------------ */
 enum { IPRGAN_LOSS_HINGE_REAL = 0,   /* mean(relu(1-x)) */
@@ -211,10 +214,10 @@ int iprgan_ssim_bwd(const float* x, const float* y, const float* gmaps, const fl
  * loss = sum_l mean(relu(gamma0 - gamma_l*sign_l)).  Pointer tables are copied into the launch. */
 int iprgan_sign_loss_fwd(const float* const* gammas, const float* const* signs, const int* sizes,
                          int nlayer, float gamma0, float* loss, void* stream);
-/* dgamma_l = (*gscale) * (-sign/n_l) * [gamma0 - gamma*sign > 0]  (overwrites dgammas[l]) */
+/* dgamma_l = beta*dgamma_l + (*gscale) * (-sign/n_l) * [gamma0 - gamma*sign > 0] */
 int iprgan_sign_loss_bwd(const float* const* gammas, const float* const* signs,
                          float* const* dgammas, const int* sizes, int nlayer, float gamma0,
-                         const float* gscale, void* stream);
+                         const float* gscale, float beta, void* stream);
 /* counts[0] = #(sign(gamma) != sign_bit) (sign(0)=0 counts as an error), counts[1] = total bits;
  * int64 device output, bit-exact. */
 int iprgan_sign_ber(const float* const* gammas, const float* const* signs, const int* sizes,
@@ -222,10 +225,12 @@ int iprgan_sign_ber(const float* const* gammas, const float* const* signs, const
 
 /* ---- Adam (torch.optim.Adam.step at models/dcgan.py:69,78) --------------------------------- */
 /* multi-tensor: HOST arrays of n DEVICE pointers; step is the 1-based step count after increment.
- * Hyper-parameters are doubles: 1-beta and the bias corrections are formed in double like torch does. */
+ * Hyper-parameters are doubles: 1-beta and the bias corrections are formed in double like torch does.
+ * grad_scale multiplies every gradient as it is read: 1/world_size turns the all-reduced SUM of the data-parallel
+ * gradients into their mean without a separate pass over the buckets (1.0 on a single GPU: exact). */
 int iprgan_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const long long* sizes, int n, double lr, double beta1,
-                     double beta2, double eps, double weight_decay, int step, void* stream);
+                     double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
 
 /* ---- measurement (bench.py roofline): when enabled, every conv-family launch is bracketed by HIP
  * events on its own stream; collect() waits for them and accumulates per-kernel launch count, device
@@ -251,6 +256,29 @@ int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand);
 /* ---- misc elementwise ----------------------------------------------------------------------- */
 int iprgan_fill(float* p, float v, size_t n, void* stream);
 int iprgan_axpy(float* y, const float* x, float a, size_t n, void* stream);   /* y += a*x */
+/* y_t += a*x_t for n tensors in one launch (HOST arrays of DEVICE pointers / element counts): the small
+ * gradients of a pass (biases, norm scales, PReLU slopes) into their gradient-bucket views */
+int iprgan_axpy_multi(float* const* y, const float* const* x, const long long* sizes, int n, float a, void* stream);
+
+/* ---- data-parallel gradient exchange: RCCL all-reduce over xGMI ---------------
+ * Replaces torch.nn.DataParallel's per-forward replicate/scatter/gather (models/dcgan.py:16-17, srgan.py:17-19,
+ * cyclegan.py:19-23) by one in-place SUM per gradient bucket and optimizer step; one process per GPU.
+ *   rank 0:     iprgan_comm_unique_id(id)      (128 bytes, HOST memory; ship it to the other ranks out of band)
+ *   every rank: iprgan_comm_init(rank, nranks, id)   binds the CURRENT HIP device; collective, blocks until all joined
+ *   per bucket: iprgan_allreduce_bucket(buf, n, IPRGAN_DTYPE_F32, side_stream)   enqueued, returns at once; the
+ *               caller orders it against its compute stream with events (record after the bucket's last producer,
+ *               wait before the optimizer reads the bucket)
+ *   shutdown:   iprgan_comm_destroy()
+ * RCCL is bound at run time (the copy already loaded in the process, else ROCm's; IPRGAN_RCCL_LIB overrides).
+ * The communicator is the only process-global handle of this group. */
+#define IPRGAN_COMM_ID_BYTES 128
+enum { IPRGAN_DTYPE_F32 = 0, IPRGAN_DTYPE_BF16 = 1 };
+int iprgan_comm_unique_id(void* id128);
+int iprgan_comm_init(int rank, int nranks, const void* id128);
+int iprgan_allreduce_bucket(void* buf, size_t n, int dtype, void* stream);
+int iprgan_comm_nranks(void);          /* 0 when no communicator exists */
+int iprgan_comm_rank(void);            /* -1 when no communicator exists */
+int iprgan_comm_destroy(void);
 
 #ifdef __cplusplus
 }

@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            float* __restrict__ dw, int nsplit, int Nrows,
                                                            int Kw, int N, int C, int Qs, int ntap,
                                                            FastDiv d_qs, FastDiv d_row, long long sn,
-                                                           long long sc) {
+                                                           long long sc, float beta) {
   __shared__ f32x4 sh[16][16];
   const int qd = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int rowlen = ntap * Qs;                     // multiple of 4 (Qs is), rows are 16-byte aligned (Kw % 64 == 0)
@@ -837,7 +837,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int c = kk - tap * Qs;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (c + j < C) dw[n * sn + (c + j) * sc + tap] = t[j];
+      if (c + j < C) {
+        float* o = dw + n * sn + (c + j) * sc + tap;
+        *o = beta != 0.f ? beta * *o + t[j] : t[j];      // beta = 1: accumulate into a gradient bucket view
+      }
   }
 }
 
@@ -1489,13 +1492,16 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
   return iprgan_reflect_fold(ws, dx, prev_out, prev_act, prev_slope, d->B, d->H, d->W, c4(d->Cin), d->pad, stream);
 }
 
+static size_t wgrad_weight_floats(const iprgan_conv_desc* d) { return (size_t)d->Cout * d->Cin * d->KH * d->KW; }
 size_t iprgan_conv_wgrad_ws_floats(const iprgan_conv_desc* d) {
   const Shape s = out_shape(d);
-  return rup4(wgrad_slab_floats(d) + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout))) + wgrad_padded_floats(d);
+  // [slabs | bias partials] [reflect-padded copy of x] [scratch dw for the autotuner's trial launches]
+  return rup4(wgrad_slab_floats(d) + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout))) + rup4(wgrad_padded_floats(d)) +
+         wgrad_weight_floats(d);
 }
 
 int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const float* dy, float* dw,
-                           float* db, float* ws, void* stream) {
+                           float* db, float* ws, float beta, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const Shape s = out_shape(d);
   const WGeom g = wgrad_geom(d);
@@ -1508,7 +1514,10 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     IPR_LAUNCH_CHECK();
     xin = xp;
   }
-  auto run = [&](int cand) -> int {
+  // the autotuner's trial launches must not touch dw (with beta = 1 it holds other passes' gradients)
+  float* dw_trial = ws + rup4(wgrad_slab_floats(d) + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout))) +
+                    rup4(wgrad_padded_floats(d));
+  auto run_to = [&](int cand, float* dw_out, float beta_out) -> int {
     WGradPlan p;
     if (!wgrad_plan_c(d, cand, p)) return -1;
     WGradArgs a;
@@ -1551,12 +1560,13 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     // dw[row * sn + qchannel * sc + tap]: Conv2d [Cout][Cin][taps], ConvTranspose2d [Cin][Cout][taps];
     // swapped roles: rows are Cin and the Q channel is Cout of a Conv2d weight
     const long long sn = g.swap ? p.ntap : (long long)p.Cq * p.ntap, sc = g.swap ? (long long)p.N * p.ntap : p.ntap;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, ws, dw,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, ws, dw_out,
                        p.nsplit, p.Nrows, p.Kw, p.N, p.Cq, p.Qs, p.ntap, make_fastdiv(p.Qs),
-                       make_fastdiv(p.ntap * p.Qs), sn, sc);
+                       make_fastdiv(p.ntap * p.Qs), sn, sc, beta_out);
     IPR_LAUNCH_CHECK();
     return 0;
   };
+  auto run = [&](int cand) -> int { return run_to(cand, dw_trial, 0.f); };
   int cand = 0;
   {
     WGradPlan p0;
@@ -1587,13 +1597,13 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     }
   }
   {
-    const int rc = run(cand);
+    const int rc = run_to(cand, dw, beta);
     if (rc) return rc;
   }
   if (db) {
     const int Cs = c4(d->Cout), M = d->B * s.OH * s.OW;
     float* part = ws + wgrad_slab_floats(d);
-    const int rc2 = colsum_launch(dy, db, part, M, Cs, d->Cout, st);
+    const int rc2 = colsum_launch(dy, db, part, M, Cs, d->Cout, st, beta);
     if (rc2) return rc2;
   }
   return 0;

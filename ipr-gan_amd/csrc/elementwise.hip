@@ -42,7 +42,7 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
 }
 // dst[b][a][k] = src[a][b][k]
 __global__ void permute_021_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int Bd,
-                                   int K) {
+                                   int K, float beta) {
   const size_t total = (size_t)A * Bd * K;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -50,7 +50,8 @@ __global__ void permute_021_kernel(const float* __restrict__ src, float* __restr
     const size_t ba = i / K;
     const int a = (int)(ba % A);
     const size_t b = ba / A;
-    dst[i] = src[((size_t)a * Bd + b) * K + k];
+    const float v = src[((size_t)a * Bd + b) * K + k];
+    dst[i] = beta != 0.f ? beta * dst[i] + v : v;
   }
 }
 
@@ -60,6 +61,21 @@ __global__ void fill_kernel(float* p, float v, size_t n) {
 }
 __global__ void axpy_kernel(float* y, const float* x, float a, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] += a * x[i];
+}
+// y_t += a * x_t for a table of tensors (small gradients - biases, norm scales - into their bucket views)
+#define AXPY_MAX_TENSORS 64
+struct AxpyTable {
+  float* y[AXPY_MAX_TENSORS];
+  const float* x[AXPY_MAX_TENSORS];
+  long long n[AXPY_MAX_TENSORS];
+};
+__global__ void axpy_multi_kernel(const AxpyTable t, float a) {
+  const int ti = blockIdx.y;
+  const long long n = t.n[ti];
+  float* __restrict__ y = t.y[ti];
+  const float* __restrict__ x = t.x[ti];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     y[i] += a * x[i];
 }
 
@@ -390,12 +406,14 @@ __global__ __launch_bounds__(256) void sign_loss_fwd_kernel(const SignTable t, f
   }
   if (threadIdx.x == 0) *loss = accumulate ? *loss + total : total;
 }
-__global__ void sign_loss_bwd_kernel(const SignTable t, float gamma0, const float* __restrict__ gscale) {
+__global__ void sign_loss_bwd_kernel(const SignTable t, float gamma0, const float* __restrict__ gscale,
+                                     float beta) {
   const int l = blockIdx.x;
   const float g = (gscale ? *gscale : 1.f) / (float)t.size[l];
   for (int i = threadIdx.x; i < t.size[l]; i += blockDim.x) {
     const float b = t.sign[l][i];
-    t.dgamma[l][i] = (gamma0 - t.gamma[l][i] * b) > 0.f ? -b * g : 0.f;
+    const float d = (gamma0 - t.gamma[l][i] * b) > 0.f ? -b * g : 0.f;
+    t.dgamma[l][i] = beta != 0.f ? beta * t.dgamma[l][i] + d : d;
   }
 }
 __global__ __launch_bounds__(256) void sign_ber_kernel(const SignTable t, long long* __restrict__ counts,
@@ -433,7 +451,7 @@ struct AdamTable {
 };
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float omb1, float beta2, float omb2,
                                                    float eps, float weight_decay, float step_size,
-                                                   float bc2_sqrt) {
+                                                   float bc2_sqrt, float grad_scale) {
   const int ti = blockIdx.y;
   const long long n = t.n[ti];
   float* __restrict__ p = t.p[ti];
@@ -442,7 +460,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float omb1
   float* __restrict__ v = t.v[ti];
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    float gi = g[i];
+    float gi = g[i] * grad_scale;       // 1/world of the summed data-parallel gradient (1 on a single GPU)
     const float pi = p[i];
     if (weight_decay != 0.f) gi += weight_decay * pi;
     const float mi = m[i] + (gi - m[i]) * omb1;               // exp_avg.lerp_(grad, 1-beta1)
@@ -487,11 +505,11 @@ int iprgan_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W
   IPR_LAUNCH_CHECK();
   return 0;
 }
-int iprgan_permute_021(const float* src, float* dst, int A, int Bd, int K, void* stream) {
+int iprgan_permute_021(const float* src, float* dst, int A, int Bd, int K, float beta, void* stream) {
   const size_t n = (size_t)A * Bd * K;
   if (!n) return 0;
   hipLaunchKernelGGL(permute_021_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, src,
-                     dst, A, Bd, K);
+                     dst, A, Bd, K, beta);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -505,6 +523,24 @@ int iprgan_axpy(float* y, const float* x, float a, size_t n, void* stream) {
   if (!n) return 0;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, y, x, a, n);
   IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+int iprgan_axpy_multi(float* const* y, const float* const* x, const long long* sizes, int n, float a, void* stream) {
+  for (int b = 0; b < n; b += AXPY_MAX_TENSORS) {
+    AxpyTable t;
+    memset(&t, 0, sizeof(t));
+    int cnt = n - b;
+    if (cnt > AXPY_MAX_TENSORS) cnt = AXPY_MAX_TENSORS;
+    long long maxn = 0;
+    for (int i = 0; i < cnt; ++i) {
+      t.y[i] = y[b + i]; t.x[i] = x[b + i]; t.n[i] = sizes[b + i];
+      if (t.n[i] > maxn) maxn = t.n[i];
+    }
+    if (maxn == 0) continue;
+    hipLaunchKernelGGL(axpy_multi_kernel, dim3(grid_for((size_t)maxn, 256), cnt), dim3(256), 0, (hipStream_t)stream, t, a);
+    IPR_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -676,11 +712,11 @@ int iprgan_sign_loss_fwd(const float* const* gammas, const float* const* signs, 
   return 0;
 }
 int iprgan_sign_loss_bwd(const float* const* gammas, const float* const* signs, float* const* dgammas,
-                         const int* sizes, int nlayer, float gamma0, const float* gscale, void* stream) {
+                         const int* sizes, int nlayer, float gamma0, const float* gscale, float beta, void* stream) {
   for (int b = 0; b < nlayer; b += SIGN_MAX_LAYERS) {
     SignTable t;
     const int cnt = fill_sign_table(t, gammas, signs, dgammas, sizes, b, nlayer);
-    hipLaunchKernelGGL(sign_loss_bwd_kernel, dim3(cnt), dim3(256), 0, (hipStream_t)stream, t, gamma0, gscale);
+    hipLaunchKernelGGL(sign_loss_bwd_kernel, dim3(cnt), dim3(256), 0, (hipStream_t)stream, t, gamma0, gscale, beta);
     IPR_LAUNCH_CHECK();
   }
   return 0;
@@ -699,7 +735,7 @@ int iprgan_sign_ber(const float* const* gammas, const float* const* signs, const
 
 int iprgan_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const long long* sizes, int n, double lr, double beta1,
-                     double beta2, double eps, double weight_decay, int step, void* stream) {
+                     double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
   IPR_CHECK(step >= 1, "adam_step: step must be >= 1");
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
@@ -719,7 +755,7 @@ int iprgan_adam_step(float* const* params, const float* const* grads, float* con
     const int gx = grid_for((size_t)maxn, 256);
     hipLaunchKernelGGL(adam_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, t,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)weight_decay, step_size, bc2_sqrt);
+                       (float)weight_decay, step_size, bc2_sqrt, (float)grad_scale);
     IPR_LAUNCH_CHECK();
   }
   return 0;

@@ -127,12 +127,12 @@ __device__ __forceinline__ void final_sums(const float* __restrict__ part, int N
 }
 
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int NB, int Cs,
-                                                           int C, float* __restrict__ out) {
+                                                           int C, float* __restrict__ out, float beta) {
   __shared__ float sh[2][FL][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
   float s0, s1;
   final_sums(part, NB, Cs, c, lane, sh, s0, s1, false);
-  if (lane == 0 && c < C) out[c] = s0;
+  if (lane == 0 && c < C) out[c] = beta != 0.f ? beta * out[c] + s0 : s0;
 }
 
 __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ part,
@@ -289,12 +289,12 @@ size_t colsum_ws_floats(int M, int Cs) {
   const ColGeom g = col_geom(M, Cs);
   return (size_t)g.NB * 2 * Cs;
 }
-int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st) {
+int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st, float beta) {
   const ColGeom g = col_geom(M, Cs);
   hipLaunchKernelGGL(colreduce_kernel<0>, dim3(g.NB, g.gy), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                      nullptr, ws, M, Cs, g.TC, g.rows_per_block, 0, 0.f);
   IPR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, st, ws, g.NB, Cs, C, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, st, ws, g.NB, Cs, C, out, beta);
   IPR_LAUNCH_CHECK();
   return 0;
 }

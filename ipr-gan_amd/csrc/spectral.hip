@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256) void snm_dot_kernel(const SNBwdTable t, float*
   s = block_sum(s, sh);
   if (threadIdx.x == 0) part[l * SNB_BLOCKS + blockIdx.x] = s;
 }
-__global__ __launch_bounds__(256) void snm_bwd_apply_kernel(const SNBwdTable t, const float* __restrict__ part) {
+__global__ __launch_bounds__(256) void snm_bwd_apply_kernel(const SNBwdTable t, const float* __restrict__ part,
+                                                            float beta) {
   const int l = blockIdx.y;
   float dot = 0.f;
   for (int i = 0; i < SNB_BLOCKS; ++i) dot += part[l * SNB_BLOCKS + i];
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256) void snm_bwd_apply_kernel(const SNBwdTable t, 
   float* dw = t.dw[l];
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
-    dw[i] = (dwsn[i] - coef * u[r] * v[c]) / sg;
+    const float g = (dwsn[i] - coef * u[r] * v[c]) / sg;
+    dw[i] = beta != 0.f ? beta * dw[i] + g : g;
   }
 }
 
@@ -389,7 +391,7 @@ int iprgan_sn_power_iter_multi(const float* const* w, float* const* u, float* co
 
 int iprgan_sn_bwd_multi(const float* const* dwsn, const float* const* w, const float* const* u,
                         const float* const* v, const float* const* sigma, float* const* dw, float* ws,
-                        const int* rows, const int* cols, int n, void* stream) {
+                        const int* rows, const int* cols, int n, float beta, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   IPR_CHECK(n >= 1 && n <= SN_MAX_LAYERS, "sn_bwd_multi: %d layers (max %d)", n, SN_MAX_LAYERS);
   SNBwdTable t;
@@ -404,7 +406,7 @@ int iprgan_sn_bwd_multi(const float* const* dwsn, const float* const* w, const f
   hipLaunchKernelGGL(snm_dot_kernel, dim3(SNB_BLOCKS, n), dim3(256), 0, st, t, ws);
   IPR_LAUNCH_CHECK();
   const int bx = (int)(cdivz(maxn, 1024) < 512 ? cdivz(maxn, 1024) : 512);
-  hipLaunchKernelGGL(snm_bwd_apply_kernel, dim3(bx > 0 ? bx : 1, n), dim3(256), 0, st, t, ws);
+  hipLaunchKernelGGL(snm_bwd_apply_kernel, dim3(bx > 0 ? bx : 1, n), dim3(256), 0, st, t, ws, beta);
   IPR_LAUNCH_CHECK();
   return 0;
 }

@@ -35,7 +35,7 @@ SIGNATURES = {
     'iprgan_version': (_I, []),
     'iprgan_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'iprgan_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    'iprgan_permute_021': (_I, [_P, _P, _I, _I, _I, _P]),
+    'iprgan_permute_021': (_I, [_P, _P, _I, _I, _I, _F, _P]),
     'iprgan_conv_wfwd_floats': (_Z, [_D]),
     'iprgan_conv_wbwd_floats': (_Z, [_D]),
     'iprgan_conv_wgrad_ws_floats': (_Z, [_D]),
@@ -45,7 +45,7 @@ SIGNATURES = {
     'iprgan_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P]),
     'iprgan_conv_bwd_data_ws_floats': (_Z, [_D]),
     'iprgan_conv_bwd_data': (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P]),
-    'iprgan_conv_bwd_weight': (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    'iprgan_conv_bwd_weight': (_I, [_D, _P, _P, _P, _P, _P, _F, _P]),
     'iprgan_act_bwd': (_I, [_P, _P, _P, _Z, _I, _F, _P]),
     'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P]),
@@ -67,7 +67,7 @@ SIGNATURES = {
     'iprgan_sn_multi_ws_floats': (_Z, [_P, _P, _I]),
     'iprgan_sn_power_iter_multi': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _P]),
     'iprgan_sn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    'iprgan_sn_bwd_multi': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'iprgan_sn_bwd_multi': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P]),
     'iprgan_loss_ws_floats': (_Z, [_Z]),
     'iprgan_loss_fwd': (_I, [_I, _P, _P, _P, _P, _Z, _P]),
     'iprgan_loss_bwd': (_I, [_I, _P, _P, _P, _P, _Z, _P]),
@@ -80,9 +80,10 @@ SIGNATURES = {
     'iprgan_ssim_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'iprgan_reparam_bwd': (_I, [_P, _P, _P, _P, _P, _Z, _P]),
     'iprgan_sign_loss_fwd': (_I, [_P, _P, _P, _I, _F, _P, _P]),
-    'iprgan_sign_loss_bwd': (_I, [_P, _P, _P, _P, _I, _F, _P, _P]),
+    'iprgan_sign_loss_bwd': (_I, [_P, _P, _P, _P, _I, _F, _P, _F, _P]),
     'iprgan_sign_ber': (_I, [_P, _P, _P, _I, _P, _P]),
-    'iprgan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
+    'iprgan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I,
+                         C.c_double, _P]),
     'iprgan_debug_force_tiles': (_I, [_I, _I]),
     'iprgan_set_math_mode': (_I, [_I]),
     'iprgan_get_math_mode': (_I, []),
@@ -92,6 +93,13 @@ SIGNATURES = {
     'iprgan_prof_get': (_I, [_I, C.c_char_p, _I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'iprgan_fill': (_I, [_P, _F, _Z, _P]),
     'iprgan_axpy': (_I, [_P, _P, _F, _Z, _P]),
+    'iprgan_axpy_multi': (_I, [_P, _P, _P, _I, _F, _P]),
+    'iprgan_comm_unique_id': (_I, [_P]),
+    'iprgan_comm_init': (_I, [_I, _I, _P]),
+    'iprgan_allreduce_bucket': (_I, [_P, _Z, _I, _P]),
+    'iprgan_comm_nranks': (_I, []),
+    'iprgan_comm_rank': (_I, []),
+    'iprgan_comm_destroy': (_I, []),
 }
 
 _lib = None

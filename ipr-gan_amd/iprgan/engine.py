@@ -14,7 +14,7 @@ import torch
 import os
 
 from . import _lib as L
-from . import ops
+from . import ops, parallel
 
 _BATCH_PREP = os.environ.get('IPRGAN_BATCH_PREP', '1') != '0'
 
@@ -28,10 +28,16 @@ class Op:
     def forward(self, x, st, train):
         raise NotImplementedError
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         """dy: gradient w.r.t. this op's output (pre-activation if ``st['dy_is_preact']``).
-        prev_act: (act, slope) of the producer to fuse into dx, or None.  Returns (dx, [param grads])."""
+        prev_act: (act, slope) of the producer to fuse into dx, or None.  Returns (dx, [param grads]).
+        sink: the GradReducer that owns this pass's gradient buckets, or None.  With a sink, large gradients are
+        accumulated straight into ``sink.view_of(param)`` and reported as ``DIRECT``; small ones are still returned
+        as tensors and added to their views in one multi-tensor launch by the executor."""
         raise NotImplementedError
+
+
+DIRECT = object()     # marker: the gradient has already been accumulated into its bucket view
 
 
 class ToNHWC(Op):
@@ -43,7 +49,7 @@ class ToNHWC(Op):
     def forward(self, x, st, train):
         return ops.nchw_to_nhwc(x)
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         return (ops.nhwc_to_nchw(dy, self.channels) if need_dx else None), []
 
 
@@ -54,7 +60,7 @@ class ToNCHW(Op):
     def forward(self, x, st, train):
         return ops.nhwc_to_nchw(x, self.channels)
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         return (ops.nchw_to_nhwc(dy) if need_dx else None), []
 
 
@@ -69,7 +75,7 @@ class View(Op):
         st['in_shape'] = tuple(x.shape)
         return x.view(x.shape[0], *self.shape)
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         return dy.view(st['in_shape']), []
 
 
@@ -115,16 +121,24 @@ class Conv(Op):
         st.update(x=x, y=y, d=d, sigma=sigma)
         return y
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         sp, d, sigma = self.spec, st['d'], st['sigma']
         if sp.act != L.ACT_NONE and not st.get('dy_is_preact', False):
             dy = ops.act_bwd(dy, st['y'], sp.act, sp.slope)
         grads = []
         if need_w:
-            dw, db = ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, self.bias is not None)
+            has_b = self.bias is not None
+            if sink is not None and self.sn is None:
+                ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, has_b, dw=sink.view_of(self.weight),
+                                    db=sink.view_of(self.bias) if has_b else None, beta=1.0)
+                grads = [DIRECT] + ([DIRECT] if has_b else [])
+            else:
+                # (spectral norm: dW_sn is a temporary - the batched SN backward accumulates dW_orig into the view -
+                # and the bias gradient joins the pass's small-gradient add)
+                dw, db = ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, has_b)
+                grads = [dw] + ([db] if has_b else [])
             if self.sn is not None:
                 st['dwsn'] = dw             # spectral-norm backward of all layers is batched by ChainFn.backward
-            grads = [dw] + ([db] if self.bias is not None else [])
         dx = None
         if need_dx:
             wb = st.pop('wb', None)
@@ -163,8 +177,12 @@ class LinearNHWC(Op):
     def forward(self, x, st, train):
         B, K = x.shape
         d = self.spec.desc(B, 1, 1)
-        wp = ops.permute_021(self.weight, self.C, self.HW, K)
-        bp = ops.permute_021(self.bias, self.C, self.HW, 1)
+        # the row-permuted copies are kept until the weight changes (the optimizer bumps the version counter)
+        key = (self.weight._version, self.weight.data_ptr(), self.bias._version, self.bias.data_ptr())
+        if getattr(self, '_perm_key', None) != key:
+            self._perm = (ops.permute_021(self.weight, self.C, self.HW, K), ops.permute_021(self.bias, self.C, self.HW, 1))
+            self._perm_key = key
+        wp, bp = self._perm
         x4 = x.contiguous().view(B, 1, 1, K)
         if self.spec.is_identity_prep:
             wf = wp
@@ -174,7 +192,7 @@ class LinearNHWC(Op):
         st.update(x=x4, y=y, d=d, wp=wp)
         return y
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         sp, d = self.spec, st['d']
         B, K = d.B, sp.cin
         if not st.get('dy_is_preact', False):
@@ -183,9 +201,14 @@ class LinearNHWC(Op):
         grads = []
         if need_w:
             dwp, dbp = ops.conv_bwd_weight(sp, d, st['x'], dy4, (sp.cout, K, 1, 1), True)
-            dw = ops.permute_021(dwp, self.HW, self.C, K).view(sp.cout, K)
-            db = ops.permute_021(dbp, self.HW, self.C, 1)
-            grads = [dw, db]
+            if sink is not None:        # un-permute straight into the bucket views
+                ops.permute_021(dwp, self.HW, self.C, K, out=sink.view_of(self.weight), beta=1.0)
+                ops.permute_021(dbp, self.HW, self.C, 1, out=sink.view_of(self.bias), beta=1.0)
+                grads = [DIRECT, DIRECT]
+            else:
+                dw = ops.permute_021(dwp, self.HW, self.C, K).view(sp.cout, K)
+                db = ops.permute_021(dbp, self.HW, self.C, 1)
+                grads = [dw, db]
         dx = None
         if need_dx:
             _, wb = ops.conv_prep(sp, d, st['wp'].view(sp.cout, K, 1, 1), fwd=False, bwd=True)
@@ -221,7 +244,7 @@ class BatchNorm(Op):
         st.update(x=x, y=y, mean=mean, invstd=invstd)
         return y
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         dx, dg, db = ops.bn_bwd(st['x'], st['y'], dy, self.m.weight, st['mean'], st['invstd'],
                                 self.act, self.slope)
         return dx, [dg, db]
@@ -266,13 +289,16 @@ class GemvHead(Op):
         if sigma is None:
             sigma = ops.sn_power_iter(self.weight, self.u, self.v, train)
             st['u'], st['v'] = self.u.clone(), self.v.clone()
-        wp = ops.permute_021(self.weight, self.C, self.HW, 1)
+        key = (self.weight._version, self.weight.data_ptr())
+        if getattr(self, '_perm_key', None) != key:
+            self._perm, self._perm_key = ops.permute_021(self.weight, self.C, self.HW, 1), key
+        wp = self._perm
         x2 = x.view(B, K)
         y = ops.gemv_fwd(x2, wp, self.bias, sigma)
         st.update(x=x2, xshape=tuple(x.shape), wp=wp, sigma=sigma)
         return y
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         pa, ps = prev_act if prev_act is not None else (L.ACT_NONE, 0.0)
         dx, dwp, db = ops.gemv_bwd(st['x'], st['wp'], dy.contiguous(), st['sigma'], need_dx, need_w,
                                    st['x'] if prev_act is not None else None, pa, ps)
@@ -299,7 +325,7 @@ class InstanceNorm(Op):
         st.update(x=x, y=y, mean=mean, invstd=invstd)
         return y
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         dx, dg, db = ops.instnorm_bwd(st['x'], st['y'], dy, self.m.weight, st['mean'], st['invstd'],
                                       self.act, self.slope)
         return dx, ([dg, db] if self.m.weight is not None else [])
@@ -319,7 +345,7 @@ class PReLU(Op):
         st['x'] = x
         return ops.prelu_fwd(x, self.m.weight)
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         dx, dalpha = ops.prelu_bwd(st['x'], dy.contiguous(), self.m.weight)
         return dx, [dalpha]
 
@@ -328,7 +354,7 @@ class PixelShuffle2(Op):
     def forward(self, x, st, train):
         return ops.pixel_shuffle2(x)
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         return ops.pixel_shuffle2(dy.contiguous(), inverse=True), []
 
 
@@ -337,7 +363,7 @@ class MaxPool2(Op):
         st['x'] = x
         return ops.maxpool2_fwd(x)
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         return ops.maxpool2_bwd(st['x'], dy.contiguous()), []
 
 
@@ -348,7 +374,7 @@ class SkipStart(Op):
         st['ctx']['skips'].append(x)
         return x
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         g = st['ctx']['skip_grads'].pop()
         return ops.add(dy, g), []
 
@@ -357,7 +383,7 @@ class SkipEnd(Op):
     def forward(self, x, st, train):
         return ops.add(x, st['ctx']['skips'].pop())
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         st['ctx']['skip_grads'].append(dy)
         return dy, []
 
@@ -371,7 +397,7 @@ class Squeeze(Op):
         B = x.shape[0]
         return ops.nhwc_to_nchw(x, 1).view(B)
 
-    def backward(self, dy, st, need_dx, need_w, prev_act):
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         B = st['shape'][0]
         return ops.nchw_to_nhwc(dy.contiguous().view(B, 1, 1, 1)), []
 
@@ -391,12 +417,23 @@ class Chain:
             raise RuntimeError('iprgan networks run on the HIP kernels only: input must be a GPU tensor '
                                '(there is no CPU fallback; use the reference/oracle for CPU runs)')
         L.load()
-        return ChainFn.apply(self, bool(train), x, *self.params)
+        params = self.params
+        red = None
+        if torch.is_grad_enabled():
+            # a recorded pass that will produce parameter gradients: its optimizer's reducer counts it, so that the
+            # backward executor knows which pass of the step is the last one (parallel.GradReducer)
+            for p in params:
+                if p.requires_grad:
+                    red = parallel.owner_of(p)
+                    break
+            if red is not None:
+                red.note_forward()
+        return ChainFn.apply(self, bool(train), red, x, *params)
 
 
 class ChainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, chain, train, x, *params):
+    def forward(ctx, chain, train, red, x, *params):
         h = x.detach()
         if h.dtype != torch.float32:
             raise RuntimeError('iprgan networks take float32 inputs')
@@ -418,28 +455,69 @@ class ChainFn(torch.autograd.Function):
                 stash[i]['wf'] = wf
         for op, st in zip(chain.ops, stash):
             h = op.forward(h, st, train)
-        ctx.chain, ctx.stash = chain, stash
+        ctx.chain, ctx.stash, ctx.red = chain, stash, red
+        # the backward pass reads the live parameters (weights for the data gradients, spectral-norm factors):
+        # remember their versions so that a step taken between this forward and its backward is an error, as it
+        # is in PyTorch for tensors saved by autograd
+        ctx.versions = [p._version for p in params]
         return h
 
     @staticmethod
     def backward(ctx, dy):
-        chain, stash = ctx.chain, ctx.stash
-        need_x = ctx.needs_input_grad[2]
-        need_p = ctx.needs_input_grad[3:]
+        chain, stash, red = ctx.chain, ctx.stash, ctx.red
+        if stash is None:
+            raise RuntimeError('this network pass has already been back-propagated: the engine frees a pass\'s '
+                               'activations in backward (retain_graph / double backward are not supported)')
+        need_x = ctx.needs_input_grad[3]
+        need_p = ctx.needs_input_grad[4:]
         ops_list = chain.ops
+        for p, v in zip(chain.params, ctx.versions):
+            if p._version != v:
+                raise RuntimeError('a parameter of this network was modified in place (optimizer step?) between the '
+                                   'forward pass and its backward pass: the gradients would be computed with the '
+                                   'new weights')
         # which ops need to produce dx: everything after the first op that has a trainable parameter
         # needing a gradient, or all of them when the input itself needs one
         first_needed = 0 if need_x else None
         pi = 0
-        op_need_w = []
+        op_need_w, op_need_p = [], []
         for i, op in enumerate(ops_list):
             n = len(op.params)
             w = any(need_p[pi:pi + n]) if n else False
             op_need_w.append(w)
+            op_need_p.append(need_p[pi:pi + n])
             if w and first_needed is None:
                 first_needed = i
             pi += n
+        # gradient sink: the optimizer's reducer when it is armed (bucket views are the .grad tensors); otherwise
+        # gradients are returned to autograd
+        wants = any(op_need_w)
+        sink = red if (wants and red is not None and red.armed
+                       and all(red.owns(p) for p, n in zip(chain.params, need_p) if n)) else None
+        counted = wants and red is not None
+        final = red.begin_pass() if counted else False
+        if sink is not None and final:          # parameters of the optimizer's OTHER networks are final already
+            mine = set(chain.params)
+            red.params_done([p for p in red.params if p not in mine])
         grads_per_op = [None] * len(ops_list)
+        small_dst, small_src, sn_wait = [], [], []
+
+        def flush():
+            """deferred writes into the bucket views: spectral-norm backward of the layers seen so far (batched) and
+            the small gradients (one multi-tensor add)"""
+            if sn_wait:
+                outs = [red.view_of(ops_list[i].weight) for i in sn_wait] if sink is not None else None
+                dws = ops.sn_bwd_multi([stash[i]['dwsn'] for i in sn_wait], [ops_list[i].weight for i in sn_wait],
+                                       [stash[i]['u'] for i in sn_wait], [stash[i]['v'] for i in sn_wait],
+                                       [stash[i]['sigma'] for i in sn_wait], outs=outs,
+                                       beta=1.0 if sink is not None else 0.0)
+                for i, dw in zip(sn_wait, dws):
+                    grads_per_op[i][0] = DIRECT if sink is not None else dw.view_as(ops_list[i].weight)
+                del sn_wait[:]
+            if small_dst:
+                ops.axpy_multi(small_dst, small_src)
+                del small_dst[:], small_src[:]
+
         if first_needed is not None and _BATCH_PREP:        # backward-data operands of every conv that must produce dx: one launch
             cv = [i for i, op in enumerate(ops_list) if isinstance(op, Conv) and (i > first_needed or (need_x and i == 0))]
             if cv:
@@ -458,23 +536,36 @@ class ChainFn(torch.autograd.Function):
             if need_dx and prev is not None and op.fuses_prev_act and prev.out_act[0] != L.ACT_NONE:
                 fuse = prev.out_act
                 stash[i - 1]['dy_is_preact'] = True
-            g, pg = op.backward(g, st, need_dx, op_need_w[i], fuse)
+            g, pg = op.backward(g, st, need_dx, op_need_w[i], fuse, sink)
             grads_per_op[i] = pg
-        # batched spectral-norm backward: dW_orig from dW_sn for every SN layer that produced a gradient
-        sn_i = [i for i in range(len(ops_list)) if grads_per_op[i] and 'dwsn' in stash[i]]
-        if sn_i:
-            dws = ops.sn_bwd_multi([stash[i]['dwsn'] for i in sn_i], [ops_list[i].weight for i in sn_i],
-                                   [stash[i]['u'] for i in sn_i], [stash[i]['v'] for i in sn_i],
-                                   [stash[i]['sigma'] for i in sn_i])
-            for i, dw in zip(sn_i, dws):
-                grads_per_op[i][0] = dw.view_as(ops_list[i].weight)
+            if op_need_w[i] and 'dwsn' in st:
+                sn_wait.append(i)
+            if sink is not None and op.params:
+                if red.trace is not None and op_need_w[i]:
+                    red.trace.append(('wgrad', i, next(parallel._seq)))
+                for k, p in enumerate(op.params):
+                    gk = pg[k] if k < len(pg) else None
+                    if gk is None or not op_need_p[i][k]:
+                        continue
+                    red.touch(p)
+                    if gk is not DIRECT and not (k == 0 and 'dwsn' in st):
+                        small_dst.append(red.view_of(p))
+                        small_src.append(gk.reshape(p.shape) if gk.shape != p.shape else gk)
+                if final:
+                    if red.bucket_would_complete(op.params):
+                        flush()
+                    red.params_done(op.params)
+        flush()
+        if counted:
+            red.end_pass()                      # last pass: everything that has not left yet is sent now
         out = []
         pi = 0
         for i, op in enumerate(ops_list):
             n = len(op.params)
             pg = grads_per_op[i] or [None] * n
             for k in range(n):
-                out.append(pg[k] if (k < len(pg) and need_p[pi + k]) else None)
+                gk = pg[k] if (k < len(pg) and need_p[pi + k]) else None
+                out.append(None if (gk is DIRECT or sink is not None) else gk)
             pi += n
         ctx.stash = None
-        return (None, None, g if need_x else None, *out)
+        return (None, None, None, g if need_x else None, *out)

@@ -78,6 +78,7 @@ def _no_param_grads(*nets):
 def _step(opt, reducer):
     reducer.reduce()
     reducer.wait()
+    opt.grad_scale = reducer.scale          # 1/world: the buckets hold the SUM over ranks
     opt.step()
 
 

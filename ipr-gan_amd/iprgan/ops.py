@@ -37,10 +37,10 @@ def nhwc_to_nchw(x, channels):
     return y
 
 
-def permute_021(src, A, Bd, K):
-    """dst[b][a][k] = src[a][b][k]; returns a flat tensor of A*Bd*K floats."""
-    dst = empty((A * Bd * K,), src)
-    call('iprgan_permute_021', ptr(src), ptr(dst), A, Bd, K, stream())
+def permute_021(src, A, Bd, K, out=None, beta=0.0):
+    """dst[b][a][k] = src[a][b][k]; returns a flat tensor of A*Bd*K floats (or ``out = beta*out + permuted``)."""
+    dst = empty((A * Bd * K,), src) if out is None else out
+    call('iprgan_permute_021', ptr(src), ptr(dst), A, Bd, K, float(beta), stream())
     return dst
 
 
@@ -119,12 +119,16 @@ def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_sl
     return dx
 
 
-def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias):
-    dw = empty(tuple(w_shape), x)
-    db = empty((spec.cout,), x) if want_bias else None
+def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0.0):
+    """dw, db given (gradient-bucket views): ``dw = beta*dw + grad`` written in place, no temporary."""
+    if dw is None:
+        dw = empty(tuple(w_shape), x)
+    if db is None and want_bias:
+        db = empty((spec.cout,), x)
     ws = empty((query('iprgan_conv_wgrad_ws_floats', C.byref(d)),), x)
-    call('iprgan_conv_bwd_weight', C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), stream())
-    return dw, db
+    call('iprgan_conv_bwd_weight', C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db) if want_bias else None, ptr(ws),
+         float(beta), stream())
+    return dw, (db if want_bias else None)
 
 
 # ---- GEMV head ----------------------------------------------------------------------------------
@@ -207,15 +211,16 @@ def sn_bwd(dwsn, w_orig, u, v, sigma):
     return dw
 
 
-def sn_bwd_multi(dwsns, weights, us, vs, sigmas):
-    """Spectral-norm backward of several layers in two launches; returns the list of dW_orig."""
+def sn_bwd_multi(dwsns, weights, us, vs, sigmas, outs=None, beta=0.0):
+    """Spectral-norm backward of several layers in two launches; returns the list of dW_orig
+    (``outs[i] = beta*outs[i] + dW_orig`` when given)."""
     n = len(weights)
     rows = [w.shape[0] for w in weights]
     cols = [w.numel() // w.shape[0] for w in weights]
-    dws = [torch.empty_like(w) for w in weights]
+    dws = [torch.empty_like(w) for w in weights] if outs is None else outs
     ws = empty((64 * 16,), weights[0])
     call('iprgan_sn_bwd_multi', L.ptr_table(dwsns), L.ptr_table(weights), L.ptr_table(us), L.ptr_table(vs),
-         L.ptr_table(sigmas), L.ptr_table(dws), ptr(ws), _int_table(rows), _int_table(cols), n, stream())
+         L.ptr_table(sigmas), L.ptr_table(dws), ptr(ws), _int_table(rows), _int_table(cols), n, float(beta), stream())
     return dws
 
 
@@ -290,10 +295,10 @@ def sign_loss_fwd(gammas, signs, gamma0):
     return out
 
 
-def sign_loss_bwd(gammas, signs, gamma0, gscale):
-    grads = [torch.empty_like(g) for g in gammas]
+def sign_loss_bwd(gammas, signs, gamma0, gscale, outs=None, beta=0.0):
+    grads = [torch.empty_like(g) for g in gammas] if outs is None else outs
     call('iprgan_sign_loss_bwd', L.ptr_table(gammas), L.ptr_table(signs), L.ptr_table(grads),
-         _int_table([g.numel() for g in gammas]), len(gammas), float(gamma0), ptr(gscale), stream())
+         _int_table([g.numel() for g in gammas]), len(gammas), float(gamma0), ptr(gscale), float(beta), stream())
     return grads
 
 
@@ -305,12 +310,25 @@ def sign_ber_counts(gammas, signs):
 
 
 # ---- Adam -----------------------------------------------------------------------------------------
-def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     n = len(params)
     sizes = (C.c_longlong * n)(*[p.numel() for p in params])
     call('iprgan_adam_step', L.ptr_table(params), L.ptr_table(grads), L.ptr_table(exp_avg),
          L.ptr_table(exp_avg_sq), sizes, n, float(lr), float(beta1), float(beta2), float(eps),
-         float(weight_decay), int(step), stream())
+         float(weight_decay), int(step), float(grad_scale), stream())
+
+
+def axpy_multi(dsts, srcs, alpha=1.0):
+    """dsts[i] += alpha * srcs[i] for a list of tensors in one launch."""
+    n = len(dsts)
+    if not n:
+        return
+    sizes = (C.c_longlong * n)(*[t.numel() for t in dsts])
+    call('iprgan_axpy_multi', L.ptr_table(dsts), L.ptr_table(srcs), sizes, n, float(alpha), stream())
+
+
+def fill(t, value=0.0):
+    call('iprgan_fill', ptr(t), float(value), t.numel(), stream())
 
 
 # ---- instance norm / PReLU / pixel shuffle / max pool / residual add ---------------------------------

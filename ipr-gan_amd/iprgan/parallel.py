@@ -1,14 +1,47 @@
-"""Data-parallel plumbing.
+"""Data-parallel plumbing: replicas that live for the run, gradient buckets owned by the engine, RCCL exchange.
 
 ``Replica`` stands where the reference puts ``torch.nn.DataParallel`` (models/dcgan.py:16-17): it owns
 ``.module``, so state_dict keys keep the ``module.`` prefix and ``named_modules()`` keeps the names the
 sign-loss buffers are derived from (tools/sign_model.py:36).  Unlike DataParallel it never replicates
-or scatters: this engine runs ONE process per GPU, each with a full replica that lives for the whole
-run, and averages gradients with RCCL all-reduce over xGMI (``GradReducer``).
+or scatters: this engine runs ONE process per GPU, each with a full replica, and sums gradients with an RCCL
+all-reduce over xGMI (``GradReducer``) once per optimizer step.
+
+Gradient flow ("launched ... as soon as its grads are final"):
+
+* ``GradReducer`` owns ONE flat fp32 allocation per optimizer, cut into buckets in REVERSE parameter order (the
+  gradients of the last layers are final first).  ``arm()`` - called between ``zero_grad()`` and ``backward()`` -
+  clears it and installs bucket views as ``p.grad``.
+* The chain executor (engine.ChainFn.backward) writes every weight gradient STRAIGHT into its view
+  (``iprgan_conv_bwd_weight(..., beta=1)``: no autograd AccumulateGrad add, no bucket copy) and tells the reducer which
+  parameters are done.  A network that runs several passes per step (real + fake batch through D; three passes through
+  each CycleGAN generator) accumulates pass after pass; the reducer counts the passes that were recorded in forward and
+  knows which backward pass is the LAST one.
+* During that last pass, the moment the last producer of a bucket has been enqueued, an event is recorded on the
+  compute stream and the bucket's ``iprgan_allreduce_bucket`` (RCCL, in place, SUM) is enqueued on a side stream
+  behind that event - the earlier layers' backward kernels keep running on the compute stream meanwhile.
+* ``wait()`` makes the compute stream wait for the buckets' completion events; the 1/world factor is folded into
+  the Adam kernel (``opt.grad_scale``), so ``p.grad`` holds the SUM over ranks and no scaling pass exists.
+
+With one rank the same code runs without the exchange: the engine still writes into the views (one fill + zero
+autograd adds per step).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few MB-sized buckets, not
+per-layer messages.
 """
+import ctypes as C
+import itertools
+import os
+import weakref
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+
+_seq = itertools.count()            # global enqueue order, for the overlap trace (tests/test_gpu_ddp.py)
+_owner = {}                         # id(parameter) -> (weakref to it, GradReducer that owns its gradient)
+
+
+def owner_of(p):
+    ent = _owner.get(id(p))
+    return ent[1] if ent is not None and ent[0]() is p else None
 
 
 class Replica(nn.Module):
@@ -28,119 +61,243 @@ def world():
     return 0, 1
 
 
+# ---- transports ---------------------------------------------------------------------------------------------
+class RcclTransport:
+    """In-place SUM through the C ABI (iprgan_comm_* in include/iprgan.h -> RCCL over xGMI).  One communicator per
+    process; torch.distributed is only the out-of-band channel that ships rank 0's 128-byte unique id."""
+    _ready = False
+
+    @classmethod
+    def ensure(cls, rank, nranks):
+        from . import _lib as L
+        if cls._ready:
+            return cls
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            L.call('iprgan_comm_unique_id', ident)
+        if nranks > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=0)
+            ident = C.create_string_buffer(box[0], 128)
+        L.call('iprgan_comm_init', rank, nranks, ident)
+        cls._ready = True
+        return cls
+
+    @staticmethod
+    def all_reduce(flat, stream):
+        from . import _lib as L
+        L.call('iprgan_allreduce_bucket', flat.data_ptr(), flat.numel(), 0, stream.cuda_stream)
+
+    @classmethod
+    def destroy(cls):
+        if cls._ready:
+            from . import _lib as L
+            L.call('iprgan_comm_destroy')
+            cls._ready = False
+
+
+class TorchDistTransport:
+    """torch.distributed all_reduce: the gloo path of the CPU tests and of two test ranks sharing one GPU."""
+
+    @staticmethod
+    def all_reduce(flat, stream):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+
+def _pick_transport(device):
+    rank, nranks = world()
+    if nranks > 1:
+        if device.type == 'cuda' and dist.get_backend() == 'nccl':
+            return RcclTransport.ensure(rank, nranks)
+        return TorchDistTransport
+    if device.type == 'cuda' and os.environ.get('IPRGAN_FORCE_COMM') == '1':
+        return RcclTransport.ensure(0, 1)          # single-rank communicator: exercises the RCCL path on one GPU
+    return None
+
+
 class GradReducer:
-    """Averages the gradients of a parameter list across ranks (one exchange per
-    optimizer step and network), overlapped with the backward pass.
+    """Gradient buckets of one optimizer's parameters + their exchange (see the module docstring)."""
 
-    Parameters are packed, in REVERSE order (gradients become final from the last layer to the first),
-    into flat fp32 buckets of ``bucket_mb``.  A post-accumulate-grad hook copies each finished gradient
-    into its bucket; when a bucket is complete its ``all_reduce(SUM)`` is launched at once on a side
-    stream (RCCL over xGMI with the nccl backend; gloo on CPU in the tests) while autograd keeps running
-    the earlier layers' backward kernels on the compute stream.  ``wait()`` - called right before the
-    optimizer step - joins the reductions, scales by 1/world and installs the averaged gradients as views
-    of the buckets.  xGMI is point-to-point (7 links x ~153 GB/s): a few large buckets, not per-layer
-    messages.  With world_size == 1 everything is a no-op and no hooks are installed.
-    """
-
-    def __init__(self, params, bucket_mb=16.0):
+    def __init__(self, params, bucket_mb=None):
         self.params = [p for p in params if p.requires_grad]
         self.rank, self.world = world()
+        self.scale = 1.0 / self.world               # folded into Adam (opt.grad_scale)
+        if bucket_mb is None:
+            bucket_mb = float(os.environ.get('IPRGAN_BUCKET_MB', '8'))
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.flat = None
         self.buckets = None
         self.stream = None
+        self.transport = None
+        self.armed = False
+        self.pending = 0                            # recorded forward passes whose backward has not run yet
+        self.in_final = False
+        self.trace = None                           # list of (kind, index, seq) when tracing (tests)
         self._handles = []
-        self._armed = False
-        self.bucket_bytes = int(bucket_mb * (1 << 20))
-        if self.world > 1:
-            for p in self.params:
-                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        for p in self.params:
+            _owner[id(p)] = (weakref.ref(p), self)
+            self._handles.append(p.register_hook(lambda g, p=p: self._on_autograd_grad(p, g)))
 
-    # -- bucket layout -----------------------------------------------------------------------------
+    # -- layout --------------------------------------------------------------------------------------------
     def _ensure(self):
-        if self.buckets is not None:
+        if self.flat is not None and self.flat.device == self.params[0].device:
             return
         dev = self.params[0].device
-        self.buckets, self.where = [], {}
-        cur, cur_bytes = [], 0
+        pad4 = lambda n: (n + 3) & ~3                    # every view starts on a 16-byte boundary
+        total = sum(pad4(p.numel()) for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.buckets, self.slot = [], {}
+        off, cur_start, cur_params = 0, 0, []
         for p in reversed(self.params):
-            if cur and cur_bytes + p.numel() * 4 > self.bucket_bytes:
-                self._close(cur, dev)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += p.numel() * 4
-        if cur:
-            self._close(cur, dev)
-        if dev.type == 'cuda':
+            n = p.numel()
+            if cur_params and (off - cur_start + n) * 4 > self.bucket_bytes:
+                self._close(cur_start, off, cur_params)
+                cur_start, cur_params = off, []
+            self.slot[p] = (len(self.buckets), self.flat[off:off + n].view_as(p))
+            cur_params.append(p)
+            off += pad4(n)
+        if cur_params:
+            self._close(cur_start, off, cur_params)
+        self.transport = _pick_transport(dev)
+        if dev.type == 'cuda' and self.transport is not None:
             self.stream = torch.cuda.Stream(device=dev)
 
-    def _close(self, plist, dev):
-        flat = torch.zeros(sum(p.numel() for p in plist), dtype=torch.float32, device=dev)
-        off, views = 0, []
-        for p in plist:
-            views.append(flat[off:off + p.numel()].view_as(p))
-            self.where[p] = (len(self.buckets), len(views) - 1)
-            off += p.numel()
-        self.buckets.append({'flat': flat, 'params': plist, 'views': views, 'pending': len(plist), 'work': None})
+    def _close(self, start, end, plist):
+        self.buckets.append({'index': len(self.buckets), 'flat': self.flat[start:end], 'params': list(plist),
+                             'left': 0, 'launched': False, 'done': None})
 
-    # -- per-step protocol ---------------------------------------------------------------------------
+    def view_of(self, p):
+        return self.slot[p][1]
+
+    def owns(self, p):
+        return self.armed and p in self.slot
+
+    # -- per-step protocol -----------------------------------------------------------------------------------
     def arm(self):
-        """Call before backward: gradients produced from now on are reduced as they complete."""
-        if self.world == 1:
+        """Between ``zero_grad()`` and ``backward()``: clear the buckets and make them the parameters' ``.grad``."""
+        if not self.params:
             return
         self._ensure()
-        for b in self.buckets:
-            b['pending'], b['work'] = len(b['params']), None
-        self._armed = True
-
-    def _on_grad(self, p):
-        if not self._armed:
-            return
-        bi, vi = self.where[p]
-        b = self.buckets[bi]
-        b['views'][vi].copy_(p.grad)
-        b['pending'] -= 1
-        if b['pending'] == 0:
-            self._launch(b)
-
-    def _launch(self, b):
-        if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+        if self.flat.is_cuda:
+            from . import ops
+            ops.fill(self.flat, 0.0)
         else:
-            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
-
-    def reduce(self):
-        """Flush: buckets whose parameters did not all receive a gradient this step (frozen or unused
-        parameters count as zero) are reduced now."""
-        if self.world == 1 or not self._armed:
-            return
+            self.flat.zero_()
+        self.touched, self.done = set(), set()
         for b in self.buckets:
-            if b['work'] is None:
-                for p, v in zip(b['params'], b['views']):
-                    if p.grad is None:
-                        v.zero_()
-                    elif b['pending'] > 0 and p.grad.data_ptr() != v.data_ptr():
-                        v.copy_(p.grad)
+            b['left'], b['launched'], b['done'] = len(b['params']), False, None
+        for p in self.params:
+            p.grad = self.slot[p][1]
+        self.armed, self.in_final = True, False
+
+    def note_forward(self):
+        """A forward pass that will contribute gradients to these parameters has been recorded."""
+        self.pending += 1
+
+    def begin_pass(self):
+        """Start of one contributor's backward.  True if it is the LAST pending one: from here on, parameters
+        reported through ``params_done`` are final and their buckets may leave."""
+        self.in_final = self.armed and self.pending == 1
+        return self.in_final
+
+    def end_pass(self):
+        self.pending = max(0, self.pending - 1)
+        if self.in_final:                     # everything this optimizer owns is final now
+            self.in_final = False
+            self.params_done(self.params, force=True)
+
+    def touch(self, p):
+        self.touched.add(p)
+
+    def params_done(self, params, force=False):
+        """Final-pass bookkeeping: ``params`` have received their last contribution (already enqueued on the
+        current stream).  Buckets that became complete are sent."""
+        if not (self.in_final or force):
+            return
+        for p in params:
+            if p in self.done or p not in self.slot:
+                continue
+            self.done.add(p)
+            b = self.buckets[self.slot[p][0]]
+            b['left'] -= 1
+            if b['left'] == 0:
                 self._launch(b)
 
-    def wait(self):
-        """Join the reductions on the compute stream and install the averaged gradients."""
-        if self.world == 1 or not self._armed:
+    def bucket_would_complete(self, params):
+        """True if reporting ``params`` done would complete (and send) a bucket - the executor flushes its
+        deferred writes (spectral-norm backward, small-gradient adds) first."""
+        if not self.in_final:
+            return False
+        left = {}
+        for p in params:
+            if p in self.done or p not in self.slot:
+                continue
+            bi = self.slot[p][0]
+            left[bi] = left.get(bi, self.buckets[bi]['left']) - 1
+        return any(v == 0 for v in left.values())
+
+    def _launch(self, b):
+        if b['launched']:
             return
-        self._armed = False
+        b['launched'] = True
+        if self.trace is not None:
+            self.trace.append(('launch', b['index'], next(_seq)))
+        if self.transport is None:
+            return
+        if self.stream is not None:
+            ready = torch.cuda.Event(enable_timing=self.trace is not None)
+            ready.record()                                   # after the bucket's last producer on the compute stream
+            self.stream.wait_event(ready)
+            with torch.cuda.stream(self.stream):
+                self.transport.all_reduce(b['flat'], self.stream)
+                b['done'] = torch.cuda.Event(enable_timing=self.trace is not None)
+                b['done'].record(self.stream)
+            if self.trace is not None:
+                b['ready'] = ready
+        else:
+            self.transport.all_reduce(b['flat'], None)
+
+    def _on_autograd_grad(self, p, g):
+        """A gradient is about to arrive through autograd's AccumulateGrad (anything that is not the chain executor or
+        the sign loss: user losses on parameters, plain torch modules in the CPU tests); it will be added in place
+        into the view.  (The executor returns None for the gradients it wrote itself: autograd calls the hook with
+        None for those.)"""
+        if g is None or not self.armed:
+            return
+        if self.buckets[self.slot[p][0]]['launched']:
+            raise RuntimeError('a gradient reached a parameter through autograd after its bucket had been sent for '
+                               'reduction; contribute it before the network\'s last backward pass')
+        self.touched.add(p)
+
+    def reduce(self):
+        """After backward: send whatever has not left yet (passes that could not be counted, unused parameters)."""
+        if not self.armed:
+            return
+        self.in_final = False
         for b in self.buckets:
-            b['work'].wait()
-            if self.stream is not None:
-                torch.cuda.current_stream().wait_stream(self.stream)
-            b['flat'].mul_(1.0 / self.world)
-            for p, v in zip(b['params'], b['views']):
-                p.grad = v
-            b['work'] = None
+            self._launch(b)
+
+    def wait(self):
+        """Before the optimizer step: the compute stream waits for the exchanged buckets.  Parameters nobody produced
+        a gradient for get ``.grad = None`` (so Adam skips them exactly as on a single GPU)."""
+        if not self.armed:
+            return
+        self.armed = False
+        self.pending = 0
+        for b in self.buckets:
+            if b['done'] is not None:
+                torch.cuda.current_stream().wait_event(b['done'])
+        for p in self.params:
+            if p not in self.touched:
+                p.grad = None
 
     def close(self):
         for h in self._handles:
             h.remove()
         self._handles = []
+        for p in self.params:
+            if owner_of(p) is self:
+                del _owner[id(p)]
 
 
 def broadcast_module(module, src=0):

@@ -44,18 +44,31 @@ def _norm_layers(model):
 
 
 class _SignLossFn(torch.autograd.Function):
-    """loss = sum_layers mean(relu(gamma0 - gamma*b)); one multi-tensor launch each way."""
+    """loss = sum_layers mean(relu(gamma0 - gamma*b)); one multi-tensor launch each way.  ``red`` is the
+    GradReducer that owns the scales' gradients (or None): when it is armed the backward pass accumulates
+    straight into its bucket views, as the network passes do (parallel.GradReducer)."""
 
     @staticmethod
-    def forward(ctx, gamma0, signs, *gammas):
+    def forward(ctx, gamma0, signs, red, *gammas):
         gs = [g.detach() for g in gammas]
-        ctx.gamma0, ctx.signs, ctx.gs = gamma0, signs, gs
+        ctx.gamma0, ctx.signs, ctx.gs, ctx.red, ctx.params = gamma0, signs, gs, red, gammas
         return ops.sign_loss_fwd(gs, signs, gamma0)
 
     @staticmethod
     def backward(ctx, gout):
+        red = ctx.red
+        if red is not None:
+            red.begin_pass()
+            if red.armed and all(red.owns(p) for p in ctx.params):
+                ops.sign_loss_bwd(ctx.gs, ctx.signs, ctx.gamma0, gout.contiguous(),
+                                  outs=[red.view_of(p) for p in ctx.params], beta=1.0)
+                for p in ctx.params:
+                    red.touch(p)
+                red.end_pass()
+                return (None, None, None) + (None,) * len(ctx.params)
+            red.end_pass()
         grads = ops.sign_loss_bwd(ctx.gs, ctx.signs, ctx.gamma0, gout.contiguous())
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 class SignLossModel(nn.Module):
@@ -81,7 +94,13 @@ class SignLossModel(nn.Module):
 
     def forward(self, model):
         gammas, signs = self._pairs(model)
-        return _SignLossFn.apply(self.gamma_0, signs, *gammas)
+        red = None
+        if torch.is_grad_enabled() and gammas and gammas[0].requires_grad:
+            from . import parallel
+            red = parallel.owner_of(gammas[0])
+            if red is not None:
+                red.note_forward()
+        return _SignLossFn.apply(self.gamma_0, signs, red, *gammas)
 
     def compute_ber(self, model):
         """bit errors / bits; the count is an exact int64 device reduction (sign(0) is an error)."""

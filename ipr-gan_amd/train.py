@@ -84,7 +84,9 @@ class Experiment:
         size = ds.get('size', None) or ds.get('crop', None) or 96
         self.data_loader = SyntheticLoader(self.kind, hp.bsz, size)
         if self.kind == 'translation':                          # iteration / log.freq are given in epochs
-            n = math.ceil(len(self.data_loader) / hp.bsz)       # image_translation.py:38-40
+            # image_translation.py:38-40 with the reference's global batch bsz * ngpu (base.py:39): one epoch is
+            # ceil(N / (bsz * world)) iterations of every rank
+            n = math.ceil(len(self.data_loader) / (hp.bsz * self.world))
             hp.iteration *= n
             self.config.log.freq *= n
 
@@ -189,6 +191,12 @@ class Experiment:
         return last
 
 
+def seed_all(seed):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
 def main():
     ap = argparse.ArgumentParser(description='Training script (HIP engine)')
     ap.add_argument('-c', '--config', required=True, help='path to a reference config file')
@@ -198,10 +206,13 @@ def main():
     config = Config.parse(args.config)
     if args.log_path:
         config.log.path = args.log_path
-    torch.manual_seed(config.seed)                              # train.py:43-47
-    np.random.seed(config.seed)
-    random.seed(config.seed)
+    seed_all(config.seed)                                       # train.py:43-47
     exp = Experiment(config)
+    # Construction used the SAME seed on every rank on purpose: the black-box trigger / target modules
+    # (RandomBitMask, RandomNoisePatch, TransformVar) and a random sign string are drawn there and must be identical
+    # across replicas.  From here on every rank draws its OWN data shard, latents and ImagePool decisions
+    # ("each rank draws its own z (seed + rank)").
+    seed_all(config.seed + exp.rank)
     ckpt = os.path.join(config.log.path, 'checkpoint.pt')
     if os.path.exists(ckpt):                                    # train.py:26-31 auto-resume
         exp.load_state_dict(torch.load(ckpt, map_location=exp.device[0]))

@@ -1,7 +1,12 @@
-"""GPU: the data-parallel step of the real engine with CUDA tensors - two ranks share the one GPU of the test
-box and exchange gradients over gloo (RCCL needs one GPU per rank; the 8-GPU run is the driver's).  Exercises
-what the CPU gloo test cannot: post-accumulate-grad hooks fired from the HIP chain's backward, bucket copies and the
-side-stream ordering against the compute stream, Adam on the averaged bucket views."""
+"""GPU: the data-parallel step of the real engine with CUDA tensors.
+
+* two ranks share the one GPU of the test box and exchange gradients over gloo (RCCL needs one GPU per rank; the
+  8-GPU run is the driver's): bucket views written by the HIP chain's backward, side-stream ordering against the
+  compute stream, Adam's folded 1/world, rank-local data;
+* one rank with a single-rank RCCL communicator (IPRGAN_FORCE_COMM=1): the C-ABI comm entry points
+  (iprgan_comm_unique_id / _init / iprgan_allreduce_bucket / _destroy) really run RCCL on the device, results are
+  bit-identical to the run without a communicator, and the exchange of the first bucket is enqueued BEFORE the
+  first layer's weight-gradient kernel of the network's last backward pass (overlap by construction)."""
 import os
 import socket
 import sys
@@ -24,10 +29,14 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out):
+def _paths():
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
+
+
+def _worker(rank, world, port, out):
+    _paths()
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from iprgan import Config, models
@@ -52,6 +61,7 @@ def _worker(rank, world, port, out):
                     'local_bn': not torch.equal(gb[0], gb[1]),
                     'finite': bool(torch.isfinite(flat).all()),
                     'ber': float(m.loss_model.compute_ber(m.G)),
+                    'scale': (m.optG.grad_scale, m.optD.grad_scale),
                     'buckets': (len(m.reduceG.buckets), len(m.reduceD.buckets))}, out)
     dist.barrier()
     dist.destroy_process_group()
@@ -64,4 +74,117 @@ def test_dcgan_steps_two_ranks_on_one_gpu(tmp_path):
     assert res['finite'] and res['ber'] == 0.0
     assert res['same_params'], 'replicas diverged: gradients were not averaged identically on both ranks'
     assert res['local_bn'], 'BatchNorm statistics are per-rank (the reference DataParallel does not sync them)'
+    assert res['scale'] == (0.5, 0.5)
     assert res['buckets'][0] >= 2 and res['buckets'][1] >= 1
+
+
+def _two_rank_average_worker(rank, world, port, out):
+    """Two ranks with the SAME weights and DIFFERENT shards: after one D update every rank's weights must equal those of
+    a single process that saw... the mean gradient.  Checked through linearity: rank r feeds shard r; a third, local
+    run computes both shards' gradients without the reducer and averages them."""
+    _paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from iprgan import Config, models
+    from oracle import cases, recipe
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    m = models.DCGAN(Config(cases.DCGAN_CFG), device=[dev])
+    recipe.fill(m.G.module, 3); recipe.fill(m.D.module, 4)
+    x = torch.tanh(recipe.tensor(70 + rank, 0, (4, 3, 64, 64)))
+    z = recipe.tensor(80 + rank, 0, (4, 128))
+    m.forward_d({'real_sample': x, 'latent': z})
+    m.compute_d_loss()
+    m.optD.zero_grad()
+    m.reduceD.arm()
+    m.LossD.backward()
+    m.reduceD.reduce(); m.reduceD.wait()
+    mine = torch.cat([p.grad.flatten() for p in m.D.parameters()]).cpu() * m.reduceD.scale
+    # the same two local gradients, exchanged by hand
+    m2 = models.DCGAN(Config(cases.DCGAN_CFG), device=[dev])
+    recipe.fill(m2.G.module, 3); recipe.fill(m2.D.module, 4)
+    m2.reduceD.close()                                          # no reducer: plain autograd accumulation
+    m2.forward_d({'real_sample': x, 'latent': z})
+    m2.compute_d_loss()
+    m2.LossD.backward()
+    local = torch.cat([p.grad.flatten() for p in m2.D.parameters()]).cpu()
+    dist.all_reduce(local)
+    want = local / world
+    if rank == 0:
+        torch.save({'err': float((mine - want).abs().max()), 'scale': float(want.abs().max())}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduced_gradient_is_the_mean_of_the_ranks_gradients(tmp_path):
+    out = str(tmp_path / 'res.pt')
+    mp.spawn(_two_rank_average_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res['err'] <= 1e-5 * res['scale'], res
+
+
+def _overlap_worker(rank, out):
+    _paths()
+    from iprgan import Config, models, parallel
+    from oracle import cases, recipe
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+
+    def run(force):
+        if force:
+            os.environ['IPRGAN_FORCE_COMM'] = '1'
+            os.environ['IPRGAN_BUCKET_MB'] = '4'
+        else:
+            os.environ.pop('IPRGAN_FORCE_COMM', None)
+        torch.manual_seed(1)
+        m = models.WhiteBoxWrapper(models.DCGAN(Config(cases.DCGAN_CFG), device=[dev]), Config(cases.WBOX_CFG))
+        recipe.fill(m.G.module, 3); recipe.fill(m.D.module, 4)
+        traces = None
+        for s in range(3):
+            x = torch.tanh(recipe.tensor(50, s, (32, 3, 64, 64)))
+            z = recipe.tensor(60, s, (32, 128))
+            if force and s == 2:
+                m.reduceD.trace, m.reduceG.trace = [], []
+            m.update_d({'real_sample': x, 'latent': z})
+            m.update_g({'fake_sample': m.fake_sample})
+        torch.cuda.synchronize()
+        info = {}
+        if force:
+            for name, red in (('D', m.reduceD), ('G', m.reduceG)):
+                info[name] = {'trace': [t for t in red.trace], 'nb': len(red.buckets),
+                              'transport': red.transport.__name__ if red.transport else 'None',
+                              'gap_ms': red.buckets[0]['ready'].elapsed_time(red.buckets[-1]['ready'])
+                              if len(red.buckets) > 1 else None}
+        flat = torch.cat([p.detach().flatten() for n in (m.G, m.D) for p in n.parameters()]).cpu()
+        return flat, m.get_metrics(), info
+
+    from iprgan import _lib
+    plain, met0, _ = run(False)
+    forced, met1, info = run(True)
+    nranks = _lib.query('iprgan_comm_nranks')
+    parallel.RcclTransport.destroy()
+    torch.save({'equal': bool(torch.equal(plain, forced)), 'metrics_equal': met0 == met1, 'info': info,
+                'nranks': nranks, 'after_destroy': _lib.query('iprgan_comm_nranks')}, out)
+
+
+def test_rccl_bucket_exchange_is_enqueued_before_the_first_layers_wgrad(tmp_path):
+    out = str(tmp_path / 'res.pt')
+    mp.spawn(_overlap_worker, args=(out,), nprocs=1, join=True)
+    res = torch.load(out)
+    assert res['nranks'] == 1 and res['after_destroy'] == 0
+    assert res['equal'] and res['metrics_equal'], 'a single-rank all-reduce must not change a single bit'
+    for name in ('D', 'G'):
+        info = res['info'][name]
+        assert info['transport'] == 'RcclTransport', info['transport']
+        tr = info['trace']
+        launches = [t for t in tr if t[0] == 'launch']
+        wgrads = [t for t in tr if t[0] == 'wgrad']
+        assert len(launches) == info['nb'] >= 2
+        # buckets leave in reverse-layer order (two buckets fed by the SAME layer - a weight and its bias - may swap)
+        assert launches[0][1] == 0 and sorted(t[1] for t in launches) == list(range(info['nb']))
+        first_layer = min(wgrads, key=lambda t: t[1])                 # smallest op index = first layer, enqueued last
+        last_pass_first_layer = max(t[2] for t in wgrads if t[1] == first_layer[1])
+        assert launches[0][2] < last_pass_first_layer, 'bucket 0 must be sent before the first layer\'s wgrad is enqueued'
+        # device time between the moment bucket 0 was ready and the moment the last bucket was: backward kernels ran
+        # in between, i.e. the first exchange had that long to hide
+        assert info['gap_ms'] > 0.0, info

@@ -443,7 +443,7 @@ def test_loss_factories_vs_oracle(name, normalized, dev):
     xb = x.clone().to(dev).requires_grad_()
     la = getattr(bbox, name)(normalized=normalized)(xa, y)
     lb = getattr(tools, name)(normalized=normalized)(xb, y.to(dev))
-    np.testing.assert_allclose(float(lb), float(la), rtol=2e-6)
+    np.testing.assert_allclose(float(lb.detach()), float(la.detach()), rtol=2e-6)
     la.backward(); lb.backward()
     np.testing.assert_allclose(xb.grad.cpu().numpy(), xa.grad.numpy(), rtol=1e-6, atol=1e-10)
 
