@@ -35,6 +35,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+_LEGACY = os.environ.get('IPRGAN_DIRECT_GRADS', '1') == '0'     # A/B switch: gradients through autograd (1 rank only)
 _seq = itertools.count()            # global enqueue order, for the overlap trace (tests/test_gpu_ddp.py)
 _owner = {}                         # id(parameter) -> (weakref to it, GradReducer that owns its gradient)
 
@@ -175,7 +176,7 @@ class GradReducer:
     # -- per-step protocol -----------------------------------------------------------------------------------
     def arm(self):
         """Between ``zero_grad()`` and ``backward()``: clear the buckets and make them the parameters' ``.grad``."""
-        if not self.params:
+        if not self.params or (_LEGACY and self.world == 1):
             return
         self._ensure()
         if self.flat.is_cuda:

@@ -179,6 +179,12 @@ class Experiment:
         for step in range(self.init_step, last + 1):
             self._step = step
             self.train()
+            if step == self.init_step + 1:
+                # long-lived objects out of the cyclic collector's sight: a generation-2 pass over torch's ~1 M objects
+                # stalls the enqueueing thread for ~100 ms every few dozen iterations otherwise
+                import gc
+                gc.collect()
+                gc.freeze()
             self.checkpoint(metrics_every)
         if last >= total:
             self._step = 'end'

@@ -47,6 +47,8 @@ def _worker(rank, world, port, out):
     for s in range(2):
         x = torch.tanh(recipe.tensor(50 + rank, s, (4, 3, 64, 64)))          # every rank its own shard
         z = recipe.tensor(60 + rank, s, (4, 128))
+        if s == 1:
+            m.reduceG.trace = []
         m.update_d({'real_sample': x, 'latent': z})
         m.update_g({'fake_sample': m.fake_sample})
     torch.cuda.synchronize()
@@ -62,6 +64,7 @@ def _worker(rank, world, port, out):
                     'finite': bool(torch.isfinite(flat).all()),
                     'ber': float(m.loss_model.compute_ber(m.G)),
                     'scale': (m.optG.grad_scale, m.optD.grad_scale),
+                    'traceG': list(m.reduceG.trace),
                     'buckets': (len(m.reduceG.buckets), len(m.reduceD.buckets))}, out)
     dist.barrier()
     dist.destroy_process_group()
@@ -75,6 +78,10 @@ def test_dcgan_steps_two_ranks_on_one_gpu(tmp_path):
     assert res['same_params'], 'replicas diverged: gradients were not averaged identically on both ranks'
     assert res['local_bn'], 'BatchNorm statistics are per-rank (the reference DataParallel does not sync them)'
     assert res['scale'] == (0.5, 0.5)
+    # on both ranks' shared GPU: G's first bucket (last layers) is sent before the first layer's wgrad is enqueued
+    launches = [t for t in res['traceG'] if t[0] == 'launch']
+    wgrads = [t for t in res['traceG'] if t[0] == 'wgrad']
+    assert launches and launches[0][1] == 0 and launches[0][2] < max(t[2] for t in wgrads if t[1] == min(w[1] for w in wgrads))
     assert res['buckets'][0] >= 2 and res['buckets'][1] >= 1
 
 
