@@ -1,25 +1,36 @@
-"""bench.py — imgs/sec of one G+D training step, DCGAN-64 + sign-loss watermark, batch 128 per GPU.
+"""bench.py — imgs/sec of one G+D training step on the HIP engine.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is launched by
 ``python -m torch.distributed.run --nproc-per-node N ...`` (one process per GPU, RCCL).  Rank 0
-prints ONE JSON line.
+prints ONE JSON line.  The default workload is the headline metric of BASELINE.json:
+
+    DCGAN-64 + sign-loss white-box watermark, batch 128 per GPU, fp32          (--workload dcgan64)
 
 A "step" is the body of the reference's hot loop, ``ImageGeneration.train()``
 (experiments/image_generation.py:86-101): ``model.update_d({real_sample, latent})`` then
 ``model.update_g({fake_sample: model.fake_sample})`` with ``models.WhiteBoxWrapper`` on top
-(configs/DCGAN: gamma_0 0.1, string 'EXAMPLE A'), fp32, Adam(2e-4, (0.5, 0.999)) on G and D.
+(configs/DCGAN: gamma_0 0.1, string 'EXAMPLE A'), Adam(2e-4, (0.5, 0.999)) on G and D.
 Inputs are synthetic (x = tanh(randn), z = randn) and already resident in HBM
 when the timed region starts; weights are random-init.  Nothing is skipped: both optimizer steps,
 spectral-norm power iterations, BatchNorm statistics and the sign loss run inside the timed region.
 
+``--workload`` selects the other BASELINE.json configs with the same JSON schema (secondary lines, not the headline):
+    dcgan128  DCGAN 128x128 batch 256 (config 5; add --math bf16 for its bf16 MFMA tiles)
+    srgan     SRGAN 24->96 GAN-phase step, batch 64, VGG19 features (image_super_resolution.py:84-113)
+    cyclegan  CycleGAN Resnet9Blocks + PatchGAN, 256x256, batch 8 per GPU (image_translation.py:90-112)
+
 Extra objects on the JSON line:
   roofline      the conv kernel with the largest share of device time: algorithmic FLOPs
-                (2*B*OH*OW*Cout*Cin*KH*KW per launch) / HIP-event launch durations, against the fp32
-                MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md)
-  cpu_baseline  the CPU oracle (oracle/gan.py, plain PyTorch fp32: the reference's own arithmetic)
-                timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1)
+                (2*B*OH*OW*Cout*Cin*KH*KW per launch) / HIP-event launch durations measured live in this run, against
+                the MFMA peak of the math mode (157.3 TFLOP/s fp32, 2500 bf16; MI355X_MICROARCH.md).  ``traffic`` and
+                ``mfma_util_pct_pmc`` are NOT measured in this run: they are read from the committed rocprofv3 --pmc
+                passes under profiles/ and carry their file name in ``*_source``.
+  cpu_baseline  the CPU oracle (oracle/gan.py, plain PyTorch fp32: the reference's own arithmetic) timed on this box's
+                host cores on a bounded sample of the same workload (rank 0, N=1), BEFORE the GPU section
 """
 import argparse
+import gc
+import glob
 import json
 import os
 import sys
@@ -33,20 +44,89 @@ for _p in (ROOT, os.path.join(ROOT, 'ipr-gan_amd')):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-BATCH = 128
 PEAK_FP32_MFMA = 157.3e12
-PROF_EVERY = int(os.environ.get('IPRGAN_BENCH_PROF_EVERY', '4'))
 PEAK_BF16_MFMA = 2500e12          # dense bf16 MFMA (MI355X_MICROARCH.md); only used with --math bf16
-DCGAN_CFG = {'G': 'ConvGenerator64', 'D': 'SNDiscriminator64', 'opt': 'Adam',
-             'opt_param': {'lr': 2.0e-4, 'betas': [0.5, 0.999]}, 'type': 'DCGAN'}
-WBOX_CFG = {'gamma_0': 0.1, 'string': 'EXAMPLE A', 'target': 'G'}
-GFLOP_PER_IMG = 3 * 0.8279 + 8 * 0.8699      # necessary fwd+dgrad+wgrad
+PROF_EVERY = int(os.environ.get('IPRGAN_BENCH_PROF_EVERY', '4'))
+WBOX_CFG = {'gamma_0': 0.1, 'string': 'EXAMPLE A'}
+ADAM_GAN = {'lr': 2.0e-4, 'betas': [0.5, 0.999]}
+
+
+def _dcgan_cfg(size):
+    return {'G': f'ConvGenerator{size}', 'D': f'SNDiscriminator{size}', 'opt': 'Adam', 'opt_param': ADAM_GAN,
+            'type': 'DCGAN'}
+
+
+DCGAN_CFG = _dcgan_cfg(64)        # (kept under this name: tests and scripts import it)
+SRGAN_CFG = {'G': 'SRResNet', 'D': 'Discriminator96', 'V': 'VGG19Feature', 'opt': 'Adam', 'opt_param': {'lr': 1.0e-4},
+             'type': 'SRGAN'}
+CYCLEGAN_CFG = {'G': 'Resnet9Blocks', 'D': 'ConvDiscriminator', 'opt': 'Adam', 'opt_param': ADAM_GAN, 'type': 'CycleGAN',
+                'pool_size': 50, 'lambda_A': 10.0, 'lambda_B': 10.0, 'lambda_idt': 0.5, 'epoch': 200}
+
+# per-sample algorithmic GFLOP of one step (SURVEY.md section 8d / BASELINE.md section 4: 2*MAC of conv / conv-transpose /
+# linear layers, forward + the backward passes whose gradient is consumed)
+WORKLOADS = {
+    'dcgan64': dict(batch=128, gflop=3 * 0.8279 + 8 * 0.8699, unit='img/s',
+                    metric='imgs/sec G+D step (DCGAN-64 bs128)',
+                    text='DCGAN-64 (ConvGenerator64 + SNDiscriminator64) + sign-loss white-box watermark, G+D step, '
+                         'batch 128 per GPU'),
+    'dcgan128': dict(batch=256, gflop=3 * 3.3114 + 8 * 3.4794, unit='img/s',
+                     metric='imgs/sec G+D step (DCGAN-128 bs256)',
+                     text='DCGAN-128 (ConvGenerator(mg=16) + SNDiscriminator(md=16)) + sign-loss white-box watermark, '
+                          'G+D step, batch 256 per GPU'),
+    'srgan': dict(batch=64, gflop=3 * 2.5553 + 8 * 1.7683 + 3 * 7.1664, unit='img/s',
+                  metric='imgs/sec G+D step (SRGAN 24->96 bs64, GAN phase)',
+                  text='SRGAN GAN phase (SRResNet + Discriminator96 + VGG19[:36] features, random-init) + sign-loss '
+                       'watermark, G+D step, 24x24 -> 96x96, batch 64 per GPU'),
+    'cyclegan': dict(batch=8, gflop=18 * 99.103 + 16 * 6.2936, unit='pairs/s',
+                     metric='image pairs/sec G+D step (CycleGAN Resnet9 256x256 bs8)',
+                     text='CycleGAN (2 x Resnet9Blocks + 2 x ConvDiscriminator) + sign-loss watermark on GB, G+D step, '
+                          '256x256, batch 8 per GPU'),
+}
+
+
+def make_workload(name, device, impl):
+    """Build the model and the step closure of a workload on ``device`` with implementation ``impl`` = (Config class,
+    models namespace): the HIP engine, or the CPU oracle for the baseline.  Returns (model, step, metrics_fn)."""
+    make_cfg, models = impl
+    w = WORKLOADS[name]
+    B = w['batch']
+    dev = device[0]
+    if name in ('dcgan64', 'dcgan128'):
+        S = 64 if name == 'dcgan64' else 128
+        model = models.WhiteBoxWrapper(models.DCGAN(make_cfg(_dcgan_cfg(S)), device=device), make_cfg(dict(WBOX_CFG, target='G')))
+        pool = 8 if S == 64 else 2                      # synthetic batches resident on the device, cycled
+        xs = [torch.tanh(torch.randn(B, 3, S, S, device=dev)) for _ in range(pool)]
+        zs = [torch.randn(B, 128, device=dev) for _ in range(pool)]
+
+        def step(i):
+            model.update_d({'real_sample': xs[i % pool], 'latent': zs[i % pool]})
+            model.update_g({'fake_sample': model.fake_sample})
+    elif name == 'srgan':
+        model = models.WhiteBoxWrapper(models.SRGAN(make_cfg(SRGAN_CFG), device=device), make_cfg(dict(WBOX_CFG, target='G')))
+        pool = 4
+        lrs = [torch.rand(B, 3, 24, 24, device=dev) for _ in range(pool)]
+        hrs = [torch.rand(B, 3, 96, 96, device=dev) for _ in range(pool)]
+
+        def step(i):
+            model.update_g({'low_res': lrs[i % pool], 'high_res': hrs[i % pool], 'pretrain': False})
+            model.update_d({'high_res': model.high_res, 'super_res': model.super_res})
+    else:
+        model = models.WhiteBoxWrapper(models.CycleGAN(make_cfg(CYCLEGAN_CFG), device=device), make_cfg(dict(WBOX_CFG, target='GB')))
+        pool = 2
+        As = [torch.tanh(torch.randn(B, 3, 256, 256, device=dev)) for _ in range(pool)]
+        Bs = [torch.tanh(torch.randn(B, 3, 256, 256, device=dev)) for _ in range(pool)]
+
+        def step(i):
+            model.update_g({'real_A': As[i % pool], 'real_B': Bs[i % pool]})
+            model.update_d({'real_A': model.real_A, 'real_B': model.real_B,
+                            'fake_A': model.fake_A.detach(), 'fake_B': model.fake_B.detach()})
+    return model, step
 
 
 def build_model(device):
+    """The headline model on ``device`` (used by scripts/ and tests)."""
     from iprgan import Config, models
-    model = models.DCGAN(Config(DCGAN_CFG), device=[device])
-    return models.WhiteBoxWrapper(model, Config(WBOX_CFG))
+    return models.WhiteBoxWrapper(models.DCGAN(Config(DCGAN_CFG), device=[device]), Config(dict(WBOX_CFG, target='G')))
 
 
 def step(model, x, z):
@@ -58,43 +138,93 @@ def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
-def cpu_baseline(max_timed=3, budget_s=25.0):
-    """The oracle's step on the host CPU: 1 warm-up + up to max_timed steps of the same workload
-    (stops early once budget_s of CPU time is spent)."""
+def host_cpu():
+    """CPU model / logical CPUs / physical cores of this box (SURVEY.md section 8d asks for them next to the baseline)."""
+    model, phys = 'unknown', set()
+    try:
+        pid = cid = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name') and model == 'unknown':
+                model = line.split(':', 1)[1].strip()
+            elif line.startswith('physical id'):
+                pid = line.split(':', 1)[1].strip()
+            elif line.startswith('core id'):
+                cid = line.split(':', 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return {'model': model, 'logical_cpus': os.cpu_count(), 'physical_cores': len(phys) or None}
+
+
+def cpu_baseline(name, warm=3, max_timed=10, budget_s=30.0):
+    """The oracle's step on the host CPU: ``warm`` warm-up + up to ``max_timed`` timed steps of the same workload,
+    bounded by ``budget_s`` seconds of timed work (at least one timed step; the warm-up is cut to one step when a
+    single step already takes more than a third of the budget).  SURVEY.md section 8d protocol: 3 warm-up + >= 10 timed
+    where the budget allows; the sample actually taken is stated in the result."""
     from oracle import gan
     torch.manual_seed(1234)
     threads = torch.get_num_threads()            # torch's default = cores this process may use
-    m = gan.WhiteBoxWrapper(gan.DCGAN(gan.Cfg(DCGAN_CFG)), gan.Cfg(WBOX_CFG))
-    x, z = torch.tanh(torch.randn(BATCH, 3, 64, 64)), torch.randn(BATCH, 128)
+    w = WORKLOADS[name]
+    model, step_fn = make_workload(name, gan.CPU, (gan.Cfg, gan))
     t0 = time.perf_counter()
-    step(m, x, z)
-    log(f'cpu baseline warm-up step {time.perf_counter() - t0:.1f}s on {threads} threads')
+    step_fn(0)
+    first = time.perf_counter() - t0
+    n_warm = 1
+    while n_warm < warm and first * 3 < budget_s:
+        step_fn(n_warm)
+        n_warm += 1
+    log(f'cpu baseline: {n_warm} warm-up step(s), first {first:.1f}s, {threads} threads')
     n_timed, t0 = 0, time.perf_counter()
     while n_timed < max_timed and (n_timed == 0 or time.perf_counter() - t0 < budget_s):
-        step(m, x, z)
+        step_fn(n_warm + n_timed)
         n_timed += 1
     dt = (time.perf_counter() - t0) / n_timed
-    return {'value': round(BATCH / dt, 2), 'unit': 'img/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n_timed} timed steps (+1 warm-up) of DCGAN-64+sign-loss B={BATCH}, fp32, '
-                      f'torch {torch.__version__} CPU, {threads} threads; {dt * 1e3:.0f} ms/step'}
+    cpu = host_cpu()
+    return {'value': round(w['batch'] / dt, 3), 'unit': w['unit'], 'cores': threads, 'kind': 'port',
+            'cpu_model': cpu['model'], 'logical_cpus': cpu['logical_cpus'], 'physical_cores': cpu['physical_cores'],
+            'sample': f'{n_timed} timed steps (+{n_warm} warm-up; budget {budget_s:.0f}s of timed work) of {w["text"]}, '
+                      f'fp32, torch {torch.__version__} CPU, {threads} threads; {dt * 1e3:.0f} ms/step'}
+
+
+def _latest_profile(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+    return files[-1] if files else None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--workload', choices=list(WORKLOADS), default='dcgan64')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--math', choices=['fp32', 'bf16'], default='fp32',
                     help="conv math mode; the headline metric is fp32 (the reference's precision). 'bf16' = bf16 MFMA "
-                         "tiles with fp32 accumulation / tensors / master weights, reported with dtype bf16")
+                         "tiles with fp32 accumulation / master weights, reported with dtype bf16")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    heavy = args.workload in ('cyclegan', 'dcgan128')
+    if args.steps is None:
+        args.steps = 10 if heavy else 50
+    if args.warmup is None:
+        args.warmup = 4 if heavy else 10
 
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU path)')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    # The CPU baseline runs FIRST (rank 0, single-GPU runs only) so that the GPU section is the last thing this process
+    # does: the driver's GPU-activity sampler then sees the timed region instead of a CPU-bound tail.
+    baseline = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        baseline = cpu_baseline(args.workload, budget_s=20.0 if heavy else 30.0)
+
     ndev = torch.cuda.device_count()
     if local >= ndev and os.environ.get('IPRGAN_SHARE_DEVICE') == '1':
         local = local % ndev            # test-only: several ranks on one GPU (needs IPRGAN_DIST_BACKEND=gloo)
@@ -107,28 +237,23 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    from iprgan import _lib
+    from iprgan import Config, _lib, models
     _lib.set_math(args.math)
-    torch.manual_seed(1234 + rank)
-    model = build_model(device)
-    pool = 8                                      # synthetic batches resident in HBM, cycled
-    xs = [torch.tanh(torch.randn(BATCH, 3, 64, 64, device=device)) for _ in range(pool)]
-    zs = [torch.randn(BATCH, 128, device=device) for _ in range(pool)]
+    torch.manual_seed(1234 + rank)              # every rank its own data shard / latents
+    model, step_fn = make_workload(args.workload, [device], (Config, models))
 
-    log(f'model built on {device}; warm-up {args.warmup} steps')
+    log(f'{args.workload}: model built on {device}; warm-up {args.warmup} steps')
     for i in range(args.warmup):
         # the last warm-up step also warms the instrumentation (HIP event pool of the per-kernel timer)
         _lib.prof_enable(i == args.warmup - 1)
-        step(model, xs[i % pool], zs[i % pool])
+        step_fn(i)
     _lib.prof_enable(False)
     _lib.prof_results()
     torch.cuda.synchronize()
     # Everything alive now (torch's import graph, the model, the kernel tables) lives for the whole run: move it out
     # of the cyclic collector's sight, so that a generation-2 pass (80-120 ms over ~1 M objects, measured: one lands in
     # any 50-step window) does not stall the enqueueing thread in the middle of the timed region.  train.py does the same.
-    import gc
     gc.collect()
     gc.freeze()
     log('warm-up done; timing')
@@ -139,7 +264,7 @@ def main():
         torch.cuda.synchronize()
 
     # Per-kernel HIP events ride on the conv-family dispatches of every PROF_EVERY-th step of the timed region
-    # (all steps when K < 2 * PROF_EVERY): timing every launch costs ~0.3 ms of a 12.5 ms step in completion-signal
+    # (all steps when K < 2 * PROF_EVERY): timing every launch costs ~0.3 ms of a 12 ms step in completion-signal
     # handling, and the headline value should not pay for its own instrumentation.
     every = PROF_EVERY if (args.steps >= 2 * PROF_EVERY or PROF_EVERY <= 0) else 1
     fence()
@@ -147,7 +272,7 @@ def main():
     stamps = []
     for i in range(args.steps):
         _lib.prof_enable(every > 0 and i % every == 0)
-        step(model, xs[i % pool], zs[i % pool])
+        step_fn(i)
         stamps.append(time.perf_counter())
     host_elapsed = time.perf_counter() - t0          # the host has ENQUEUED all steps (no sync inside the loop)
     fence()
@@ -168,22 +293,24 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
+        B = wl['batch']
         ms = elapsed / args.steps * 1e3
-        value = BATCH * world * args.steps / elapsed
+        value = B * world * args.steps / elapsed
         dom = max(kernels, key=lambda k: k['ms']) if kernels else None
         roof = None
-        traffic = None
+        peak_mode = PEAK_BF16_MFMA if args.math == 'bf16' else PEAK_FP32_MFMA
+        tag = '' if args.workload == 'dcgan64' else args.workload + '_'
+        traffic = traffic_src = util_pmc = util_src = None
         try:          # HBM bytes per launch from the committed PMC passes (profiles/: separate rocprofv3 runs)
-            import glob
-            tf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]
+            tf = _latest_profile(f'r*_{tag}pmc_traffic.json')
             traffic = json.load(open(tf))['kernels'][dom['name']]['hbm_bytes_per_launch']
+            traffic_src = os.path.relpath(tf, ROOT)
         except Exception:
             pass
-        util_pmc = None
         try:          # hardware MFMA utilisation of the step's conv kernels from the committed PMC pass
-            import glob
-            uf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_mfma_util.json')))[-1]
+            uf = _latest_profile(f'r*_{tag}mfma_util.json')
             util_pmc = json.load(open(uf))['all_conv']['mfma_util_pct']
+            util_src = os.path.relpath(uf, ROOT)
         except Exception:
             pass
         if dom:
@@ -191,36 +318,37 @@ def main():
             peak = PEAK_BF16_MFMA if 'bf16' in dom['name'] else PEAK_FP32_MFMA
             roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': round(ach / 1e12, 2),
                     'peak': round(peak / 1e12, 1), 'unit': 'TFLOP/s',
-                    'frac': round(ach / peak, 4), 'traffic': traffic,
-                    'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2)}
+                    'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                    'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
+                    'source': 'HIP events on the launch stream, this run'}
         conv_ms = sum(k['ms'] for k in kernels)
         conv_flops = sum(k['flops'] for k in kernels)
         out = {
-            'metric': 'imgs/sec G+D step (DCGAN-64 bs128)', 'value': round(value, 1), 'unit': 'img/s',
+            'metric': wl['metric'], 'value': round(value, 2), 'unit': wl['unit'],
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.math == 'fp32' else 'bf16',
             'data': 'synthetic',
-            'config': {'workload': 'DCGAN-64 (ConvGenerator64 + SNDiscriminator64) + sign-loss white-box '
-                                   'watermark, G+D step, batch 128 per GPU, ' +
-                                   ('fp32' if args.math == 'fp32' else 'bf16 MFMA tiles (fp32 accumulate, fp32 tensors)') +
+            'config': {'workload': wl['text'] + ', ' +
+                                   ('fp32' if args.math == 'fp32' else 'bf16 MFMA tiles (fp32 accumulate, fp32 master weights)') +
                                    ', Adam',
-                       'global_batch': BATCH * world, 'parallelism': f'dp{world}'},
+                       'global_batch': B * world, 'parallelism': f'dp{world}'},
             'roofline': roof,
             'conv_kernels': {'device_ms_per_step': round(conv_ms / prof_steps, 3), 'steps_sampled': prof_steps,
                              'tflops': round(conv_flops / max(conv_ms, 1e-9) / 1e9, 2),
-                             'mfma_util_pct': round(100 * conv_flops / max(conv_ms, 1e-9) / 1e9 / 157.3, 1),
-                             'mfma_util_pct_pmc': util_pmc,
+                             'mfma_util_pct': round(100 * conv_flops / max(conv_ms, 1e-9) / 1e-3 / peak_mode, 1),
+                             'mfma_util_pct_pmc': util_pmc, 'mfma_util_pct_pmc_source': util_src,
                              'by_kernel': [{'name': k['name'], 'launches': k['launches'],
                                             'ms': round(k['ms'], 2),
                                             'tflops': round(k['flops'] / max(k['ms'], 1e-9) / 1e9, 2)}
                                            for k in kernels]},
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
-            'step_algorithmic_tflops': round(GFLOP_PER_IMG * BATCH * world / ms, 2),
+            'step_algorithmic_tflops': round(wl['gflop'] * B * world / ms, 2),
+            'step_roofline_frac': round(wl['gflop'] * B * world / ms * 1e12 / peak_mode, 4),
             'metrics_last_step': {k: round(v, 5) for k, v in metrics.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+        if baseline is not None:
+            out['cpu_baseline'] = baseline
         print(json.dumps(out), flush=True)
     if world > 1:
         from iprgan import parallel

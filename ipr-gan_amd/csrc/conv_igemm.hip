@@ -32,6 +32,8 @@ static ProfSlot g_slots[] = {
     {"gconv_kernel<64x128>", 0, 0, 0},  {"gconv_kernel<128x128,8w>", 0, 0, 0},
     {"gconv_kernel<128x64,8w>", 0, 0, 0}, {"wgrad_kernel<128x128,8w>", 0, 0, 0},
     {"gconv_bf16_kernel", 0, 0, 0},     {"wgrad_bf16_kernel", 0, 0, 0},
+    {"wgrad_t_kernel<128x128>", 0, 0, 0}, {"wgrad_t_kernel<128x64>", 0, 0, 0},
+    {"wgrad_t_kernel<64x64>", 0, 0, 0},   {"wgrad_t_kernel<128x128,8w>", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; };
@@ -513,6 +515,7 @@ struct WGradArgs {
   int chunks_per_split;
   unsigned p_bytes, q_bytes;
   int dx32, dy32;            // 32 rows of m = db32 images + dy32 rows + dx32 pixels (mixed radix of PH x PW)
+  int xcd;                   // wgrad_t_kernel: XCD-contiguous tile order
   unsigned bstep0, bstep1;   // byte step of the image base for db32 / db32+1 images
   double flops;
 };
@@ -773,6 +776,227 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
             const f32x4 v = {t[j][0], t[j][1], t[j][2], t[j][3]};
             *(f32x4*)(row + k) = v;
           }
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward-weight, second form ("transposed image"): the same GEMM  ws[split][n][k] = sum_m P[m][n] Q[m][k], but
+// the LDS tiles have the layout of gconv_kernel - one 128-byte row per OUTPUT row (n for P, k for Q) holding the 32
+// reduction indices m of the stage as eight 16-byte chunks of 4 consecutive m - so that the fragment reads are the
+// conflict-free ds_read_b128 pairs of gconv_kernel (one pair feeds 4 MFMAs; 16 LDS reads per 64 MFMAs instead of 32)
+// and the inner loop IS gconv's.  The data arrive from HBM the other way round (a 16-byte load = 4 channels of ONE
+// pixel), so every loader thread owns a 4 pixel x 4 channel block: four 16-byte loads (consecutive pixels), a 4x4
+// transpose in registers, four 16-byte stores (one per channel).  Lanes 0-7 of a store group cover 4 channel chunks x
+// 2 pixel groups: their 8 slots of the 128-byte bank line are distinct (chunk c of row r sits at c ^ ((r >> 1) & 7)).
+// With PW % 4 == 0 (every map of the three GANs except the PatchGAN's 31/30-pixel ones) the four pixels of a block
+// lie in one image row: one (y, x) state per thread instead of four, and the tap / border arithmetic is shared.
+// ------------------------------------------------------------------------------------------
+template <int WGM, int WGN, int WM, int WN, bool REFLECT, bool ROW4>
+__global__ __launch_bounds__(WGM * WGN * 64) void wgrad_t_kernel(const WGradArgs a) {
+  constexpr int BN = WGM * WM * 32, BK = WGN * WN * 32, NT = WGM * WGN * 64;
+  constexpr int CH = 8;
+  constexpr int NPB = BN / 4 * 8, NQB = BK / 4 * 8;        // 4x4 blocks per operand and stage
+  constexpr bool SPLIT = NPB + NQB <= NT;                  // enough threads: disjoint loaders for P and Q
+  static_assert(NPB <= NT && NQB <= NT, "one block per thread and operand");
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  f32x4* A4 = lds;
+  f32x4* B4 = lds + BN * CH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  // logical tile order: with a.xcd the blocks of one split (which read the same P / Q rows) run on one XCD
+  unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if (a.xcd) lin = xcd_remap(lin, gridDim.x * gridDim.y * gridDim.z);
+  const int tiles = gridDim.x * gridDim.y;
+  const int split = (int)(lin / tiles), tile = (int)(lin % tiles);
+  const int k0 = (tile % (int)gridDim.x) * BK, n0 = (tile / (int)gridDim.x) * BN;
+
+  // loader roles: block index -> (channel chunk c, pixel group g); lane bits [c0 c1 | g0 | c2.. | g1 g2]
+  const bool doP = tid < NPB;
+  const int qt = SPLIT ? tid - (NT - NQB) : tid;
+  const bool doQ = qt >= 0 && qt < NQB;
+  auto decode = [](int idx, int C, int& c, int& g) {
+    const int chi = (idx >> 3) & (C / 4 - 1);
+    c = chi * 4 + (idx & 3);
+    g = ((idx >> 3) / (C / 4)) * 2 + ((idx >> 2) & 1);
+  };
+  int pc = 0, pg = 0, qc = 0, qg = 0;
+  decode(doP ? tid : 0, BN / 4, pc, pg);
+  decode(doQ ? qt : 0, BK / 4, qc, qg);
+
+  // this thread's fixed k-chunk of the Q tile
+  const int q = k0 / 4 + qc;
+  const int t = fdiv(q, a.d_c4n);
+  const int c4 = q - t * a.c4n;
+  const bool qvalid = doQ && t < a.ntap;
+  const int ty = fdiv(t, a.d_tw), tx = t - ty * a.tw;
+  const int dy = (ty - a.pad) * a.flip, dx = (tx - a.pad) * a.flip;
+  const bool pvalid = doP && (n0 + pc * 4) < a.Pvalid;
+  const int plane = a.PH * a.PW;
+
+  const int chunk_begin = split * a.chunks_per_split;
+  int chunk_end = chunk_begin + a.chunks_per_split;
+  const int total_chunks = (a.M + 31) / 32;
+  if (chunk_end > total_chunks) chunk_end = total_chunks;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.P, 0, a.p_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)a.Q, 0, a.q_bytes, 0x00020000);
+  const int M = a.M, PW = a.PW, PH = a.PH, QH = a.QH, QW = a.QW, isy = a.isy, isx = a.isx;
+  const int Qs4 = a.Qs * 4, dx32 = a.dx32, dy32 = a.dy32;
+  const unsigned prow = (unsigned)a.Ps * 4u, pstep = 32u * prow, bstep0 = a.bstep0, bstep1 = a.bstep1;
+
+  f32x4 rP[4], rQ[4];
+  // P: rows m = 32 chunk + 4 pg + i; rows past M fall outside the buffer (p_bytes = M * Ps * 4)
+  unsigned po = pvalid ? (unsigned)((chunk_begin * 32 + 4 * pg) * a.Ps) * 4u + (unsigned)(n0 + pc * 4) * 4u : OOB_OFFSET;
+  // Q: running pixel state (see wgrad_kernel), one per block (ROW4) or one per pixel
+  constexpr int NS = ROW4 ? 1 : 4;
+  unsigned qb[NS];
+  int qm[NS], qy[NS], qx[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int m = chunk_begin * 32 + 4 * qg + i;
+    const int b = fdiv(m, a.d_plane);
+    const int rem = m - b * plane;
+    qy[i] = fdiv(rem, a.d_pw);
+    qx[i] = rem - qy[i] * PW;
+    qm[i] = m;
+    qb[i] = (unsigned)b * (unsigned)(QH * QW) * (unsigned)Qs4 + (qvalid ? (unsigned)c4 * 16u : OOB_OFFSET);
+  }
+
+  auto gload = [&]() {
+    if (doP) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rP[i] = buf_load4(rs_p, pvalid ? po + (unsigned)i * prow : OOB_OFFSET);
+      po += pstep;
+    }
+    if (doQ) {
+      if (ROW4) {
+        int iy = __mul24(qy[0], isy) + dy;
+        const int ix0 = __mul24(qx[0], isx) + dx;
+        bool oky = qm[0] < M;
+        if (REFLECT) iy = reflect_idx(iy, QH); else oky = oky && (unsigned)iy < (unsigned)QH;
+        const unsigned rowoff = qb[0] + (unsigned)__mul24(__mul24(iy, QW), Qs4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int ix = ix0 + i * isx;
+          bool ok = oky;
+          if (REFLECT) ix = reflect_idx(ix, QW); else ok = ok && (unsigned)ix < (unsigned)QW;
+          rQ[i] = buf_load4(rs_q, ok ? rowoff + (unsigned)__mul24(ix, Qs4) : OOB_OFFSET);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int iy = __mul24(qy[i], isy) + dy, ix = __mul24(qx[i], isx) + dx;
+          bool ok = qm[i] < M;
+          if (REFLECT) {
+            iy = reflect_idx(iy, QH);
+            ix = reflect_idx(ix, QW);
+          } else {
+            ok = ok && (unsigned)iy < (unsigned)QH && (unsigned)ix < (unsigned)QW;
+          }
+          rQ[i] = buf_load4(rs_q, ok ? qb[i] + (unsigned)__mul24(__mul24(iy, QW) + ix, Qs4) : OOB_OFFSET);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        int x = qx[i] + dx32, y = qy[i] + dy32;
+        const bool cx = x >= PW;
+        x -= cx ? PW : 0;
+        y += cx ? 1 : 0;
+        const bool cy = y >= PH;
+        y -= cy ? PH : 0;
+        qb[i] += cy ? bstep1 : bstep0;
+        qx[i] = x; qy[i] = y; qm[i] += 32;
+      }
+    }
+  };
+  auto lstore = [&]() {
+    if (doP) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * pc + j;
+        const f32x4 v = {rP[0][j], rP[1][j], rP[2][j], rP[3][j]};
+        A4[r * CH + (pg ^ ((r >> 1) & 7))] = v;
+      }
+    }
+    if (doQ) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * qc + j;
+        const f32x4 v = {rQ[0][j], rQ[1][j], rQ[2][j], rQ[3][j]};
+        B4[r * CH + (qg ^ ((r >> 1) & 7))] = v;
+      }
+    }
+  };
+  auto compute = [&]() {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      f32x4 af[WM], bf[WN];
+      const int c = 2 * kq + half;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int r = (wm * WM + i) * 32 + l31;
+        af[i] = A4[r * CH + (c ^ ((r >> 1) & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int r = (wn * WN + j) * 32 + l31;
+        bf[j] = B4[r * CH + (c ^ ((r >> 1) & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  if (chunk_begin < chunk_end) {
+    gload();
+    lstore();
+    __syncthreads();
+    for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+      const bool more = ch + 1 < chunk_end;
+      if (more) gload();
+      compute();
+      __syncthreads();
+      if (more) lstore();
+      __syncthreads();
+    }
+  }
+
+  // slab store: quad transpose (see gconv epilogue) so that every lane writes 16 contiguous bytes
+  const int half = lane >> 5, l31 = lane & 31;
+  const int qp = lane & 3, q4 = (l31 >> 2);
+  float* slab = a.ws + (size_t)split * a.Nrows * a.Kw;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + (wm * WM + i) * 32 + 8 * g + 4 * half + qp;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        float t0 = acc[i][j][4 * g], t1 = acc[i][j][4 * g + 1], t2 = acc[i][j][4 * g + 2], t3 = acc[i][j][4 * g + 3];
+        quad_transpose(t0, t1, t2, t3, qp);
+        const int k = k0 + (wn * WN + j) * 32 + 4 * q4;
+        if (n < a.Nrows && k < a.Kw) {
+          const f32x4 v = {t0, t1, t2, t3};
+          *(f32x4*)(slab + (size_t)n * a.Kw + k) = v;
         }
       }
     }
@@ -1224,6 +1448,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
 // ---- backward-weight ------------------------------------------------------------------------
 struct WGradPlan {
   int N, Cq, Ps, Qs, ntap, Kw, Nrows, bn, bk, tiles, nsplit, cps, M, w8;
+  int variant;      // 0: wgrad_kernel ([m][n] LDS image), 1: wgrad_t_kernel (transposed image), 2: the same, XCD-contiguous splits
 };
 // cand = 4 * target + shape.  shape: 0 = 128x128 tiles, 1 = 64x64, 2 = 128x64, 3 = 128x128 on 8 waves;
 // target blocks {768, 1536, 3072, 6144, 384}.  768 blocks are ONE round of 3 blocks per CU; on long reductions
@@ -1231,7 +1456,9 @@ struct WGradPlan {
 // traffic of the extra splits costs more.  (Starting the blocks of a round out of phase with s_sleep did nothing.)
 #define WGRAD_NSHAPE 4
 #define WGRAD_NTARGET 5
-#define WGRAD_NCAND (WGRAD_NSHAPE * WGRAD_NTARGET)
+#define WGRAD_NBASE (WGRAD_NSHAPE * WGRAD_NTARGET)
+#define WGRAD_NVARIANT 3
+#define WGRAD_NCAND (WGRAD_NBASE * WGRAD_NVARIANT)     // cand = WGRAD_NBASE * variant + 4 * target + shape
 #define WGRAD_MAX_SLAB_FLOATS ((size_t)128 << 20)      // candidates needing more than 512 MB of slabs are skipped
 // Roles of the two tensors.  P is walked on its own pixel grid (the GEMM's reduction index m), Q is gathered
 // around it tap by tap; the slab is [P channel][(tap, Q channel)].
@@ -1271,6 +1498,10 @@ static size_t wgrad_padded_floats(const iprgan_conv_desc* d) {
 
 static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   const WGeom g = wgrad_geom(d);
+  if (cand < 0 || cand >= WGRAD_NCAND) return false;
+  p.variant = cand / WGRAD_NBASE;
+  cand %= WGRAD_NBASE;
+  if (p.variant && (g.N <= 32 || g_math == IPRGAN_MATH_BF16)) return false;   // the 32-row tile and the bf16 image exist in the first form only
   p.N = g.N;
   p.Cq = g.Cq;
   p.Ps = c4(p.N); p.Qs = c4(p.Cq);
@@ -1278,7 +1509,6 @@ static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   p.M = d->B * g.PH * g.PW;
   const int K = p.ntap * p.Qs;
   static const int targets[WGRAD_NTARGET] = {768, 1536, 3072, 6144, 384};
-  if (cand < 0 || cand >= WGRAD_NCAND) return false;
   const int shape = (cand % WGRAD_NSHAPE) == 3 ? 0 : cand % WGRAD_NSHAPE;
   const int target = targets[cand / WGRAD_NSHAPE];
   p.w8 = (cand % WGRAD_NSHAPE) == 3 ? 1 : 0;
@@ -1352,6 +1582,32 @@ static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st
                        : launch_wgrad_tn<WGM, WGN, WM, WN, 2, true>(a, p, st);
   return g_nbuf == 1 ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, false>(a, p, st)
                      : launch_wgrad_tn<WGM, WGN, WM, WN, 2, false>(a, p, st);
+}
+
+template <int WGM, int WGN, int WM, int WN, bool REFLECT, bool ROW4>
+static int launch_wgrad_t2r(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
+  constexpr int BN = WGM * WM * 32, BK = WGN * WN * 32;
+  const size_t smem = (size_t)(BN + BK) * 8 * sizeof(f32x4);
+  auto kern = wgrad_t_kernel<WGM, WGN, WM, WN, REFLECT, ROW4>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(p.Kw / BK, p.Nrows / BN, p.nsplit);
+  prof_launch(kern, grid, dim3(WGM * WGN * 64), smem, st,
+              WGM * WGN == 8 ? 17 : BN == 128 ? (BK == 128 ? 14 : 15) : 16, a.flops, a);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+template <int WGM, int WGN, int WM, int WN>
+static int launch_wgrad_t2(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
+  const bool row4 = (a.PW % 4) == 0;
+  if (a.pad_mode == IPRGAN_PAD_REFLECT)
+    return row4 ? launch_wgrad_t2r<WGM, WGN, WM, WN, true, true>(a, p, st)
+                : launch_wgrad_t2r<WGM, WGN, WM, WN, true, false>(a, p, st);
+  return row4 ? launch_wgrad_t2r<WGM, WGN, WM, WN, false, true>(a, p, st)
+              : launch_wgrad_t2r<WGM, WGN, WM, WN, false, false>(a, p, st);
 }
 
 }  // namespace iprgan
@@ -1549,6 +1805,13 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW
                             : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
     int rc;
+    a.xcd = p.variant == 2;
+    if (p.variant) {
+      if (p.w8) rc = launch_wgrad_t2<2, 4, 2, 1>(a, p, st);
+      else if (p.bn == 128 && p.bk == 128) rc = launch_wgrad_t2<2, 2, 2, 2>(a, p, st);
+      else if (p.bn == 64) rc = launch_wgrad_t2<2, 2, 1, 1>(a, p, st);
+      else rc = launch_wgrad_t2<2, 2, 2, 1>(a, p, st);
+    } else
     if (p.w8) rc = launch_wgrad_t<2, 4, 2, 1>(a, p, st);        // 128x128, 8 waves of 64x32
     else if (p.bn == 128 && p.bk == 128) rc = launch_wgrad_t<2, 2, 2, 2>(a, p, st);
     else if (p.bn == 64) rc = launch_wgrad_t<2, 2, 1, 1>(a, p, st);

@@ -457,8 +457,11 @@ def test_every_gconv_tile_variant(dev, tile):
         _lib.call('iprgan_debug_force_tiles', -1, -1)
 
 
-@pytest.mark.parametrize('cand', range(20))
+@pytest.mark.parametrize('cand', range(60))
 def test_every_wgrad_candidate(dev, cand):
+    """cand = 20 * variant + 4 * block target + tile shape; variant 0 = [m][n] LDS image, 1 = transposed image
+    (wgrad_t_kernel), 2 = transposed image with XCD-contiguous splits.  A candidate that does not apply to a layer falls
+    back to the default inside the library, so every shape is checked under every forced candidate."""
     from iprgan import _lib, ops
     try:
         _lib.call('iprgan_debug_force_tiles', -1, cand)
