@@ -74,13 +74,22 @@ int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* co
  * one dense 1x1 GEMM over tap planes + a gather instead of a 3/32-full MFMA tile); NULL = generic kernel. */
 size_t iprgan_conv_fwd_ws_floats(const iprgan_conv_desc* d);
 int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd, const float* bias,
-                    float* y, float* ws, void* stream);
+                    float* y, float* ws, const float* pair_sigma0, const float* pair_sigma1, void* stream);
 /* dx = conv_bwd_data(dy, w) [* act'(x_out_prev)]: if prev_out != NULL the result is multiplied by the
  * derivative of activation prev_act evaluated from the saved OUTPUT prev_out of the previous layer
  * (same shape as dx), i.e. the previous layer's activation backward is fused into this epilogue. */
 size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d);   /* reflect padding, or <= 4 input channels */
 int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
-                         const float* prev_out, int prev_act, float prev_slope, void* stream);
+                         const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
+                         const float* pair_sigma1, void* stream);
+/* Paired pass (pair_sigma0/1 non-NULL, device scalars; B even): the batch holds TWO half-batches that the reference
+ * sends through a spectrally normalised network one after the other (models/dcgan.py:47-48: D(real), D(fake)) - between
+ * them the power iteration advances, so the halves see W/sigma0 and W/sigma1.  The operands are prepared from the
+ * un-normalised W (inv_scale NULL) and the rows of the first / second half are divided by sigma0 / sigma1 in the
+ * epilogue (before the bias; conv is linear in W).  One launch of twice the size fills the GPU better than two. */
+/* out[c] = beta*out[c] + sum_m x[m][c], c < C, over x[M][Cs] (bias gradients); ws: iprgan_colsum_ws_floats(M, Cs) floats */
+size_t iprgan_colsum_ws_floats(int M, int Cs);
+int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, float beta, void* stream);
 /* dw (PyTorch layout) = beta*dw + conv_bwd_weight(x, dy); db (optional, length Cout) = beta*db + sum dy.
  * beta = 0 overwrites; beta = 1 accumulates straight into a gradient bucket (what autograd's AccumulateGrad
  * add plus DDP's bucket copy do in two extra passes).  ws: workspace of iprgan_conv_wgrad_ws_floats(d) floats.

@@ -102,6 +102,10 @@ struct GConvArgs {
   float* ws;           // host-side only: workspace for the small-N path (may be null)
   size_t ws_floats;
   int nphase;
+  const float* rs0;    // paired pass (two half-batches through one launch, each with its own spectral-norm sigma):
+  const float* rs1;    //   rows of the first / second half of every phase are divided by *rs0 / *rs1 before the bias
+  int ksplit;          // > 1: blockIdx.z splits the K loop (single-phase geometries); partial tiles go to slabs of M*Ns floats
+  int wmod, wk1;       // > 0: operand row r lives at (r % wmod) * Kp + (r / wmod) * wk1 floats (full-map conv backward-data)
   Phase ph[4];
   double flops;   // algorithmic 2*MAC of this launch (host-side bookkeeping only)
 };
@@ -176,12 +180,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
                                 gridDim.x * gridDim.y * gridDim.z);
   const unsigned lq = lt / gridDim.y;
-  const int pz = (int)(lq % gridDim.z);
+  const int zi = (int)(lq % gridDim.z);
+  const int pz = a.ksplit > 1 ? 0 : zi;          // blockIdx.z: sub-pixel phase, or K split of a single-phase geometry
   const int pM = a.ph[pz].M;
   const int m0 = (int)(lq / gridDim.z) * BM, n0 = (int)(lt % gridDim.y) * BN;
   if (m0 >= pM) return;
   // phase constants into scalars once (the K loop must not re-read the kernel arguments)
-  const int p_ntap = a.ph[pz].ntap, p_tw = a.ph[pz].tw, p_steps = (a.ph[pz].steps * 32 + BK - 1) / BK;
+  const int p_ntap = a.ph[pz].ntap, p_tw = a.ph[pz].tw;
+  int p_steps = (a.ph[pz].steps * 32 + BK - 1) / BK, s_begin = 0;
+  if (a.ksplit > 1) {
+    const int per = (p_steps + a.ksplit - 1) / a.ksplit;
+    s_begin = zi * per;
+    p_steps = s_begin + per < p_steps ? s_begin + per : p_steps;      // = end step of this split
+  }
   const int p_dy0 = a.ph[pz].dy0, p_dx0 = a.ph[pz].dx0, p_dys = a.ph[pz].dys, p_dxs = a.ph[pz].dxs;
   const int p_wbase = a.ph[pz].wbase, p_wsy = a.ph[pz].wsy, p_wsx = a.ph[pz].wsx;
   const int p_owg = a.ph[pz].owg, plane = a.ph[pz].ohg * a.ph[pz].owg;
@@ -217,7 +228,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
     }
   }
 #pragma unroll
-  for (int i = 0; i < RB; ++i) wrow[i] = (unsigned)((n0 + lrow + RP * i) * a.Kp) * 4u + (FAST ? chunk * 16u : 0u);
+  for (int i = 0; i < RB; ++i) {
+    const int r = n0 + lrow + RP * i;
+    const unsigned base = a.wmod > 0 ? (unsigned)((r % a.wmod) * a.Kp + (r / a.wmod) * a.wk1) : (unsigned)(r * a.Kp);
+    wrow[i] = base * 4u + (FAST ? chunk * 16u : 0u);
+  }
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -230,6 +245,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   f32x4 ra[RA], rb[RB];
   // wave-uniform tap walk for the FAST path
   int u_c4 = 0, u_ty = 0, u_tx = 0;
+  if (FAST && s_begin > 0) {                      // K split: start the walk at step s_begin
+    const int q0 = s_begin * CH, t0 = q0 / a.c4n;
+    u_c4 = q0 - t0 * a.c4n;
+    u_ty = t0 / p_tw;
+    u_tx = t0 - u_ty * p_tw;
+  }
 
   auto gload = [&](int step) {
     if (FAST) {
@@ -365,16 +386,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
     }
   };
 
-  if (p_steps > 0) {
-    gload(0);
+  if (p_steps > s_begin) {
+    gload(s_begin);
     lstore(0);
     __syncthreads();
-    for (int s = 0; s < p_steps; ++s) {
+    for (int s = s_begin; s < p_steps; ++s) {
       const bool more = s + 1 < p_steps;
       if (more) gload(s + 1);
       if (NBUF == 2) {           // double-buffered LDS: one barrier per K step, 2 blocks per CU
-        compute(s & 1);
-        if (more) lstore((s + 1) & 1);
+        compute((s - s_begin) & 1);
+        if (more) lstore((s + 1 - s_begin) & 1);
         __syncthreads();
       } else {                   // single LDS buffer (half the LDS -> 3-4 blocks per CU), two barriers
         compute(0);
@@ -392,6 +413,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   const int half = lane >> 5, l31 = lane & 31;
   const int ooy = a.ph[pz].ooy, oox = a.ph[pz].oox;
   const int qp = lane & 3, qcol = l31 & ~3;
+  float rsc0 = 1.f, rsc1 = 1.f;
+  if (a.rs0) { rsc0 = 1.f / *a.rs0; rsc1 = 1.f / *a.rs1; }
+  const int halfM = pM >> 1;
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -415,13 +439,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
         const int n = n0 + (wn * WN + j) * 32 + qcol;
         if (!mok || n >= a.Ns) continue;
         f32x4 v = {c0, c1, c2, c3};
+        if (a.rs0) v *= (m < halfM ? rsc0 : rsc1);
         if (a.bias) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) if (n + k < a.N) v[k] += a.bias[n + k];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], a.act, a.slope);
-        const size_t idx = a.planar_M ? ((size_t)(n >> 2) * a.planar_M + opix) * 4 : opix * a.Ns + n;
+        const size_t idx = (a.planar_M ? ((size_t)(n >> 2) * a.planar_M + opix) * 4 : opix * a.Ns + n) +
+                           (a.ksplit > 1 ? (size_t)zi * pM * a.Ns : 0);
         if (a.aux) {
           const f32x4 o = *(const f32x4*)(a.aux + idx);
 #pragma unroll
@@ -1002,6 +1028,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_t_kernel(const WGradArgs
     }
 }
 
+// out[m][n] = act(sum_z slab[z][m][n] + bias[n]) in fixed split order (deterministic); pad channels stay zero
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restrict__ slab, const float* __restrict__ bias,
+                                                            f32x4* __restrict__ out, unsigned n4, unsigned Ns4, int N,
+                                                            int ksplit, int act, float slope) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    f32x4 v = slab[i];
+    for (int z = 1; z < ksplit; ++z) v += slab[(size_t)z * n4 + i];
+    const int n = (int)(i % Ns4) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = v[k];
+      if (bias && n + k < N) t += bias[n + k];
+      t = act_apply(t, act, slope);
+      v[k] = n + k < N ? t : 0.f;
+    }
+    out[i] = v;
+  }
+}
+
 // x[B][H][W][C4] -> xp[B][H+2p][W+2p][C4] with ReflectionPad2d borders (only for the swapped-role wgrad of the
 // reflect-padded RGB heads, see WGeom)
 __global__ void reflect_pad_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ xp, int B, int H, int W,
@@ -1274,7 +1319,7 @@ static int launch_gconv_tfnk(const GConvArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.nphase);
+  dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.ksplit > 1 ? a.ksplit : a.nphase);
   prof_launch(kern, grid, dim3(WGM * WGN * 64), smem, st,
               BF16 ? 12 : WGM * WGN == 8 ? (BN == 128 ? 9 : 10) : BM == 128 ? (BN == 128 ? 0 : (BN == 64 ? 1 : 3)) : (BN == 128 ? 8 : 2),
               a.flops, a);
@@ -1305,7 +1350,7 @@ static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
 static int launch_gconv(const GConvArgs& ain, hipStream_t st);
 
 static bool smalln_eligible(const GConvArgs& a) {
-  return g_smalln && a.Ns == 4 && a.nphase == 1 && a.isy == 1 && a.isx == 1 && a.osy == 1 && a.osx == 1 &&
+  return g_smalln && !a.rs0 && a.Ns == 4 && a.nphase == 1 && a.isy == 1 && a.isx == 1 && a.osy == 1 && a.osx == 1 &&
          (a.Cs % 32) == 0 && a.ph[0].ntap >= 2 && !a.planar_M;
 }
 static size_t smalln_ws_floats(const GConvArgs& a) {
@@ -1388,7 +1433,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   GConvArgs a = ain;
   {
     const unsigned long long inb = (unsigned long long)a.B * a.IH * a.IW * a.Cs * 4ull;
-    const unsigned long long wtb = (unsigned long long)rup(a.N, 128) * a.Kp * 4ull;
+    const unsigned long long wtb = (unsigned long long)rup(a.wmod > 0 ? a.wmod : a.N, 128) * a.Kp * 4ull;
     IPR_CHECK(inb < 0x7fffffffull && wtb < 0x7fffffffull, "conv: tensor larger than 2 GiB (%llu / %llu bytes)", inb, wtb);
     a.in_bytes = (unsigned)inb; a.wt_bytes = (unsigned)wtb;
     a.linear_out = (a.nphase == 1 && a.osy == 1 && a.osx == 1 && a.ph[0].ooy == 0 && a.ph[0].oox == 0) ? 1 : 0;
@@ -1424,7 +1469,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   // geometry times every tile on the caller's stream and keeps the fastest.  Tiles only change the summation
   // order, results stay within fp32 rounding of each other.
   TuneKey key = {{a.B, a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.isy, a.osy, a.nphase, a.ph[0].th, a.ph[0].tw,
-                  a.ph[0].ohg, a.ph[0].owg, a.pad_mode + 16 * g_math, a.Kp}};
+                  a.ph[0].ohg, a.ph[0].owg, a.pad_mode + 16 * g_math + 64 * a.ksplit + 8192 * (a.wmod > 0) + 16384 * (a.rs0 != nullptr), a.Kp}};
   tune_load();
   auto it = g_tune.find(key);
   if (it != g_tune.end()) return run(it->second);
@@ -1443,6 +1488,25 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
     fprintf(stderr, "[iprgan tune] gconv B%d in %dx%dx%d out %dx%dx%d taps %dx%d phases %d -> tile %d (%.1f us)\n", a.B,
             a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.ph[0].th, a.ph[0].tw, a.nphase, best, best_us);
   return run(best);
+}
+
+// ---- full-map convolutions (kernel = whole input map, output 1x1: the "FC" layer of networks/discriminator_96.py:20)
+// are skinny GEMMs, M = batch rows: Y[B][Cout] = X[B][H*W*Cin] W^T.  As a convolution they fill 1/16 of the GPU
+// (B = 64: one 64-row tile per 64 output channels) and their backward-data multiplies 35 of 36 taps by zero.  Here the
+// forward pass is a 1x1 convolution over the flattened NHWC map (its (tap, channel) order IS the K order of the
+// prepared operand) with the K loop split over blockIdx.z and a fixed-order slab reduce; backward-data is a 1x1
+// convolution with (tap, channel) output columns whose operand rows are read out of the backward operand in place.
+static bool fullmap_conv(const iprgan_conv_desc* d) {
+  return !d->transposed && d->KH == d->H && d->KW == d->W && d->pad == 0 && d->stride == 1 && d->KH * d->KW > 1 &&
+         (d->Cin % 32) == 0 && d->pad_mode == IPRGAN_PAD_ZERO;
+}
+static int fullmap_ksplit(const iprgan_conv_desc* d) {
+  const int steps = d->KH * d->KW * d->Cin / 32;
+  const int ntile = cdiv(c4(d->Cout), 64) * cdiv(d->B, 64);
+  int ks = cdiv(576, ntile);                  // ~2 blocks of 4 waves per CU
+  if (ks > steps / 4) ks = steps / 4;         // at least 4 K steps per block
+  if (ks > 64) ks = 64;
+  return ks < 1 ? 1 : ks;
 }
 
 // ---- backward-weight ------------------------------------------------------------------------
@@ -1658,7 +1722,13 @@ static size_t smalln_ws_for(const iprgan_conv_desc* d, bool fwd) {
   const int ntap = d->KH * d->KW;
   return (size_t)rup(ntap * 4, 128) * c4(c_red) + (size_t)ntap * pix * 4;
 }
-size_t iprgan_conv_fwd_ws_floats(const iprgan_conv_desc* d) { return smalln_ws_for(d, true); }
+size_t iprgan_conv_fwd_ws_floats(const iprgan_conv_desc* d) {
+  if (fullmap_conv(d)) {
+    const int ks = fullmap_ksplit(d);
+    return ks > 1 ? (size_t)ks * d->B * c4(d->Cout) : 0;
+  }
+  return smalln_ws_for(d, true);
+}
 
 
 int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* const* w,
@@ -1698,11 +1768,32 @@ int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* co
 }
 
 int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd, const float* bias,
-                    float* y, float* ws, void* stream) {
+                    float* y, float* ws, const float* pair_sigma0, const float* pair_sigma1, void* stream) {
+  IPR_CHECK(!pair_sigma0 == !pair_sigma1 && (!pair_sigma0 || ((d->B & 1) == 0 && !fullmap_conv(d))),
+            "conv_fwd: a paired pass needs both sigmas, an even batch and a regular convolution");
   IPR_CHECK(d->stride >= 1 && d->stride <= 2, "conv_fwd: stride %d unsupported", d->stride);
   GConvArgs a;
   memset(&a, 0, sizeof(a));
   const Shape s = out_shape(d);
+  if (fullmap_conv(d)) {
+    const int K = d->KH * d->KW * d->Cin, ks = fullmap_ksplit(d);
+    geom_forward_form(a, d->B, 1, 1, K, 1, 1, d->Cout, 1, 1, 1, 0);
+    a.in = x; a.wt = wfwd; a.flops = 2.0 * d->B * (double)d->Cout * K;
+    if (ks > 1) {
+      IPR_CHECK(ws, "conv_fwd: the full-map path needs its workspace (iprgan_conv_fwd_ws_floats)");
+      a.ksplit = ks; a.out = ws; a.act = IPRGAN_ACT_NONE;
+      int rc = launch_gconv(a, (hipStream_t)stream);
+      if (rc) return rc;
+      const unsigned n4 = (unsigned)d->B * (unsigned)(c4(d->Cout) / 4);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int)n4, 256) < 1024 ? cdiv((int)n4, 256) : 1024), dim3(256), 0,
+                         (hipStream_t)stream, (const f32x4*)ws, bias, (f32x4*)y, n4, (unsigned)(c4(d->Cout) / 4), d->Cout,
+                         ks, d->act, d->slope);
+      IPR_LAUNCH_CHECK();
+      return 0;
+    }
+    a.bias = bias; a.out = y; a.act = d->act; a.slope = d->slope;
+    return launch_gconv(a, (hipStream_t)stream);
+  }
   if (!d->transposed) {
     geom_forward_form(a, d->B, d->H, d->W, d->Cin, s.OH, s.OW, d->Cout, d->KH, d->KW, d->stride, d->pad);
     a.pad_mode = d->pad_mode;
@@ -1711,6 +1802,7 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
     geom_bwd_form(a, d->B, d->H, d->W, d->Cin, s.OH, s.OW, d->Cout, d->KH, d->KW, d->stride, d->pad);
   }
   a.in = x; a.wt = wfwd; a.bias = bias; a.out = y; a.aux = nullptr;
+  a.rs0 = pair_sigma0; a.rs1 = pair_sigma1;
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = d->act; a.slope = d->slope;
   a.ws = ws; a.ws_floats = ws ? iprgan_conv_fwd_ws_floats(d) : 0;
@@ -1723,12 +1815,27 @@ size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d) {
 }
 
 int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
-                         const float* prev_out, int prev_act, float prev_slope, void* stream) {
+                         const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
+                         const float* pair_sigma1, void* stream) {
+  IPR_CHECK(!pair_sigma0 == !pair_sigma1 &&
+            (!pair_sigma0 || ((d->B & 1) == 0 && !fullmap_conv(d) && d->pad_mode != IPRGAN_PAD_REFLECT)),
+            "conv_bwd_data: a paired pass needs both sigmas, an even batch and a zero-padded regular convolution");
   IPR_CHECK(d->stride >= 1 && d->stride <= 2, "conv_bwd_data: stride %d unsupported", d->stride);
   GConvArgs a;
   memset(&a, 0, sizeof(a));
   const Shape s = out_shape(d);
   const bool reflect = d->pad_mode == IPRGAN_PAD_REFLECT;
+  if (fullmap_conv(d) && (d->Cout % 32) == 0) {
+    // dx[b][(tap, c)] = sum_n dy[b][n] W[n][c][tap]: operand row (tap, c) = row c of the backward operand at k offset tap*Cout
+    const int ntap = d->KH * d->KW;
+    geom_forward_form(a, d->B, 1, 1, d->Cout, 1, 1, ntap * d->Cin, 1, 1, 1, 0);
+    a.Kp = rup(ntap * c4(d->Cout), 32);                 // row pitch of the backward operand
+    a.wmod = d->Cin; a.wk1 = c4(d->Cout);
+    a.in = dy; a.wt = wbwd; a.out = dx; a.act = IPRGAN_ACT_NONE;
+    a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope;
+    a.flops = 2.0 * d->B * (double)d->Cout * d->Cin * ntap;
+    return launch_gconv(a, (hipStream_t)stream);
+  }
   if (reflect) {
     // gradient w.r.t. the reflection-padded image (a zero-pad conv with pad 0 over H+2p), then fold
     IPR_CHECK(!d->transposed && ws, "conv_bwd_data: reflect pad needs a Conv2d and a workspace");
@@ -1740,6 +1847,7 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
     geom_forward_form(a, d->B, s.OH, s.OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad);
   }
   a.in = dy; a.wt = wbwd; a.bias = nullptr; a.out = reflect ? ws : dx;
+  a.rs0 = pair_sigma0; a.rs1 = pair_sigma1;
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = IPRGAN_ACT_NONE; a.slope = 0.f;
   if (!reflect) { a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.ws = ws; a.ws_floats = ws ? smalln_ws_for(d, false) : 0; }

@@ -371,6 +371,12 @@ size_t iprgan_instnorm_ws_floats(int B, int HW, int C) {
   return (size_t)B * ((size_t)g.NB * 2 * C + 2 * (size_t)C);
 }
 
+int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, float beta, void* stream) {
+  IPR_CHECK(Cs % 4 == 0 && M > 0 && C <= Cs, "colsum: row length %d must be a multiple of 4 >= C=%d, M=%d positive", Cs, C, M);
+  return colsum_launch(x, out, ws, M, Cs, C, (hipStream_t)stream, beta);
+}
+size_t iprgan_colsum_ws_floats(int M, int C) { return colsum_ws_floats(M, C); }
+
 int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                   float* running_var, float* save_mean, float* save_invstd, float* ws, int M, int C,
                   float eps, float momentum, int use_running, int act, float slope, void* stream) {

@@ -42,9 +42,11 @@ SIGNATURES = {
     'iprgan_conv_weight_prep': (_I, [_D, _P, _P, _P, _P, _P]),
     'iprgan_conv_weight_prep_multi': (_I, [_P, _P, _P, _P, _P, _I, _P]),
     'iprgan_conv_fwd_ws_floats': (_Z, [_D]),
-    'iprgan_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    'iprgan_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P]),
     'iprgan_conv_bwd_data_ws_floats': (_Z, [_D]),
-    'iprgan_conv_bwd_data': (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P]),
+    'iprgan_conv_bwd_data': (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P]),
+    'iprgan_colsum_ws_floats': (_Z, [_I, _I]),
+    'iprgan_colsum': (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     'iprgan_conv_bwd_weight': (_I, [_D, _P, _P, _P, _P, _P, _F, _P]),
     'iprgan_act_bwd': (_I, [_P, _P, _P, _Z, _I, _F, _P]),
     'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
@@ -178,7 +180,17 @@ MATH_MODES = {'fp32': 0, 'bf16': 1}
 def set_math(mode):
     """Process-wide math mode of the conv family (include/iprgan.h: iprgan_set_math_mode): 'fp32' (default) or
     'bf16' (bf16 MFMA tiles, fp32 accumulation, fp32 tensors and master weights in HBM)."""
-    call('iprgan_set_math_mode', MATH_MODES[mode] if isinstance(mode, str) else int(mode))
+    global _math_cached
+    _math_cached = MATH_MODES[mode] if isinstance(mode, str) else int(mode)
+    call('iprgan_set_math_mode', _math_cached)
+
+
+_math_cached = 0
+
+
+def get_math_cached():
+    """The math mode last set through set_math (no library call: part of per-pass cache keys)."""
+    return _math_cached
 
 
 def get_math():

@@ -105,19 +105,41 @@ class Conv(Op):
     def params(self):
         return (self.weight,) + ((self.bias,) if self.bias is not None else ())
 
+    # prepared operands ('wf' forward, 'wb' backward-data) of layers WITHOUT spectral norm, keyed on the weight's
+    # version counter and storage (optimizer steps, load_state_dict and .to() all change the key)
+    def _operand_key(self):
+        w = self.weight
+        return (w._version, w.data_ptr(), L.get_math_cached())
+
+    def cached_operand(self, which, st):
+        if self.is_sn or st.get('sigma') is not None:
+            return False
+        ent = self.__dict__.get('_op_' + which)
+        if ent is not None and ent[0] == self._operand_key():
+            st[which] = ent[1]
+            return True
+        return False
+
+    def keep_operand(self, which, tensor, st):
+        if not self.is_sn and st.get('sigma') is None:
+            self.__dict__['_op_' + which] = (self._operand_key(), tensor)
+
     def forward(self, x, st, train):
         sp = self.spec
         B, H, W, _ = x.shape
         d = sp.desc(B, H, W)
         sigma = st.get('sigma')             # set by Chain's batched spectral-norm pre-pass
-        if self.sn is not None and sigma is None:
+        if self.sn is not None and sigma is None and st.get('pair') is None:
             u, v = self.sn
             sigma = ops.sn_power_iter(self.weight, u, v, train)
             st['u'], st['v'] = u.clone(), v.clone()     # this pass's u, v (later passes overwrite the buffers)
         wf = st.pop('wf', None)             # set by Chain's batched weight-prep pre-pass
+        pair = st.get('pair')               # paired pass: (sigma of the first half-batch, of the second); W un-normalised
+        if pair is not None:
+            sigma = None
         if wf is None:
             wf, _ = ops.conv_prep(sp, d, self.weight, sigma, fwd=True, bwd=False)
-        y = ops.conv_fwd(sp, d, x, wf, self.bias)
+        y = ops.conv_fwd(sp, d, x, wf, self.bias, pair=pair)
         st.update(x=x, y=y, d=d, sigma=sigma)
         return y
 
@@ -126,7 +148,19 @@ class Conv(Op):
         if sp.act != L.ACT_NONE and not st.get('dy_is_preact', False):
             dy = ops.act_bwd(dy, st['y'], sp.act, sp.slope)
         grads = []
-        if need_w:
+        pair = st.get('pair')
+        if need_w and pair is not None:
+            # the two half-batches have their own spectral-norm factors: one weight gradient per half (the SN backward
+            # is not linear across them), one bias gradient over the whole batch
+            has_b = self.bias is not None
+            B2 = d.B // 2
+            dh = sp.desc(B2, d.H, d.W)
+            x_ = st['x']
+            dwa, _ = ops.conv_bwd_weight(sp, dh, x_[:B2], dy[:B2], self.weight.shape, False)
+            dwb, _ = ops.conv_bwd_weight(sp, dh, x_[B2:], dy[B2:], self.weight.shape, False)
+            st['dwsn'] = [(dwa, st['uv'][0][0], st['uv'][0][1], pair[0]), (dwb, st['uv'][1][0], st['uv'][1][1], pair[1])]
+            grads = [dwa] + ([ops.colsum(dy, sp.cout)] if has_b else [])
+        elif need_w:
             has_b = self.bias is not None
             if sink is not None and self.sn is None:
                 ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, has_b, dw=sink.view_of(self.weight),
@@ -137,17 +171,17 @@ class Conv(Op):
                 # and the bias gradient joins the pass's small-gradient add)
                 dw, db = ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, has_b)
                 grads = [dw] + ([db] if has_b else [])
-            if self.sn is not None:
-                st['dwsn'] = dw             # spectral-norm backward of all layers is batched by ChainFn.backward
+            if self.sn is not None:         # spectral-norm backward of all layers is batched by ChainFn.backward
+                st['dwsn'] = [(dw, st['u'], st['v'], st['sigma'])]
         dx = None
         if need_dx:
             wb = st.pop('wb', None)
             if wb is None:
                 _, wb = ops.conv_prep(sp, d, self.weight, sigma, fwd=False, bwd=True)
             if prev_act is not None:
-                dx = ops.conv_bwd_data(sp, d, dy, wb, st['x'], prev_act[0], prev_act[1])
+                dx = ops.conv_bwd_data(sp, d, dy, wb, st['x'], prev_act[0], prev_act[1], pair=pair)
             else:
-                dx = ops.conv_bwd_data(sp, d, dy, wb)
+                dx = ops.conv_bwd_data(sp, d, dy, wb, pair=pair)
         return dx, grads
 
 
@@ -286,7 +320,8 @@ class GemvHead(Op):
         B = x.shape[0]
         K = self.C * self.HW
         sigma = st.get('sigma')
-        if sigma is None:
+        pair = st.get('pair')
+        if sigma is None and pair is None:
             sigma = ops.sn_power_iter(self.weight, self.u, self.v, train)
             st['u'], st['v'] = self.u.clone(), self.v.clone()
         key = (self.weight._version, self.weight.data_ptr())
@@ -294,18 +329,44 @@ class GemvHead(Op):
             self._perm, self._perm_key = ops.permute_021(self.weight, self.C, self.HW, 1), key
         wp = self._perm
         x2 = x.view(B, K)
-        y = ops.gemv_fwd(x2, wp, self.bias, sigma)
+        if pair is not None:                # paired pass: each half-batch with its own sigma
+            B2 = B // 2
+            y = ops.empty((B,), x2)
+            ops.gemv_fwd(x2[:B2], wp, self.bias, pair[0], out=y[:B2])
+            ops.gemv_fwd(x2[B2:], wp, self.bias, pair[1], out=y[B2:])
+        else:
+            y = ops.gemv_fwd(x2, wp, self.bias, sigma)
         st.update(x=x2, xshape=tuple(x.shape), wp=wp, sigma=sigma)
         return y
 
     def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         pa, ps = prev_act if prev_act is not None else (L.ACT_NONE, 0.0)
-        dx, dwp, db = ops.gemv_bwd(st['x'], st['wp'], dy.contiguous(), st['sigma'], need_dx, need_w,
+        pair = st.get('pair')
+        dy = dy.contiguous()
+        unperm = lambda t: ops.permute_021(t, self.HW, self.C, 1).view(1, -1)
+        if pair is not None:
+            x2 = st['x']
+            B2 = x2.shape[0] // 2
+            dx = torch.empty_like(x2) if need_dx else None
+            entries, dbs = [], []
+            for h, sl in enumerate((slice(0, B2), slice(B2, None))):
+                _, dwp, db = ops.gemv_bwd(x2[sl], st['wp'], dy[sl], pair[h], need_dx, need_w,
+                                          x2[sl] if prev_act is not None else None, pa, ps,
+                                          dx_out=dx[sl] if need_dx else None)
+                if need_w:
+                    entries.append((unperm(dwp), st['uv'][h][0], st['uv'][h][1], pair[h]))
+                    dbs.append(db)
+            grads = []
+            if need_w:
+                st['dwsn'] = entries
+                grads = [entries[0][0], ops.add(dbs[0], dbs[1])]
+            return (dx.view(st['xshape']) if dx is not None else None), grads
+        dx, dwp, db = ops.gemv_bwd(st['x'], st['wp'], dy, st['sigma'], need_dx, need_w,
                                    st['x'] if prev_act is not None else None, pa, ps)
         grads = []
         if need_w:
-            dwsn = ops.permute_021(dwp, self.HW, self.C, 1).view(1, -1)
-            st['dwsn'] = dwsn
+            dwsn = unperm(dwp)
+            st['dwsn'] = [(dwsn, st['u'], st['v'], st['sigma'])]
             grads = [dwsn, db]
         return (dx.view(st['xshape']) if dx is not None else None), grads
 
@@ -412,7 +473,10 @@ class Chain:
     def params(self):
         return [p for op in self.ops for p in op.params]
 
-    def __call__(self, x, train):
+    def __call__(self, x, train, pair=False):
+        """pair=True: ``x`` holds two half-batches that the reference sends through this (spectrally normalised) network
+        one after the other; the power iteration runs twice and each half is scaled by its own sigma
+        (include/iprgan.h: paired pass)."""
         if not x.is_cuda:
             raise RuntimeError('iprgan networks run on the HIP kernels only: input must be a GPU tensor '
                                '(there is no CPU fallback; use the reference/oracle for CPU runs)')
@@ -428,12 +492,13 @@ class Chain:
                     break
             if red is not None:
                 red.note_forward()
-        return ChainFn.apply(self, bool(train), red, x, *params)
+        return ChainFn.apply(self, (bool(train), red, bool(pair)), x, *params)
 
 
 class ChainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, chain, train, red, x, *params):
+    def forward(ctx, chain, opts, x, *params):
+        train, red, pair = opts
         h = x.detach()
         if h.dtype != torch.float32:
             raise RuntimeError('iprgan networks take float32 inputs')
@@ -444,15 +509,27 @@ class ChainFn(torch.autograd.Function):
         if sn_idx:
             ws_, us_, vs_ = zip(*[(chain.ops[i].weight,) + tuple(chain.ops[i].sn) for i in sn_idx])
             sig, uo, vo = ops.sn_power_iter_multi(list(ws_), list(us_), list(vs_), train)
-            for k, i in enumerate(sn_idx):
-                stash[i].update(sigma=sig[k:k + 1], u=uo[k], v=vo[k])
-        # ... and every conv layer's forward operand (tap-major copy, divided by sigma) in one launch
+            if pair:                        # the second half-batch sees the NEXT power iteration, as two calls would
+                sig2, uo2, vo2 = ops.sn_power_iter_multi(list(ws_), list(us_), list(vs_), train)
+                for k, i in enumerate(sn_idx):
+                    stash[i].update(pair=(sig[k:k + 1], sig2[k:k + 1]), uv=((uo[k], vo[k]), (uo2[k], vo2[k])))
+            else:
+                for k, i in enumerate(sn_idx):
+                    stash[i].update(sigma=sig[k:k + 1], u=uo[k], v=vo[k])
+        elif pair:
+            raise RuntimeError('a paired pass is for spectrally normalised networks')
+        # ... and every conv layer's forward operand (tap-major copy, divided by sigma) in one launch.  Operands of
+        # layers without spectral norm depend on the weight only: they are kept until the weight changes (the optimizer
+        # bumps the version counter), so the second and third pass of a step - and a frozen network like VGG19 for the
+        # whole run - reuse them.
         cv = [i for i, op in enumerate(chain.ops) if isinstance(op, Conv)] if _BATCH_PREP else []
-        if cv:
-            wfs = ops.conv_prep_multi([chain.ops[i].spec for i in cv], [chain.ops[i].weight for i in cv],
-                                      [stash[i].get('sigma') for i in cv])
-            for i, wf in zip(cv, wfs):
+        todo = [i for i in cv if not chain.ops[i].cached_operand('wf', stash[i])]
+        if todo:
+            wfs = ops.conv_prep_multi([chain.ops[i].spec for i in todo], [chain.ops[i].weight for i in todo],
+                                      [stash[i].get('sigma') for i in todo])
+            for i, wf in zip(todo, wfs):
                 stash[i]['wf'] = wf
+                chain.ops[i].keep_operand('wf', wf, stash[i])
         for op, st in zip(chain.ops, stash):
             h = op.forward(h, st, train)
         ctx.chain, ctx.stash, ctx.red = chain, stash, red
@@ -468,8 +545,8 @@ class ChainFn(torch.autograd.Function):
         if stash is None:
             raise RuntimeError('this network pass has already been back-propagated: the engine frees a pass\'s '
                                'activations in backward (retain_graph / double backward are not supported)')
-        need_x = ctx.needs_input_grad[3]
-        need_p = ctx.needs_input_grad[4:]
+        need_x = ctx.needs_input_grad[2]
+        need_p = ctx.needs_input_grad[3:]
         ops_list = chain.ops
         for p, v in zip(chain.params, ctx.versions):
             if p._version != v:
@@ -502,29 +579,39 @@ class ChainFn(torch.autograd.Function):
         grads_per_op = [None] * len(ops_list)
         small_dst, small_src, sn_wait = [], [], []
 
+        small_seen = set()
+
         def flush():
-            """deferred writes into the bucket views: spectral-norm backward of the layers seen so far (batched) and
-            the small gradients (one multi-tensor add)"""
+            """deferred writes into the bucket views: spectral-norm backward of the layers seen so far (batched; a paired
+            pass has two (dW_sn, u, v, sigma) entries per layer: two rounds, the second accumulating) and the small
+            gradients (one multi-tensor add)"""
             if sn_wait:
-                outs = [red.view_of(ops_list[i].weight) for i in sn_wait] if sink is not None else None
-                dws = ops.sn_bwd_multi([stash[i]['dwsn'] for i in sn_wait], [ops_list[i].weight for i in sn_wait],
-                                       [stash[i]['u'] for i in sn_wait], [stash[i]['v'] for i in sn_wait],
-                                       [stash[i]['sigma'] for i in sn_wait], outs=outs,
-                                       beta=1.0 if sink is not None else 0.0)
-                for i, dw in zip(sn_wait, dws):
-                    grads_per_op[i][0] = DIRECT if sink is not None else dw.view_as(ops_list[i].weight)
+                out_of = {i: (red.view_of(ops_list[i].weight) if sink is not None else torch.empty_like(ops_list[i].weight))
+                          for i in sn_wait}
+                for r in range(max(len(stash[i]['dwsn']) for i in sn_wait)):
+                    idx = [i for i in sn_wait if len(stash[i]['dwsn']) > r]
+                    ent = [stash[i]['dwsn'][r] for i in idx]
+                    ops.sn_bwd_multi([e[0] for e in ent], [ops_list[i].weight for i in idx], [e[1] for e in ent],
+                                     [e[2] for e in ent], [e[3] for e in ent], outs=[out_of[i].view_as(ops_list[i].weight)
+                                                                                      for i in idx],
+                                     beta=1.0 if (sink is not None or r > 0) else 0.0)
+                for i in sn_wait:
+                    grads_per_op[i][0] = DIRECT if sink is not None else out_of[i]
                 del sn_wait[:]
             if small_dst:
                 ops.axpy_multi(small_dst, small_src)
                 del small_dst[:], small_src[:]
+                small_seen.clear()
 
         if first_needed is not None and _BATCH_PREP:        # backward-data operands of every conv that must produce dx: one launch
             cv = [i for i, op in enumerate(ops_list) if isinstance(op, Conv) and (i > first_needed or (need_x and i == 0))]
-            if cv:
-                wbs = ops.conv_prep_multi([ops_list[i].spec for i in cv], [ops_list[i].weight for i in cv],
-                                          [stash[i].get('sigma') for i in cv], bwd=True)
-                for i, wb in zip(cv, wbs):
+            todo = [i for i in cv if not ops_list[i].cached_operand('wb', stash[i])]
+            if todo:
+                wbs = ops.conv_prep_multi([ops_list[i].spec for i in todo], [ops_list[i].weight for i in todo],
+                                          [stash[i].get('sigma') for i in todo], bwd=True)
+                for i, wb in zip(todo, wbs):
                     stash[i]['wb'] = wb
+                    ops_list[i].keep_operand('wb', wb, stash[i])
         g = dy.contiguous()
         for i in range(len(ops_list) - 1, -1, -1):
             op, st = ops_list[i], stash[i]
@@ -549,6 +636,9 @@ class ChainFn(torch.autograd.Function):
                         continue
                     red.touch(p)
                     if gk is not DIRECT and not (k == 0 and 'dwsn' in st):
+                        if id(p) in small_seen:          # one destination per launch
+                            flush()
+                        small_seen.add(id(p))
                         small_dst.append(red.view_of(p))
                         small_src.append(gk.reshape(p.shape) if gk.shape != p.shape else gk)
                 if final:
@@ -568,4 +658,4 @@ class ChainFn(torch.autograd.Function):
                 out.append(None if (gk is DIRECT or sink is not None) else gk)
             pi += n
         ctx.stash = None
-        return (None, None, None, g if need_x else None, *out)
+        return (None, None, g if need_x else None, *out)

@@ -17,6 +17,10 @@ from . import networks, optim, tools
 from .parallel import GradReducer, Replica, broadcast_module
 from .tools import loss_sum, loss_value
 
+import os
+
+_PAIR_D = os.environ.get('IPRGAN_PAIR_D', '1') != '0'       # A/B switch for the paired discriminator pass
+
 __all__ = ['Model', 'Wrapper', 'DCGAN', 'SRGAN', 'CycleGAN', 'VAE', 'ImagePool', 'BlackBoxWrapper',
            'WhiteBoxWrapper', 'DisableBatchNormStats']
 
@@ -124,8 +128,14 @@ class DCGAN(Model):
         self.latent = self._dev(data['latent'])
         self.real_sample = self._dev(data['real_sample'])
         self.fake_sample = self.G(self.latent)
-        self.real_logits = self.D(self.real_sample)
-        self.fake_logits = self.D(self.fake_sample.detach())
+        fake = self.fake_sample.detach()
+        if _PAIR_D and hasattr(self.D.module, 'forward_pair') and fake.shape == self.real_sample.shape \
+                and fake.shape[0] % 2 == 0:
+            # D(real) and D(fake) as one pass of twice the batch (each half with its own spectral-norm sigma)
+            self.real_logits, self.fake_logits = self.D.module.forward_pair(self.real_sample, fake)
+        else:
+            self.real_logits = self.D(self.real_sample)
+            self.fake_logits = self.D(fake)
 
     def forward_g(self, data):
         self.generated = data['fake_sample']

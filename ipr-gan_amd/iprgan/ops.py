@@ -101,22 +101,35 @@ def conv_prep_multi(specs, weights, sigmas, bwd=False):
     return outs
 
 
-def conv_fwd(spec, d, x, wfwd, bias):
+def conv_fwd(spec, d, x, wfwd, bias, pair=None):
+    """pair = (sigma0, sigma1): paired pass, see include/iprgan.h (rows of the two half-batches divided by their sigma)."""
     OH, OW = spec.out_hw(d.H, d.W)
     y = empty((d.B, OH, OW, c4(spec.cout)), x)
     nws = query('iprgan_conv_fwd_ws_floats', C.byref(d))
     ws = empty((nws,), x) if nws else None
-    call('iprgan_conv_fwd', C.byref(d), ptr(x), ptr(wfwd), ptr(bias), ptr(y), ptr(ws), stream())
+    p0, p1 = (ptr(pair[0]), ptr(pair[1])) if pair is not None else (None, None)
+    call('iprgan_conv_fwd', C.byref(d), ptr(x), ptr(wfwd), ptr(bias), ptr(y), ptr(ws), p0, p1, stream())
     return y
 
 
-def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0):
+def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0, pair=None):
     dx = empty((d.B, d.H, d.W, c4(spec.cin)), dy)
     nws = query('iprgan_conv_bwd_data_ws_floats', C.byref(d))
     ws = empty((nws,), dy) if nws else None
+    p0, p1 = (ptr(pair[0]), ptr(pair[1])) if pair is not None else (None, None)
     call('iprgan_conv_bwd_data', C.byref(d), ptr(dy), ptr(wbwd), ptr(dx), ptr(ws), ptr(prev_out), prev_act,
-         float(prev_slope), stream())
+         float(prev_slope), p0, p1, stream())
     return dx
+
+
+def colsum(x2d_like, channels, out=None, beta=0.0):
+    """Column sums of an activation tensor [..., C4] over all leading dims -> [channels] (bias gradient)."""
+    C_ = x2d_like.shape[-1]
+    M = x2d_like.numel() // C_
+    res = empty((channels,), x2d_like) if out is None else out
+    ws = empty((query('iprgan_colsum_ws_floats', M, C_),), x2d_like)
+    call('iprgan_colsum', ptr(x2d_like), ptr(res), ptr(ws), M, C_, channels, float(beta), stream())
+    return res
 
 
 def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0.0):
@@ -132,16 +145,16 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
 
 
 # ---- GEMV head ----------------------------------------------------------------------------------
-def gemv_fwd(x2d, w, bias, sigma):
+def gemv_fwd(x2d, w, bias, sigma, out=None):
     B, K = x2d.shape
-    y = empty((B,), x2d)
+    y = empty((B,), x2d) if out is None else out
     call('iprgan_gemv_fwd', ptr(x2d), ptr(w), ptr(bias), ptr(sigma), ptr(y), B, K, stream())
     return y
 
 
-def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0):
+def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0, dx_out=None):
     B, K = x2d.shape
-    dx = torch.empty_like(x2d) if need_dx else None
+    dx = (torch.empty_like(x2d) if dx_out is None else dx_out) if need_dx else None
     dw = empty((K,), x2d) if need_dw else None
     db = empty((1,), x2d) if need_dw else None
     call('iprgan_gemv_bwd', ptr(x2d), ptr(w), ptr(dy), ptr(sigma), ptr(dx), ptr(dw), ptr(db),

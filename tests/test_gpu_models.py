@@ -69,8 +69,10 @@ def step_policy(steps, lr=2e-4):
                          and k.split('::')[0].rsplit('.', 1)[-1] not in cases.BUFFER_LEAVES
                          and parts[1] not in ('fake_sample', 'super_res', 'fake_B'))
             # weights after the first Adam step: +-lr even where the gradient is pure noise (e.g. the
-            # bias of a conv feeding a norm layer, whose true gradient is zero)
-            return (1e-3, 2 * lr + 1e-4) if is_weight else (1e-3, 1e-4)
+            # bias of a conv feeding a norm layer, whose true gradient is zero); the spectral-norm vectors are
+            # functions of those weights (for the 1 x 32768 head, v = W / |W| element by element) and inherit the slack
+            is_sn_vec = k.split('::')[0].rsplit('.', 1)[-1] in ('weight_u', 'weight_v')
+            return (1e-3, 2 * lr + 1e-4) if (is_weight or is_sn_vec) else (1e-3, 1e-4)
         if k.startswith('step'):
             return (1e-2, 1e-3)
         leaf = k.rsplit('.', 1)[-1]
@@ -500,3 +502,27 @@ def test_patchgan_odd_maps_vs_oracle(hw, dev):
         # the bias of a conv that feeds an InstanceNorm has an exactly-zero gradient: both sides hold summation noise
         slack = 1e-3 if (k.endswith('.bias') and k not in ('0.bias', '11.bias')) else 1e-5
         assert float((ga - gb).norm()) <= 2e-3 * float(ga.norm()) + slack, k
+
+
+def test_paired_discriminator_pass_matches_two_passes(dev):
+    """SNDiscriminator.forward_pair(real, fake) - one pass of twice the batch, each half normalised by its own
+    spectral-norm sigma - against the reference's two consecutive calls on the oracle: logits, every parameter
+    gradient of the hinge loss, and the power-iteration buffers after the pass (they advance twice either way)."""
+    from iprgan import networks
+    a, b = nets.SNDiscriminator64(), networks.SNDiscriminator64()
+    recipe.fill(a, 33); recipe.fill(b, 33)
+    b.to(dev); a.train(); b.train()
+    xr = torch.tanh(recipe.tensor(33, 1, (6, 3, 64, 64)))
+    xf = torch.tanh(recipe.tensor(33, 2, (6, 3, 64, 64)))
+    ra, fa = a(xr), a(xf)
+    rb, fb = b.forward_pair(xr.to(dev), xf.to(dev))
+    np.testing.assert_allclose(rb.detach().cpu().numpy(), ra.detach().numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(fb.detach().cpu().numpy(), fa.detach().numpy(), rtol=RTOL, atol=ATOL)
+    (torch.relu(1 - ra).mean() + torch.relu(1 + fa).mean()).backward()
+    (torch.relu(1 - rb).mean() + torch.relu(1 + fb).mean()).backward()
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        ga, gb = pa.grad.double(), pb.grad.cpu().double()
+        assert float((ga - gb).norm()) <= 2e-3 * float(ga.norm()) + 1e-7, k
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        if k.endswith(('weight_u', 'weight_v')):
+            np.testing.assert_allclose(vb.cpu().numpy(), va.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)

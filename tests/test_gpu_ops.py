@@ -66,7 +66,9 @@ CONVS = [
     (64, 32, 3, 2, 1, 1, True, 6, 5, 2, 'relu'),           # CycleGAN up-conv (output_padding)
     (256, 512, 3, 1, 1, 0, False, 8, 8, 2, 'lrelu'),
     (128, 128, 1, 1, 0, 0, False, 5, 5, 2, 'none'),        # 1x1
-    (512, 64, 6, 1, 0, 0, False, 6, 6, 3, 'lrelu'),        # D96 "FC" conv
+    (512, 64, 6, 1, 0, 0, False, 6, 6, 3, 'lrelu'),        # D96 "FC" conv: full-map path (split-K forward, remapped dgrad)
+    (512, 1024, 6, 1, 0, 0, False, 6, 6, 64, 'lrelu'),     # ... at its real size (batch 64, 75 MB of weights)
+    (64, 96, 4, 1, 0, 0, False, 4, 4, 70, 'none'),         # full-map, ragged batch (two 64-row tiles) and Cout
     # few output channels, stride 1: backward-weight runs with swapped roles (P = x, Q = dy, negated taps)
     (64, 3, 9, 1, 4, 0, False, 12, 12, 2, 'none'),         # SRGAN head
     (64, 3, 7, 1, 3, 0, False, 13, 11, 2, 'tanh'),         # ragged
