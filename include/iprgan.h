@@ -74,14 +74,24 @@ int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* co
  * one dense 1x1 GEMM over tap planes + a gather instead of a 3/32-full MFMA tile); NULL = generic kernel. */
 size_t iprgan_conv_fwd_ws_floats(const iprgan_conv_desc* d);
 int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd, const float* bias,
-                    float* y, float* ws, const float* pair_sigma0, const float* pair_sigma1, void* stream);
+                    float* y, float* ws, const float* pair_sigma0, const float* pair_sigma1, float* stat_part,
+                    int* stat_rows, void* stream);
+/* Column statistics from the epilogue (stat_part non-NULL, iprgan_conv_stat_floats(d, 0) floats; *stat_rows, HOST int,
+ * receives the number of partial rows written): every output tile also stores the column sums s1 = sum acc and
+ * s2 = sum acc^2 of its rows, acc = the accumulator BEFORE bias and activation, as stat_part[row][2][C4(Cout)]; rows of
+ * one sample (and of one sub-pixel phase) are contiguous when its pixel count is a multiple of 128.  A BatchNorm /
+ * InstanceNorm that follows the convolution takes them instead of reading the activation once more for its statistics
+ * (iprgan_bn_fwd / iprgan_instnorm_fwd: conv_part, conv_part_rows, conv_bias).  iprgan_conv_bwd_data has the same
+ * pair of arguments: there the sums are over the STORED values (s1 = column sums of dx after the fused activation
+ * derivative = the bias gradient of the layer below, combined with iprgan_colsum_partials). */
+size_t iprgan_conv_stat_floats(const iprgan_conv_desc* d, int backward);
 /* dx = conv_bwd_data(dy, w) [* act'(x_out_prev)]: if prev_out != NULL the result is multiplied by the
  * derivative of activation prev_act evaluated from the saved OUTPUT prev_out of the previous layer
  * (same shape as dx), i.e. the previous layer's activation backward is fused into this epilogue. */
 size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d);   /* reflect padding, or <= 4 input channels */
 int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
                          const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
-                         const float* pair_sigma1, void* stream);
+                         const float* pair_sigma1, float* stat_part, int* stat_rows, void* stream);
 /* Paired pass (pair_sigma0/1 non-NULL, device scalars; B even): the batch holds TWO half-batches that the reference
  * sends through a spectrally normalised network one after the other (models/dcgan.py:47-48: D(real), D(fake)) - between
  * them the power iteration advances, so the halves see W/sigma0 and W/sigma1.  The operands are prepared from the
@@ -90,6 +100,8 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
 /* out[c] = beta*out[c] + sum_m x[m][c], c < C, over x[M][Cs] (bias gradients); ws: iprgan_colsum_ws_floats(M, Cs) floats */
 size_t iprgan_colsum_ws_floats(int M, int Cs);
 int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, float beta, void* stream);
+/* the same from per-tile partials part[rows][2][Cs] (first of the two sums) written by a convolution epilogue */
+int iprgan_colsum_partials(const float* part, int rows, int Cs, int C, float* out, float beta, void* stream);
 /* dw (PyTorch layout) = beta*dw + conv_bwd_weight(x, dy); db (optional, length Cout) = beta*db + sum dy.
  * beta = 0 overwrites; beta = 1 accumulates straight into a gradient bucket (what autograd's AccumulateGrad
  * add plus DDP's bucket copy do in two extra passes).  ws: workspace of iprgan_conv_wgrad_ws_floats(d) floats.
@@ -114,11 +126,15 @@ int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float
 size_t iprgan_bn_ws_floats(int M, int C);
 /* training forward: batch statistics over M=B*H*W rows of x[M,C]; y = act((x-mean)*invstd*g+b);
  * save_mean/save_invstd [C] out; running stats updated in place (momentum, unbiased var) when
- * running_mean != NULL.  eval forward: use_running=1 normalises with the running stats. */
+ * running_mean != NULL.  eval forward: use_running=1 normalises with the running stats.
+ * conv_part / conv_part_rows / conv_bias: column sums emitted by the convolution that produced x (iprgan_conv_fwd:
+ * stat_part), taken before its bias (conv_bias, may be NULL) was added - the statistics then cost no pass over x.
+ * num_batches_tracked (int64 device scalar, may be NULL) is incremented by the statistics kernel in training mode. */
 int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* beta,
                   float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                   float* ws, int M, int C, float eps, float momentum, int use_running, int act,
-                  float slope, void* stream);
+                  float slope, const float* conv_part, int conv_part_rows, const float* conv_bias,
+                  long long* num_batches_tracked, void* stream);
 /* backward through act + BN: inputs x (pre-norm), y (post-act output), dy.  dx, dgamma, dbeta out. */
 int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
@@ -130,7 +146,7 @@ int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* 
 size_t iprgan_instnorm_ws_floats(int B, int HW, int C);
 int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                         float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,
-                        void* stream);
+                        const float* conv_part, int conv_part_rows, const float* conv_bias, void* stream);
 int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                         const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                         float* dbeta, float* ws, int B, int HW, int C, int act, float slope, void* stream);

@@ -104,6 +104,8 @@ struct GConvArgs {
   int nphase;
   const float* rs0;    // paired pass (two half-batches through one launch, each with its own spectral-norm sigma):
   const float* rs1;    //   rows of the first / second half of every phase are divided by *rs0 / *rs1 before the bias
+  float* stat_part;    // STATS kernels: per-tile column sums [tile rows][2][Ns] (see gconv_kernel)
+  int stat_mode;
   int ksplit;          // > 1: blockIdx.z splits the K loop (single-phase geometries); partial tiles go to slabs of M*Ns floats
   int wmod, wk1;       // > 0: operand row r lives at (r % wmod) * Kp + (r / wmod) * wk1 floats (full-map conv backward-data)
   Phase ph[4];
@@ -163,7 +165,12 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned total) {
 // is then 32 k x 2 B = 64 B = four 16-byte chunks of 8 consecutive k; lane half h of MFMA kk reads chunk
 // 2 kk + h; chunk c of row r sits at c ^ ((r >> 2) & 3), which makes the 16-lane groups of ds_read_b128 hit 16
 // distinct slots of the 256-B bank line (4 rows).
-template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false>
+// STATS: the epilogue also emits per-tile COLUMN sums (s1 = sum t, s2 = sum t^2 over the tile's valid rows) into
+// a.stat_part[(tile row lq)][2][Ns], combined afterwards in fixed order (deterministic).  stat_mode 1: t = the
+// accumulator before bias and activation - the batch / instance statistics of the norm layer that follows the
+// convolution come for free instead of from another pass over its output (mean = bias + s1/M, var = s2/M - (s1/M)^2);
+// stat_mode 2: t = the value stored - column sums of a backward-data result = the bias gradient of the layer below.
+template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false, bool STATS = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a) {
   static_assert(!BF16 || BK == 32, "the bf16 tile is written for 32-deep K steps");
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
@@ -184,7 +191,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   const int pz = a.ksplit > 1 ? 0 : zi;          // blockIdx.z: sub-pixel phase, or K split of a single-phase geometry
   const int pM = a.ph[pz].M;
   const int m0 = (int)(lq / gridDim.z) * BM, n0 = (int)(lt % gridDim.y) * BN;
-  if (m0 >= pM) return;
+  if (m0 >= pM) {
+    if (STATS) {                 // a tile past the end of a short phase still owns a row of partials: zeros
+      for (int c = threadIdx.x; c < BN; c += NT)
+        if (n0 + c < a.Ns) { a.stat_part[((size_t)lq * 2) * a.Ns + n0 + c] = 0.f; a.stat_part[((size_t)lq * 2 + 1) * a.Ns + n0 + c] = 0.f; }
+    }
+    return;
+  }
   // phase constants into scalars once (the K loop must not re-read the kernel arguments)
   const int p_ntap = a.ph[pz].ntap, p_tw = a.ph[pz].tw;
   int p_steps = (a.ph[pz].steps * 32 + BK - 1) / BK, s_begin = 0;
@@ -416,6 +429,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   float rsc0 = 1.f, rsc1 = 1.f;
   if (a.rs0) { rsc0 = 1.f / *a.rs0; rsc1 = 1.f / *a.rs1; }
   const int halfM = pM >> 1;
+  float cs1[WN][4], cs2[WN][4];
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cs1[j][k] = cs2[j][k] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -440,6 +460,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
         if (!mok || n >= a.Ns) continue;
         f32x4 v = {c0, c1, c2, c3};
         if (a.rs0) v *= (m < halfM ? rsc0 : rsc1);
+        if (STATS && a.stat_mode == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { cs1[j][k] += v[k]; cs2[j][k] += v[k] * v[k]; }
+        }
         if (a.bias) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) if (n + k < a.N) v[k] += a.bias[n + k];
@@ -453,7 +477,41 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] *= act_grad_from_out(o[k], a.aux_act, a.aux_slope);
         }
+        if (STATS && a.stat_mode == 2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { cs1[j][k] += v[k]; cs2[j][k] += v[k] * v[k]; }
+        }
         *(f32x4*)(a.out + idx) = v;
+      }
+    }
+  }
+  if (STATS) {
+    // rows of one column quad live in the 8 lanes that differ in lane bits 0, 1 (row inside the transposed quad) and 5
+    // (row group); then the WGM waves that share the columns are combined through LDS, in wave order
+    float* red = (float*)lds;                    // the staging buffers are free: every wave is past its last compute()
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float s1 = cs1[j][k], s2 = cs2[j][k];
+        s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+        s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (qp == 0 && half == 0) {
+          const int c = (wn * WN + j) * 32 + qcol + k;
+          red[(wm * BN + c) * 2] = s1;
+          red[(wm * BN + c) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) { s1 += red[(w * BN + c) * 2]; s2 += red[(w * BN + c) * 2 + 1]; }
+      if (n0 + c < a.Ns) {
+        a.stat_part[((size_t)lq * 2) * a.Ns + n0 + c] = s1;
+        a.stat_part[((size_t)lq * 2 + 1) * a.Ns + n0 + c] = s2;
       }
     }
   }
@@ -1304,22 +1362,25 @@ static int g_force_tile = -1, g_force_wgrad = -1;     // test hook: iprgan_debug
 static int g_autotune = getenv("IPRGAN_AUTOTUNE") ? atoi(getenv("IPRGAN_AUTOTUNE")) : 1;
 static int g_smalln = getenv("IPRGAN_SMALLN") ? atoi(getenv("IPRGAN_SMALLN")) : 1;
 static int g_math = IPRGAN_MATH_FP32;                 // iprgan_set_math_mode
-static int g_nbuf = getenv("IPRGAN_LDS_BUFS") ? atoi(getenv("IPRGAN_LDS_BUFS")) : 1;  // 1 = single LDS buffer (measured faster: 3-4 blocks/CU)
+static int g_nbuf = getenv("IPRGAN_LDS_BUFS") ? atoi(getenv("IPRGAN_LDS_BUFS")) : 1;  // wgrad_kernel only: 1 = single LDS buffer (measured faster: 3-4 blocks/CU)
 
-template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false>
+static thread_local int t_last_bm = 0;      // M tile of the last gconv launch of this thread (partial-row count of STATS launches)
+
+template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false, bool STATS = false>
 static int launch_gconv_tfnk(const GConvArgs& a, hipStream_t st) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   if (maxM == 0) return 0;
   const size_t smem = NBUF * (size_t)(BM + BN) * (BF16 ? BK / 8 : BK / 4) * sizeof(f32x4);
-  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST, NBUF, BK, BF16>;
+  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST, NBUF, BK, BF16, STATS>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.ksplit > 1 ? a.ksplit : a.nphase);
+  t_last_bm = BM;
   prof_launch(kern, grid, dim3(WGM * WGN * 64), smem, st,
               BF16 ? 12 : WGM * WGN == 8 ? (BN == 128 ? 9 : 10) : BM == 128 ? (BN == 128 ? 0 : (BN == 64 ? 1 : 3)) : (BN == 128 ? 8 : 2),
               a.flops, a);
@@ -1327,30 +1388,26 @@ static int launch_gconv_tfnk(const GConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF>
-static int launch_gconv_tfn(const GConvArgs& a, hipStream_t st) {
-  // K step 32 everywhere: a 64-deep step was measured neutral-to-slower (-15 % on the N = 64 layers)
-  return launch_gconv_tfnk<WGM, WGN, WM, WN, FAST, NBUF, 32>(a, st);
-}
-
-template <int WGM, int WGN, int WM, int WN, bool FAST>
-static int launch_gconv_tf(const GConvArgs& a, hipStream_t st) {
-  return g_nbuf == 1 ? launch_gconv_tfn<WGM, WGN, WM, WN, FAST, 1>(a, st)
-                     : launch_gconv_tfn<WGM, WGN, WM, WN, FAST, 2>(a, st);
-}
-
 template <int WGM, int WGN, int WM, int WN>
 static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
+  // K step 32 everywhere (a 64-deep step was measured neutral-to-slower, -15 % on the N = 64 layers) and ONE LDS buffer
+  // (two barriers per step but 3-4 blocks per CU: measured faster than double buffering, which is no longer built)
   const bool fast = (a.Cs % 32) == 0;
   // bf16 math: layers whose K step lies in one tap (C4 % 32 == 0); RGB stems / heads keep the fp32 kernel
-  if (g_math == IPRGAN_MATH_BF16 && fast) return launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true>(a, st);
-  return fast ? launch_gconv_tf<WGM, WGN, WM, WN, true>(a, st) : launch_gconv_tf<WGM, WGN, WM, WN, false>(a, st);
+  if (g_math == IPRGAN_MATH_BF16 && fast)
+    return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, true>(a, st)
+                       : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, false>(a, st);
+  if (a.stat_part)
+    return fast ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, false, true>(a, st)
+                : launch_gconv_tfnk<WGM, WGN, WM, WN, false, 1, 32, false, true>(a, st);
+  return fast ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, false, false>(a, st)
+              : launch_gconv_tfnk<WGM, WGN, WM, WN, false, 1, 32, false, false>(a, st);
 }
 
 static int launch_gconv(const GConvArgs& ain, hipStream_t st);
 
 static bool smalln_eligible(const GConvArgs& a) {
-  return g_smalln && !a.rs0 && a.Ns == 4 && a.nphase == 1 && a.isy == 1 && a.isx == 1 && a.osy == 1 && a.osx == 1 &&
+  return g_smalln && !a.rs0 && !a.stat_part && a.Ns == 4 && a.nphase == 1 && a.isy == 1 && a.isx == 1 && a.osy == 1 && a.osx == 1 &&
          (a.Cs % 32) == 0 && a.ph[0].ntap >= 2 && !a.planar_M;
 }
 static size_t smalln_ws_floats(const GConvArgs& a) {
@@ -1469,7 +1526,8 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   // geometry times every tile on the caller's stream and keeps the fastest.  Tiles only change the summation
   // order, results stay within fp32 rounding of each other.
   TuneKey key = {{a.B, a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.isy, a.osy, a.nphase, a.ph[0].th, a.ph[0].tw,
-                  a.ph[0].ohg, a.ph[0].owg, a.pad_mode + 16 * g_math + 64 * a.ksplit + 8192 * (a.wmod > 0) + 16384 * (a.rs0 != nullptr), a.Kp}};
+                  a.ph[0].ohg, a.ph[0].owg, a.pad_mode + 16 * g_math + 64 * a.ksplit + 8192 * (a.wmod > 0) + 16384 * (a.rs0 != nullptr) +
+                      32768 * (a.stat_part != nullptr), a.Kp}};
   tune_load();
   auto it = g_tune.find(key);
   if (it != g_tune.end()) return run(it->second);
@@ -1674,11 +1732,29 @@ static int launch_wgrad_t2(const WGradArgs& a, const WGradPlan& p, hipStream_t s
               : launch_wgrad_t2r<WGM, WGN, WM, WN, false, false>(a, p, st);
 }
 
+// partial rows written by the last STATS launch of geometry a: (M tiles of the tile that ran) x (phases)
+static int stat_rows_of(const GConvArgs& a) {
+  int maxM = 0;
+  for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
+  return cdiv(maxM, t_last_bm) * a.nphase;
+}
+
 }  // namespace iprgan
 
 using namespace iprgan;
 
 extern "C" {
+
+size_t iprgan_conv_stat_floats(const iprgan_conv_desc* d, int backward) {
+  // worst case: 64-row tiles.  forward: output grid of the layer; backward-data: its input grid.  Phases (stride 2
+  // transposed / backward forms) split the grid, each phase has its own tile rows.
+  const Shape s = out_shape(d);
+  const bool fwd_form = backward ? (d->transposed != 0) : (d->transposed == 0);
+  const int gh = backward ? d->H : s.OH, gw = backward ? d->W : s.OW, st = fwd_form ? 1 : d->stride;
+  const int nph = st * st;
+  const long long rows = ((long long)d->B * cdiv(gh, st) * cdiv(gw, st) + 63) / 64 + 1;
+  return (size_t)rows * nph * 2 * c4(backward ? d->Cin : d->Cout);
+}
 
 size_t iprgan_conv_wfwd_floats(const iprgan_conv_desc* d) {
   // Conv2d fwd uses rows=Cout,k=(tap,Cin); ConvT fwd uses rows=Cout,k=(tap,Cin) as well
@@ -1768,7 +1844,10 @@ int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* co
 }
 
 int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd, const float* bias,
-                    float* y, float* ws, const float* pair_sigma0, const float* pair_sigma1, void* stream) {
+                    float* y, float* ws, const float* pair_sigma0, const float* pair_sigma1, float* stat_part,
+                    int* stat_rows, void* stream) {
+  IPR_CHECK(!stat_part || (stat_rows && !fullmap_conv(d) && c4(d->Cout) > 4),
+            "conv_fwd: column statistics need the row-count output and a regular convolution with more than 4 channels");
   IPR_CHECK(!pair_sigma0 == !pair_sigma1 && (!pair_sigma0 || ((d->B & 1) == 0 && !fullmap_conv(d))),
             "conv_fwd: a paired pass needs both sigmas, an even batch and a regular convolution");
   IPR_CHECK(d->stride >= 1 && d->stride <= 2, "conv_fwd: stride %d unsupported", d->stride);
@@ -1806,7 +1885,10 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = d->act; a.slope = d->slope;
   a.ws = ws; a.ws_floats = ws ? iprgan_conv_fwd_ws_floats(d) : 0;
-  return launch_gconv(a, (hipStream_t)stream);
+  a.stat_part = stat_part; a.stat_mode = 1;
+  const int rc = launch_gconv(a, (hipStream_t)stream);
+  if (stat_part && !rc) *stat_rows = stat_rows_of(a);
+  return rc;
 }
 
 size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d) {
@@ -1816,7 +1898,9 @@ size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d) {
 
 int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
                          const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
-                         const float* pair_sigma1, void* stream) {
+                         const float* pair_sigma1, float* stat_part, int* stat_rows, void* stream) {
+  IPR_CHECK(!stat_part || (stat_rows && !fullmap_conv(d) && d->pad_mode != IPRGAN_PAD_REFLECT && c4(d->Cin) > 4),
+            "conv_bwd_data: column sums need the row-count output and a zero-padded regular convolution with more than 4 input channels");
   IPR_CHECK(!pair_sigma0 == !pair_sigma1 &&
             (!pair_sigma0 || ((d->B & 1) == 0 && !fullmap_conv(d) && d->pad_mode != IPRGAN_PAD_REFLECT)),
             "conv_bwd_data: a paired pass needs both sigmas, an even batch and a zero-padded regular convolution");
@@ -1851,7 +1935,9 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = IPRGAN_ACT_NONE; a.slope = 0.f;
   if (!reflect) { a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.ws = ws; a.ws_floats = ws ? smalln_ws_for(d, false) : 0; }
+  a.stat_part = stat_part; a.stat_mode = 2;
   const int rc = launch_gconv(a, (hipStream_t)stream);
+  if (stat_part && !rc) *stat_rows = stat_rows_of(a);
   if (rc || !reflect) return rc;
   return iprgan_reflect_fold(ws, dx, prev_out, prev_act, prev_slope, d->B, d->H, d->W, c4(d->Cin), d->pad, stream);
 }

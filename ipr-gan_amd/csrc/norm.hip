@@ -141,12 +141,17 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
                                                              float* __restrict__ running_mean,
                                                              float* __restrict__ running_var,
                                                              float* __restrict__ save_mean,
-                                                             float* __restrict__ save_invstd) {
+                                                             float* __restrict__ save_invstd,
+                                                             int shift_vec, long long* __restrict__ counter) {
+  // shift_vec 0: the sums are about s = x[0][c] of the group (colreduce_kernel<1>); 1: about the per-channel vector
+  // x[c] itself, or about zero when x is null (sums emitted by the producing convolution's epilogue, taken before
+  // its bias was added: s = bias)
   const int grp = blockIdx.y;
   part += (size_t)grp * NB * 2 * C;
-  x += (size_t)grp * M * C;
+  if (!shift_vec) x += (size_t)grp * M * C;
   save_mean += (size_t)grp * C;
   save_invstd += (size_t)grp * C;
+  if (counter && blockIdx.x == 0 && grp == 0 && threadIdx.x == 0) *counter += 1;     // num_batches_tracked
   __shared__ float sh[2][FL][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
   float s0, s1;
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
   if (lane != 0 || c >= C) return;
   const float invM = 1.0f / (float)M;
   const float d = s0 * invM;                 // E[x - s]
-  const float mean = x[c] + d;
+  const float mean = (x ? x[c] : 0.f) + d;
   float var = s1 * invM - d * d;             // biased variance
   if (var < 0.f) var = 0.f;
   save_mean[c] = mean;
@@ -305,20 +310,27 @@ using namespace iprgan;
 
 static int norm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_invstd, float* ws, int G, int M, int C,
-                    float eps, float momentum, int use_running, int act, float slope, hipStream_t st) {
+                    float eps, float momentum, int use_running, int act, float slope, hipStream_t st,
+                    const float* part = nullptr, int part_rows = 0, const float* shift = nullptr,
+                    long long* counter = nullptr) {
   IPR_CHECK(C % 4 == 0, "norm_fwd: C=%d must be a multiple of 4", C);
   IPR_CHECK(M > 0 && G > 0, "norm_fwd: empty input");
   if (use_running) {
     IPR_CHECK(running_mean && running_var && G == 1, "norm_fwd: eval mode needs running stats");
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, running_mean,
                        running_var, eps, C, save_mean, save_invstd);
+  } else if (part) {
+    // column sums already emitted tile by tile by the convolution that produced x: no pass over x for statistics
+    IPR_CHECK(part_rows > 0 && part_rows % G == 0, "norm_fwd: %d partial rows for %d groups", part_rows, G);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, part, shift, part_rows / G, M,
+                       C, eps, momentum, running_mean, running_var, save_mean, save_invstd, 1, counter);
   } else {
     const ColGeom g = col_geom(M, C);
     hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.NB, g.gy, G), dim3(256), 0, st, x, nullptr, nullptr,
                        nullptr, nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f);
     IPR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, x, g.NB, M, C,
-                       eps, momentum, running_mean, running_var, save_mean, save_invstd);
+                       eps, momentum, running_mean, running_var, save_mean, save_invstd, 0, counter);
   }
   IPR_LAUNCH_CHECK();
   const size_t n4 = (size_t)G * M * C / 4;
@@ -376,12 +388,20 @@ int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, f
   return colsum_launch(x, out, ws, M, Cs, C, (hipStream_t)stream, beta);
 }
 size_t iprgan_colsum_ws_floats(int M, int C) { return colsum_ws_floats(M, C); }
+int iprgan_colsum_partials(const float* part, int rows, int Cs, int C, float* out, float beta, void* stream) {
+  IPR_CHECK(rows > 0 && C <= Cs, "colsum_partials: %d rows, C=%d, Cs=%d", rows, C, Cs);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, (hipStream_t)stream, part, rows, Cs, C, out, beta);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
 
 int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                   float* running_var, float* save_mean, float* save_invstd, float* ws, int M, int C,
-                  float eps, float momentum, int use_running, int act, float slope, void* stream) {
+                  float eps, float momentum, int use_running, int act, float slope, const float* conv_part,
+                  int conv_part_rows, const float* conv_bias, long long* num_batches_tracked, void* stream) {
   return norm_fwd(x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, 1, M, C, eps,
-                  momentum, use_running, act, slope, (hipStream_t)stream);
+                  momentum, use_running, act, slope, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias,
+                  use_running ? nullptr : num_batches_tracked);
 }
 int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
@@ -391,9 +411,9 @@ int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* 
 }
 int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                         float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,
-                        void* stream) {
+                        const float* conv_part, int conv_part_rows, const float* conv_bias, void* stream) {
   return norm_fwd(x, y, gamma, beta, nullptr, nullptr, save_mean, save_invstd, ws, B, HW, C, eps, 0.f, 0, act,
-                  slope, (hipStream_t)stream);
+                  slope, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias);
 }
 int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
                         const float* save_mean, const float* save_invstd, float* dx, float* dgamma,

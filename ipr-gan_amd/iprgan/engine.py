@@ -17,6 +17,7 @@ from . import _lib as L
 from . import ops, parallel
 
 _BATCH_PREP = os.environ.get('IPRGAN_BATCH_PREP', '1') != '0'
+_FUSE_STATS = os.environ.get('IPRGAN_FUSE_STATS', '1') != '0'       # A/B switch: column sums from conv epilogues
 
 
 class Op:
@@ -139,9 +140,25 @@ class Conv(Op):
             sigma = None
         if wf is None:
             wf, _ = ops.conv_prep(sp, d, self.weight, sigma, fwd=True, bwd=False)
-        y = ops.conv_fwd(sp, d, x, wf, self.bias, pair=pair)
+        if st.get('emit_stats'):            # the norm layer that follows takes its statistics from this epilogue
+            y, stats = ops.conv_fwd(sp, d, x, wf, self.bias, pair=pair, stats=True)
+            st['ctx']['conv_stats'] = (stats, self.bias)
+        else:
+            y = ops.conv_fwd(sp, d, x, wf, self.bias, pair=pair)
         st.update(x=x, y=y, d=d, sigma=sigma)
         return y
+
+    def can_emit_stats(self, H, W, per_instance):
+        """Column statistics from the epilogue: any BatchNorm; InstanceNorm when every sample's rows (per sub-pixel
+        phase) form whole tiles (include/iprgan.h)."""
+        sp = self.spec
+        if ops.c4(sp.cout) <= 4 or (sp.k == H and sp.k == W and sp.pad == 0 and not sp.transposed and sp.k > 1):
+            return False
+        if not per_instance:
+            return True
+        OH, OW = sp.out_hw(H, W)
+        s_ = sp.stride if sp.transposed else 1
+        return OH % s_ == 0 and OW % s_ == 0 and ((OH // s_) * (OW // s_)) % 128 == 0
 
     def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         sp, d, sigma = self.spec, st['d'], st['sigma']
@@ -159,18 +176,30 @@ class Conv(Op):
             dwa, _ = ops.conv_bwd_weight(sp, dh, x_[:B2], dy[:B2], self.weight.shape, False)
             dwb, _ = ops.conv_bwd_weight(sp, dh, x_[B2:], dy[B2:], self.weight.shape, False)
             st['dwsn'] = [(dwa, st['uv'][0][0], st['uv'][0][1], pair[0]), (dwb, st['uv'][1][0], st['uv'][1][1], pair[1])]
-            grads = [dwa] + ([ops.colsum(dy, sp.cout)] if has_b else [])
+            dbp = st.get('db_part')
+            db = (ops.colsum_partials(dbp[0], dbp[1], dy.shape[-1], sp.cout) if dbp is not None
+                  else ops.colsum(dy, sp.cout)) if has_b else None
+            grads = [dwa] + ([db] if has_b else [])
         elif need_w:
             has_b = self.bias is not None
+            dbp = st.get('db_part') if has_b else None     # column sums of dy from the epilogue that produced it
+            db_done = None
+            if dbp is not None:
+                if sink is not None:
+                    ops.colsum_partials(dbp[0], dbp[1], dy.shape[-1], sp.cout, out=sink.view_of(self.bias), beta=1.0)
+                    db_done = DIRECT
+                else:
+                    db_done = ops.colsum_partials(dbp[0], dbp[1], dy.shape[-1], sp.cout)
+            want_b = has_b and db_done is None
             if sink is not None and self.sn is None:
-                ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, has_b, dw=sink.view_of(self.weight),
-                                    db=sink.view_of(self.bias) if has_b else None, beta=1.0)
+                ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, want_b, dw=sink.view_of(self.weight),
+                                    db=sink.view_of(self.bias) if want_b else None, beta=1.0)
                 grads = [DIRECT] + ([DIRECT] if has_b else [])
             else:
                 # (spectral norm: dW_sn is a temporary - the batched SN backward accumulates dW_orig into the view -
                 # and the bias gradient joins the pass's small-gradient add)
-                dw, db = ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, has_b)
-                grads = [dw] + ([db] if has_b else [])
+                dw, db = ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, want_b)
+                grads = [dw] + ([db if want_b else db_done] if has_b else [])
             if self.sn is not None:         # spectral-norm backward of all layers is batched by ChainFn.backward
                 st['dwsn'] = [(dw, st['u'], st['v'], st['sigma'])]
         dx = None
@@ -178,11 +207,17 @@ class Conv(Op):
             wb = st.pop('wb', None)
             if wb is None:
                 _, wb = ops.conv_prep(sp, d, self.weight, sigma, fwd=False, bwd=True)
-            if prev_act is not None:
-                dx = ops.conv_bwd_data(sp, d, dy, wb, st['x'], prev_act[0], prev_act[1], pair=pair)
-            else:
-                dx = ops.conv_bwd_data(sp, d, dy, wb, pair=pair)
+            want_cs = st.get('want_dx_colsums', False)
+            pa = (st['x'], prev_act[0], prev_act[1]) if prev_act is not None else (None, L.ACT_NONE, 0.0)
+            dx = ops.conv_bwd_data(sp, d, dy, wb, pa[0], pa[1], pa[2], pair=pair, colsums=want_cs)
+            if want_cs:
+                dx, st['dx_colsums'] = dx
         return dx, grads
+
+    def can_emit_dx_colsums(self, H, W):
+        sp = self.spec
+        fullmap = sp.k == H and sp.k == W and sp.pad == 0 and not sp.transposed and sp.k > 1
+        return ops.c4(sp.cin) > 4 and sp.pad_mode == L.PAD_ZERO and not fullmap
 
 
 class LinearNHWC(Op):
@@ -267,14 +302,20 @@ class BatchNorm(Op):
         use_batch = train or not m.track_running_stats
         track = train and m.track_running_stats
         mom = m.momentum
+        counter = None
         if track and m.num_batches_tracked is not None:
-            m.num_batches_tracked.add_(1)
-            if mom is None:
+            if mom is None:                 # cumulative moving average: the host needs the count (never in the reference)
+                m.num_batches_tracked.add_(1)
                 mom = 1.0 / float(m.num_batches_tracked)
+            else:
+                counter = m.num_batches_tracked       # incremented by the statistics kernel
+        cs = st['ctx'].pop('conv_stats', None) if use_batch else None
         y, mean, invstd = ops.bn_fwd(x, m.weight, m.bias,
                                      m.running_mean if (track or not use_batch) else None,
                                      m.running_var if (track or not use_batch) else None,
-                                     m.eps, mom if mom is not None else 0.0, use_batch, self.act, self.slope)
+                                     m.eps, mom if mom is not None else 0.0, use_batch, self.act, self.slope,
+                                     conv_stats=cs[0] if cs else None, conv_bias=cs[1] if cs else None,
+                                     counter=counter)
         st.update(x=x, y=y, mean=mean, invstd=invstd)
         return y
 
@@ -382,7 +423,9 @@ class InstanceNorm(Op):
         return (self.m.weight, self.m.bias) if self.m.weight is not None else ()
 
     def forward(self, x, st, train):
-        y, mean, invstd = ops.instnorm_fwd(x, self.m.weight, self.m.bias, self.m.eps, self.act, self.slope)
+        cs = st['ctx'].pop('conv_stats', None)
+        y, mean, invstd = ops.instnorm_fwd(x, self.m.weight, self.m.bias, self.m.eps, self.act, self.slope,
+                                           conv_stats=cs[0] if cs else None, conv_bias=cs[1] if cs else None)
         st.update(x=x, y=y, mean=mean, invstd=invstd)
         return y
 
@@ -530,8 +573,16 @@ class ChainFn(torch.autograd.Function):
             for i, wf in zip(todo, wfs):
                 stash[i]['wf'] = wf
                 chain.ops[i].keep_operand('wf', wf, stash[i])
-        for op, st in zip(chain.ops, stash):
+        n_ops = len(chain.ops)
+        for i, (op, st) in enumerate(zip(chain.ops, stash)):
+            if _FUSE_STATS and isinstance(op, Conv) and i + 1 < n_ops and not pair and h.dim() == 4:
+                nxt = chain.ops[i + 1]
+                per_inst = isinstance(nxt, InstanceNorm)
+                if (per_inst or (isinstance(nxt, BatchNorm) and (train or not nxt.m.track_running_stats))) \
+                        and op.can_emit_stats(h.shape[1], h.shape[2], per_inst):
+                    st['emit_stats'] = True
             h = op.forward(h, st, train)
+            shared.pop('conv_stats', None) if not isinstance(op, Conv) else None
         ctx.chain, ctx.stash, ctx.red = chain, stash, red
         # the backward pass reads the live parameters (weights for the data gradients, spectral-norm factors):
         # remember their versions so that a step taken between this forward and its backward is an error, as it
@@ -623,7 +674,13 @@ class ChainFn(torch.autograd.Function):
             if need_dx and prev is not None and op.fuses_prev_act and prev.out_act[0] != L.ACT_NONE:
                 fuse = prev.out_act
                 stash[i - 1]['dy_is_preact'] = True
+            if (_FUSE_STATS and need_dx and isinstance(op, Conv) and isinstance(prev, Conv) and prev.bias is not None
+                    and op_need_w[i - 1] and (fuse is not None or prev.out_act[0] == L.ACT_NONE)
+                    and op.can_emit_dx_colsums(st['d'].H, st['d'].W)):
+                st['want_dx_colsums'] = True      # the column sums of this dx are the bias gradient of the layer below
             g, pg = op.backward(g, st, need_dx, op_need_w[i], fuse, sink)
+            if 'dx_colsums' in st:
+                stash[i - 1]['db_part'] = st.pop('dx_colsums')
             grads_per_op[i] = pg
             if op_need_w[i] and 'dwsn' in st:
                 sn_wait.append(i)

@@ -101,25 +101,42 @@ def conv_prep_multi(specs, weights, sigmas, bwd=False):
     return outs
 
 
-def conv_fwd(spec, d, x, wfwd, bias, pair=None):
-    """pair = (sigma0, sigma1): paired pass, see include/iprgan.h (rows of the two half-batches divided by their sigma)."""
+def conv_fwd(spec, d, x, wfwd, bias, pair=None, stats=False):
+    """pair = (sigma0, sigma1): paired pass, see include/iprgan.h (rows of the two half-batches divided by their sigma).
+    stats=True: also returns (partials, rows): per-tile column sums of the pre-bias accumulator for the norm layer that
+    follows (include/iprgan.h: column statistics from the epilogue)."""
     OH, OW = spec.out_hw(d.H, d.W)
     y = empty((d.B, OH, OW, c4(spec.cout)), x)
     nws = query('iprgan_conv_fwd_ws_floats', C.byref(d))
     ws = empty((nws,), x) if nws else None
     p0, p1 = (ptr(pair[0]), ptr(pair[1])) if pair is not None else (None, None)
-    call('iprgan_conv_fwd', C.byref(d), ptr(x), ptr(wfwd), ptr(bias), ptr(y), ptr(ws), p0, p1, stream())
-    return y
+    part, rows = None, C.c_int(0)
+    if stats:
+        part = empty((query('iprgan_conv_stat_floats', C.byref(d), 0),), x)
+    call('iprgan_conv_fwd', C.byref(d), ptr(x), ptr(wfwd), ptr(bias), ptr(y), ptr(ws), p0, p1, ptr(part),
+         C.byref(rows), stream())
+    return (y, (part, rows.value)) if stats else y
 
 
-def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0, pair=None):
+def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0, pair=None, colsums=False):
+    """colsums=True: also returns (partials, rows): per-tile column sums of dx (after the fused activation derivative),
+    i.e. the bias gradient of the layer that produced this layer's input, up to ``colsum_partials``."""
     dx = empty((d.B, d.H, d.W, c4(spec.cin)), dy)
     nws = query('iprgan_conv_bwd_data_ws_floats', C.byref(d))
     ws = empty((nws,), dy) if nws else None
     p0, p1 = (ptr(pair[0]), ptr(pair[1])) if pair is not None else (None, None)
+    part, rows = None, C.c_int(0)
+    if colsums:
+        part = empty((query('iprgan_conv_stat_floats', C.byref(d), 1),), dy)
     call('iprgan_conv_bwd_data', C.byref(d), ptr(dy), ptr(wbwd), ptr(dx), ptr(ws), ptr(prev_out), prev_act,
-         float(prev_slope), p0, p1, stream())
-    return dx
+         float(prev_slope), p0, p1, ptr(part), C.byref(rows), stream())
+    return (dx, (part, rows.value)) if colsums else dx
+
+
+def colsum_partials(part, rows, Cs, channels, out=None, beta=0.0):
+    res = empty((channels,), part) if out is None else out
+    call('iprgan_colsum_partials', ptr(part), int(rows), int(Cs), int(channels), ptr(res), float(beta), stream())
+    return res
 
 
 def colsum(x2d_like, channels, out=None, beta=0.0):
@@ -163,15 +180,20 @@ def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_
 
 
 # ---- batch norm -----------------------------------------------------------------------------------
-def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, act, slope=0.0):
+def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, act, slope=0.0, conv_stats=None,
+           conv_bias=None, counter=None):
+    """conv_stats = (partials, rows) from conv_fwd(stats=True): the statistics are taken from them instead of a pass
+    over x.  counter: the module's int64 num_batches_tracked, incremented on the device."""
     C_ = x.shape[-1]
     M = x.numel() // C_
     y = torch.empty_like(x)
     mean, invstd = empty((C_,), x), empty((C_,), x)
-    ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    part, rows = conv_stats if conv_stats is not None else (None, 0)
+    ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
     call('iprgan_bn_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
          ptr(mean), ptr(invstd), ptr(ws), M, C_, float(eps), float(momentum), 0 if training else 1,
-         act, float(slope), stream())
+         act, float(slope), ptr(part), int(rows), ptr(conv_bias) if part is not None else None,
+         counter.data_ptr() if counter is not None else None, stream())
     return y, mean, invstd
 
 
@@ -345,13 +367,15 @@ def fill(t, value=0.0):
 
 
 # ---- instance norm / PReLU / pixel shuffle / max pool / residual add ---------------------------------
-def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0):
+def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias=None):
     B, H, W, C_ = x.shape
     y = torch.empty_like(x)
     mean, invstd = empty((B, C_), x), empty((B, C_), x)
-    ws = empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
+    part, rows = conv_stats if conv_stats is not None else (None, 0)
+    ws = None if part is not None else empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
     call('iprgan_instnorm_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(ws),
-         B, H * W, C_, float(eps), act, float(slope), stream())
+         B, H * W, C_, float(eps), act, float(slope), ptr(part), int(rows),
+         ptr(conv_bias) if part is not None else None, stream())
     return y, mean, invstd
 
 

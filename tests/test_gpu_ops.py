@@ -572,3 +572,55 @@ def test_north_star_conv_shapes_full_size(dev, cfg):
     xin = F.pad(x, (p, p, p, p), mode='reflect') if pm else x
     dwr = torch.nn.grad.conv2d_weight(xin, w.shape, gy, stride=s, padding=0 if pm else p)
     close(dw, dwr, what='wgrad')
+
+
+STAT_SHAPES = [  # cin, cout, k, s, p, outpad, transposed, H, W, B
+    (64, 64, 3, 1, 1, 0, False, 16, 16, 4),       # 256 rows per sample
+    (128, 64, 4, 2, 1, 0, True, 8, 8, 6),         # ConvT k4s2: four sub-pixel phases of 64 rows per sample
+    (32, 96, 3, 2, 1, 0, False, 15, 13, 3),       # ragged rows, Cout not a tile multiple
+    (64, 32, 3, 2, 1, 1, True, 6, 5, 2),          # ConvT with output_padding: phases of different sizes
+]
+
+
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('shape', STAT_SHAPES, ids=lambda c: '-'.join(map(str, c)))
+def test_conv_epilogue_column_sums(dev, shape, tile):
+    """Column sums emitted by the conv epilogues, under every tile variant: forward (sum acc, sum acc^2 of the pre-bias
+    accumulator per tile row -> reduced here over all rows) against torch; backward-data (column sums of dx after the
+    fused activation derivative) against torch.  Also: outputs are unchanged by the extra epilogue work."""
+    from iprgan import _lib, ops
+    cin, cout, k, s, p, op, tr, H, W, B = shape
+    x = rnd(B, cin, H, W, seed=1)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w, b = rnd(*wshape, seed=2, scale=(cin * k * k) ** -0.5), rnd(cout, seed=3, scale=0.3)
+    conv = (lambda t: F.conv_transpose2d(t, w, None, stride=s, padding=p, output_padding=op)) if tr else \
+           (lambda t: F.conv2d(t, w, None, stride=s, padding=p))
+    acc = conv(x)
+    spec = ops.ConvSpec(cin, cout, k, s, p, op, tr)
+    d = spec.desc(B, H, W)
+    try:
+        _lib.call('iprgan_debug_force_tiles', tile, -1)
+        wf, wb = ops.conv_prep(spec, d, w.to(dev), None, True, True)
+        xd = to_nhwc(x).to(dev)
+        y0 = ops.conv_fwd(spec, d, xd, wf, b.to(dev))
+        y, (part, rows) = ops.conv_fwd(spec, d, xd, wf, b.to(dev), stats=True)
+        assert torch.equal(y, y0)
+        Cs = ops.c4(cout)
+        pr = part[:rows * 2 * Cs].view(rows, 2, Cs).double().sum(0).cpu()
+        ref1, ref2 = acc.double().sum((0, 2, 3)), (acc.double() ** 2).sum((0, 2, 3))
+        assert float((pr[0, :cout] - ref1).abs().max()) <= 2e-4 * float(acc.abs().max()) * acc[:, 0].numel() ** 0.5
+        assert float((pr[1, :cout] - ref2).abs().max()) <= 2e-4 * float(ref2.abs().max())
+        # backward-data: dx * lrelu'(x_in) summed over all pixels = bias gradient of a producer conv with LeakyReLU
+        g = rnd(*acc.shape, seed=4)
+        xin = F.leaky_relu(x, 0.1).requires_grad_()
+        conv(xin).backward(g)
+        want = (xin.grad * torch.where(xin > 0, 1.0, 0.1))
+        xin_d = to_nhwc(xin.detach()).to(dev)
+        dx0 = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb, xin_d, 2, 0.1)
+        dx, (part, rows) = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb, xin_d, 2, 0.1, colsums=True)
+        assert torch.equal(dx, dx0)
+        cs = ops.colsum_partials(part, rows, ops.c4(cin), cin).cpu().double()
+        refc = want.double().sum((0, 2, 3))
+        assert float((cs - refc).abs().max()) <= 2e-4 * float(want.abs().max()) * want[:, 0].numel() ** 0.5
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
