@@ -1753,7 +1753,8 @@ size_t iprgan_conv_stat_floats(const iprgan_conv_desc* d, int backward) {
   const int gh = backward ? d->H : s.OH, gw = backward ? d->W : s.OW, st = fwd_form ? 1 : d->stride;
   const int nph = st * st;
   const long long rows = ((long long)d->B * cdiv(gh, st) * cdiv(gw, st) + 63) / 64 + 1;
-  return (size_t)rows * nph * 2 * c4(backward ? d->Cin : d->Cout);
+  // + room for the compacted rows of the final reduction (norm.hip: compact_partials; 32 rows per group, <= B groups)
+  return ((size_t)rows * nph + 32 * (size_t)d->B) * 2 * c4(backward ? d->Cin : d->Cout);
 }
 
 size_t iprgan_conv_wfwd_floats(const iprgan_conv_desc* d) {

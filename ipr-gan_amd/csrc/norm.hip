@@ -126,6 +126,43 @@ __device__ __forceinline__ void final_sums(const float* __restrict__ part, int N
   for (int l = 0; l < FL; ++l) { s0 += sh[0][l][cl]; s1 += sh[1][l][cl]; }
 }
 
+// Convolution epilogues emit one row of column sums per OUTPUT TILE (thousands of rows for the large layers); the
+// final kernels walk their partial rows with 16 lanes per channel, which is latency-bound beyond a few hundred rows.
+// This pre-pass folds part[G][rows][W] (W = 2*Cs floats per row) down to out[G][NBC][W], slice by slice in row order.
+#define NBC 32
+__global__ __launch_bounds__(256) void part_compact_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ out,
+                                                           int rows, int W4, int rps) {
+  __shared__ f32x4 sh[4][64];
+  const int grp = blockIdx.z, q = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  part += (size_t)grp * rows * W4;
+  const int r0 = blockIdx.x * rps;
+  int r1 = r0 + rps;
+  if (r1 > rows) r1 = rows;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+  if (q < W4) {
+    int r = r0 + rl;
+    for (; r + 4 < r1; r += 8) { a += part[(size_t)r * W4 + q]; b += part[(size_t)(r + 4) * W4 + q]; }
+    if (r < r1) a += part[(size_t)r * W4 + q];
+  }
+  sh[rl][threadIdx.x & 63] = a + b;
+  __syncthreads();
+  if (rl == 0 && q < W4)
+    out[((size_t)grp * gridDim.x + blockIdx.x) * W4 + q] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+// returns the partial pointer / row count the final kernel should read (compacted into the spare room behind the rows
+// when there are many: iprgan_conv_stat_floats reserves it)
+static int compact_partials(const float*& part, int& rows_per_group, int G, int Cs, hipStream_t st) {
+  if (rows_per_group <= 4 * NBC) return 0;
+  float* out = const_cast<float*>(part) + (size_t)G * rows_per_group * 2 * Cs;
+  const int W4 = 2 * Cs / 4, rps = cdiv(rows_per_group, NBC), nb = cdiv(rows_per_group, rps);
+  hipLaunchKernelGGL(part_compact_kernel, dim3(nb, cdiv(W4, 64), G), dim3(256), 0, st, (const f32x4*)part, (f32x4*)out,
+                     rows_per_group, W4, rps);
+  IPR_LAUNCH_CHECK();
+  part = out;
+  rows_per_group = nb;
+  return 0;
+}
+
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int NB, int Cs,
                                                            int C, float* __restrict__ out, float beta) {
   __shared__ float sh[2][FL][64];
@@ -322,7 +359,9 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
   } else if (part) {
     // column sums already emitted tile by tile by the convolution that produced x: no pass over x for statistics
     IPR_CHECK(part_rows > 0 && part_rows % G == 0, "norm_fwd: %d partial rows for %d groups", part_rows, G);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, part, shift, part_rows / G, M,
+    int rpg = part_rows / G;
+    if (compact_partials(part, rpg, G, C, st)) return 2;
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, part, shift, rpg, M,
                        C, eps, momentum, running_mean, running_var, save_mean, save_invstd, 1, counter);
   } else {
     const ColGeom g = col_geom(M, C);
@@ -390,6 +429,7 @@ int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, f
 size_t iprgan_colsum_ws_floats(int M, int C) { return colsum_ws_floats(M, C); }
 int iprgan_colsum_partials(const float* part, int rows, int Cs, int C, float* out, float beta, void* stream) {
   IPR_CHECK(rows > 0 && C <= Cs, "colsum_partials: %d rows, C=%d, Cs=%d", rows, C, Cs);
+  if (compact_partials(part, rows, 1, Cs, (hipStream_t)stream)) return 2;
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, (hipStream_t)stream, part, rows, Cs, C, out, beta);
   IPR_LAUNCH_CHECK();
   return 0;
