@@ -135,10 +135,14 @@ int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* bet
                   float* ws, int M, int C, float eps, float momentum, int use_running, int act,
                   float slope, const float* conv_part, int conv_part_rows, const float* conv_bias,
                   long long* num_batches_tracked, void* stream);
-/* backward through act + BN: inputs x (pre-norm), y (post-act output), dy.  dx, dgamma, dbeta out. */
-int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+/* backward through act + BN: inputs x (pre-norm), dy, and y (post-act output; NOT read for no activation and for
+ * ReLU / LeakyReLU, whose derivative mask is recomputed from x with gamma / beta - may be NULL then).  dx, dgamma, dbeta
+ * out.  dbias_prev (optional, dbias_n floats): dbias_prev = dbias_beta*dbias_prev + column sums of dx, i.e. the bias
+ * gradient of the convolution that produced x, accumulated on the apply pass itself. */
+int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
-                  float* dbeta, float* ws, int M, int C, int act, float slope, void* stream);
+                  float* dbeta, float* ws, int M, int C, int act, float slope, float* dbias_prev, int dbias_n,
+                  float dbias_beta, void* stream);
 
 /* ---- InstanceNorm2d (networks/resnet_generator.py:8-49 affine, conv_discriminator.py:10-18 plain):
  * per-(sample, channel) statistics over HW rows of x[B,HW,C]; gamma/beta may be NULL; never tracks
@@ -147,9 +151,10 @@ size_t iprgan_instnorm_ws_floats(int B, int HW, int C);
 int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                         float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,
                         const float* conv_part, int conv_part_rows, const float* conv_bias, void* stream);
-int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
-                        float* dbeta, float* ws, int B, int HW, int C, int act, float slope, void* stream);
+                        float* dbeta, float* ws, int B, int HW, int C, int act, float slope, float* dbias_prev,
+                        int dbias_n, float dbias_beta, void* stream);
 
 /* ---- PReLU / PixelShuffle / MaxPool / residual add / reflection-pad backward ----------------------------
  * nn.PReLU() with one slope (sr_resnet.py:7,14,43): y = x>0 ? x : alpha*x; dalpha = sum dy*x*[x<=0];

@@ -38,6 +38,11 @@ static ColGeom col_geom(int M, int C) {
 // MODE 0: s0 = sum x                     (bias gradient)
 // MODE 1: s0 = sum (x-s), s1 = sum (x-s)^2            (BN statistics, s = x[0][c])
 // MODE 2: s0 = sum dz, s1 = sum dz*xhat, dz = dy*act'(y), xhat = (x-mean)*invstd   (BN backward)
+// Backward of norm + activation: the derivative mask of ReLU / LeakyReLU is recomputed from x (v = (x - mean) * invstd
+// * gamma + beta, the forward's own expression: y > 0 <=> v > 0) instead of reading the saved output y - one tensor
+// less per pass; with no activation y is not read either.  Other activations (never fused into a norm here) read y.
+__host__ __device__ __forceinline__ bool act_from_x(int act) { return act == IPRGAN_ACT_RELU || act == IPRGAN_ACT_LRELU; }
+
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ y,
@@ -45,11 +50,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ invstd,
                                                         float* __restrict__ part, int M, int C, int TC,
-                                                        int rows_per_block, int act, float slope) {
+                                                        int rows_per_block, int act, float slope,
+                                                        const float* __restrict__ gamma = nullptr,
+                                                        const float* __restrict__ beta = nullptr) {
   // blockIdx.z = group (InstanceNorm: one group per sample; BatchNorm: a single group)
   const int grp = blockIdx.z;
   x += (size_t)grp * M * C;
-  if (MODE == 2) { y += (size_t)grp * M * C; dy += (size_t)grp * M * C; mean += (size_t)grp * C; invstd += (size_t)grp * C; }
+  if (MODE == 2) { if (y) y += (size_t)grp * M * C; dy += (size_t)grp * M * C; mean += (size_t)grp * C; invstd += (size_t)grp * C; }
   part += (size_t)grp * gridDim.x * 2 * C;
   __shared__ f32x4 sh[2][256];
   const int TR = 256 / TC;
@@ -63,7 +70,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   if (ok) {
     f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {1.f, 1.f, 1.f, 1.f};
     if (MODE == 1) p0 = *(const f32x4*)(x + cq * 4);
-    if (MODE == 2) { p0 = *(const f32x4*)(mean + cq * 4); p1 = *(const f32x4*)(invstd + cq * 4); }
+    f32x4 pg = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 2) {
+      p0 = *(const f32x4*)(mean + cq * 4); p1 = *(const f32x4*)(invstd + cq * 4);
+      if (gamma) pg = *(const f32x4*)(gamma + cq * 4);
+      if (beta) pb = *(const f32x4*)(beta + cq * 4);
+    }
+    const bool from_x = MODE == 2 && act_from_x(act), no_act = MODE == 2 && act == IPRGAN_ACT_NONE;
     for (int r = r0 + tr; r < r1; r += TR) {
       const size_t off = (size_t)r * C + cq * 4;
       if (MODE == 0) {
@@ -73,10 +86,16 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
         a0 += d;
         a1 += d * d;
       } else {
-        const f32x4 xv = *(const f32x4*)(x + off), yv = *(const f32x4*)(y + off), gv = *(const f32x4*)(dy + off);
-        f32x4 dz;
+        const f32x4 xv = *(const f32x4*)(x + off), gv = *(const f32x4*)(dy + off);
+        f32x4 dz = gv;
+        if (from_x) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dz[k] = gv[k] * act_grad_from_out(yv[k], act, slope);
+          for (int k = 0; k < 4; ++k) dz[k] = gv[k] * act_grad_from_out((xv[k] - p0[k]) * p1[k] * pg[k] + pb[k], act, slope);
+        } else if (!no_act) {
+          const f32x4 yv = *(const f32x4*)(y + off);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dz[k] = gv[k] * act_grad_from_out(yv[k], act, slope);
+        }
         a0 += dz;
         a1 += dz * ((xv - p0) * p1);
       }
@@ -281,37 +300,58 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restr
 template <bool FIXED>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ y,
                                                            const f32x4* __restrict__ dy, f32x4* __restrict__ dx,
-                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ sums,
                                                            unsigned n4, int C4n, int C, FastDiv d_c4n, FastDiv d_group4,
-                                                           float invM, int act, float slope) {
+                                                           float invM, int act, float slope, float* __restrict__ colpart) {
+  // colpart (needs 256 % C4n == 0: a thread keeps its channel chunk): per-block column sums of dx, [block][2][C] like
+  // every other partial buffer - the bias gradient of the convolution that feeds this norm layer, without another
+  // pass over dx (colreduce_kernel<0>)
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  auto body = [&](unsigned idx, const f32x4& g, const f32x4& m, const f32x4& is, const f32x4& s1, const f32x4& s2) {
-    const f32x4 xv = x[idx], yv = y[idx], gv = dy[idx];
+  const bool from_x = act_from_x(act), no_act = act == IPRGAN_ACT_NONE;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  auto body = [&](unsigned idx, const f32x4& g, const f32x4& b, const f32x4& m, const f32x4& is, const f32x4& s1,
+                  const f32x4& s2) {
+    const f32x4 xv = x[idx], gv = dy[idx];
+    f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+    if (!from_x && !no_act) yv = y[idx];
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float xh = (xv[k] - m[k]) * is[k];
-      const float dz = gv[k] * act_grad_from_out(yv[k], act, slope);
-      o[k] = g[k] * is[k] * (dz - s1[k] * invM - xh * s2[k] * invM);
+      const float t = (xv[k] - m[k]) * is[k];
+      const float dz = no_act ? gv[k] : gv[k] * act_grad_from_out(from_x ? t * g[k] + b[k] : yv[k], act, slope);
+      o[k] = g[k] * is[k] * (dz - s1[k] * invM - t * s2[k] * invM);
     }
     dx[idx] = o;
+    csum += o;
   };
   if (FIXED) {               // see bn_apply_kernel
     const int c = (int)(threadIdx.x % (unsigned)C4n) * 4;
-    const f32x4 g = ld4(gamma, c, 1.f), m = ld4(mean, c, 0.f), is = ld4(invstd, c, 1.f);
+    const f32x4 g = ld4(gamma, c, 1.f), b = ld4(beta, c, 0.f), m = ld4(mean, c, 0.f), is = ld4(invstd, c, 1.f);
     const f32x4 s1 = ld4(sums, c, 0.f), s2 = ld4(sums + C, c, 0.f);
 #pragma unroll 2
-    for (; i < n4; i += stride) body(i, g, m, is, s1, s2);
-    return;
+    for (; i < n4; i += stride) body(i, g, b, m, is, s1, s2);
+  } else {
+    for (; i < n4; i += stride) {
+      const int c = (int)(i - fdiv(i, d_c4n) * (unsigned)C4n) * 4;
+      const size_t grp = fdiv(i, d_group4);
+      const f32x4 g = ld4(gamma, c, 1.f), b = ld4(beta, c, 0.f), m = ld4(mean + grp * C, c, 0.f),
+                  is = ld4(invstd + grp * C, c, 1.f);
+      const f32x4 s1 = ld4(sums + grp * 2 * C, c, 0.f), s2 = ld4(sums + grp * 2 * C + C, c, 0.f);
+      body(i, g, b, m, is, s1, s2);
+    }
   }
-  for (; i < n4; i += stride) {
-    const int c = (int)(i - fdiv(i, d_c4n) * (unsigned)C4n) * 4;
-    const size_t grp = fdiv(i, d_group4);
-    const f32x4 g = ld4(gamma, c, 1.f), m = ld4(mean + grp * C, c, 0.f), is = ld4(invstd + grp * C, c, 1.f);
-    const f32x4 s1 = ld4(sums + grp * 2 * C, c, 0.f), s2 = ld4(sums + grp * 2 * C + C, c, 0.f);
-    body(i, g, m, is, s1, s2);
+  if (colpart) {
+    __shared__ f32x4 sh[256];
+    sh[threadIdx.x] = csum;
+    __syncthreads();
+    if ((int)threadIdx.x < C4n) {
+      f32x4 t = sh[threadIdx.x];
+      for (int k = threadIdx.x + C4n; k < 256; k += C4n) t += sh[k];
+      *(f32x4*)(colpart + ((size_t)blockIdx.x * 2) * C + threadIdx.x * 4) = t;
+    }
   }
 }
 
@@ -383,14 +423,17 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
   return 0;
 }
 
-static int norm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+static int norm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                     const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
-                    float* ws, int G, int M, int C, int act, float slope, hipStream_t st) {
+                    float* ws, int G, int M, int C, int act, float slope, hipStream_t st,
+                    float* dbias_prev = nullptr, int dbias_n = 0, float dbias_beta = 0.f) {
   IPR_CHECK(C % 4 == 0, "norm_bwd: C=%d must be a multiple of 4", C);
+  IPR_CHECK(act == IPRGAN_ACT_NONE || act_from_x(act) || y, "norm_bwd: this activation needs the saved output y");
+  IPR_CHECK(!act_from_x(act) || !gamma == !beta, "norm_bwd: the ReLU mask is recomputed from x: gamma and beta are both needed (or both absent)");
   const ColGeom g = col_geom(M, C);
   float* sums = ws + (size_t)G * g.NB * 2 * C;
   hipLaunchKernelGGL(colreduce_kernel<2>, dim3(g.NB, g.gy, G), dim3(256), 0, st, x, y, dy, save_mean,
-                     save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope);
+                     save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope, gamma, beta);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, g.NB, C, sums,
                      G == 1 ? dgamma : nullptr, G == 1 ? dbeta : nullptr);
@@ -401,25 +444,47 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
   }
   const size_t n4 = (size_t)G * M * C / 4;
   IPR_CHECK(n4 < 0x7fffffffull, "norm_bwd: tensor of %zu elements is too large", n4 * 4);
-  const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
+  int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
   const bool fixed = G == 1 && 256 % (C / 4) == 0;
+  // column sums of dx (bias gradient of the producing convolution) ride on the apply pass when a thread keeps its
+  // channel chunk; the per-block partials live behind the reduction workspace
+  float* colpart = nullptr;
+  if (dbias_prev && 256 % (C / 4) == 0) {
+    if (blocks > 1024) blocks = 1024;
+    colpart = sums + (size_t)G * 2 * C;
+  }
   hipLaunchKernelGGL(fixed ? bn_bwd_apply_kernel<true> : bn_bwd_apply_kernel<false>, dim3(blocks), dim3(256), 0, st,
                      (const f32x4*)x, (const f32x4*)y,
-                     (const f32x4*)dy, (f32x4*)dx, gamma, save_mean, save_invstd, sums, (unsigned)n4, C / 4, C,
-                     make_fastdiv(C / 4), make_fastdiv((uint32_t)((size_t)M * C / 4)), 1.0f / (float)M, act, slope);
+                     (const f32x4*)dy, (f32x4*)dx, gamma, beta, save_mean, save_invstd, sums, (unsigned)n4, C / 4, C,
+                     make_fastdiv(C / 4), make_fastdiv((uint32_t)((size_t)M * C / 4)), 1.0f / (float)M, act, slope,
+                     colpart);
   IPR_LAUNCH_CHECK();
+  if (dbias_prev) {
+    if (colpart) {
+      const float* pp = colpart;
+      int rows = blocks;
+      if (compact_partials(pp, rows, 1, C, st)) return 2;
+      hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(dbias_n, 64)), dim3(64 * FL), 0, st, pp, rows, C, dbias_n,
+                         dbias_prev, dbias_beta);
+      IPR_LAUNCH_CHECK();
+    } else {                 // channel counts that do not divide the block: the separate column-sum pass
+      const int rc = colsum_launch(dx, dbias_prev, ws, G * M, C, dbias_n, st, dbias_beta);
+      if (rc) return rc;
+    }
+  }
   return 0;
 }
 
 extern "C" {
 
+// [reduction partials | sums] + [per-block column sums of dx (1024 blocks) | their compacted rows] for the bias gradient
 size_t iprgan_bn_ws_floats(int M, int C) {
   const ColGeom g = col_geom(M, C);
-  return (size_t)g.NB * 2 * C + 2 * (size_t)C;
+  return (size_t)g.NB * 2 * C + 2 * (size_t)C + (size_t)(1024 + NBC) * 2 * C;
 }
 size_t iprgan_instnorm_ws_floats(int B, int HW, int C) {
   const ColGeom g = col_geom(HW, C);
-  return (size_t)B * ((size_t)g.NB * 2 * C + 2 * (size_t)C);
+  return (size_t)B * ((size_t)g.NB * 2 * C + 2 * (size_t)C) + (size_t)(1024 + NBC) * 2 * C;
 }
 
 int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, float beta, void* stream) {
@@ -443,11 +508,12 @@ int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* bet
                   momentum, use_running, act, slope, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias,
                   use_running ? nullptr : num_batches_tracked);
 }
-int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
-                  float* dbeta, float* ws, int M, int C, int act, float slope, void* stream) {
-  return norm_bwd(x, y, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta, ws, 1, M, C, act, slope,
-                  (hipStream_t)stream);
+                  float* dbeta, float* ws, int M, int C, int act, float slope, float* dbias_prev, int dbias_n,
+                  float dbias_beta, void* stream) {
+  return norm_bwd(x, y, dy, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, ws, 1, M, C, act, slope,
+                  (hipStream_t)stream, dbias_prev, dbias_n, dbias_beta);
 }
 int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                         float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,
@@ -455,11 +521,12 @@ int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const floa
   return norm_fwd(x, y, gamma, beta, nullptr, nullptr, save_mean, save_invstd, ws, B, HW, C, eps, 0.f, 0, act,
                   slope, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias);
 }
-int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
-                        float* dbeta, float* ws, int B, int HW, int C, int act, float slope, void* stream) {
-  return norm_bwd(x, y, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta, ws, B, HW, C, act, slope,
-                  (hipStream_t)stream);
+                        float* dbeta, float* ws, int B, int HW, int C, int act, float slope, float* dbias_prev,
+                        int dbias_n, float dbias_beta, void* stream) {
+  return norm_bwd(x, y, dy, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, ws, B, HW, C, act, slope,
+                  (hipStream_t)stream, dbias_prev, dbias_n, dbias_beta);
 }
 
 }  // extern "C"

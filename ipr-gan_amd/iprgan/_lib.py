@@ -55,10 +55,10 @@ SIGNATURES = {
     'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P]),
     'iprgan_bn_ws_floats': (_Z, [_I, _I]),
     'iprgan_bn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _P, _P, _P]),
-    'iprgan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    'iprgan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _F, _P]),
     'iprgan_instnorm_ws_floats': (_Z, [_I, _I, _I]),
     'iprgan_instnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _I, _P, _P]),
-    'iprgan_instnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    'iprgan_instnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _F, _P]),
     'iprgan_prelu_fwd': (_I, [_P, _P, _P, _Z, _P]),
     'iprgan_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _P]),
     'iprgan_pixel_shuffle2': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

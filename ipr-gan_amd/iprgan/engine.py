@@ -183,8 +183,8 @@ class Conv(Op):
         elif need_w:
             has_b = self.bias is not None
             dbp = st.get('db_part') if has_b else None     # column sums of dy from the epilogue that produced it
-            db_done = None
-            if dbp is not None:
+            db_done = st.get('db_done') if has_b else None      # ... or already accumulated by the norm layer above
+            if db_done is None and dbp is not None:
                 if sink is not None:
                     ops.colsum_partials(dbp[0], dbp[1], dy.shape[-1], sp.cout, out=sink.view_of(self.bias), beta=1.0)
                     db_done = DIRECT
@@ -320,8 +320,10 @@ class BatchNorm(Op):
         return y
 
     def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
+        tgt = st.get('dbias_prev')          # (tensor, beta): bias gradient of the convolution below, see ChainFn.backward
         dx, dg, db = ops.bn_bwd(st['x'], st['y'], dy, self.m.weight, st['mean'], st['invstd'],
-                                self.act, self.slope)
+                                self.act, self.slope, beta=self.m.bias, dbias=tgt[0] if tgt else None,
+                                dbias_beta=tgt[1] if tgt else 0.0)
         return dx, [dg, db]
 
 
@@ -430,8 +432,10 @@ class InstanceNorm(Op):
         return y
 
     def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
+        tgt = st.get('dbias_prev')
         dx, dg, db = ops.instnorm_bwd(st['x'], st['y'], dy, self.m.weight, st['mean'], st['invstd'],
-                                      self.act, self.slope)
+                                      self.act, self.slope, beta=self.m.bias, dbias=tgt[0] if tgt else None,
+                                      dbias_beta=tgt[1] if tgt else 0.0)
         return dx, ([dg, db] if self.m.weight is not None else [])
 
 
@@ -678,6 +682,17 @@ class ChainFn(torch.autograd.Function):
                     and op_need_w[i - 1] and (fuse is not None or prev.out_act[0] == L.ACT_NONE)
                     and op.can_emit_dx_colsums(st['d'].H, st['d'].W)):
                 st['want_dx_colsums'] = True      # the column sums of this dx are the bias gradient of the layer below
+            if (_FUSE_STATS and isinstance(op, (BatchNorm, InstanceNorm)) and isinstance(prev, Conv)
+                    and prev.bias is not None and op_need_w[i - 1] and 'pair' not in stash[i - 1]):
+                # the column sums of this norm layer's dx are the bias gradient of the convolution below: they ride on the
+                # norm's apply pass (straight into the bucket view when there is one)
+                if sink is not None:
+                    st['dbias_prev'] = (red.view_of(prev.bias), 1.0)
+                    stash[i - 1]['db_done'] = DIRECT
+                else:
+                    t = ops.empty((prev.bias.numel(),), g)
+                    st['dbias_prev'] = (t, 0.0)
+                    stash[i - 1]['db_done'] = t
             g, pg = op.backward(g, st, need_dx, op_need_w[i], fuse, sink)
             if 'dx_colsums' in st:
                 stash[i - 1]['db_part'] = st.pop('dx_colsums')

@@ -197,14 +197,17 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, a
     return y, mean, invstd
 
 
-def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0):
+def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None, dbias_beta=0.0):
+    """dbias: a tensor that receives (beta-accumulates) the column sums of dx = the bias gradient of the convolution
+    that produced x."""
     C_ = x.shape[-1]
     M = x.numel() // C_
     dx = torch.empty_like(x)
     dgamma, dbeta = empty((C_,), x), empty((C_,), x)
     ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
-    call('iprgan_bn_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
-         ptr(dgamma), ptr(dbeta), ptr(ws), M, C_, act, float(slope), stream())
+    call('iprgan_bn_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
+         ptr(dgamma), ptr(dbeta), ptr(ws), M, C_, act, float(slope), ptr(dbias), dbias.numel() if dbias is not None else 0,
+         float(dbias_beta), stream())
     return dx, dgamma, dbeta
 
 
@@ -379,14 +382,15 @@ def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias
     return y, mean, invstd
 
 
-def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0):
+def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None, dbias_beta=0.0):
     B, H, W, C_ = x.shape
     dx = torch.empty_like(x)
     dgamma = empty((C_,), x) if gamma is not None else None
     dbeta = empty((C_,), x) if gamma is not None else None
     ws = empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
-    call('iprgan_instnorm_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
-         ptr(dgamma), ptr(dbeta), ptr(ws), B, H * W, C_, act, float(slope), stream())
+    call('iprgan_instnorm_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
+         ptr(dgamma), ptr(dbeta), ptr(ws), B, H * W, C_, act, float(slope), ptr(dbias),
+         dbias.numel() if dbias is not None else 0, float(dbias_beta), stream())
     return dx, dgamma, dbeta
 
 

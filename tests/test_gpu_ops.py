@@ -168,8 +168,14 @@ def test_batchnorm(dev, M, C, act):
     close(y.view(M, C), yr.view(M, C), 1e-4, 'bn fwd')
     close(rmd, bn.running_mean, 1e-5, 'running_mean')
     close(rvd, bn.running_var, 1e-5, 'running_var')
-    dx, dg, db = ops.bn_bwd(xd, y, g.to(dev).view(1, M, 1, C), gamma.to(dev), mean, invstd, *ACT[act])
+    # y is passed as None for relu / lrelu / none: the derivative mask is recomputed from x (needs gamma AND beta);
+    # dbias = column sums of dx (bias gradient of a producing conv) accumulated on the apply pass
+    dbias = torch.full((C,), 7.0, device=dev)
+    dx, dg, db = ops.bn_bwd(xd, None, g.to(dev).view(1, M, 1, C), gamma.to(dev), mean, invstd, *ACT[act],
+                            beta=beta.to(dev), dbias=dbias, dbias_beta=1.0)
     close(dx.view(M, C), xr.grad.view(M, C), 2e-4, 'bn dx')
+    want_db = xr.grad.view(M, C).double().sum(0)
+    assert float((dbias.cpu().double() - 7.0 - want_db).abs().max()) <= 1e-3 * float(xr.grad.abs().max()) * M ** 0.5
     close(dg, bn.weight.grad, 2e-4, 'bn dgamma')
     close(db, bn.bias.grad, 2e-4, 'bn dbeta')
     # eval mode uses running stats
@@ -398,8 +404,11 @@ def test_instance_norm(dev, affine, act):
     xd = to_nhwc(x).to(dev)
     y, mean, invstd = ops.instnorm_fwd(xd, gam, bet, 1e-5, *ACT[act])
     close(from_nhwc(y.cpu(), C), yr, 1e-4, 'in fwd')
-    dx, dg, db = ops.instnorm_bwd(xd, y, to_nhwc(g).to(dev), gam, mean, invstd, *ACT[act])
+    dbias = torch.zeros(C, device=dev)
+    dx, dg, db = ops.instnorm_bwd(xd, None, to_nhwc(g).to(dev), gam, mean, invstd, *ACT[act], beta=bet, dbias=dbias)
     close(from_nhwc(dx.cpu(), C), xr.grad, 2e-4, 'in dx')
+    want_db = xr.grad.double().sum((0, 2, 3))
+    assert float((dbias.cpu().double() - want_db).abs().max()) <= 1e-3 * float(xr.grad.abs().max()) * (B * H * W) ** 0.5
     if affine:
         close(dg, m.weight.grad, 2e-4, 'in dgamma'); close(db, m.bias.grad, 2e-4, 'in dbeta')
 
