@@ -299,16 +299,18 @@ def main():
         dom = max(kernels, key=lambda k: k['ms']) if kernels else None
         roof = None
         peak_mode = PEAK_BF16_MFMA if args.math == 'bf16' else PEAK_FP32_MFMA
+        # profiles/<round>_[<workload>_]pmc_traffic.json; the headline workload has no infix
         tag = '' if args.workload == 'dcgan64' else args.workload + '_'
+        rnd = 'r[0-9][0-9]_'
         traffic = traffic_src = util_pmc = util_src = None
         try:          # HBM bytes per launch from the committed PMC passes (profiles/: separate rocprofv3 runs)
-            tf = _latest_profile(f'r*_{tag}pmc_traffic.json')
+            tf = _latest_profile(f'{rnd}{tag}pmc_traffic.json')
             traffic = json.load(open(tf))['kernels'][dom['name']]['hbm_bytes_per_launch']
             traffic_src = os.path.relpath(tf, ROOT)
         except Exception:
             pass
         try:          # hardware MFMA utilisation of the step's conv kernels from the committed PMC pass
-            uf = _latest_profile(f'r*_{tag}mfma_util.json')
+            uf = _latest_profile(f'{rnd}{tag}mfma_util.json')
             util_pmc = json.load(open(uf))['all_conv']['mfma_util_pct']
             util_src = os.path.relpath(uf, ROOT)
         except Exception:

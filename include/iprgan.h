@@ -7,7 +7,19 @@
  *
  * Conventions
  *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory unless noted
- *   - all work is enqueued on the caller's hipStream_t (passed as void*); no allocation, no sync
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*); no allocation.  No synchronisation either,
+ *     with ONE exception: the convolution entry points autotune their tile (the reference trains with
+ *     cudnn.benchmark = True, train.py:44-45) - the FIRST call with a new layer geometry times the candidate tiles
+ *     on the caller's stream and blocks the calling host thread on HIP events until they have run (a few ms per
+ *     geometry, once per process; outputs are written normally).  Every later call with that geometry only enqueues.
+ *     IPRGAN_AUTOTUNE=0 in the environment disables it (a block-count heuristic picks the tile, nothing ever blocks);
+ *     IPRGAN_TUNE_CACHE=<file> stores the choices and replays them in later processes (per rank: <file>.<RANK>).
+ *   - limits: every tensor handed to a convolution entry point must be smaller than 2 GiB (the kernels address them
+ *     through 32-bit buffer offsets, which is also how out-of-image taps are zero-filled without branches) and an
+ *     image smaller than 2^24 pixels; larger inputs are refused with an error, never truncated
+ *   - process-global state: the conv tile table (mutex-guarded), the math mode, the per-kernel timer and the RCCL
+ *     communicator.  Everything else is re-entrant; concurrent calls from several host threads are safe as long as
+ *     they use different streams and do not flip the math mode under each other
  *   - return 0 on success, non-zero on error; text via iprgan_last_error() (thread-local)
  *   - activations are fp32 NHWC with the channel count padded to a multiple of 4
  *     ("C4" = (C+3)&~3; RGB images are NHWC4 with a zero 4th channel)
@@ -91,7 +103,11 @@ size_t iprgan_conv_stat_floats(const iprgan_conv_desc* d, int backward);
 size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d);   /* reflect padding, or <= 4 input channels */
 int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
                          const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
-                         const float* pair_sigma1, float* stat_part, int* stat_rows, void* stream);
+                         const float* pair_sigma1, float* stat_part, int* stat_rows, const float* residual,
+                         void* stream);
+/* residual (optional, same shape as dx): dx = backward-data(...) * act'(prev_out) + residual - the gradient that arrives
+ * over a skip connection at the input of a residual block (networks/sr_resnet.py:37-38, resnet_generator.py:52-53) is
+ * added in the epilogue instead of by a separate pass. */
 /* Paired pass (pair_sigma0/1 non-NULL, device scalars; B even): the batch holds TWO half-batches that the reference
  * sends through a spectrally normalised network one after the other (models/dcgan.py:47-48: D(real), D(fake)) - between
  * them the power iteration advances, so the halves see W/sigma0 and W/sigma1.  The operands are prepared from the
@@ -134,7 +150,8 @@ int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* bet
                   float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                   float* ws, int M, int C, float eps, float momentum, int use_running, int act,
                   float slope, const float* conv_part, int conv_part_rows, const float* conv_bias,
-                  long long* num_batches_tracked, void* stream);
+                  long long* num_batches_tracked, const float* residual, void* stream);
+/* residual (optional, same shape as y): y = act(norm(x)) + residual, the skip connection closing a residual block. */
 /* backward through act + BN: inputs x (pre-norm), dy, and y (post-act output; NOT read for no activation and for
  * ReLU / LeakyReLU, whose derivative mask is recomputed from x with gamma / beta - may be NULL then).  dx, dgamma, dbeta
  * out.  dbias_prev (optional, dbias_n floats): dbias_prev = dbias_beta*dbias_prev + column sums of dx, i.e. the bias
@@ -150,7 +167,8 @@ int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* 
 size_t iprgan_instnorm_ws_floats(int B, int HW, int C);
 int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                         float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,
-                        const float* conv_part, int conv_part_rows, const float* conv_bias, void* stream);
+                        const float* conv_part, int conv_part_rows, const float* conv_bias, const float* residual,
+                        void* stream);
 int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                         float* dbeta, float* ws, int B, int HW, int C, int act, float slope, float* dbias_prev,
@@ -170,7 +188,7 @@ int iprgan_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, vo
 int iprgan_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream);
 int iprgan_add(const float* a, const float* b, float* out, size_t n, void* stream);
 int iprgan_reflect_fold(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope,
-                        int B, int H, int W, int C, int pad, void* stream);
+                        const float* residual, int B, int H, int W, int C, int pad, void* stream);
 
 /* ---- spectral norm (torch.nn.utils.spectral_norm at networks/sn_discriminator.py:9,11,18,21) */
 size_t iprgan_sn_ws_floats(int rows, int cols);

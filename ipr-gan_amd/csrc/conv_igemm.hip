@@ -11,6 +11,8 @@
 // A second kernel computes backward-weight as a split-M GEMM into partial slabs that a
 // fixed-order reduce sums (deterministic) and scatters into PyTorch's weight layout.
 #include <map>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -102,6 +104,7 @@ struct GConvArgs {
   float* ws;           // host-side only: workspace for the small-N path (may be null)
   size_t ws_floats;
   int nphase;
+  const float* res;    // added to the stored value (same layout as out): the gradient arriving over a skip connection
   const float* rs0;    // paired pass (two half-batches through one launch, each with its own spectral-norm sigma):
   const float* rs1;    //   rows of the first / second half of every phase are divided by *rs0 / *rs1 before the bias
   float* stat_part;    // STATS kernels: per-tile column sums [tile rows][2][Ns] (see gconv_kernel)
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] *= act_grad_from_out(o[k], a.aux_act, a.aux_slope);
         }
+        if (a.res) v += *(const f32x4*)(a.res + idx);
         if (STATS && a.stat_mode == 2) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) { cs1[j][k] += v[k]; cs2[j][k] += v[k] * v[k]; }
@@ -1329,14 +1333,26 @@ struct TuneKey {
   bool operator<(const TuneKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
 };
 static std::map<TuneKey, int> g_tune;
+static std::mutex g_tune_mutex;                 // the tune table and its cache file: several host threads may launch
 // IPRGAN_TUNE_CACHE=<file>: tuning decisions are appended to the file and read back by later processes, which
 // then launch no tuning trials (start-up time; and a profiler run sees only the launches of the step itself).
+// Under a multi-process launcher (RANK set, WORLD_SIZE > 1) every rank uses its own file <file>.<RANK>: ranks tune
+// independently and must not interleave their appends.
 static bool g_tune_loaded = false;
-static void tune_load() {
+static std::string tune_path() {
+  const char* path = getenv("IPRGAN_TUNE_CACHE");
+  if (!path) return std::string();
+  std::string p(path);
+  const char* ws = getenv("WORLD_SIZE");
+  const char* rk = getenv("RANK");
+  if (ws && rk && atoi(ws) > 1) p += std::string(".") + rk;
+  return p;
+}
+static void tune_load() {              // caller holds g_tune_mutex
   if (g_tune_loaded) return;
   g_tune_loaded = true;
-  const char* path = getenv("IPRGAN_TUNE_CACHE");
-  FILE* f = path ? fopen(path, "r") : nullptr;
+  const std::string path = tune_path();
+  FILE* f = path.empty() ? nullptr : fopen(path.c_str(), "r");
   if (!f) return;
   TuneKey k;
   int v;
@@ -1349,10 +1365,19 @@ static void tune_load() {
   }
   fclose(f);
 }
+static bool tune_lookup(const TuneKey& k, int* v) {
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  tune_load();
+  auto it = g_tune.find(k);
+  if (it == g_tune.end()) return false;
+  *v = it->second;
+  return true;
+}
 static void tune_store(const TuneKey& k, int v) {
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
   g_tune[k] = v;
-  const char* path = getenv("IPRGAN_TUNE_CACHE");
-  FILE* f = path ? fopen(path, "a") : nullptr;
+  const std::string path = tune_path();
+  FILE* f = path.empty() ? nullptr : fopen(path.c_str(), "a");
   if (!f) return;
   for (int i = 0; i < 16; ++i) fprintf(f, "%d ", k.v[i]);
   fprintf(f, "%d\n", v);
@@ -1528,9 +1553,10 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   TuneKey key = {{a.B, a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.isy, a.osy, a.nphase, a.ph[0].th, a.ph[0].tw,
                   a.ph[0].ohg, a.ph[0].owg, a.pad_mode + 16 * g_math + 64 * a.ksplit + 8192 * (a.wmod > 0) + 16384 * (a.rs0 != nullptr) +
                       32768 * (a.stat_part != nullptr), a.Kp}};
-  tune_load();
-  auto it = g_tune.find(key);
-  if (it != g_tune.end()) return run(it->second);
+  {
+    int cached;
+    if (tune_lookup(key, &cached)) return run(cached);
+  }
   const bool prof_was = g_prof_on;
   g_prof_on = false;
   float best_us = 0.f;
@@ -1899,7 +1925,8 @@ size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d) {
 
 int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
                          const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
-                         const float* pair_sigma1, float* stat_part, int* stat_rows, void* stream) {
+                         const float* pair_sigma1, float* stat_part, int* stat_rows, const float* residual,
+                         void* stream) {
   IPR_CHECK(!stat_part || (stat_rows && !fullmap_conv(d) && d->pad_mode != IPRGAN_PAD_REFLECT && c4(d->Cin) > 4),
             "conv_bwd_data: column sums need the row-count output and a zero-padded regular convolution with more than 4 input channels");
   IPR_CHECK(!pair_sigma0 == !pair_sigma1 &&
@@ -1917,7 +1944,7 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
     a.Kp = rup(ntap * c4(d->Cout), 32);                 // row pitch of the backward operand
     a.wmod = d->Cin; a.wk1 = c4(d->Cout);
     a.in = dy; a.wt = wbwd; a.out = dx; a.act = IPRGAN_ACT_NONE;
-    a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope;
+    a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.res = residual;
     a.flops = 2.0 * d->B * (double)d->Cout * d->Cin * ntap;
     return launch_gconv(a, (hipStream_t)stream);
   }
@@ -1937,10 +1964,13 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
   a.act = IPRGAN_ACT_NONE; a.slope = 0.f;
   if (!reflect) { a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.ws = ws; a.ws_floats = ws ? smalln_ws_for(d, false) : 0; }
   a.stat_part = stat_part; a.stat_mode = 2;
+  if (!reflect) a.res = residual;
+  IPR_CHECK(!residual || reflect || !(smalln_eligible(a) && ws), "conv_bwd_data: no residual input on the few-channel path");
   const int rc = launch_gconv(a, (hipStream_t)stream);
   if (stat_part && !rc) *stat_rows = stat_rows_of(a);
   if (rc || !reflect) return rc;
-  return iprgan_reflect_fold(ws, dx, prev_out, prev_act, prev_slope, d->B, d->H, d->W, c4(d->Cin), d->pad, stream);
+  return iprgan_reflect_fold(ws, dx, prev_out, prev_act, prev_slope, residual, d->B, d->H, d->W, c4(d->Cin), d->pad,
+                             stream);
 }
 
 static size_t wgrad_weight_floats(const iprgan_conv_desc* d) { return (size_t)d->Cout * d->Cin * d->KH * d->KW; }
@@ -2036,10 +2066,9 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   } else if (g_autotune) {     // same scheme as the forward/backward-data tiles: time every candidate once per geometry
     TuneKey key = {{d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->outpad,
                     d->transposed, d->pad_mode, -7, g_math, 0, 0}};
-    tune_load();
-    auto it = g_tune.find(key);
-    if (it != g_tune.end()) {
-      cand = it->second;
+    int cached;
+    if (tune_lookup(key, &cached)) {
+      cand = cached;
     } else {
       const bool prof_was = g_prof_on;
       g_prof_on = false;

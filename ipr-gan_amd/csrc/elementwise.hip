@@ -362,7 +362,8 @@ __device__ __forceinline__ int refl_pre(int i, int n, int p, int* out) {
 typedef float rf_f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const rf_f4* __restrict__ dxp, rf_f4* __restrict__ dx,
                                                            const rf_f4* __restrict__ prev_out, int prev_act,
-                                                           float prev_slope, unsigned total4, int H, int W, int C4n,
+                                                           float prev_slope, const rf_f4* __restrict__ residual,
+                                                           unsigned total4, int H, int W, int C4n,
                                                            int p, FastDiv d_c4n, FastDiv d_w, FastDiv d_h) {
   const int HP = H + 2 * p, WP = W + 2 * p;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const rf_f4* __restri
 #pragma unroll
       for (int k = 0; k < 4; ++k) s[k] *= act_grad_from_out(o[k], prev_act, prev_slope);
     }
+    if (residual) s += residual[i];
     dx[i] = s;
   }
 }
@@ -615,14 +617,16 @@ int iprgan_add(const float* a, const float* b, float* out, size_t n, void* strea
   IPR_LAUNCH_CHECK();
   return 0;
 }
-int iprgan_reflect_fold(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope, int B,
+int iprgan_reflect_fold(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope,
+                        const float* residual, int B,
                         int H, int W, int C, int pad, void* stream) {
   const size_t n = (size_t)B * H * W * C;
   IPR_CHECK(pad < H && pad < W, "reflect_fold: pad %d must be smaller than the image", pad);
   IPR_CHECK(C % 4 == 0 && n / 4 < 0x7fffffffull, "reflect_fold: C=%d must be a multiple of 4 (and < 2^33 elements)", C);
   if (!n) return 0;
   hipLaunchKernelGGL(reflect_fold_kernel, dim3(grid_for(n / 4, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     (const rf_f4*)dxp, (rf_f4*)dx, (const rf_f4*)prev_out, prev_act, prev_slope, (unsigned)(n / 4), H, W,
+                     (const rf_f4*)dxp, (rf_f4*)dx, (const rf_f4*)prev_out, prev_act, prev_slope, (const rf_f4*)residual,
+                     (unsigned)(n / 4), H, W,
                      C / 4, pad, make_fastdiv(C / 4), make_fastdiv(W), make_fastdiv(H));
   IPR_LAUNCH_CHECK();
   return 0;

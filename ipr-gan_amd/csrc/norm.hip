@@ -251,7 +251,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const f32x4* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        unsigned n4, int C4n, FastDiv d_c4n, FastDiv d_group4, int act,
-                                                       float slope) {
+                                                       float slope, const f32x4* __restrict__ residual) {
+  // residual: y = act(norm(x)) + residual - the skip connection that closes a residual block right after its last norm
+  // layer (networks/sr_resnet.py:37-38, resnet_generator.py:52-53), folded into this pass
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (FIXED) {
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const f32x4* __restrict__
       f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = act_apply((v[k] - m[k]) * is[k] * g[k] + b[k], act, slope);
+      if (residual) o += residual[i];
       y[i] = o;
     }
     return;
@@ -275,6 +278,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const f32x4* __restrict__
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = act_apply((v[k] - m[k]) * is[k] * g[k] + b[k], act, slope);
+    if (residual) o += residual[i];
     y[i] = o;
   }
 }
@@ -389,7 +393,7 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
                     float* running_var, float* save_mean, float* save_invstd, float* ws, int G, int M, int C,
                     float eps, float momentum, int use_running, int act, float slope, hipStream_t st,
                     const float* part = nullptr, int part_rows = 0, const float* shift = nullptr,
-                    long long* counter = nullptr) {
+                    long long* counter = nullptr, const float* residual = nullptr) {
   IPR_CHECK(C % 4 == 0, "norm_fwd: C=%d must be a multiple of 4", C);
   IPR_CHECK(M > 0 && G > 0, "norm_fwd: empty input");
   if (use_running) {
@@ -418,7 +422,7 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
   const bool fixed = G == 1 && 256 % (C / 4) == 0;
   hipLaunchKernelGGL(fixed ? bn_apply_kernel<true> : bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, st,
                      (const f32x4*)x, (f32x4*)y, gamma, beta, save_mean, save_invstd, (unsigned)n4, C / 4,
-                     make_fastdiv(C / 4), make_fastdiv((uint32_t)((size_t)M * C / 4)), act, slope);
+                     make_fastdiv(C / 4), make_fastdiv((uint32_t)((size_t)M * C / 4)), act, slope, (const f32x4*)residual);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -503,10 +507,11 @@ int iprgan_colsum_partials(const float* part, int rows, int Cs, int C, float* ou
 int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                   float* running_var, float* save_mean, float* save_invstd, float* ws, int M, int C,
                   float eps, float momentum, int use_running, int act, float slope, const float* conv_part,
-                  int conv_part_rows, const float* conv_bias, long long* num_batches_tracked, void* stream) {
+                  int conv_part_rows, const float* conv_bias, long long* num_batches_tracked, const float* residual,
+                  void* stream) {
   return norm_fwd(x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, 1, M, C, eps,
                   momentum, use_running, act, slope, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias,
-                  use_running ? nullptr : num_batches_tracked);
+                  use_running ? nullptr : num_batches_tracked, residual);
 }
 int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
@@ -517,9 +522,10 @@ int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* 
 }
 int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                         float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,
-                        const float* conv_part, int conv_part_rows, const float* conv_bias, void* stream) {
+                        const float* conv_part, int conv_part_rows, const float* conv_bias, const float* residual,
+                        void* stream) {
   return norm_fwd(x, y, gamma, beta, nullptr, nullptr, save_mean, save_invstd, ws, B, HW, C, eps, 0.f, 0, act,
-                  slope, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias);
+                  slope, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias, nullptr, residual);
 }
 int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, float* dx, float* dgamma,

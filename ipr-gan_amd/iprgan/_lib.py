@@ -46,7 +46,7 @@ SIGNATURES = {
     'iprgan_conv_stat_floats': (_Z, [_D, _I]),
     'iprgan_colsum_partials': (_I, [_P, _I, _I, _I, _P, _F, _P]),
     'iprgan_conv_bwd_data_ws_floats': (_Z, [_D]),
-    'iprgan_conv_bwd_data': (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, C.POINTER(C.c_int), _P]),
+    'iprgan_conv_bwd_data': (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, C.POINTER(C.c_int), _P, _P]),
     'iprgan_colsum_ws_floats': (_Z, [_I, _I]),
     'iprgan_colsum': (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     'iprgan_conv_bwd_weight': (_I, [_D, _P, _P, _P, _P, _P, _F, _P]),
@@ -54,10 +54,10 @@ SIGNATURES = {
     'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P]),
     'iprgan_bn_ws_floats': (_Z, [_I, _I]),
-    'iprgan_bn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _P, _P, _P]),
+    'iprgan_bn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _P, _P, _P, _P]),
     'iprgan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _F, _P]),
     'iprgan_instnorm_ws_floats': (_Z, [_I, _I, _I]),
-    'iprgan_instnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _I, _P, _P]),
+    'iprgan_instnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _I, _P, _P, _P]),
     'iprgan_instnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _F, _P]),
     'iprgan_prelu_fwd': (_I, [_P, _P, _P, _Z, _P]),
     'iprgan_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _P]),
@@ -65,7 +65,7 @@ SIGNATURES = {
     'iprgan_maxpool2_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'iprgan_maxpool2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'iprgan_add': (_I, [_P, _P, _P, _Z, _P]),
-    'iprgan_reflect_fold': (_I, [_P, _P, _P, _I, _F, _I, _I, _I, _I, _I, _P]),
+    'iprgan_reflect_fold': (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _P]),
     'iprgan_sn_ws_floats': (_Z, [_I, _I]),
     'iprgan_sn_power_iter': (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     'iprgan_sn_multi_ws_floats': (_Z, [_P, _P, _I]),

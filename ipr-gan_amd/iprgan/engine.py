@@ -209,7 +209,11 @@ class Conv(Op):
                 _, wb = ops.conv_prep(sp, d, self.weight, sigma, fwd=False, bwd=True)
             want_cs = st.get('want_dx_colsums', False)
             pa = (st['x'], prev_act[0], prev_act[1]) if prev_act is not None else (None, L.ACT_NONE, 0.0)
-            dx = ops.conv_bwd_data(sp, d, dy, wb, pa[0], pa[1], pa[2], pair=pair, colsums=want_cs)
+            res = None
+            if st.get('open_skip'):         # this conv opens a residual branch: the skip gradient is added in its epilogue
+                res = st['ctx']['skip_grads'][-1]
+                st['ctx']['skip_grad_fused'] = True
+            dx = ops.conv_bwd_data(sp, d, dy, wb, pa[0], pa[1], pa[2], pair=pair, colsums=want_cs, residual=res)
             if want_cs:
                 dx, st['dx_colsums'] = dx
         return dx, grads
@@ -310,12 +314,16 @@ class BatchNorm(Op):
             else:
                 counter = m.num_batches_tracked       # incremented by the statistics kernel
         cs = st['ctx'].pop('conv_stats', None) if use_batch else None
+        res = None
+        if st.get('close_skip'):            # the residual block ends right behind this layer: its add rides on the apply
+            res = st['ctx']['skips'][-1]
+            st['ctx']['skip_fused'] = True
         y, mean, invstd = ops.bn_fwd(x, m.weight, m.bias,
                                      m.running_mean if (track or not use_batch) else None,
                                      m.running_var if (track or not use_batch) else None,
                                      m.eps, mom if mom is not None else 0.0, use_batch, self.act, self.slope,
                                      conv_stats=cs[0] if cs else None, conv_bias=cs[1] if cs else None,
-                                     counter=counter)
+                                     counter=counter, residual=res)
         st.update(x=x, y=y, mean=mean, invstd=invstd)
         return y
 
@@ -426,8 +434,13 @@ class InstanceNorm(Op):
 
     def forward(self, x, st, train):
         cs = st['ctx'].pop('conv_stats', None)
+        res = None
+        if st.get('close_skip'):
+            res = st['ctx']['skips'][-1]
+            st['ctx']['skip_fused'] = True
         y, mean, invstd = ops.instnorm_fwd(x, self.m.weight, self.m.bias, self.m.eps, self.act, self.slope,
-                                           conv_stats=cs[0] if cs else None, conv_bias=cs[1] if cs else None)
+                                           conv_stats=cs[0] if cs else None, conv_bias=cs[1] if cs else None,
+                                           residual=res)
         st.update(x=x, y=y, mean=mean, invstd=invstd)
         return y
 
@@ -484,12 +497,17 @@ class SkipStart(Op):
 
     def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         g = st['ctx']['skip_grads'].pop()
+        if st['ctx'].pop('skip_grad_fused', False):      # already added in the epilogue of the branch's first dgrad
+            return dy, []
         return ops.add(dy, g), []
 
 
 class SkipEnd(Op):
     def forward(self, x, st, train):
-        return ops.add(x, st['ctx']['skips'].pop())
+        skip = st['ctx']['skips'].pop()
+        if st['ctx'].pop('skip_fused', False):           # the norm layer in front of this op added it on its apply pass
+            return x
+        return ops.add(x, skip)
 
     def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         st['ctx']['skip_grads'].append(dy)
@@ -585,6 +603,8 @@ class ChainFn(torch.autograd.Function):
                 if (per_inst or (isinstance(nxt, BatchNorm) and (train or not nxt.m.track_running_stats))) \
                         and op.can_emit_stats(h.shape[1], h.shape[2], per_inst):
                     st['emit_stats'] = True
+            if _FUSE_STATS and isinstance(op, (BatchNorm, InstanceNorm)) and i + 1 < n_ops and isinstance(chain.ops[i + 1], SkipEnd):
+                st['close_skip'] = True
             h = op.forward(h, st, train)
             shared.pop('conv_stats', None) if not isinstance(op, Conv) else None
         ctx.chain, ctx.stash, ctx.red = chain, stash, red
@@ -693,6 +713,9 @@ class ChainFn(torch.autograd.Function):
                     t = ops.empty((prev.bias.numel(),), g)
                     st['dbias_prev'] = (t, 0.0)
                     stash[i - 1]['db_done'] = t
+            if (_FUSE_STATS and need_dx and isinstance(op, Conv) and isinstance(prev, SkipStart)
+                    and not (ops.c4(op.spec.cin) <= 4 and op.spec.stride == 1)):
+                st['open_skip'] = True
             g, pg = op.backward(g, st, need_dx, op_need_w[i], fuse, sink)
             if 'dx_colsums' in st:
                 stash[i - 1]['db_part'] = st.pop('dx_colsums')

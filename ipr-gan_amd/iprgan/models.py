@@ -130,7 +130,7 @@ class DCGAN(Model):
         self.fake_sample = self.G(self.latent)
         fake = self.fake_sample.detach()
         if _PAIR_D and hasattr(self.D.module, 'forward_pair') and fake.shape == self.real_sample.shape \
-                and fake.shape[0] % 2 == 0:
+                and self.D.module.can_pair(fake):
             # D(real) and D(fake) as one pass of twice the batch (each half with its own spectral-norm sigma)
             self.real_logits, self.fake_logits = self.D.module.forward_pair(self.real_sample, fake)
         else:

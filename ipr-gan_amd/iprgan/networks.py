@@ -138,6 +138,13 @@ class SNDiscriminator(_HipNet):
         n = xa.shape[0]
         return out[:n], out[n:]
 
+    @staticmethod
+    def can_pair(x):
+        """The largest activation of the paired pass ([2B, H, W, 64] floats behind the first convolution) must stay
+        below the 2 GiB tensor limit of the convolution entry points (include/iprgan.h)."""
+        B, _, H, W = x.shape
+        return 2 * B * H * W * 64 * 4 < (1 << 31)
+
 
 def SNDiscriminator32():
     return SNDiscriminator(md=4)

@@ -118,7 +118,8 @@ def conv_fwd(spec, d, x, wfwd, bias, pair=None, stats=False):
     return (y, (part, rows.value)) if stats else y
 
 
-def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0, pair=None, colsums=False):
+def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0, pair=None, colsums=False,
+                  residual=None):
     """colsums=True: also returns (partials, rows): per-tile column sums of dx (after the fused activation derivative),
     i.e. the bias gradient of the layer that produced this layer's input, up to ``colsum_partials``."""
     dx = empty((d.B, d.H, d.W, c4(spec.cin)), dy)
@@ -129,7 +130,7 @@ def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_sl
     if colsums:
         part = empty((query('iprgan_conv_stat_floats', C.byref(d), 1),), dy)
     call('iprgan_conv_bwd_data', C.byref(d), ptr(dy), ptr(wbwd), ptr(dx), ptr(ws), ptr(prev_out), prev_act,
-         float(prev_slope), p0, p1, ptr(part), C.byref(rows), stream())
+         float(prev_slope), p0, p1, ptr(part), C.byref(rows), ptr(residual), stream())
     return (dx, (part, rows.value)) if colsums else dx
 
 
@@ -181,7 +182,7 @@ def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_
 
 # ---- batch norm -----------------------------------------------------------------------------------
 def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, act, slope=0.0, conv_stats=None,
-           conv_bias=None, counter=None):
+           conv_bias=None, counter=None, residual=None):
     """conv_stats = (partials, rows) from conv_fwd(stats=True): the statistics are taken from them instead of a pass
     over x.  counter: the module's int64 num_batches_tracked, incremented on the device."""
     C_ = x.shape[-1]
@@ -193,7 +194,7 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, a
     call('iprgan_bn_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
          ptr(mean), ptr(invstd), ptr(ws), M, C_, float(eps), float(momentum), 0 if training else 1,
          act, float(slope), ptr(part), int(rows), ptr(conv_bias) if part is not None else None,
-         counter.data_ptr() if counter is not None else None, stream())
+         counter.data_ptr() if counter is not None else None, ptr(residual), stream())
     return y, mean, invstd
 
 
@@ -370,7 +371,7 @@ def fill(t, value=0.0):
 
 
 # ---- instance norm / PReLU / pixel shuffle / max pool / residual add ---------------------------------
-def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias=None):
+def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias=None, residual=None):
     B, H, W, C_ = x.shape
     y = torch.empty_like(x)
     mean, invstd = empty((B, C_), x), empty((B, C_), x)
@@ -378,7 +379,7 @@ def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias
     ws = None if part is not None else empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
     call('iprgan_instnorm_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(ws),
          B, H * W, C_, float(eps), act, float(slope), ptr(part), int(rows),
-         ptr(conv_bias) if part is not None else None, stream())
+         ptr(conv_bias) if part is not None else None, ptr(residual), stream())
     return y, mean, invstd
 
 

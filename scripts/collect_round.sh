@@ -1,0 +1,13 @@
+#!/bin/bash
+# After `gpurun -- 'bash scripts/gpu_round.sh <tag>'`: copy the judged summaries from gpurun_out/ into profiles/.
+TAG=${1:-r02}
+cd "$(dirname "$0")/.."
+for t in $TAG ${TAG}_srgan ${TAG}_cyclegan; do
+  python scripts/summarize_profiles.py gpurun_out/prof $t profiles/$t
+  cp gpurun_out/${t}_bench_under_rocprof.json profiles/ 2>/dev/null
+done
+for f in ${TAG}_bench.json ${TAG}_bench_srgan.json ${TAG}_bench_cyclegan.json ${TAG}_bench_dcgan128.json \
+         ${TAG}_bench_dcgan128_bf16.json ${TAG}_bench_dcgan64_bf16.json ${TAG}_conv_bench.jsonl; do
+  cp gpurun_out/$f profiles/ 2>/dev/null
+done
+ls -la profiles | grep $TAG

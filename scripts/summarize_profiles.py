@@ -14,7 +14,8 @@ import sys
 
 
 def short(k):
-    m = re.match(r'void iprgan::gconv_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)(?:, (true|false))?>', k)
+    """rocprof kernel name -> the name bench.py reports (iprgan_prof_get slots)."""
+    m = re.match(r'void iprgan::gconv_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)(?:, (true|false))?(?:, (true|false))?>', k)
     if m:
         if m.group(8) == 'true':
             return 'gconv_bf16_kernel'
@@ -26,6 +27,10 @@ def short(k):
             return 'wgrad_bf16_kernel'
         wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
         return f'wgrad_kernel<{wgm * wm * 32}x{wgn * wn * 32}' + (',8w>' if wgm * wgn == 8 else '>')
+    m = re.match(r'void iprgan::wgrad_t_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>', k)
+    if m:
+        wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
+        return f'wgrad_t_kernel<{wgm * wm * 32}x{wgn * wn * 32}' + (',8w>' if wgm * wgn == 8 else '>')
     return k.split('(')[0].replace('void ', '').replace('iprgan::', '')
 
 
@@ -43,7 +48,7 @@ def main():
     shutil.copy(f'{prof}/{tag}_kernel_stats.csv', f'{out}_bench_kernel_stats.csv')
     f, w = agg(f'{prof}/{tag}_fetch_counter_collection.csv', 'FETCH_SIZE'), agg(f'{prof}/{tag}_write_counter_collection.csv', 'WRITE_SIZE')
     res = {'_how': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (with --kernel-trace only) over '
-                   '`bench.py --steps 4 --warmup 8` with the tile choices replayed from IPRGAN_TUNE_CACHE (no tuning launches); '
+                   '`bench.py [--workload W] --steps 4 --warmup 8` (see scripts/gpu_round.sh) with the tile choices replayed from IPRGAN_TUNE_CACHE (no tuning launches); '
                    'counter unit KiB; FETCH_SIZE x2 (gfx950 correction, checked on bn_apply whose byte count is known); '
                    'averages over all launches of a kernel name (layers of different sizes share kernels).',
            'kernels': {}}
@@ -63,7 +68,7 @@ def main():
                         '"all_conv" weighs every gconv / wgrad launch of the step by its cycles.', 'kernels': {}}
         tb = tg = 0.0
         for k in sorted(busy):
-            if 'gconv' not in k and 'wgrad_kernel' not in k:
+            if 'gconv' not in k and 'wgrad_kernel' not in k and 'wgrad_t_kernel' not in k:
                 continue
             b, g = busy[k][1], gui[k][1]
             tb += b

@@ -375,7 +375,21 @@ def test_dcgan128_steps_vs_reference_golden(golden, dev):
     batch 8 in fp32 against the REAL reference's run (tests/golden/dcgan128_steps_wbox.npz)."""
     from iprgan import Config, models
     res = cases.run_dcgan_steps(Config, models, [dev], n_steps=2, batch=8, seed=91, cfg=cases.DCGAN128_CFG, size=128)
-    compare(res, golden('dcgan128_steps_wbox'), policy=step_policy(2))
+    base = step_policy(2)
+
+    def policy(k):
+        # At batch 8 one ReLU / BatchNorm-boundary element of these 128x128 maps that rounds to the other side of zero
+        # moves a whole row of a gradient by O(1e-3) of its scale (see test_dcgan128_networks_vs_oracle); which elements
+        # flip depends on the summation order, i.e. on the tile the autotuner picked in this process.  Measured on the
+        # full tensors against the live oracle (scripts/dbg/d128_moments.py): the generator's step-0 moments
+        # (= gradients, four BatchNorm + ReLU stages deep) agree to 1-2.5 % in L2 whatever engine features are on,
+        # the discriminator's to 1e-3 (first, LeakyReLU-only layers) .. 3e-6 (last layers).  Element-wise bounds:
+        if k.startswith('step0/optG'):
+            return (3e-2, 5e-2, 'relmax')
+        if k.startswith('step0/optD'):
+            return (5e-3, 2e-2, 'relmax')
+        return base(k)
+    compare(res, golden('dcgan128_steps_wbox'), policy=policy)
 
 
 def test_dcgan128_bf16_steps_vs_reference_golden(golden, dev):
