@@ -257,6 +257,17 @@ int iprgan_ssim_fwd(const float* x, const float* y, float* loss, float* gmaps, f
 int iprgan_ssim_bwd(const float* x, const float* y, const float* gmaps, const float* gscale, float* dx,
                     int planes, int H, int W, int denorm, void* stream);
 
+/* ---- MS-SSIM loss: 1 - MS_SSIM(data_range=1)(x, y) (tools/loss.py:78-80; pytorch-msssim 0.2.1 restated: five scales,
+ * 2x2 average pooling with zero padding on odd sizes, cs at scales 1-4 and ssim at scale 5, weights 0.0448 0.2856 0.3001
+ * 0.2363 0.1333, per (image, channel) product of relu(mean)^w, mean over planes).  x, y: NCHW planes [planes][H][W]
+ * with min(H, W) > 160.  iprgan_msssim_sizes gives the three buffer sizes (floats); the forward pass fills them, the
+ * backward pass (gradient w.r.t. x only) reads them and needs ws = 2 * planes * ceil(H/2) * ceil(W/2) floats more. */
+int iprgan_msssim_sizes(int planes, int H, int W, size_t* pyr_floats, size_t* gmap_floats, size_t* small_floats);
+int iprgan_msssim_fwd(const float* x, const float* y, float* loss, float* pyr, float* gmaps, float* small, int planes,
+                      int H, int W, int denorm, int want_grad, void* stream);
+int iprgan_msssim_bwd(const float* x, const float* y, const float* pyr, const float* gmaps, const float* small,
+                      const float* gscale, float* dx, float* ws, int planes, int H, int W, int denorm, void* stream);
+
 /* ---- sign-loss watermark (tools/sign_model.py:42-60) --------------------------------------- */
 /* gammas/signs/dgammas: HOST arrays of nlayer DEVICE pointers, sizes: HOST array of channel counts.
  * loss = sum_l mean(relu(gamma0 - gamma_l*sign_l)).  Pointer tables are copied into the launch. */

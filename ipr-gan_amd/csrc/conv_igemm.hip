@@ -945,21 +945,30 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_t_kernel(const WGradArgs
 
   f32x4 rP[4], rQ[4];
   // P: rows m = 32 chunk + 4 pg + i; rows past M fall outside the buffer (p_bytes = M * Ps * 4)
-  unsigned po = pvalid ? (unsigned)((chunk_begin * 32 + 4 * pg) * a.Ps) * 4u + (unsigned)(n0 + pc * 4) * 4u : OOB_OFFSET;
   // Q: running pixel state (see wgrad_kernel), one per block (ROW4) or one per pixel
   constexpr int NS = ROW4 ? 1 : 4;
+  unsigned po = OOB_OFFSET;
   unsigned qb[NS];
   int qm[NS], qy[NS], qx[NS];
+  auto init_state = [&](int chunk) {
+    po = pvalid ? (unsigned)((chunk * 32 + 4 * pg) * a.Ps) * 4u + (unsigned)(n0 + pc * 4) * 4u : OOB_OFFSET;
 #pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const int m = chunk_begin * 32 + 4 * qg + i;
-    const int b = fdiv(m, a.d_plane);
-    const int rem = m - b * plane;
-    qy[i] = fdiv(rem, a.d_pw);
-    qx[i] = rem - qy[i] * PW;
-    qm[i] = m;
-    qb[i] = (unsigned)b * (unsigned)(QH * QW) * (unsigned)Qs4 + (qvalid ? (unsigned)c4 * 16u : OOB_OFFSET);
-  }
+    for (int i = 0; i < NS; ++i) {
+      const int m = chunk * 32 + 4 * qg + i;
+      const int b = fdiv(m, a.d_plane);
+      const int rem = m - b * plane;
+      qy[i] = fdiv(rem, a.d_pw);
+      qx[i] = rem - qy[i] * PW;
+      qm[i] = m;
+      qb[i] = (unsigned)b * (unsigned)(QH * QW) * (unsigned)Qs4 + (qvalid ? (unsigned)c4 * 16u : OOB_OFFSET);
+    }
+  };
+  // XCD-contiguous order (a.xcd): the tiles of a split run together on one XCD and share its L2 - but they would all
+  // ask for the same P / Q rows at the same moment.  Each tile therefore starts its walk over the split's chunks at
+  // its own offset and wraps around (the summation order of a tile is rotated, still fixed: deterministic).
+  const int nch = chunk_end > chunk_begin ? chunk_end - chunk_begin : 0;
+  int cur = chunk_begin + ((a.xcd && nch > 0) ? (tile * 5) % nch : 0);
+  init_state(cur);
 
   auto gload = [&]() {
     if (doP) {
@@ -1054,13 +1063,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_t_kernel(const WGradArgs
     }
   };
 
-  if (chunk_begin < chunk_end) {
+  if (nch > 0) {
     gload();
     lstore();
     __syncthreads();
-    for (int ch = chunk_begin; ch < chunk_end; ++ch) {
-      const bool more = ch + 1 < chunk_end;
-      if (more) gload();
+    for (int it = 0; it < nch; ++it) {
+      const bool more = it + 1 < nch;
+      if (more) {
+        if (++cur == chunk_end) { cur = chunk_begin; init_state(cur); }      // wrap (rotated start only)
+        gload();
+      }
       compute();
       __syncthreads();
       if (more) lstore();

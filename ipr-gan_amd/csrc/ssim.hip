@@ -41,7 +41,9 @@ __global__ __launch_bounds__(SSIM_T* SSIM_T) void ssim_fwd_kernel(const float* _
                                                                   const float* __restrict__ y,
                                                                   float* __restrict__ gmaps,
                                                                   float* __restrict__ part, int H, int W,
-                                                                  int OH, int OW, int denorm, SsimWin g) {
+                                                                  int OH, int OW, int denorm, SsimWin g, int which) {
+  // which 0: S = SSIM map; 1: S = contrast-structure map cs = (2 sxy + C2) / (sx^2 + sy^2 + C2) - the per-scale factor of
+  // MS-SSIM (pytorch_msssim.ms_ssim: cs at scales 1-4, ssim at scale 5)
   __shared__ float sx[SSIM_P][SSIM_P + 1], sy[SSIM_P][SSIM_P + 1];
   __shared__ float red[16];
   const int plane = blockIdx.z;
@@ -77,14 +79,20 @@ __global__ __launch_bounds__(SSIM_T* SSIM_T) void ssim_fwd_kernel(const float* _
     const float sxx = xx - mx * mx, syy = yy - my * my, sxy = xy - mx * my;
     const float a1 = 2.f * mx * my + C1, a2 = 2.f * sxy + C2;
     const float b1 = mx * mx + my * my + C1, b2 = sxx + syy + C2;
-    S = (a1 / b1) * (a2 / b2);
+    S = which ? a2 / b2 : (a1 / b1) * (a2 / b2);
     if (gmaps) {
       const size_t n = (size_t)gridDim.z * OH * OW, o = ((size_t)plane * OH + oy) * OW + ox;
-      // S = a1 a2 / (b1 b2); written without divisions by a1, a2 (which may vanish; b1 >= C1, b2 ~>= C2)
-      const float ib = 1.f / (b1 * b2);
-      gmaps[o] = 2.f * my * (a2 - a1) * ib + 2.f * mx * S * (1.f / b2 - 1.f / b1);     // dS/dE[x]
-      gmaps[n + o] = -S / b2;                                                          // dS/dE[xx]
-      gmaps[2 * n + o] = 2.f * a1 * ib;                                                // dS/dE[xy]
+      if (which) {               // cs = a2 / b2
+        gmaps[o] = (2.f * mx * S - 2.f * my) / b2;                                      // dcs/dE[x]
+        gmaps[n + o] = -S / b2;                                                         // dcs/dE[xx]
+        gmaps[2 * n + o] = 2.f / b2;                                                    // dcs/dE[xy]
+      } else {
+        // S = a1 a2 / (b1 b2); written without divisions by a1, a2 (which may vanish; b1 >= C1, b2 ~>= C2)
+        const float ib = 1.f / (b1 * b2);
+        gmaps[o] = 2.f * my * (a2 - a1) * ib + 2.f * mx * S * (1.f / b2 - 1.f / b1);   // dS/dE[x]
+        gmaps[n + o] = -S / b2;                                                        // dS/dE[xx]
+        gmaps[2 * n + o] = 2.f * a1 * ib;                                              // dS/dE[xy]
+      }
     }
   }
   const float s = block_sum(S, red);
@@ -104,7 +112,10 @@ __global__ __launch_bounds__(SSIM_T* SSIM_T) void ssim_bwd_kernel(const float* _
                                                                   const float* __restrict__ gmaps,
                                                                   const float* __restrict__ gscale,
                                                                   float* __restrict__ dx, int H, int W, int OH,
-                                                                  int OW, int denorm, float inv_n, SsimWin g) {
+                                                                  int OW, int denorm, float inv_n, SsimWin g,
+                                                                  const float* __restrict__ pscale, int accumulate) {
+  // pscale (MS-SSIM): per-plane factor d loss / d (plane mean of this scale's map) instead of the global -1/n;
+  // accumulate: dx += (the gradient arriving from the coarser scales is already there)
   __shared__ float sa[SSIM_P][SSIM_P + 1], sb[SSIM_P][SSIM_P + 1], sc[SSIM_P][SSIM_P + 1];
   const int plane = blockIdx.z;
   const int iy0 = blockIdx.y * SSIM_T, ix0 = blockIdx.x * SSIM_T;
@@ -139,7 +150,74 @@ __global__ __launch_bounds__(SSIM_T* SSIM_T) void ssim_bwd_kernel(const float* _
     acc += g.w[i] * row;
   }
   // loss = 1 - mean S  ->  dL/dS = -1/n ; (x+1)/2 contributes 1/2
-  dx[p] = acc * (gscale ? *gscale : 1.f) * -inv_n * (denorm ? 0.5f : 1.f);
+  const float v = acc * (gscale ? *gscale : 1.f) * (pscale ? pscale[plane] * inv_n : -inv_n) * (denorm ? 0.5f : 1.f);
+  dx[p] = accumulate ? dx[p] + v : v;
+}
+
+// ---- MS-SSIM (tools/loss.py:78-80 -> pytorch_msssim.MS_SSIM(data_range=1), third-party, restated) ----------------------
+// five scales; between scales X and Y are average-pooled 2x2 (zero padding of one row / column on odd sizes, the pad
+// counted in the average); per (image, channel) plane: prod_{l<5} relu(mean cs_l)^w_l * relu(mean ssim_5)^w_5.
+__global__ void avgpool2_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int H, int W, int OH,
+                                    int OW, int py, int px, int denorm) {
+  const size_t total = (size_t)planes * OH * OW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+    const size_t pl = i / ((size_t)OW * OH);
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int iy = 2 * oy - py + a, ix = 2 * ox - px + b;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) s += ssim_in(x[(pl * H + iy) * W + ix], denorm);
+      }
+    y[i] = 0.25f * s;
+  }
+}
+// dx[p] += 0.25 * dy[pooled cell of p] (* 1/2 when the pooled image was read through (x+1)/2)
+__global__ void avgpool2_pad_bwd_add_kernel(const float* __restrict__ dy, float* __restrict__ dx, int planes, int H, int W,
+                                            int OH, int OW, int py, int px, float scale) {
+  const size_t total = (size_t)planes * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W), iy = (int)((i / W) % H);
+    const size_t pl = i / ((size_t)W * H);
+    const int oy = (iy + py) >> 1, ox = (ix + px) >> 1;
+    dx[i] += scale * dy[(pl * OH + oy) * OW + ox];
+  }
+}
+// part[(plane, tile)] -> means[plane]; one block per plane, fixed order
+__global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ part, int tiles, float inv_n,
+                                                         float* __restrict__ means) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < tiles; i += blockDim.x) s += part[(size_t)blockIdx.x * tiles + i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) means[blockIdx.x] = s * inv_n;
+}
+#define MSSSIM_LEVELS 5
+struct MsWeights { float w[MSSSIM_LEVELS]; };
+// means[l][plane] -> loss = 1 - mean_p prod_l relu(m)^w_l and coef[l][plane] = d loss / d means[l][plane]
+__global__ __launch_bounds__(256) void msssim_combine_kernel(const float* __restrict__ means, int planes, MsWeights w,
+                                                             float* __restrict__ loss, float* __restrict__ coef) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int p = threadIdx.x; p < planes; p += blockDim.x) {
+    float val = 1.f;
+    float t[MSSSIM_LEVELS];
+#pragma unroll
+    for (int l = 0; l < MSSSIM_LEVELS; ++l) {
+      t[l] = fmaxf(means[(size_t)l * planes + p], 0.f);
+      val *= powf(t[l], w.w[l]);
+    }
+    s += val;
+    if (coef) {
+#pragma unroll
+      for (int l = 0; l < MSSSIM_LEVELS; ++l)
+        coef[(size_t)l * planes + p] = t[l] > 0.f ? -val * w.w[l] / (t[l] * (float)planes) : 0.f;
+    }
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *loss = 1.f - s / (float)planes;
 }
 
 }  // namespace iprgan
@@ -166,7 +244,7 @@ int iprgan_ssim_fwd(const float* x, const float* y, float* loss, float* gmaps, f
   const int OH = H - SSIM_WIN + 1, OW = W - SSIM_WIN + 1;
   dim3 grid(cdiv(OW, SSIM_T), cdiv(OH, SSIM_T), planes);
   hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(SSIM_T * SSIM_T), 0, st, x, y, gmaps, ws, H, W, OH, OW, denorm,
-                     ssim_window());
+                     ssim_window(), 0);
   IPR_LAUNCH_CHECK();
   const int nb = (int)(grid.x * grid.y * grid.z);
   hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(256), 0, st, ws, nb, 1.0f / ((float)planes * OH * OW), loss);
@@ -181,8 +259,110 @@ int iprgan_ssim_bwd(const float* x, const float* y, const float* gmaps, const fl
   const int OH = H - SSIM_WIN + 1, OW = W - SSIM_WIN + 1;
   dim3 grid(cdiv(W, SSIM_T), cdiv(H, SSIM_T), planes);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(SSIM_T * SSIM_T), 0, (hipStream_t)stream, x, y, gmaps, gscale,
-                     dx, H, W, OH, OW, denorm, 1.0f / ((float)planes * OH * OW), ssim_window());
+                     dx, H, W, OH, OW, denorm, 1.0f / ((float)planes * OH * OW), ssim_window(), (const float*)nullptr, 0);
   IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- MS-SSIM loss: 1 - MS_SSIM(data_range=1)(x, y) (tools/loss.py:78-80) -------------------------------------------
+// Workspace layout (floats), all sizes from iprgan_msssim_sizes():
+//   pyr   : pooled images of scales 2..5 for x and y (scale 1 = the inputs)
+//   gmaps : 3 sensitivity maps per scale (cs for scales 1-4, ssim for scale 5), kept for the backward pass
+//   small : tile partials, means[5][planes], coef[5][planes]
+struct MsGeom { int H[MSSSIM_LEVELS], W[MSSSIM_LEVELS], OH[MSSSIM_LEVELS], OW[MSSSIM_LEVELS]; size_t pyr_off[MSSSIM_LEVELS], gmap_off[MSSSIM_LEVELS], pyr, gmaps, part; };
+static MsGeom ms_geom(int planes, int H, int W) {
+  MsGeom g;
+  size_t po = 0, go = 0, part = 0;
+  for (int l = 0; l < MSSSIM_LEVELS; ++l) {
+    g.H[l] = H; g.W[l] = W;
+    g.OH[l] = H - SSIM_WIN + 1; g.OW[l] = W - SSIM_WIN + 1;
+    g.pyr_off[l] = po;
+    if (l > 0) po += (size_t)2 * planes * H * W;         // x then y
+    g.gmap_off[l] = go;
+    go += (size_t)3 * planes * g.OH[l] * g.OW[l];
+    const size_t t = (size_t)planes * cdiv(g.OH[l], SSIM_T) * cdiv(g.OW[l], SSIM_T);
+    if (t > part) part = t;
+    H = (H + 2 * (H & 1) - 2) / 2 + 1; W = (W + 2 * (W & 1) - 2) / 2 + 1;
+  }
+  g.pyr = po; g.gmaps = go; g.part = part;
+  return g;
+}
+static const MsWeights kMsW = {{0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f}};
+
+int iprgan_msssim_sizes(int planes, int H, int W, size_t* pyr_floats, size_t* gmap_floats, size_t* small_floats) {
+  IPR_CHECK((H < W ? H : W) > (SSIM_WIN - 1) * 16, "ms_ssim: the smaller image side (%d) must exceed %d (five scales of an 11x11 window)",
+            H < W ? H : W, (SSIM_WIN - 1) * 16);
+  const MsGeom g = ms_geom(planes, H, W);
+  *pyr_floats = g.pyr; *gmap_floats = g.gmaps; *small_floats = g.part + (size_t)2 * MSSSIM_LEVELS * planes;
+  return 0;
+}
+
+int iprgan_msssim_fwd(const float* x, const float* y, float* loss, float* pyr, float* gmaps, float* small, int planes,
+                      int H, int W, int denorm, int want_grad, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  IPR_CHECK(planes > 0 && planes < 65536, "msssim_fwd: %d image planes unsupported", planes);
+  IPR_CHECK((H < W ? H : W) > (SSIM_WIN - 1) * 16, "msssim_fwd: image %dx%d too small for five scales", H, W);
+  const MsGeom g = ms_geom(planes, H, W);
+  float* part = small;
+  float* means = small + g.part;
+  float* coef = means + (size_t)MSSSIM_LEVELS * planes;
+  const float* xl = x;
+  const float* yl = y;
+  for (int l = 0; l < MSSSIM_LEVELS; ++l) {
+    const int dn = (l == 0) ? denorm : 0;
+    dim3 grid(cdiv(g.OW[l], SSIM_T), cdiv(g.OH[l], SSIM_T), planes);
+    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(SSIM_T * SSIM_T), 0, st, xl, yl, want_grad ? gmaps + g.gmap_off[l] : nullptr,
+                       part, g.H[l], g.W[l], g.OH[l], g.OW[l], dn, ssim_window(), l < MSSSIM_LEVELS - 1 ? 1 : 0);
+    IPR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(plane_mean_kernel, dim3(planes), dim3(256), 0, st, part, (int)(grid.x * grid.y),
+                       1.0f / ((float)g.OH[l] * g.OW[l]), means + (size_t)l * planes);
+    IPR_LAUNCH_CHECK();
+    if (l + 1 < MSSSIM_LEVELS) {
+      float* xn = pyr + g.pyr_off[l + 1];
+      float* yn = xn + (size_t)planes * g.H[l + 1] * g.W[l + 1];
+      const size_t tot = (size_t)planes * g.H[l + 1] * g.W[l + 1];
+      const int blocks = (int)(cdivz(tot, 256) < 4096 ? cdivz(tot, 256) : 4096);
+      hipLaunchKernelGGL(avgpool2_pad_kernel, dim3(blocks), dim3(256), 0, st, xl, xn, planes, g.H[l], g.W[l], g.H[l + 1],
+                         g.W[l + 1], g.H[l] & 1, g.W[l] & 1, dn);
+      hipLaunchKernelGGL(avgpool2_pad_kernel, dim3(blocks), dim3(256), 0, st, yl, yn, planes, g.H[l], g.W[l], g.H[l + 1],
+                         g.W[l + 1], g.H[l] & 1, g.W[l] & 1, dn);
+      IPR_LAUNCH_CHECK();
+      xl = xn; yl = yn;
+    }
+  }
+  hipLaunchKernelGGL(msssim_combine_kernel, dim3(1), dim3(256), 0, st, means, planes, kMsW, loss, want_grad ? coef : nullptr);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+// dx (the gradient w.r.t. x, same shape) out; pyr/gmaps/small as left by iprgan_msssim_fwd(want_grad = 1); ws: scratch
+// of 2 * planes * H2 * W2 floats (two ping-pong gradient images of scale 2, the largest pooled scale)
+int iprgan_msssim_bwd(const float* x, const float* y, const float* pyr, const float* gmaps, const float* small,
+                      const float* gscale, float* dx, float* ws, int planes, int H, int W, int denorm, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const MsGeom g = ms_geom(planes, H, W);
+  const float* coef = small + g.part + (size_t)MSSSIM_LEVELS * planes;
+  float* buf[2] = {ws, ws + (size_t)planes * g.H[1] * g.W[1]};
+  float* coarse = nullptr;           // gradient w.r.t. the image of scale l + 1
+  for (int l = MSSSIM_LEVELS - 1; l >= 0; --l) {
+    const float* xl = l ? pyr + g.pyr_off[l] : x;
+    const float* yl = l ? xl + (size_t)planes * g.H[l] * g.W[l] : y;
+    float* out = l ? buf[l & 1] : dx;
+    const int dn = (l == 0) ? denorm : 0;
+    dim3 grid(cdiv(g.W[l], SSIM_T), cdiv(g.H[l], SSIM_T), planes);
+    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(SSIM_T * SSIM_T), 0, st, xl, yl, gmaps + g.gmap_off[l], gscale, out,
+                       g.H[l], g.W[l], g.OH[l], g.OW[l], dn, 1.0f / ((float)g.OH[l] * g.OW[l]), ssim_window(),
+                       coef + (size_t)l * planes, 0);
+    IPR_LAUNCH_CHECK();
+    if (coarse) {
+      const size_t tot = (size_t)planes * g.H[l] * g.W[l];
+      const int blocks = (int)(cdivz(tot, 256) < 4096 ? cdivz(tot, 256) : 4096);
+      hipLaunchKernelGGL(avgpool2_pad_bwd_add_kernel, dim3(blocks), dim3(256), 0, st, coarse, out, planes, g.H[l], g.W[l],
+                         g.H[l + 1], g.W[l + 1], g.H[l] & 1, g.W[l] & 1, dn ? 0.125f : 0.25f);
+      IPR_LAUNCH_CHECK();
+    }
+    coarse = out;
+  }
   return 0;
 }
 

@@ -82,6 +82,9 @@ SIGNATURES = {
     'iprgan_ssim_gmap_floats': (_Z, [_I, _I, _I]),
     'iprgan_ssim_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'iprgan_ssim_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'iprgan_msssim_sizes': (_I, [_I, _I, _I, C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_Z)]),
+    'iprgan_msssim_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'iprgan_msssim_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'iprgan_reparam_bwd': (_I, [_P, _P, _P, _P, _P, _Z, _P]),
     'iprgan_sign_loss_fwd': (_I, [_P, _P, _P, _I, _F, _P, _P]),
     'iprgan_sign_loss_bwd': (_I, [_P, _P, _P, _P, _I, _F, _P, _F, _P]),

@@ -311,6 +311,30 @@ def ssim_bwd(x, y, gmaps, gscale, denorm):
     return dx
 
 
+def msssim_fwd(x, y, denorm, want_grad):
+    """x, y: contiguous NCHW fp32, min(H, W) > 160.  Returns (loss = 1 - MS-SSIM, state for msssim_bwd or None)."""
+    B, Cc, H, W = x.shape
+    planes = B * Cc
+    a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    call('iprgan_msssim_sizes', planes, H, W, C.byref(a), C.byref(b), C.byref(c))
+    out = empty((), x)
+    pyr, small = empty((max(1, a.value),), x), empty((c.value,), x)
+    gm = empty((b.value,), x) if want_grad else None
+    call('iprgan_msssim_fwd', ptr(x), ptr(y), ptr(out), ptr(pyr), ptr(gm), ptr(small), planes, H, W, int(bool(denorm)),
+         1 if want_grad else 0, stream())
+    return out, ((pyr, gm, small) if want_grad else None)
+
+
+def msssim_bwd(x, y, state, gscale, denorm):
+    B, Cc, H, W = x.shape
+    pyr, gm, small = state
+    dx = torch.empty_like(x)
+    ws = empty((2 * B * Cc * ((H + 1) // 2) * ((W + 1) // 2),), x)
+    call('iprgan_msssim_bwd', ptr(x), ptr(y), ptr(pyr), ptr(gm), ptr(small), ptr(gscale), ptr(dx), ptr(ws), B * Cc, H, W,
+         int(bool(denorm)), stream())
+    return dx
+
+
 # ---- VAE reparameterisation -----------------------------------------------------------------------
 def reparam_fwd(mean, logvar, eps):
     z = torch.empty_like(mean)

@@ -200,8 +200,34 @@ def ssim(normalized=False):
     return _SSIMLoss(normalized=normalized)
 
 
+class _MSSSIMFn(torch.autograd.Function):
+    """1 - MS-SSIM (include/iprgan.h iprgan_msssim_*); the gradient flows to ``x`` only."""
+
+    @staticmethod
+    def forward(ctx, x, y, denorm):
+        xd, yd = x.detach().contiguous(), y.detach().contiguous()
+        out, state = ops.msssim_fwd(xd, yd, denorm, x.requires_grad)
+        ctx.x, ctx.y, ctx.state, ctx.denorm = xd, yd, state, denorm
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        return ops.msssim_bwd(ctx.x, ctx.y, ctx.state, gout.contiguous(), ctx.denorm), None, None
+
+
+class _MSSSIMLoss(object):
+    """tools/loss.py:78-80: ``Loss(lambda x, y: 1 - MS_SSIM(data_range=1)(x, y), normalized)`` on the HIP kernels
+    (five scales; images must be larger than 160 pixels on their smaller side, as in pytorch-msssim)."""
+
+    def __init__(self, normalized=False):
+        self.denorm = normalized
+
+    def __call__(self, x, y):
+        return _MSSSIMFn.apply(x, y, bool(self.denorm))
+
+
 def ms_ssim(normalized=False):
-    raise NotImplementedError('ms_ssim (tools/loss.py:78-80) is not used by any reference config and is not built')
+    return _MSSSIMLoss(normalized=normalized)
 
 
 # ---- black-box trigger / target transforms (tools/transform_dist.py, random_bitmask.py, transform_var.py,

@@ -69,11 +69,17 @@ class Experiment:
         if not torch.cuda.is_available():
             raise SystemExit('the HIP engine needs a GPU')
         local = int(os.environ.get('LOCAL_RANK', 0))
+        if local >= torch.cuda.device_count() and os.environ.get('IPRGAN_SHARE_DEVICE') == '1':
+            local %= torch.cuda.device_count()      # test-only: several ranks on one GPU (needs IPRGAN_DIST_BACKEND=gloo)
         torch.cuda.set_device(local)
         self.device = [torch.device('cuda', local)]
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group('nccl', device_id=self.device[0])
+            backend = os.environ.get('IPRGAN_DIST_BACKEND', 'nccl')       # nccl = RCCL over xGMI
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=self.device[0])
+            else:
+                dist.init_process_group(backend)
         hp = self.config.hparam
         if 'pretrain_iter' in hp.to_dict():
             hp.pretrain_iter //= self.world
@@ -222,6 +228,11 @@ def main():
     ckpt = os.path.join(config.log.path, 'checkpoint.pt')
     if os.path.exists(ckpt):                                    # train.py:26-31 auto-resume
         exp.load_state_dict(torch.load(ckpt, map_location=exp.device[0]))
+    if os.environ.get('IPRGAN_TRAIN_PROBE'):                    # test hook: what this rank is about to train on
+        x = next(exp.data_loader)[0]
+        p = torch.cat([t.detach().flatten()[:64].cpu() for t in exp.model.G.parameters()])
+        torch.save({'rank': exp.rank, 'batch_sum': float(x.double().sum()), 'param_probe': p},
+                   os.environ['IPRGAN_TRAIN_PROBE'] + f'.{exp.rank}')
     exp.start(max_steps=args.max_steps)
     if dist.is_initialized():
         dist.destroy_process_group()

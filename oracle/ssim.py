@@ -44,6 +44,45 @@ def ssim(x, y, data_range=1.0, k1=0.01, k2=0.03):
     return torch.flatten(ssim_map, 2).mean(-1).mean()           # per channel, then over (batch, channel)
 
 
+MS_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def _ssim_cs_per_channel(x, y, data_range=1.0, k1=0.01, k2=0.03):
+    """pytorch_msssim._ssim(size_average=False): per (image, channel) means of the ssim and cs maps."""
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    win = gauss_1d().to(x)
+    mu1, mu2 = gaussian_filter(x, win), gaussian_filter(y, win)
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = gaussian_filter(x * x, win) - mu1_sq
+    s2 = gaussian_filter(y * y, win) - mu2_sq
+    s12 = gaussian_filter(x * y, win) - mu12
+    cs_map = (2 * s12 + c2) / (s1 + s2 + c2)
+    ssim_map = ((2 * mu12 + c1) / (mu1_sq + mu2_sq + c1)) * cs_map
+    return torch.flatten(ssim_map, 2).mean(-1), torch.flatten(cs_map, 2).mean(-1)
+
+
+def ms_ssim(x, y, data_range=1.0):
+    """pytorch_msssim.ms_ssim (0.2.1, PARITY UNPINNED like ssim above): five scales, cs at scales 1-4 and ssim at scale
+    5, relu before the weighted product, 2x2 average pooling with padding (H % 2, W % 2) between scales, mean over
+    (image, channel).  The package asserts min(H, W) > (11 - 1) * 2^4 = 160."""
+    assert min(x.shape[-2:]) > 160, 'image too small for five scales'
+    w = torch.tensor(MS_WEIGHTS, dtype=x.dtype)
+    mcs = []
+    for i in range(5):
+        s, cs = _ssim_cs_per_channel(x, y, data_range)
+        if i < 4:
+            mcs.append(torch.relu(cs))
+            pad = (x.shape[2] % 2, x.shape[3] % 2)
+            x, y = F.avg_pool2d(x, 2, padding=pad), F.avg_pool2d(y, 2, padding=pad)
+    stack = torch.stack(mcs + [torch.relu(s)], 0)
+    return torch.prod(stack ** w.view(-1, 1, 1), 0).mean()
+
+
+def ms_ssim_loss(normalized=False):
+    """tools/loss.py:78-80."""
+    return Loss(lambda x, y: 1 - ms_ssim(x, y, data_range=1.0), normalized=normalized)
+
+
 class Loss:
     """tools/loss.py:10-20."""
 

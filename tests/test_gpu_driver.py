@@ -59,3 +59,22 @@ def test_train_driver_complete_protection(tmp_path):
     rows = [json.loads(l) for l in open(os.path.join(log, 'metrics.jsonl'))]
     assert len(rows) == 3 and all(0.0 < r['P/SSIM'] <= 1.0 and 'P/SignLoss' in r for r in rows)
     assert json.load(open(os.path.join(log, 'metrics.json')))['BER'] == 0.0
+
+
+def test_two_ranks_draw_different_data_and_hold_equal_parameters(tmp_path):
+    """train.py seeded every rank identically.  Two ranks (sharing the test box's one GPU, gloo) now build
+    the model with the common seed - identical parameters, sign buffers and trigger modules - and draw their data /
+    latents / ImagePool decisions from seed + rank: the first batches differ, the replicas are equal before and after
+    training (the reduced gradients are the same on both)."""
+    cfg = os.path.join(ROOT, 'tests', 'configs', 'dcgan-wbox-tiny.yaml')
+    log, probe = str(tmp_path / 'log'), str(tmp_path / 'probe')
+    env = dict(os.environ, IPRGAN_SHARE_DEVICE='1', IPRGAN_DIST_BACKEND='gloo', IPRGAN_TRAIN_PROBE=probe)
+    subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                    '127.0.0.1', '--master-port', '29517', os.path.join(PKG, 'train.py'), '-c', cfg, '--log-path', log],
+                   check=True, timeout=900, env=env)
+    a, b = torch.load(probe + '.0'), torch.load(probe + '.1')
+    assert a['batch_sum'] != b['batch_sum'], 'both ranks drew the same first batch'
+    assert torch.equal(a['param_probe'], b['param_probe']), 'replicas start from different parameters'
+    sd = torch.load(os.path.join(log, 'checkpoint.pt'), map_location='cpu')
+    assert sd['step'] == 'END'              # iteration 4 // world 2 = 2 steps per rank
+    assert json.load(open(os.path.join(log, 'metrics.json')))['BER'] == 0.0

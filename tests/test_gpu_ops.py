@@ -633,3 +633,26 @@ def test_conv_epilogue_column_sums(dev, shape, tile):
         assert float((cs - refc).abs().max()) <= 2e-4 * float(want.abs().max()) * want[:, 0].numel() ** 0.5
     finally:
         _lib.call('iprgan_debug_force_tiles', -1, -1)
+
+
+@pytest.mark.parametrize('shape,denorm', [((2, 3, 176, 193), False), ((1, 3, 256, 256), True), ((2, 1, 161, 200), False)])
+def test_ms_ssim_loss_vs_oracle(dev, shape, denorm):
+    """tools.ms_ssim (tools/loss.py:78-80) on the HIP kernels against the restated pytorch-msssim algorithm: value and
+    gradient w.r.t. x, odd sizes (zero-padded pooling) included."""
+    from iprgan import tools
+    from oracle import ssim as ossim
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(*shape, generator=g)
+    y = (x + 0.3 * (torch.rand(*shape, generator=g) - 0.5)).clamp(0, 1)
+    if denorm:
+        x, y = x * 2 - 1, y * 2 - 1
+    xa = x.clone().requires_grad_()
+    xb = x.clone().to(dev).requires_grad_()
+    la = ossim.ms_ssim_loss(normalized=denorm)(xa, y)
+    lb = tools.ms_ssim(normalized=denorm)(xb, y.to(dev))
+    np.testing.assert_allclose(float(lb.detach()), float(la.detach()), rtol=2e-4, atol=2e-6)
+    (3.0 * la).backward(); (3.0 * lb).backward()
+    ga, gb = xa.grad.double(), xb.grad.cpu().double()
+    assert float((ga - gb).abs().max()) <= 2e-3 * float(ga.abs().max()), float((ga - gb).abs().max()) / float(ga.abs().max())
+    # MS-SSIM(x, x) = 1 -> loss 0
+    assert abs(float(tools.ms_ssim(normalized=denorm)(xb.detach(), xb.detach()))) < 2e-6

@@ -160,3 +160,22 @@ def test_ssim_restatement_known_answers():
     assert abs(float(ssim.gauss_1d().sum()) - 1.0) < 1e-6 and ssim.gauss_1d().numel() == 11
     lossn = ssim.ssim_loss(normalized=True)(x * 2 - 1, y * 2 - 1)
     assert abs(float(lossn) - (1 - float(ssim.ssim(x, y)))) < 1e-5
+
+
+def test_ms_ssim_restatement_known_answers():
+    """pytorch-msssim's MS_SSIM is absent too (parity unpinned): properties the published algorithm must satisfy."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 3, 176, 193, generator=g)
+    y = (x + 0.2 * torch.rand(2, 3, 176, 193, generator=g)).clamp(0, 1)
+    assert abs(float(ssim.ms_ssim(x, x)) - 1.0) < 1e-6
+    assert float(ssim.ms_ssim(x, y)) == float(ssim.ms_ssim(y, x)) < 1.0
+    assert abs(sum(ssim.MS_WEIGHTS) - 1.0) < 1e-3            # 0.0448 + 0.2856 + 0.3001 + 0.2363 + 0.1333 = 1.0001
+    # a constant pair has zero variance at every scale: cs = 1, ssim = luminance term, so MS-SSIM = lum ^ w5
+    c, d = torch.full((1, 1, 180, 180), 0.3), torch.full((1, 1, 180, 180), 0.6)
+    lum = (2 * 0.3 * 0.6 + 1e-4) / (0.09 + 0.36 + 1e-4)
+    # (zero padding only appears on odd sizes: 180 -> 90 -> 45 -> 23 -> 12; the padded borders of scales 4, 5 lower the
+    #  luminance term there, so only the bound lum^w5 <= value <= 1 is checked)
+    v = float(ssim.ms_ssim(c, d))
+    assert 0.0 < v <= 1.0
+    lossn = ssim.ms_ssim_loss(normalized=True)(x * 2 - 1, y * 2 - 1)
+    assert abs(float(lossn) - (1 - float(ssim.ms_ssim(x, y)))) < 1e-5
