@@ -201,9 +201,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--workload', choices=list(WORKLOADS), default='dcgan64')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--math', choices=['fp32', 'bf16'], default='fp32',
+    ap.add_argument('--math', choices=['fp32', 'bf16', 'bf16act'], default='fp32',
                     help="conv math mode; the headline metric is fp32 (the reference's precision). 'bf16' = bf16 MFMA "
-                         "tiles with fp32 accumulation / master weights, reported with dtype bf16")
+                         "tiles with fp32 accumulation / master weights, reported with dtype bf16; 'bf16act' additionally "
+                         "keeps activations with a multiple of 64 channels as bf16 in HBM")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     heavy = args.workload in ('cyclegan', 'dcgan128')
@@ -298,7 +299,7 @@ def main():
         value = B * world * args.steps / elapsed
         dom = max(kernels, key=lambda k: k['ms']) if kernels else None
         roof = None
-        peak_mode = PEAK_BF16_MFMA if args.math == 'bf16' else PEAK_FP32_MFMA
+        peak_mode = PEAK_BF16_MFMA if args.math != 'fp32' else PEAK_FP32_MFMA
         # profiles/<round>_[<workload>_]pmc_traffic.json; the headline workload has no infix
         tag = '' if args.workload == 'dcgan64' else args.workload + '_'
         rnd = 'r[0-9][0-9]_'
@@ -332,7 +333,8 @@ def main():
             'dtype': 'f32' if args.math == 'fp32' else 'bf16',
             'data': 'synthetic',
             'config': {'workload': wl['text'] + ', ' +
-                                   ('fp32' if args.math == 'fp32' else 'bf16 MFMA tiles (fp32 accumulate, fp32 master weights)') +
+                                   {'fp32': 'fp32', 'bf16': 'bf16 MFMA tiles (fp32 accumulate, fp32 tensors and master weights)',
+                                    'bf16act': 'bf16 MFMA tiles, bf16 activations in HBM (fp32 accumulate, statistics, master weights)'}[args.math] +
                                    ', Adam',
                        'global_batch': B * world, 'parallelism': f'dp{world}'},
             'roofline': roof,

@@ -50,7 +50,14 @@ typedef struct {
   int32_t pad_mode;       /* IPRGAN_PAD_*: reflect = ReflectionPad2d(pad) folded into the gather */
   int32_t act;            /* IPRGAN_ACT_* fused into the forward epilogue */
   float   slope;          /* LeakyReLU negative slope */
+  int32_t x_bf16;         /* storage type of the layer's INPUT activation x (and of dx, prev_out): 0 = fp32, 1 = bf16 */
+  int32_t y_bf16;         /* storage type of the layer's OUTPUT activation y (and of dy) */
 } iprgan_conv_desc;
+/* bf16 activations ("bf16 in HBM", BASELINE config 5): only with IPRGAN_MATH_BF16 and only for tensors whose padded
+ * channel count is a multiple of 64; such a tensor is bf16 for EVERY entry point that touches it (element offsets and
+ * shapes are unchanged, the `float*` in the signatures is then a bf16 buffer).  Prepared weights follow the operand
+ * they are multiplied with: iprgan_conv_weight_prep emits bf16 operands for a bf16 x (forward) / bf16 y (backward).
+ * Weight gradients, statistics, losses, master weights and Adam stay fp32. */
 
 const char* iprgan_last_error(void);
 int iprgan_version(void);
@@ -115,7 +122,7 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
  * epilogue (before the bias; conv is linear in W).  One launch of twice the size fills the GPU better than two. */
 /* out[c] = beta*out[c] + sum_m x[m][c], c < C, over x[M][Cs] (bias gradients); ws: iprgan_colsum_ws_floats(M, Cs) floats */
 size_t iprgan_colsum_ws_floats(int M, int Cs);
-int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, float beta, void* stream);
+int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, float beta, int x_bf16, void* stream);
 /* the same from per-tile partials part[rows][2][Cs] (first of the two sums) written by a convolution epilogue */
 int iprgan_colsum_partials(const float* part, int rows, int Cs, int C, float* out, float beta, void* stream);
 /* dw (PyTorch layout) = beta*dw + conv_bwd_weight(x, dy); db (optional, length Cout) = beta*db + sum dy.
@@ -125,18 +132,18 @@ int iprgan_colsum_partials(const float* part, int rows, int Cs, int C, float* ou
 int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const float* dy, float* dw,
                            float* db, float* ws, float beta, void* stream);
 /* dz = dy * act'(out) elementwise (activation backward from the saved output), n floats. */
-int iprgan_act_bwd(const float* dy, const float* out, float* dz, size_t n, int act, float slope,
+int iprgan_act_bwd(const float* dy, const float* out, float* dz, size_t n, int act, float slope, int act_bf16,
                    void* stream);
 
 /* ---- GEMV head: SN-Linear 512*md*md -> 1 (networks/sn_discriminator.py:21) -------------- */
 /* y[b] = dot(x[b,:], w)/(*inv_scale) + bias[0];  x [B,K] */
-int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const float* inv_scale,
-                    float* y, int B, int K, void* stream);
+int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const float* inv_scale, float* y,
+                    int B, int K, int x_bf16, void* stream);
 /* dx[b,k] = dy[b]*w[k]/(*inv_scale) [* act'(prev_out)];  dw[k] = sum_b dy[b]*x[b,k] (gradient w.r.t.
  * the NORMALISED weight w/sigma; feed it to iprgan_sn_bwd);  db[0] = sum dy.  dx/dw/db may be NULL. */
-int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float* inv_scale,
-                    float* dx, float* dw, float* db, const float* prev_out, int prev_act,
-                    float prev_slope, int B, int K, void* stream);
+int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float* inv_scale, float* dx,
+                    float* dw, float* db, const float* prev_out, int prev_act, float prev_slope, int B,
+                    int K, int x_bf16, void* stream);
 
 /* ---- BatchNorm2d (networks/conv_generator.py:9, sr_resnet.py:23, discriminator_96.py:31) -- */
 size_t iprgan_bn_ws_floats(int M, int C);
@@ -150,7 +157,7 @@ int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* bet
                   float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                   float* ws, int M, int C, float eps, float momentum, int use_running, int act,
                   float slope, const float* conv_part, int conv_part_rows, const float* conv_bias,
-                  long long* num_batches_tracked, const float* residual, void* stream);
+                  long long* num_batches_tracked, const float* residual, int act_bf16, void* stream);
 /* residual (optional, same shape as y): y = act(norm(x)) + residual, the skip connection closing a residual block. */
 /* backward through act + BN: inputs x (pre-norm), dy, and y (post-act output; NOT read for no activation and for
  * ReLU / LeakyReLU, whose derivative mask is recomputed from x with gamma / beta - may be NULL then).  dx, dgamma, dbeta
@@ -159,7 +166,7 @@ int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* bet
 int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                   float* dbeta, float* ws, int M, int C, int act, float slope, float* dbias_prev, int dbias_n,
-                  float dbias_beta, void* stream);
+                  float dbias_beta, int act_bf16, void* stream);
 
 /* ---- InstanceNorm2d (networks/resnet_generator.py:8-49 affine, conv_discriminator.py:10-18 plain):
  * per-(sample, channel) statistics over HW rows of x[B,HW,C]; gamma/beta may be NULL; never tracks
@@ -168,11 +175,11 @@ size_t iprgan_instnorm_ws_floats(int B, int HW, int C);
 int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                         float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,
                         const float* conv_part, int conv_part_rows, const float* conv_bias, const float* residual,
-                        void* stream);
+                        int act_bf16, void* stream);
 int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                         float* dbeta, float* ws, int B, int HW, int C, int act, float slope, float* dbias_prev,
-                        int dbias_n, float dbias_beta, void* stream);
+                        int dbias_n, float dbias_beta, int act_bf16, void* stream);
 
 /* ---- PReLU / PixelShuffle / MaxPool / residual add / reflection-pad backward ----------------------------
  * nn.PReLU() with one slope (sr_resnet.py:7,14,43): y = x>0 ? x : alpha*x; dalpha = sum dy*x*[x<=0];
@@ -314,6 +321,10 @@ int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand);
 
 /* ---- misc elementwise ----------------------------------------------------------------------- */
 int iprgan_fill(float* p, float v, size_t n, void* stream);
+/* dst[i] = src[i] for n elements between the fp32 and bf16 storage types (round-to-nearest-even) */
+int iprgan_cast(const float* src, float* dst, size_t n, int src_bf16, int dst_bf16, void* stream);
+/* 1 if iprgan_conv_bwd_weight consumes bf16 x / dy of this layer directly (desc flags set), 0 if it wants fp32 copies */
+int iprgan_conv_wgrad_takes_bf16(const iprgan_conv_desc* d);
 int iprgan_axpy(float* y, const float* x, float a, size_t n, void* stream);   /* y += a*x */
 /* y_t += a*x_t for n tensors in one launch (HOST arrays of DEVICE pointers / element counts): the small
  * gradients of a pass (biases, norm scales, PReLU slopes) into their gradient-bucket views */

@@ -12,7 +12,7 @@ namespace iprgan {
 void set_error(const char* fmt, ...);
 // norm.hip: deterministic column sums of x[M][Cs] -> out[C] (bias gradients)
 size_t colsum_ws_floats(int M, int Cs);
-int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st, float beta = 0.f);
+int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st, float beta = 0.f, int b16 = 0);
 
 #define IPR_CHECK(cond, ...)                 \
   do {                                       \

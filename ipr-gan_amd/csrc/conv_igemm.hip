@@ -73,6 +73,12 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 f) {      // round-to-nearest-
   const bf16x4 v = {(__bf16)f.x, (__bf16)f.y, (__bf16)f.z, (__bf16)f.w};
   return v;
 }
+// 4 consecutive bf16 elements (element index idx of a tensor whose storage type is bf16) -> 4 floats
+__device__ __forceinline__ f32x4 ld_bf16x4(const float* base, size_t idx) {
+  const bf16x4 h = *(const bf16x4*)((const __bf16*)base + idx);
+  const f32x4 v = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+  return v;
+}
 
 struct Phase {
   int th, tw, ntap;
@@ -107,6 +113,8 @@ struct GConvArgs {
   const float* res;    // added to the stored value (same layout as out): the gradient arriving over a skip connection
   const float* rs0;    // paired pass (two half-batches through one launch, each with its own spectral-norm sigma):
   const float* rs1;    //   rows of the first / second half of every phase are divided by *rs0 / *rs1 before the bias
+  int in16;            // both operands (activation and prepared weight) are bf16 in HBM -> IN16 kernels
+  int out16, aux16;    // bf16 storage: out (and res) / aux are bf16 tensors (element offsets stay the same)
   float* stat_part;    // STATS kernels: per-tile column sums [tile rows][2][Ns] (see gconv_kernel)
   int stat_mode;
   int ksplit;          // > 1: blockIdx.z splits the K loop (single-phase geometries); partial tiles go to slabs of M*Ns floats
@@ -127,6 +135,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+}
+// 4 consecutive bf16 elements (8 bytes) widened to fp32; out-of-range offsets give zeros like buf_load4
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 buf_load4_bf16(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
+  const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+  const f32x4 v = {__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                   __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u)};
+  return v;
 }
 
 // 4x4 transpose across the four lanes of a quad: afterwards register k of lane p holds what register p of
@@ -173,12 +189,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned total) {
 // accumulator before bias and activation - the batch / instance statistics of the norm layer that follows the
 // convolution come for free instead of from another pass over its output (mean = bias + s1/M, var = s2/M - (s1/M)^2);
 // stat_mode 2: t = the value stored - column sums of a backward-data result = the bias gradient of the layer below.
-template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false, bool STATS = false>
+// IN16 (math mode 2, "bf16 activations"): both operands ARE bf16 in HBM (activations with C4 % 32 == 0 are stored as
+// bf16 by every producer, prepared weights are emitted as bf16): a 16-byte load is 8 K-elements and goes to the LDS
+// image as it is - half the loader bytes of the fp32-in-HBM form, no conversion in the staging path.
+template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false, bool STATS = false, bool IN16 = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a) {
-  static_assert(!BF16 || BK == 32, "the bf16 tile is written for 32-deep K steps");
+  static_assert(!BF16 || BK == 32 || BK == 64 || BK == 128, "bf16 tiles: K steps of 32, 64 or 128");
+  static_assert(!IN16 || (BF16 && FAST), "bf16 operands in HBM: bf16 tiles on the one-tap-per-step path");
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;            // threads: one wave per (32*WM)x(32*WN) sub-tile
-  constexpr int CH = BK / 4;                    // 16-byte chunks per tile row (K step = BK floats)
+  constexpr int CH = IN16 ? BK / 8 : BK / 4;    // 16-byte chunks per tile row the LOADER handles (K step = BK elements)
+  constexpr int ESZ = IN16 ? 2 : 4;             // bytes per operand element in HBM
+  constexpr int KG = BK / 4;                    // 4-channel groups per K step (the unit of the tap walk)
   constexpr int RP = NT / CH;                   // tile rows loaded per pass of the block
   constexpr int RA = BM / RP, RB = BN / RP;
   constexpr int CHB = BK / 8;                   // bf16 mode: 16-byte chunks per tile row
@@ -221,6 +243,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   const int chunk = tid % CH, lrow = tid / CH;
   // LDS chunk swizzle: conflict-free ds_read_b128 fragments (row stride 128 B: 2 rows per bank row; 256 B: 1)
   auto swz = [](int r) { return CH == 8 ? ((r >> 1) & 7) : (r & 15); };
+  // bf16 image: a row holds BK bf16 = CHB 16-byte chunks (64 / 128 / 256 bytes): 4 / 2 / 1 rows per 256-byte bank line
+  auto swzb = [](int r) { return CHB == 4 ? ((r >> 2) & 3) : CHB == 8 ? ((r >> 1) & 7) : (r & 15); };
 
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
@@ -238,7 +262,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
       const int x = rem - y * p_owg;
       aiy[i] = y * a.isy;
       aix[i] = x * a.isx;
-      arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * 4u + (FAST ? chunk * 16u : 0u);
+      arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * (unsigned)ESZ + (FAST ? chunk * 16u : 0u);
     } else {
       aiy[i] = ROW_INVALID; aix[i] = 0; arow[i] = 0;
     }
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   for (int i = 0; i < RB; ++i) {
     const int r = n0 + lrow + RP * i;
     const unsigned base = a.wmod > 0 ? (unsigned)((r % a.wmod) * a.Kp + (r / a.wmod) * a.wk1) : (unsigned)(r * a.Kp);
-    wrow[i] = base * 4u + (FAST ? chunk * 16u : 0u);
+    wrow[i] = base * (unsigned)ESZ + (FAST ? chunk * 16u : 0u);
   }
 
   f32x16 acc[WM][WN];
@@ -262,7 +286,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   // wave-uniform tap walk for the FAST path
   int u_c4 = 0, u_ty = 0, u_tx = 0;
   if (FAST && s_begin > 0) {                      // K split: start the walk at step s_begin
-    const int q0 = s_begin * CH, t0 = q0 / a.c4n;
+    const int q0 = s_begin * KG, t0 = q0 / a.c4n;
     u_c4 = q0 - t0 * a.c4n;
     u_ty = t0 / p_tw;
     u_tx = t0 - u_ty * p_tw;
@@ -271,8 +295,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   auto gload = [&](int step) {
     if (FAST) {
       const int dy = p_dy0 + u_ty * p_dys, dx = p_dx0 + u_tx * p_dxs;
-      const int tapoff = ((dy * IW + dx) * Cs + u_c4 * 4) * 4;                         // bytes, uniform
-      const unsigned wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c4 * 4) * 4u;
+      const int tapoff = ((dy * IW + dx) * Cs + u_c4 * 4) * ESZ;                       // bytes, uniform
+      const unsigned wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c4 * 4) * (unsigned)ESZ;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int iy = aiy[i] + dy, ix = aix[i] + dx;
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
         if (reflect) {            // wave-uniform branch: ReflectionPad2d folded into the gather
           ok = aiy[i] != ROW_INVALID;
           const int ry = reflect_idx(iy, IH), rx = reflect_idx(ix, IW);
-          off = arow[i] + (unsigned)((((ry - aiy[i]) * IW + (rx - aix[i])) * Cs + u_c4 * 4) * 4);
+          off = arow[i] + (unsigned)((((ry - aiy[i]) * IW + (rx - aix[i])) * Cs + u_c4 * 4) * ESZ);
         } else {
           ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
           off = arow[i] + (unsigned)tapoff;
@@ -290,7 +314,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i) rb[i] = buf_load4(rs_wt, wrow[i] + wk);
-      u_c4 += CH;
+      u_c4 += KG;
       if (u_c4 >= a.c4n) { u_c4 = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
     } else {
       const int q = step * CH + chunk;
@@ -319,18 +343,33 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
     }
   };
   auto lstore = [&](int buf) {
+    if (IN16) {                  // the 16 bytes loaded ARE chunk `chunk` of the bf16 row image
+      f32x4* A16 = lds + buf * TILE4;
+      f32x4* B16 = A16 + BM * CHB;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int r = lrow + RP * i;
+        A16[r * CHB + (chunk ^ swzb(r))] = ra[i];
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int r = lrow + RP * i;
+        B16[r * CHB + (chunk ^ swzb(r))] = rb[i];
+      }
+      return;
+    }
     if (BF16) {                  // this thread's 4 floats are half of 16-byte chunk (chunk >> 1)
       bf16x4* A8 = (bf16x4*)(lds + buf * TILE4);
       bf16x4* B8 = A8 + BM * CHB * 2;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int r = lrow + RP * i;
-        A8[(r * CHB + ((chunk >> 1) ^ ((r >> 2) & 3))) * 2 + (chunk & 1)] = to_bf16x4(ra[i]);
+        A8[(r * CHB + ((chunk >> 1) ^ swzb(r))) * 2 + (chunk & 1)] = to_bf16x4(ra[i]);
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int r = lrow + RP * i;
-        B8[(r * CHB + ((chunk >> 1) ^ ((r >> 2) & 3))) * 2 + (chunk & 1)] = to_bf16x4(rb[i]);
+        B8[(r * CHB + ((chunk >> 1) ^ swzb(r))) * 2 + (chunk & 1)] = to_bf16x4(rb[i]);
       }
       return;
     }
@@ -359,12 +398,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
           const int r = (wm * WM + i) * 32 + l31;
-          af[i] = A16[r * CHB + (c ^ ((r >> 2) & 3))];
+          af[i] = A16[r * CHB + (c ^ swzb(r))];
         }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
           const int r = (wn * WN + j) * 32 + l31;
-          bf[j] = B16[r * CHB + (c ^ ((r >> 2) & 3))];
+          bf[j] = B16[r * CHB + (c ^ swzb(r))];
         }
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -476,16 +515,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
         const size_t idx = (a.planar_M ? ((size_t)(n >> 2) * a.planar_M + opix) * 4 : opix * a.Ns + n) +
                            (a.ksplit > 1 ? (size_t)zi * pM * a.Ns : 0);
         if (a.aux) {
-          const f32x4 o = *(const f32x4*)(a.aux + idx);
+          const f32x4 o = a.aux16 ? ld_bf16x4(a.aux, idx) : *(const f32x4*)(a.aux + idx);
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] *= act_grad_from_out(o[k], a.aux_act, a.aux_slope);
         }
-        if (a.res) v += *(const f32x4*)(a.res + idx);
+        if (a.res) v += a.out16 ? ld_bf16x4(a.res, idx) : *(const f32x4*)(a.res + idx);
         if (STATS && a.stat_mode == 2) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) { cs1[j][k] += v[k]; cs2[j][k] += v[k] * v[k]; }
         }
-        *(f32x4*)(a.out + idx) = v;
+        if (a.out16) *(bf16x4*)((__bf16*)a.out + idx) = to_bf16x4(v);        // mode 2: this tensor lives as bf16
+        else *(f32x4*)(a.out + idx) = v;
       }
     }
   }
@@ -528,7 +568,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 // is a coalesced gather over tap planes (HBM-bound).  Stride-1 forward- or backward-form geometries only.
 // ------------------------------------------------------------------------------------------
 __global__ void smalln_weight_kernel(const float* __restrict__ wt, float* __restrict__ w2, int Kp, int Cs,
-                                     int ntap, int tw, int wbase, int wsy, int wsx, int rows_alloc) {
+                                     int ntap, int tw, int wbase, int wsy, int wsx, int rows_alloc, int bf16) {
   const int total = rows_alloc * Cs;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int c = i % Cs, r = i / Cs;
@@ -536,9 +576,11 @@ __global__ void smalln_weight_kernel(const float* __restrict__ wt, float* __rest
     float v = 0.f;
     if (t < ntap) {
       const int ty = t / tw, tx = t - ty * tw;
-      v = wt[(size_t)n * Kp + (size_t)(wbase + ty * wsy + tx * wsx) * Cs + c];
+      const size_t src = (size_t)n * Kp + (size_t)(wbase + ty * wsy + tx * wsx) * Cs + c;
+      v = bf16 ? (float)((const __bf16*)wt)[src] : wt[src];
     }
-    w2[i] = v;
+    if (bf16) ((__bf16*)w2)[i] = (__bf16)v;       // (exact: v already is a bf16 value)
+    else w2[i] = v;
   }
 }
 
@@ -604,6 +646,8 @@ struct WGradArgs {
   unsigned p_bytes, q_bytes;
   int dx32, dy32;            // 32 rows of m = db32 images + dy32 rows + dx32 pixels (mixed radix of PH x PW)
   int xcd;                   // wgrad_t_kernel: XCD-contiguous tile order
+  int in16;                  // P and Q are bf16 tensors and the bf16 image applies (host-side: picks the IN16 kernel)
+  int p16, q16;              // storage type of P / Q (kernels without IN16 widen bf16 chunks on arrival)
   unsigned bstep0, bstep1;   // byte step of the image base for db32 / db32+1 images
   double flops;
 };
@@ -627,12 +671,14 @@ __device__ __forceinline__ bf16x8 wg_tr_read8(const char* base, unsigned off0, u
   return u.v;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = false>
+template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = false, bool IN16 = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a) {
   static_assert(!BF16 || (WGM * WM == 4 && WGN * WN == 4), "the bf16 wgrad image is written for 128x128 tiles");
+  static_assert(!IN16 || BF16, "bf16 operands in HBM need the bf16 image");
   constexpr int BN = WGM * WM * 32;   // tile over n (P channels)  -> MFMA rows
   constexpr int BK = WGN * WN * 32;   // tile over k (tap,c)       -> MFMA cols
-  constexpr int CP = BN / 4, CQ = BK / 4;          // 16-B chunks per tile row
+  constexpr int EPC = IN16 ? 8 : 4;                // elements per loader chunk (IN16: P and Q are bf16 tensors, 16-byte chunks of 8)
+  constexpr int CP = BN / EPC, CQ = BK / EPC;      // 16-B chunks per tile row
   constexpr int NT = WGM * WGN * 64;               // threads: one wave per (32*WM)x(32*WN) sub-tile
   constexpr int RPP = NT / CP, RPQ = NT / CQ;      // rows per pass
   constexpr int NP = 32 / RPP, NQ = 32 / RPQ;      // passes per 32-row chunk
@@ -648,14 +694,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
   const int cp = tid % CP, rp = tid / CP;
   const int cq = tid % CQ, rq = tid / CQ;
 
-  // this thread's fixed k-chunk of the Q tile
-  const int q = k0 / 4 + cq;
-  const int t = fdiv(q, a.d_c4n);
-  const int c4 = q - t * a.c4n;
+  // this thread's fixed k-chunk of the Q tile (IN16: chunks of 8 channels)
+  const int q = k0 / EPC + cq;
+  const int cpn = IN16 ? a.c4n / 2 : a.c4n;            // chunks per pixel
+  const int t = IN16 ? q / cpn : (int)fdiv(q, a.d_c4n);
+  const int c4 = q - t * cpn;
   const bool qvalid = t < a.ntap;
   const int ty = fdiv(t, a.d_tw), tx = t - ty * a.tw;
   const int dy = (ty - a.pad) * a.flip, dx = (tx - a.pad) * a.flip;
-  const bool pvalid = (n0 + cp * 4) < a.Pvalid;
+  const bool pvalid = (n0 + cp * EPC) < a.Pvalid;
   const int plane = a.PH * a.PW;
 
   const int chunk_begin = split * a.chunks_per_split;
@@ -676,8 +723,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
   const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.P, 0, a.p_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)a.Q, 0, a.q_bytes, 0x00020000);
   const int M = a.M, PW = a.PW, PH = a.PH, QH = a.QH, QW = a.QW, isy = a.isy, isx = a.isx;
-  const int Qs4 = a.Qs * 4, dx32 = a.dx32, dy32 = a.dy32;
-  const unsigned pstep = 32u * (unsigned)a.Ps * 4u, bstep0 = a.bstep0, bstep1 = a.bstep1;
+  // element sizes in HBM: IN16 kernels read bf16 chunks of 8 channels; the other kernels read chunks of 4 channels that
+  // are fp32 (16 bytes) or, for a bf16 tensor (a.p16 / a.q16), 8 bytes widened to fp32 on arrival
+  const unsigned pes = IN16 ? 2u : (a.p16 ? 2u : 4u), qes = IN16 ? 2u : (a.q16 ? 2u : 4u);
+  const int Qs4 = a.Qs * (int)qes, dx32 = a.dx32, dy32 = a.dy32;          // bytes per Q pixel
+  const unsigned pstep = 32u * (unsigned)a.Ps * pes, bstep0 = a.bstep0, bstep1 = a.bstep1;
 
   // Running state of this thread's rows, advanced by 32 rows of m per chunk with adds and selects only.
   // The integer work of the loader competes with the MFMAs for issue slots (the waves of a block are
@@ -689,7 +739,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
   int qm[NQ], qy[NQ], qx[NQ];
 #pragma unroll
   for (int i = 0; i < NP; ++i)
-    po[i] = pvalid ? (unsigned)((chunk_begin * 32 + rp + RPP * i) * a.Ps) * 4u + (unsigned)(n0 + cp * 4) * 4u
+    po[i] = pvalid ? (unsigned)((chunk_begin * 32 + rp + RPP * i) * a.Ps) * pes + (unsigned)(n0 + cp * EPC) * pes
                    : OOB_OFFSET;
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
@@ -699,13 +749,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
     qy[i] = fdiv(rem, a.d_pw);
     qx[i] = rem - qy[i] * PW;
     qm[i] = m;
-    qb[i] = (unsigned)b * (unsigned)(QH * QW) * (unsigned)Qs4 + (qvalid ? (unsigned)c4 * 16u : OOB_OFFSET);
+    qb[i] = (unsigned)b * (unsigned)(QH * QW) * (unsigned)Qs4 + (qvalid ? (unsigned)c4 * (unsigned)EPC * qes : OOB_OFFSET);
   }
 
   auto gload = [&]() {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      rP[i] = buf_load4(rs_p, po[i]);
+      rP[i] = (!IN16 && a.p16) ? buf_load4_bf16(rs_p, po[i]) : buf_load4(rs_p, po[i]);
       po[i] += pstep;
     }
 #pragma unroll
@@ -719,7 +769,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
         ok = ok && (unsigned)iy < (unsigned)QH && (unsigned)ix < (unsigned)QW;
       }
       const unsigned off = qb[i] + (unsigned)__mul24(__mul24(iy, QW) + ix, Qs4);
-      rQ[i] = buf_load4(rs_q, ok ? off : OOB_OFFSET);
+      rQ[i] = (!IN16 && a.q16) ? buf_load4_bf16(rs_q, ok ? off : OOB_OFFSET) : buf_load4(rs_q, ok ? off : OOB_OFFSET);
       int x = qx[i] + dx32, y = qy[i] + dy32;
       const bool cx = x >= PW;
       x -= cx ? PW : 0;
@@ -731,6 +781,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
     }
   };
   auto lstore = [&](int buf) {
+    if (IN16) {               // the 16 bytes loaded are chunk cp of row r of the [32][128] bf16 image
+      char* Pb = (char*)lds + buf * 16384;
+      char* Qb = Pb + 8192;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) *(f32x4*)(Pb + wg_bf16_off(rp + RPP * i, cp)) = rP[i];
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) *(f32x4*)(Qb + wg_bf16_off(rq + RPQ * i, cq)) = rQ[i];
+      return;
+    }
     if (BF16) {               // stage = two [32][128] bf16 images of 8 KB
       char* Pb = (char*)lds + buf * 16384;
       char* Qb = Pb + 8192;
@@ -1191,7 +1250,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //                                                      and it[R1][K1] (row d1, k = tap*C4(D0)+d0)
 __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ inv_scale,
                                    float* __restrict__ dst, int rows_alloc, int Kp, int Drow,
-                                   int Dcol, int Cs, int ntap, int row_is_d0) {
+                                   int Dcol, int Cs, int ntap, int row_is_d0, int out16) {
   const float sc = inv_scale ? *inv_scale : 1.f;
   const long long total = (long long)rows_alloc * Kp;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -1206,7 +1265,8 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __r
       v = w[src];
       if (inv_scale) v = v / sc;
     }
-    dst[i] = v;
+    if (out16) ((__bf16*)dst)[i] = (__bf16)v;      // operand of a bf16 activation: rounded once here (nearest-even)
+    else dst[i] = v;
   }
 }
 
@@ -1217,7 +1277,7 @@ struct PrepEntry {
   const float* w;
   const float* inv_scale;
   float* dst;
-  int rows_alloc, Kp, Drow, Dcol, Cs, ntap, row_is_d0;
+  int rows_alloc, Kp, Drow, Dcol, Cs, ntap, row_is_d0, out16;
   FastDiv d_ntap;
 };
 struct PrepTable {
@@ -1236,6 +1296,7 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const PrepTable 
   const float sc = e.inv_scale ? *e.inv_scale : 1.f;
   const int c0 = blockIdx.y * PREP_CCH;
   float* out = e.dst + (size_t)r * e.Kp;
+  __bf16* out16 = (__bf16*)e.dst + (size_t)r * e.Kp;
   const int pitch = e.ntap + 1;
   if (c0 < e.Cs) {
     const bool live = r < e.Drow;
@@ -1255,19 +1316,32 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const PrepTable 
     __syncthreads();
     for (int i = threadIdx.x; i < n_el; i += blockDim.x) {
       const int tap = i / PREP_CCH, cl = i % PREP_CCH;
-      if (c0 + cl < e.Cs) out[tap * e.Cs + c0 + cl] = psh[cl * pitch + tap];
+      if (c0 + cl < e.Cs) {
+        if (e.out16) out16[tap * e.Cs + c0 + cl] = (__bf16)psh[cl * pitch + tap];
+        else out[tap * e.Cs + c0 + cl] = psh[cl * pitch + tap];
+      }
     }
   }
   // K padding behind the last tap (Kp is a multiple of 32): the first channel slice clears it
   if (blockIdx.y == 0)
-    for (int k = e.ntap * e.Cs + threadIdx.x; k < e.Kp; k += blockDim.x) out[k] = 0.f;
+    for (int k = e.ntap * e.Cs + threadIdx.x; k < e.Kp; k += blockDim.x) {
+      if (e.out16) out16[k] = (__bf16)0.f;
+      else out[k] = 0.f;
+    }
 }
 
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
-                               float* __restrict__ dz, size_t n, int act, float slope) {
+                               float* __restrict__ dz, size_t n, int act, float slope, int b16) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x)
-    dz[i] = dy[i] * act_grad_from_out(out[i], act, slope);
+       i += (size_t)gridDim.x * blockDim.x) {
+    if (b16) {
+      const __bf16* d = (const __bf16*)dy;
+      const __bf16* o = (const __bf16*)out;
+      ((__bf16*)dz)[i] = (__bf16)((float)d[i] * act_grad_from_out((float)o[i], act, slope));
+    } else {
+      dz[i] = dy[i] * act_grad_from_out(out[i], act, slope);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1399,18 +1473,19 @@ static int g_force_tile = -1, g_force_wgrad = -1;     // test hook: iprgan_debug
 static int g_autotune = getenv("IPRGAN_AUTOTUNE") ? atoi(getenv("IPRGAN_AUTOTUNE")) : 1;
 static int g_smalln = getenv("IPRGAN_SMALLN") ? atoi(getenv("IPRGAN_SMALLN")) : 1;
 static int g_math = IPRGAN_MATH_FP32;                 // iprgan_set_math_mode
+static int g_bf16_bk = getenv("IPRGAN_BF16_BK") ? atoi(getenv("IPRGAN_BF16_BK")) : 64;   // K step of the bf16 gconv tiles
 static int g_nbuf = getenv("IPRGAN_LDS_BUFS") ? atoi(getenv("IPRGAN_LDS_BUFS")) : 1;  // wgrad_kernel only: 1 = single LDS buffer (measured faster: 3-4 blocks/CU)
 
 static thread_local int t_last_bm = 0;      // M tile of the last gconv launch of this thread (partial-row count of STATS launches)
 
-template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false, bool STATS = false>
+template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false, bool STATS = false, bool IN16 = false>
 static int launch_gconv_tfnk(const GConvArgs& a, hipStream_t st) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   if (maxM == 0) return 0;
   const size_t smem = NBUF * (size_t)(BM + BN) * (BF16 ? BK / 8 : BK / 4) * sizeof(f32x4);
-  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST, NBUF, BK, BF16, STATS>;
+  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST, NBUF, BK, BF16, STATS, IN16>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1431,9 +1506,20 @@ static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
   // (two barriers per step but 3-4 blocks per CU: measured faster than double buffering, which is no longer built)
   const bool fast = (a.Cs % 32) == 0;
   // bf16 math: layers whose K step lies in one tap (C4 % 32 == 0); RGB stems / heads keep the fp32 kernel
-  if (g_math == IPRGAN_MATH_BF16 && fast)
+  if (a.in16)        // bf16 operands in HBM: 64-deep K steps (8 loader chunks per row)
+    return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, true, true>(a, st)
+                       : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, false, true>(a, st);
+  if (g_math == IPRGAN_MATH_BF16 && fast) {
+    // the bf16 MFMA retires a 32-deep K step in a quarter of the fp32 time, so the two barriers per step dominate:
+    // deeper steps (more MFMAs per barrier pair) when the channel count allows a step to stay inside one tap
+    // (measured on DCGAN-128: 32 -> 64 deep +2 %, 128 deep -10 %: the staging path, not the barrier count, is the limit)
+    const int bk = (g_bf16_bk >= 64 && a.Cs % 64 == 0) ? 64 : 32;
+    if (bk == 64)
+      return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, true>(a, st)
+                         : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, false>(a, st);
     return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, true>(a, st)
                        : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, false>(a, st);
+  }
   if (a.stat_part)
     return fast ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, false, true>(a, st)
                 : launch_gconv_tfnk<WGM, WGN, WM, WN, false, 1, 32, false, true>(a, st);
@@ -1456,12 +1542,12 @@ static int launch_smalln(const GConvArgs& a, hipStream_t st) {
   float* w2 = a.ws;
   float* T = a.ws + (size_t)rows * a.Cs;
   hipLaunchKernelGGL(smalln_weight_kernel, dim3(cdiv(rows * a.Cs, 256)), dim3(256), 0, st, a.wt, w2, a.Kp, a.Cs,
-                     ntap, p.tw, p.wbase, p.wsy, p.wsx, rows);
+                     ntap, p.tw, p.wbase, p.wsy, p.wsx, rows, a.in16);
   IPR_LAUNCH_CHECK();
   GConvArgs g;
   memset(&g, 0, sizeof(g));
   geom_forward_form(g, a.B, a.IH, a.IW, a.Cs, a.IH, a.IW, ntap * 4, 1, 1, 1, 0);
-  g.in = a.in; g.wt = w2; g.out = T;
+  g.in = a.in; g.wt = w2; g.out = T; g.in16 = a.in16;
   g.planar_M = a.B * a.IH * a.IW;
   g.flops = a.flops;                       // the algorithmic FLOPs of the convolution are accounted here
   int rc = launch_gconv(g, st);
@@ -1526,8 +1612,11 @@ static int tune_pick(int ncand, Run run, hipStream_t st, int fallback, float* be
 static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   GConvArgs a = ain;
   {
-    const unsigned long long inb = (unsigned long long)a.B * a.IH * a.IW * a.Cs * 4ull;
-    const unsigned long long wtb = (unsigned long long)rup(a.wmod > 0 ? a.wmod : a.N, 128) * a.Kp * 4ull;
+    const unsigned long long esz = a.in16 ? 2ull : 4ull;
+    const unsigned long long inb = (unsigned long long)a.B * a.IH * a.IW * a.Cs * esz;
+    const unsigned long long wtb = (unsigned long long)rup(a.wmod > 0 ? a.wmod : a.N, 128) * a.Kp * esz;
+    IPR_CHECK(!a.in16 || (g_math == IPRGAN_MATH_BF16 && (a.Cs % 64) == 0 && !a.wmod && a.ksplit <= 1),
+              "conv: bf16 activations need IPRGAN_MATH_BF16, a channel count that is a multiple of 64 and a regular convolution");
     IPR_CHECK(inb < 0x7fffffffull && wtb < 0x7fffffffull, "conv: tensor larger than 2 GiB (%llu / %llu bytes)", inb, wtb);
     a.in_bytes = (unsigned)inb; a.wt_bytes = (unsigned)wtb;
     a.linear_out = (a.nphase == 1 && a.osy == 1 && a.osx == 1 && a.ph[0].ooy == 0 && a.ph[0].oox == 0) ? 1 : 0;
@@ -1564,7 +1653,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   // order, results stay within fp32 rounding of each other.
   TuneKey key = {{a.B, a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.isy, a.osy, a.nphase, a.ph[0].th, a.ph[0].tw,
                   a.ph[0].ohg, a.ph[0].owg, a.pad_mode + 16 * g_math + 64 * a.ksplit + 8192 * (a.wmod > 0) + 16384 * (a.rs0 != nullptr) +
-                      32768 * (a.stat_part != nullptr), a.Kp}};
+                      32768 * (a.stat_part != nullptr) + 65536 * a.in16 + 131072 * a.out16, a.Kp}};
   {
     int cached;
     if (tune_lookup(key, &cached)) return run(cached);
@@ -1656,12 +1745,17 @@ static size_t wgrad_padded_floats(const iprgan_conv_desc* d) {
   return g.padded ? (size_t)d->B * g.PH * g.PW * c4(d->Cin) : 0;
 }
 
+// both operands bf16 in HBM and the bf16 [32][128] image applicable: the IN16 kernel runs on the 128x128 tiles
+static bool wgrad_in16(const iprgan_conv_desc* d) {
+  return d->x_bf16 && d->y_bf16 && g_math == IPRGAN_MATH_BF16 && d->pad_mode == IPRGAN_PAD_ZERO;
+}
 static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   const WGeom g = wgrad_geom(d);
   if (cand < 0 || cand >= WGRAD_NCAND) return false;
   p.variant = cand / WGRAD_NBASE;
   cand %= WGRAD_NBASE;
   if (p.variant && (g.N <= 32 || g_math == IPRGAN_MATH_BF16)) return false;   // the 32-row tile and the bf16 image exist in the first form only
+  if (p.variant && (d->x_bf16 || d->y_bf16)) return false;      // the transposed-image kernel reads fp32 tensors only
   p.N = g.N;
   p.Cq = g.Cq;
   p.Ps = c4(p.N); p.Qs = c4(p.Cq);
@@ -1672,12 +1766,13 @@ static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   const int shape = (cand % WGRAD_NSHAPE) == 3 ? 0 : cand % WGRAD_NSHAPE;
   const int target = targets[cand / WGRAD_NSHAPE];
   p.w8 = (cand % WGRAD_NSHAPE) == 3 ? 1 : 0;
-  if (p.w8 && (p.N < 128 || K < 128)) return false;
+  if (p.w8 && ((p.N < 128 && !(wgrad_in16(d) && p.N >= 64)) || K < 128)) return false;
   if (p.N <= 32) {
     if (shape != 0) return false;
     p.bn = 32; p.bk = 128;
   } else if (shape == 0) {
-    if (p.N < 128 || K < 128) return false;
+    // (a 64-row P of bf16 tensors still takes the 128x128 bf16 tile: the upper half of the rows reads zeros)
+    if ((p.N < 128 && !(wgrad_in16(d) && p.N >= 64)) || K < 128) return false;
     p.bn = 128; p.bk = 128;
   } else if (shape == 1) {
     p.bn = 64; p.bk = 64;
@@ -1713,11 +1808,11 @@ static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that
   return m;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = false>
+template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = false, bool IN16 = false>
 static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
   constexpr int BN = WGM * WM * 32, BK = WGN * WN * 32;
   const size_t smem = NBUF * (size_t)32 * (BN + BK) * (BF16 ? 2 : sizeof(float));
-  auto kern = wgrad_kernel<WGM, WGN, WM, WN, NBUF, REFLECT, BF16>;
+  auto kern = wgrad_kernel<WGM, WGN, WM, WN, NBUF, REFLECT, BF16, IN16>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1733,6 +1828,7 @@ static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t s
 template <int WGM, int WGN, int WM, int WN>
 static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
   if constexpr (WGM * WM == 4 && WGN * WN == 4) {       // bf16 math: the 128x128 tiles (4 and 8 waves)
+    if (a.in16) return launch_wgrad_tn<WGM, WGN, WM, WN, 1, false, true, true>(a, p, st);
     if (g_math == IPRGAN_MATH_BF16)
       return a.pad_mode == IPRGAN_PAD_REFLECT ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true, true>(a, p, st)
                                               : launch_wgrad_tn<WGM, WGN, WM, WN, 1, false, true>(a, p, st);
@@ -1820,7 +1916,7 @@ int iprgan_conv_weight_prep(const iprgan_conv_desc* d, const float* w, const flo
     const long long total = (long long)R * Kp;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(weight_prep_kernel, dim3(blocks), dim3(256), 0, st, w, inv_scale, dst, R, Kp,
-                       rows, red, Cs, ntap, row_is_d0);
+                       rows, red, Cs, ntap, row_is_d0, (which == 0 ? d->x_bf16 : d->y_bf16) != 0);
     IPR_LAUNCH_CHECK();
   }
   return 0;
@@ -1875,6 +1971,7 @@ int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* co
       if (e.Cs > maxcs) maxcs = e.Cs;
       if (ntap > maxtap) maxtap = ntap;
       e.row_is_d0 = ((which == 0) != (d->transposed != 0)) ? 1 : 0;
+      e.out16 = (which == 0 ? d->x_bf16 : d->y_bf16) != 0;
       if (e.rows_alloc > maxrows) maxrows = e.rows_alloc;
       if (cnt == PREP_MAX) { const int rc = flush(); if (rc) return rc; }
     }
@@ -1921,6 +2018,7 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
   }
   a.in = x; a.wt = wfwd; a.bias = bias; a.out = y; a.aux = nullptr;
   a.rs0 = pair_sigma0; a.rs1 = pair_sigma1;
+  a.in16 = d->x_bf16 != 0; a.out16 = d->y_bf16 != 0;
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = d->act; a.slope = d->slope;
   a.ws = ws; a.ws_floats = ws ? iprgan_conv_fwd_ws_floats(d) : 0;
@@ -1972,6 +2070,8 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
   }
   a.in = dy; a.wt = wbwd; a.bias = nullptr; a.out = reflect ? ws : dx;
   a.rs0 = pair_sigma0; a.rs1 = pair_sigma1;
+  a.in16 = d->y_bf16 != 0; a.out16 = d->x_bf16 != 0; a.aux16 = d->x_bf16 != 0;
+  IPR_CHECK(!(reflect && (a.in16 || a.out16)), "conv_bwd_data: bf16 activations with reflection padding are not built");
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = IPRGAN_ACT_NONE; a.slope = 0.f;
   if (!reflect) { a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.ws = ws; a.ws_floats = ws ? smalln_ws_for(d, false) : 0; }
@@ -1993,9 +2093,17 @@ size_t iprgan_conv_wgrad_ws_floats(const iprgan_conv_desc* d) {
          wgrad_weight_floats(d);
 }
 
+int iprgan_conv_wgrad_takes_bf16(const iprgan_conv_desc* d) {
+  // bf16 x and / or dy (desc flags) are read directly by every backward-weight kernel except the reflect-padded
+  // swapped form (which copies x into a padded fp32 image first): there the caller hands an fp32 x (iprgan_cast)
+  const WGeom g = wgrad_geom(d);
+  return !(g.padded && d->x_bf16);
+}
+
 int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const float* dy, float* dw,
                            float* db, float* ws, float beta, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  IPR_CHECK(iprgan_conv_wgrad_takes_bf16(d), "conv_bwd_weight: this layer needs an fp32 x (iprgan_conv_wgrad_takes_bf16)");
   const Shape s = out_shape(d);
   const WGeom g = wgrad_geom(d);
   const float* xin = x;
@@ -2027,8 +2135,13 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     a.isy = a.isx = d->stride; a.pad = g.pad; a.tw = d->KW; a.ntap = p.ntap; a.flip = g.flip;
     a.pad_mode = g.swap ? IPRGAN_PAD_ZERO : d->pad_mode;      // swapped + reflect runs on the padded copy
     a.Kw = p.Kw; a.Nrows = p.Nrows; a.chunks_per_split = p.cps;
-    const unsigned long long pb = (unsigned long long)a.M * a.Ps * 4ull;
-    const unsigned long long qb = (unsigned long long)d->B * a.QH * a.QW * a.Qs * 4ull;
+    const bool p_is_x = d->transposed || g.swap;
+    a.p16 = (p_is_x ? d->x_bf16 : d->y_bf16) != 0;
+    a.q16 = (p_is_x ? d->y_bf16 : d->x_bf16) != 0;
+    a.in16 = wgrad_in16(d) && p.bn == 128 && p.bk == 128;
+    const unsigned long long pesz = a.p16 ? 2ull : 4ull, esz = a.q16 ? 2ull : 4ull;
+    const unsigned long long pb = (unsigned long long)a.M * a.Ps * pesz;
+    const unsigned long long qb = (unsigned long long)d->B * a.QH * a.QW * a.Qs * esz;
     IPR_CHECK(pb < 0x7fffffffull && qb < 0x7fffffffull, "conv_bwd_weight: tensor larger than 2 GiB");
     a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
     IPR_CHECK(a.QH * (long long)a.QW < (1 << 24) && a.PH * (long long)a.PW < (1 << 24),
@@ -2036,7 +2149,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     {
       const int plane = a.PH * a.PW, db = 32 / plane, r = 32 % plane;
       a.dy32 = r / a.PW; a.dx32 = r % a.PW;
-      const unsigned img = (unsigned)a.QH * a.QW * a.Qs * 4u;
+      const unsigned img = (unsigned)a.QH * a.QW * a.Qs * (unsigned)esz;
       a.bstep0 = (unsigned)db * img; a.bstep1 = (unsigned)(db + 1) * img;
     }
     a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW
@@ -2077,7 +2190,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     if (wgrad_plan_c(d, g_force_wgrad, pf)) cand = g_force_wgrad;
   } else if (g_autotune) {     // same scheme as the forward/backward-data tiles: time every candidate once per geometry
     TuneKey key = {{d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->outpad,
-                    d->transposed, d->pad_mode, -7, g_math, 0, 0}};
+                    d->transposed, d->pad_mode, -7, g_math, d->x_bf16, 0}};
     int cached;
     if (tune_lookup(key, &cached)) {
       cand = cached;
@@ -2102,7 +2215,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   if (db) {
     const int Cs = c4(d->Cout), M = d->B * s.OH * s.OW;
     float* part = ws + wgrad_slab_floats(d);
-    const int rc2 = colsum_launch(dy, db, part, M, Cs, d->Cout, st, beta);
+    const int rc2 = colsum_launch(dy, db, part, M, Cs, d->Cout, st, beta, d->y_bf16);
     if (rc2) return rc2;
   }
   return 0;
@@ -2147,12 +2260,12 @@ int iprgan_prof_get(int i, char* name, int name_len, long long* launches, double
   return 0;
 }
 
-int iprgan_act_bwd(const float* dy, const float* out, float* dz, size_t n, int act, float slope,
+int iprgan_act_bwd(const float* dy, const float* out, float* dz, size_t n, int act, float slope, int act_bf16,
                    void* stream) {
   if (n == 0) return 0;
   const int blocks = (int)(cdivz(n, 256) < 8192 ? cdivz(n, 256) : 8192);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, out, dz, n,
-                     act, slope);
+                     act, slope, act_bf16);
   IPR_LAUNCH_CHECK();
   return 0;
 }

@@ -15,6 +15,19 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// element access for activation tensors that may be stored as bf16 ("bf16 activations", include/iprgan.h)
+__device__ __forceinline__ float lde(const float* p, size_t i, int b16) {
+  return b16 ? (float)((const __bf16*)p)[i] : p[i];
+}
+__device__ __forceinline__ void ste(float* p, size_t i, float v, int b16) {
+  if (b16) ((__bf16*)p)[i] = (__bf16)v;
+  else p[i] = v;
+}
+__global__ void cast_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, int src16, int dst16) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    ste(dst, i, lde(src, i, src16), dst16);
+}
+
 // ---- layout --------------------------------------------------------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C,
                                     int HW, int Cs) {
@@ -83,12 +96,20 @@ __global__ void axpy_multi_kernel(const AxpyTable t, float a) {
 __global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ inv_scale,
-                                                       float* __restrict__ y, int K) {
+                                                       float* __restrict__ y, int K, int x16) {
   __shared__ float sh[16];
-  const float* xr = x + (size_t)blockIdx.x * K;
+  const size_t row = (size_t)blockIdx.x * K;
   float s = 0.f;
   for (int k = threadIdx.x * 4; k < K; k += blockDim.x * 4) {
-    const float4 a = *(const float4*)(xr + k), b = *(const float4*)(w + k);
+    float4 a;
+    if (x16) {
+      typedef __bf16 h4 __attribute__((ext_vector_type(4)));
+      const h4 h = *(const h4*)((const __bf16*)x + row + k);
+      a = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+    } else {
+      a = *(const float4*)(x + row + k);
+    }
+    const float4 b = *(const float4*)(w + k);
     s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
   }
   s = block_sum(s, sh);
@@ -100,7 +121,7 @@ __global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__
 __global__ void gemv_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
                                    const float* __restrict__ inv_scale, float* __restrict__ dx,
                                    const float* __restrict__ prev_out, int prev_act, float prev_slope,
-                                   int B, int K) {
+                                   int B, int K, int x16) {
   const float sc = inv_scale ? *inv_scale : 1.f;
   const size_t total = (size_t)B * K;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
@@ -108,16 +129,16 @@ __global__ void gemv_bwd_dx_kernel(const float* __restrict__ w, const float* __r
     const int k = (int)(i % K);
     const int b = (int)(i / K);
     float v = dy[b] * (w[k] / sc);
-    if (prev_out) v *= act_grad_from_out(prev_out[i], prev_act, prev_slope);
-    dx[i] = v;
+    if (prev_out) v *= act_grad_from_out(lde(prev_out, i, x16), prev_act, prev_slope);
+    ste(dx, i, v, x16);
   }
 }
 __global__ void gemv_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                   float* __restrict__ dw, float* __restrict__ db, int B, int K) {
+                                   float* __restrict__ dw, float* __restrict__ db, int B, int K, int x16) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < K && dw) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dy[b] * x[(size_t)b * K + k];
+    for (int b = 0; b < B; ++b) s += dy[b] * lde(x, (size_t)b * K + k, x16);
     dw[k] = s;
   }
   if (db && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -546,26 +567,33 @@ int iprgan_axpy_multi(float* const* y, const float* const* x, const long long* s
   return 0;
 }
 
+int iprgan_cast(const float* src, float* dst, size_t n, int src_bf16, int dst_bf16, void* stream) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, n, src_bf16, dst_bf16);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
 int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const float* inv_scale, float* y,
-                    int B, int K, void* stream) {
+                    int B, int K, int x_bf16, void* stream) {
   IPR_CHECK(K % 4 == 0, "gemv_fwd: K=%d must be a multiple of 4", K);
   if (B == 0) return 0;
-  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, w, bias, inv_scale, y, K);
+  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, w, bias, inv_scale, y, K, x_bf16);
   IPR_LAUNCH_CHECK();
   return 0;
 }
 int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float* inv_scale, float* dx,
                     float* dw, float* db, const float* prev_out, int prev_act, float prev_slope, int B,
-                    int K, void* stream) {
+                    int K, int x_bf16, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) return 0;
   if (dx) {
     hipLaunchKernelGGL(gemv_bwd_dx_kernel, dim3(grid_for((size_t)B * K, 4096)), dim3(256), 0, st, w, dy,
-                       inv_scale, dx, prev_out, prev_act, prev_slope, B, K);
+                       inv_scale, dx, prev_out, prev_act, prev_slope, B, K, x_bf16);
     IPR_LAUNCH_CHECK();
   }
   if (dw || db) {
-    hipLaunchKernelGGL(gemv_bwd_dw_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, x, dy, dw, db, B, K);
+    hipLaunchKernelGGL(gemv_bwd_dw_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, x, dy, dw, db, B, K, x_bf16);
     IPR_LAUNCH_CHECK();
   }
   return 0;

@@ -13,6 +13,27 @@
 namespace iprgan {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
+// Activation storage: fp32, or bf16 (B16: "bf16 activations", include/iprgan.h iprgan_conv_desc).  `e` is the ELEMENT
+// index of 4 consecutive channels; arithmetic is fp32 either way.
+template <bool B16>
+__device__ __forceinline__ f32x4 ldv(const float* base, size_t e) {
+  if (B16) {
+    const nbf16x4 h = *(const nbf16x4*)((const __bf16*)base + e);
+    const f32x4 v = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    return v;
+  }
+  return *(const f32x4*)(base + e);
+}
+template <bool B16>
+__device__ __forceinline__ void stv(float* base, size_t e, const f32x4& v) {
+  if (B16) {
+    const nbf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *(nbf16x4*)((__bf16*)base + e) = h;
+  } else {
+    *(f32x4*)(base + e) = v;
+  }
+}
 
 struct ColGeom {
   int TC, TR, gy, NB, rows_per_block;
@@ -43,7 +64,7 @@ static ColGeom col_geom(int M, int C) {
 // less per pass; with no activation y is not read either.  Other activations (never fused into a norm here) read y.
 __host__ __device__ __forceinline__ bool act_from_x(int act) { return act == IPRGAN_ACT_RELU || act == IPRGAN_ACT_LRELU; }
 
-template <int MODE>
+template <int MODE, bool B16 = false>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ y,
                                                         const float* __restrict__ dy,
@@ -55,8 +76,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
                                                         const float* __restrict__ beta = nullptr) {
   // blockIdx.z = group (InstanceNorm: one group per sample; BatchNorm: a single group)
   const int grp = blockIdx.z;
-  x += (size_t)grp * M * C;
-  if (MODE == 2) { if (y) y += (size_t)grp * M * C; dy += (size_t)grp * M * C; mean += (size_t)grp * C; invstd += (size_t)grp * C; }
+  const size_t gofs = (size_t)grp * M * C;       // element offset of the group (pointer arithmetic below is per element)
+  if (MODE == 2) { mean += (size_t)grp * C; invstd += (size_t)grp * C; }
   part += (size_t)grp * gridDim.x * 2 * C;
   __shared__ f32x4 sh[2][256];
   const int TR = 256 / TC;
@@ -69,7 +90,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   if (ok) {
     f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {1.f, 1.f, 1.f, 1.f};
-    if (MODE == 1) p0 = *(const f32x4*)(x + cq * 4);
+    if (MODE == 1) p0 = ldv<B16>(x, gofs + cq * 4);
     f32x4 pg = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 2) {
       p0 = *(const f32x4*)(mean + cq * 4); p1 = *(const f32x4*)(invstd + cq * 4);
@@ -78,21 +99,21 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
     const bool from_x = MODE == 2 && act_from_x(act), no_act = MODE == 2 && act == IPRGAN_ACT_NONE;
     for (int r = r0 + tr; r < r1; r += TR) {
-      const size_t off = (size_t)r * C + cq * 4;
+      const size_t off = gofs + (size_t)r * C + cq * 4;
       if (MODE == 0) {
-        a0 += *(const f32x4*)(x + off);
+        a0 += ldv<B16>(x, off);
       } else if (MODE == 1) {
-        const f32x4 d = *(const f32x4*)(x + off) - p0;
+        const f32x4 d = ldv<B16>(x, off) - p0;
         a0 += d;
         a1 += d * d;
       } else {
-        const f32x4 xv = *(const f32x4*)(x + off), gv = *(const f32x4*)(dy + off);
+        const f32x4 xv = ldv<B16>(x, off), gv = ldv<B16>(dy, off);
         f32x4 dz = gv;
         if (from_x) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) dz[k] = gv[k] * act_grad_from_out((xv[k] - p0[k]) * p1[k] * pg[k] + pb[k], act, slope);
         } else if (!no_act) {
-          const f32x4 yv = *(const f32x4*)(y + off);
+          const f32x4 yv = ldv<B16>(y, off);
 #pragma unroll
           for (int k = 0; k < 4; ++k) dz[k] = gv[k] * act_grad_from_out(yv[k], act, slope);
         }
@@ -198,13 +219,13 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
                                                              float* __restrict__ running_var,
                                                              float* __restrict__ save_mean,
                                                              float* __restrict__ save_invstd,
-                                                             int shift_vec, long long* __restrict__ counter) {
+                                                             int shift_vec, long long* __restrict__ counter, int x_b16) {
   // shift_vec 0: the sums are about s = x[0][c] of the group (colreduce_kernel<1>); 1: about the per-channel vector
   // x[c] itself, or about zero when x is null (sums emitted by the producing convolution's epilogue, taken before
   // its bias was added: s = bias)
   const int grp = blockIdx.y;
   part += (size_t)grp * NB * 2 * C;
-  if (!shift_vec) x += (size_t)grp * M * C;
+  const size_t xofs = shift_vec ? 0 : (size_t)grp * M * C;
   save_mean += (size_t)grp * C;
   save_invstd += (size_t)grp * C;
   if (counter && blockIdx.x == 0 && grp == 0 && threadIdx.x == 0) *counter += 1;     // num_batches_tracked
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
   if (lane != 0 || c >= C) return;
   const float invM = 1.0f / (float)M;
   const float d = s0 * invM;                 // E[x - s]
-  const float mean = (x ? x[c] : 0.f) + d;
+  const float mean = (x ? ((x_b16 && !shift_vec) ? (float)((const __bf16*)x)[xofs + c] : x[xofs + c]) : 0.f) + d;
   float var = s1 * invM - d * d;             // biased variance
   if (var < 0.f) var = 0.f;
   save_mean[c] = mean;
@@ -246,12 +267,12 @@ __device__ __forceinline__ f32x4 ld4(const float* p, int c, float dflt) {
   const f32x4 d = {dflt, dflt, dflt, dflt};
   return d;
 }
-template <bool FIXED>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
+template <bool FIXED, bool B16 = false>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        unsigned n4, int C4n, FastDiv d_c4n, FastDiv d_group4, int act,
-                                                       float slope, const f32x4* __restrict__ residual) {
+                                                       float slope, const float* __restrict__ residual) {
   // residual: y = act(norm(x)) + residual - the skip connection that closes a residual block right after its last norm
   // layer (networks/sr_resnet.py:37-38, resnet_generator.py:52-53), folded into this pass
   const unsigned stride = gridDim.x * blockDim.x;
@@ -261,12 +282,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const f32x4* __restrict__
     const f32x4 g = ld4(gamma, c, 1.f), b = ld4(beta, c, 0.f), m = ld4(mean, c, 0.f), is = ld4(invstd, c, 1.f);
 #pragma unroll 4
     for (; i < n4; i += stride) {
-      const f32x4 v = x[i];
+      const f32x4 v = ldv<B16>(x, (size_t)i * 4);
       f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = act_apply((v[k] - m[k]) * is[k] * g[k] + b[k], act, slope);
-      if (residual) o += residual[i];
-      y[i] = o;
+      if (residual) o += ldv<B16>(residual, (size_t)i * 4);
+      stv<B16>(y, (size_t)i * 4, o);
     }
     return;
   }
@@ -274,12 +295,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const f32x4* __restrict__
     const int c = (int)(i - fdiv(i, d_c4n) * (unsigned)C4n) * 4;
     const size_t go = (size_t)fdiv(i, d_group4) * (size_t)C4n * 4;     // group offset into mean/invstd
     const f32x4 g = ld4(gamma, c, 1.f), b = ld4(beta, c, 0.f), m = ld4(mean + go, c, 0.f), is = ld4(invstd + go, c, 1.f);
-    const f32x4 v = x[i];
+    const f32x4 v = ldv<B16>(x, (size_t)i * 4);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = act_apply((v[k] - m[k]) * is[k] * g[k] + b[k], act, slope);
-    if (residual) o += residual[i];
-    y[i] = o;
+    if (residual) o += ldv<B16>(residual, (size_t)i * 4);
+    stv<B16>(y, (size_t)i * 4, o);
   }
 }
 
@@ -301,9 +322,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restr
   if (dbeta) dbeta[c] = s1;
 }
 
-template <bool FIXED>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ y,
-                                                           const f32x4* __restrict__ dy, f32x4* __restrict__ dx,
+template <bool FIXED, bool B16 = false>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, float* __restrict__ dx,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ sums,
@@ -318,9 +339,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   auto body = [&](unsigned idx, const f32x4& g, const f32x4& b, const f32x4& m, const f32x4& is, const f32x4& s1,
                   const f32x4& s2) {
-    const f32x4 xv = x[idx], gv = dy[idx];
+    const f32x4 xv = ldv<B16>(x, (size_t)idx * 4), gv = ldv<B16>(dy, (size_t)idx * 4);
     f32x4 yv = {0.f, 0.f, 0.f, 0.f};
-    if (!from_x && !no_act) yv = y[idx];
+    if (!from_x && !no_act) yv = ldv<B16>(y, (size_t)idx * 4);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
       const float dz = no_act ? gv[k] : gv[k] * act_grad_from_out(from_x ? t * g[k] + b[k] : yv[k], act, slope);
       o[k] = g[k] * is[k] * (dz - s1[k] * invM - t * s2[k] * invM);
     }
-    dx[idx] = o;
+    stv<B16>(dx, (size_t)idx * 4, o);
     csum += o;
   };
   if (FIXED) {               // see bn_apply_kernel
@@ -375,10 +396,11 @@ size_t colsum_ws_floats(int M, int Cs) {
   const ColGeom g = col_geom(M, Cs);
   return (size_t)g.NB * 2 * Cs;
 }
-int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st, float beta) {
+int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st, float beta, int b16) {
   const ColGeom g = col_geom(M, Cs);
-  hipLaunchKernelGGL(colreduce_kernel<0>, dim3(g.NB, g.gy), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
-                     nullptr, ws, M, Cs, g.TC, g.rows_per_block, 0, 0.f);
+  auto kr0 = b16 ? colreduce_kernel<0, true> : colreduce_kernel<0, false>;
+  hipLaunchKernelGGL(kr0, dim3(g.NB, g.gy), dim3(256), 0, st, x,
+                     nullptr, nullptr, nullptr, nullptr, ws, M, Cs, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, st, ws, g.NB, Cs, C, out, beta);
   IPR_LAUNCH_CHECK();
@@ -393,7 +415,7 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
                     float* running_var, float* save_mean, float* save_invstd, float* ws, int G, int M, int C,
                     float eps, float momentum, int use_running, int act, float slope, hipStream_t st,
                     const float* part = nullptr, int part_rows = 0, const float* shift = nullptr,
-                    long long* counter = nullptr, const float* residual = nullptr) {
+                    long long* counter = nullptr, const float* residual = nullptr, int b16 = 0) {
   IPR_CHECK(C % 4 == 0, "norm_fwd: C=%d must be a multiple of 4", C);
   IPR_CHECK(M > 0 && G > 0, "norm_fwd: empty input");
   if (use_running) {
@@ -406,23 +428,25 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
     int rpg = part_rows / G;
     if (compact_partials(part, rpg, G, C, st)) return 2;
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, part, shift, rpg, M,
-                       C, eps, momentum, running_mean, running_var, save_mean, save_invstd, 1, counter);
+                       C, eps, momentum, running_mean, running_var, save_mean, save_invstd, 1, counter, 0);
   } else {
     const ColGeom g = col_geom(M, C);
-    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(g.NB, g.gy, G), dim3(256), 0, st, x, nullptr, nullptr,
-                       nullptr, nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f);
+    auto kr1 = b16 ? colreduce_kernel<1, true> : colreduce_kernel<1, false>;
+  hipLaunchKernelGGL(kr1, dim3(g.NB, g.gy, G), dim3(256), 0, st,
+                       x, nullptr, nullptr, nullptr, nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr);
     IPR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, x, g.NB, M, C,
-                       eps, momentum, running_mean, running_var, save_mean, save_invstd, 0, counter);
+                       eps, momentum, running_mean, running_var, save_mean, save_invstd, 0, counter, b16);
   }
   IPR_LAUNCH_CHECK();
   const size_t n4 = (size_t)G * M * C / 4;
   IPR_CHECK(n4 < 0x7fffffffull, "norm_fwd: tensor of %zu elements is too large", n4 * 4);
   const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
   const bool fixed = G == 1 && 256 % (C / 4) == 0;
-  hipLaunchKernelGGL(fixed ? bn_apply_kernel<true> : bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, st,
-                     (const f32x4*)x, (f32x4*)y, gamma, beta, save_mean, save_invstd, (unsigned)n4, C / 4,
-                     make_fastdiv(C / 4), make_fastdiv((uint32_t)((size_t)M * C / 4)), act, slope, (const f32x4*)residual);
+  auto kern = b16 ? (fixed ? bn_apply_kernel<true, true> : bn_apply_kernel<false, true>)
+                  : (fixed ? bn_apply_kernel<true, false> : bn_apply_kernel<false, false>);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_invstd, (unsigned)n4, C / 4,
+                     make_fastdiv(C / 4), make_fastdiv((uint32_t)((size_t)M * C / 4)), act, slope, residual);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -430,14 +454,15 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
 static int norm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                     const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
                     float* ws, int G, int M, int C, int act, float slope, hipStream_t st,
-                    float* dbias_prev = nullptr, int dbias_n = 0, float dbias_beta = 0.f) {
+                    float* dbias_prev = nullptr, int dbias_n = 0, float dbias_beta = 0.f, int b16 = 0) {
   IPR_CHECK(C % 4 == 0, "norm_bwd: C=%d must be a multiple of 4", C);
   IPR_CHECK(act == IPRGAN_ACT_NONE || act_from_x(act) || y, "norm_bwd: this activation needs the saved output y");
   IPR_CHECK(!act_from_x(act) || !gamma == !beta, "norm_bwd: the ReLU mask is recomputed from x: gamma and beta are both needed (or both absent)");
   const ColGeom g = col_geom(M, C);
   float* sums = ws + (size_t)G * g.NB * 2 * C;
-  hipLaunchKernelGGL(colreduce_kernel<2>, dim3(g.NB, g.gy, G), dim3(256), 0, st, x, y, dy, save_mean,
-                     save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope, gamma, beta);
+  auto kr2 = b16 ? colreduce_kernel<2, true> : colreduce_kernel<2, false>;
+  hipLaunchKernelGGL(kr2, dim3(g.NB, g.gy, G), dim3(256), 0, st,
+                     x, y, dy, save_mean, save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope, gamma, beta);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, g.NB, C, sums,
                      G == 1 ? dgamma : nullptr, G == 1 ? dbeta : nullptr);
@@ -457,9 +482,10 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
     if (blocks > 1024) blocks = 1024;
     colpart = sums + (size_t)G * 2 * C;
   }
-  hipLaunchKernelGGL(fixed ? bn_bwd_apply_kernel<true> : bn_bwd_apply_kernel<false>, dim3(blocks), dim3(256), 0, st,
-                     (const f32x4*)x, (const f32x4*)y,
-                     (const f32x4*)dy, (f32x4*)dx, gamma, beta, save_mean, save_invstd, sums, (unsigned)n4, C / 4, C,
+  auto kern = b16 ? (fixed ? bn_bwd_apply_kernel<true, true> : bn_bwd_apply_kernel<false, true>)
+                  : (fixed ? bn_bwd_apply_kernel<true, false> : bn_bwd_apply_kernel<false, false>);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, x, y, dy, dx, gamma, beta, save_mean, save_invstd, sums,
+                     (unsigned)n4, C / 4, C,
                      make_fastdiv(C / 4), make_fastdiv((uint32_t)((size_t)M * C / 4)), 1.0f / (float)M, act, slope,
                      colpart);
   IPR_LAUNCH_CHECK();
@@ -472,7 +498,7 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
                          dbias_prev, dbias_beta);
       IPR_LAUNCH_CHECK();
     } else {                 // channel counts that do not divide the block: the separate column-sum pass
-      const int rc = colsum_launch(dx, dbias_prev, ws, G * M, C, dbias_n, st, dbias_beta);
+      const int rc = colsum_launch(dx, dbias_prev, ws, G * M, C, dbias_n, st, dbias_beta, b16);
       if (rc) return rc;
     }
   }
@@ -491,9 +517,9 @@ size_t iprgan_instnorm_ws_floats(int B, int HW, int C) {
   return (size_t)B * ((size_t)g.NB * 2 * C + 2 * (size_t)C) + (size_t)(1024 + NBC) * 2 * C;
 }
 
-int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, float beta, void* stream) {
+int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, float beta, int x_bf16, void* stream) {
   IPR_CHECK(Cs % 4 == 0 && M > 0 && C <= Cs, "colsum: row length %d must be a multiple of 4 >= C=%d, M=%d positive", Cs, C, M);
-  return colsum_launch(x, out, ws, M, Cs, C, (hipStream_t)stream, beta);
+  return colsum_launch(x, out, ws, M, Cs, C, (hipStream_t)stream, beta, x_bf16);
 }
 size_t iprgan_colsum_ws_floats(int M, int C) { return colsum_ws_floats(M, C); }
 int iprgan_colsum_partials(const float* part, int rows, int Cs, int C, float* out, float beta, void* stream) {
@@ -508,31 +534,31 @@ int iprgan_bn_fwd(const float* x, float* y, const float* gamma, const float* bet
                   float* running_var, float* save_mean, float* save_invstd, float* ws, int M, int C,
                   float eps, float momentum, int use_running, int act, float slope, const float* conv_part,
                   int conv_part_rows, const float* conv_bias, long long* num_batches_tracked, const float* residual,
-                  void* stream) {
+                  int act_bf16, void* stream) {
   return norm_fwd(x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, 1, M, C, eps,
                   momentum, use_running, act, slope, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias,
-                  use_running ? nullptr : num_batches_tracked, residual);
+                  use_running ? nullptr : num_batches_tracked, residual, act_bf16);
 }
 int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                   float* dbeta, float* ws, int M, int C, int act, float slope, float* dbias_prev, int dbias_n,
-                  float dbias_beta, void* stream) {
+                  float dbias_beta, int act_bf16, void* stream) {
   return norm_bwd(x, y, dy, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, ws, 1, M, C, act, slope,
-                  (hipStream_t)stream, dbias_prev, dbias_n, dbias_beta);
+                  (hipStream_t)stream, dbias_prev, dbias_n, dbias_beta, act_bf16);
 }
 int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                         float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,
                         const float* conv_part, int conv_part_rows, const float* conv_bias, const float* residual,
-                        void* stream) {
+                        int act_bf16, void* stream) {
   return norm_fwd(x, y, gamma, beta, nullptr, nullptr, save_mean, save_invstd, ws, B, HW, C, eps, 0.f, 0, act,
-                  slope, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias, nullptr, residual);
+                  slope, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias, nullptr, residual, act_bf16);
 }
 int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                         float* dbeta, float* ws, int B, int HW, int C, int act, float slope, float* dbias_prev,
-                        int dbias_n, float dbias_beta, void* stream) {
+                        int dbias_n, float dbias_beta, int act_bf16, void* stream) {
   return norm_bwd(x, y, dy, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, ws, B, HW, C, act, slope,
-                  (hipStream_t)stream, dbias_prev, dbias_n, dbias_beta);
+                  (hipStream_t)stream, dbias_prev, dbias_n, dbias_beta, act_bf16);
 }
 
 }  // extern "C"

@@ -22,7 +22,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('B', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad', 'outpad',
-                 'transposed', 'pad_mode', 'act')] + [('slope', C.c_float)]
+                 'transposed', 'pad_mode', 'act')] + [('slope', C.c_float), ('x_bf16', C.c_int32), ('y_bf16', C.c_int32)]
 
 
 _P, _F, _I, _Z, _LL = C.c_void_p, C.c_float, C.c_int, C.c_size_t, C.c_longlong
@@ -48,17 +48,19 @@ SIGNATURES = {
     'iprgan_conv_bwd_data_ws_floats': (_Z, [_D]),
     'iprgan_conv_bwd_data': (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, C.POINTER(C.c_int), _P, _P]),
     'iprgan_colsum_ws_floats': (_Z, [_I, _I]),
-    'iprgan_colsum': (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    'iprgan_colsum': (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
     'iprgan_conv_bwd_weight': (_I, [_D, _P, _P, _P, _P, _P, _F, _P]),
-    'iprgan_act_bwd': (_I, [_P, _P, _P, _Z, _I, _F, _P]),
-    'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
-    'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _P]),
+    'iprgan_act_bwd': (_I, [_P, _P, _P, _Z, _I, _F, _I, _P]),
+    'iprgan_cast': (_I, [_P, _P, _Z, _I, _I, _P]),
+    'iprgan_conv_wgrad_takes_bf16': (_I, [_D]),
+    'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P]),
     'iprgan_bn_ws_floats': (_Z, [_I, _I]),
-    'iprgan_bn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _P, _P, _P, _P]),
-    'iprgan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _F, _P]),
+    'iprgan_bn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _P, _P, _P, _I, _P]),
+    'iprgan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _F, _I, _P]),
     'iprgan_instnorm_ws_floats': (_Z, [_I, _I, _I]),
-    'iprgan_instnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _I, _P, _P, _P]),
-    'iprgan_instnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _F, _P]),
+    'iprgan_instnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _I, _P, _P, _I, _P]),
+    'iprgan_instnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _F, _I, _P]),
     'iprgan_prelu_fwd': (_I, [_P, _P, _P, _Z, _P]),
     'iprgan_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _P]),
     'iprgan_pixel_shuffle2': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -146,10 +148,17 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise RuntimeError('iprgan kernels need GPU tensors (got a CPU tensor); there is no CPU path')
-    if t.dtype != torch.float32 or not t.is_contiguous():
-        raise RuntimeError(f'iprgan kernels need contiguous float32 tensors (got {t.dtype}, '
-                           f'contiguous={t.is_contiguous()})')
+    if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous():
+        raise RuntimeError(f'iprgan kernels need contiguous float32 (or, for activations in bf16-activation mode, '
+                           f'bfloat16) tensors (got {t.dtype}, contiguous={t.is_contiguous()})')
     return t.data_ptr()
+
+
+def ptr32(t):
+    """ptr() for arguments that are ALWAYS fp32 (weights, statistics, gradients of parameters, RGB images)."""
+    if t is not None and t.dtype != torch.float32:
+        raise RuntimeError(f'this iprgan kernel argument must be float32 (got {t.dtype})')
+    return ptr(t)
 
 
 def stream():
@@ -179,15 +188,24 @@ def prof_results():
     return out
 
 
-MATH_MODES = {'fp32': 0, 'bf16': 1}
+MATH_MODES = {'fp32': 0, 'bf16': 1, 'bf16act': 1}
+_act_bf16 = False
 
 
 def set_math(mode):
-    """Process-wide math mode of the conv family (include/iprgan.h: iprgan_set_math_mode): 'fp32' (default) or
-    'bf16' (bf16 MFMA tiles, fp32 accumulation, fp32 tensors and master weights in HBM)."""
-    global _math_cached
+    """Process-wide math mode of the conv family (include/iprgan.h: iprgan_set_math_mode): 'fp32' (default), 'bf16'
+    (bf16 MFMA tiles, fp32 accumulation, fp32 tensors and master weights in HBM) or 'bf16act' (the same tiles, and
+    activations whose padded channel count is a multiple of 64 LIVE as bf16 in HBM: half the activation traffic, operands
+    reach LDS without a conversion; DCGAN-family layers only this round)."""
+    global _math_cached, _act_bf16
+    _act_bf16 = mode == 'bf16act'
     _math_cached = MATH_MODES[mode] if isinstance(mode, str) else int(mode)
     call('iprgan_set_math_mode', _math_cached)
+
+
+def act_bf16():
+    """True in 'bf16act' mode (host-side allocation rule; the kernels are told per tensor through the descriptors)."""
+    return _act_bf16
 
 
 _math_cached = 0
@@ -195,8 +213,8 @@ _math_cached = 0
 
 def get_math_cached():
     """The math mode last set through set_math (no library call: part of per-pass cache keys)."""
-    return _math_cached
+    return _math_cached + (2 if _act_bf16 else 0)
 
 
 def get_math():
-    return {v: k for k, v in MATH_MODES.items()}[load().iprgan_get_math_mode()]
+    return 'bf16act' if _act_bf16 else {0: 'fp32', 1: 'bf16'}[load().iprgan_get_math_mode()]

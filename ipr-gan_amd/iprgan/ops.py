@@ -18,12 +18,38 @@ def _int_table(sizes):
     return (C.c_int * len(sizes))(*sizes)
 
 
-def empty(shape, like):
-    return torch.empty(shape, dtype=torch.float32, device=like.device)
+def empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def act_dtype(channels):
+    """Storage type of an NHWC activation with ``channels`` channels: bf16 in 'bf16act' mode when the padded channel
+    count is a multiple of 64 (include/iprgan.h: bf16 activations), fp32 otherwise (always in the other modes)."""
+    return torch.bfloat16 if (L.act_bf16() and c4(channels) % 64 == 0) else torch.float32
+
+
+def is16(t):
+    return 1 if (t is not None and t.dtype == torch.bfloat16) else 0
+
+
+def cast(t, dtype):
+    """fp32 <-> bf16 copy of an activation (round-to-nearest-even)."""
+    if t.dtype == dtype:
+        return t
+    out = torch.empty(t.shape, dtype=dtype, device=t.device)
+    call('iprgan_cast', ptr(t), ptr(out), t.numel(), is16(t), is16(out), stream())
+    return out
+
+
+def _f32(*tensors):
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError('this op has no bf16-activation form yet (bf16act mode covers the DCGAN-family layers)')
 
 
 # ---- layout ---------------------------------------------------------------------------------
 def nchw_to_nhwc(x):
+    _f32(x)
     B, Cc, H, W = x.shape
     y = empty((B, H, W, c4(Cc)), x)
     call('iprgan_nchw_to_nhwc', ptr(x.contiguous()), ptr(y), B, Cc, H, W, stream())
@@ -31,6 +57,8 @@ def nchw_to_nhwc(x):
 
 
 def nhwc_to_nchw(x, channels):
+    if x.dtype != torch.float32:
+        x = cast(x, torch.float32)
     B, H, W, _ = x.shape
     y = empty((B, channels, H, W), x)
     call('iprgan_nhwc_to_nchw', ptr(x), ptr(y), B, channels, H, W, stream())
@@ -45,8 +73,10 @@ def permute_021(src, A, Bd, K, out=None, beta=0.0):
 
 
 def act_bwd(dy, out, act, slope=0.0):
+    if dy.dtype != out.dtype:
+        dy = cast(dy, out.dtype)
     dz = torch.empty_like(dy)
-    call('iprgan_act_bwd', ptr(dy), ptr(out), ptr(dz), dy.numel(), act, float(slope), stream())
+    call('iprgan_act_bwd', ptr(dy), ptr(out), ptr(dz), dy.numel(), act, float(slope), is16(dy), stream())
     return dz
 
 
@@ -67,14 +97,19 @@ class ConvSpec:
             f = lambda n: (n + 2 * self.pad - self.k) // self.stride + 1
         return f(H), f(W)
 
-    def desc(self, B, H, W):
+    def desc(self, B, H, W, x16=None, y16=None):
+        """x16 / y16: storage type of the layer's input / output activation (default: the bf16act rule)."""
+        x16 = (act_dtype(self.cin) == torch.bfloat16) if x16 is None else x16
+        y16 = (act_dtype(self.cout) == torch.bfloat16) if y16 is None else y16
         return ConvDesc(B, H, W, self.cin, self.cout, self.k, self.k, self.stride, self.pad,
-                        self.outpad, int(self.transposed), self.pad_mode, self.act, float(self.slope))
+                        self.outpad, int(self.transposed), self.pad_mode, self.act, float(self.slope), int(x16), int(y16))
 
     @property
     def is_identity_prep(self):
-        """1x1 convs whose PyTorch weight already is the forward operand (rows=Cout, k=Cin)."""
-        return (self.k == 1 and not self.transposed and self.cin % 32 == 0 and self.cout % 128 == 0)
+        """1x1 convs whose PyTorch weight already is the forward operand (rows=Cout, k=Cin); not with a bf16 input
+        (the operand is then emitted as bf16)."""
+        return (self.k == 1 and not self.transposed and self.cin % 32 == 0 and self.cout % 128 == 0
+                and act_dtype(self.cin) == torch.float32)
 
 
 def conv_prep(spec, d, w, sigma=None, fwd=True, bwd=False):
@@ -106,7 +141,9 @@ def conv_fwd(spec, d, x, wfwd, bias, pair=None, stats=False):
     stats=True: also returns (partials, rows): per-tile column sums of the pre-bias accumulator for the norm layer that
     follows (include/iprgan.h: column statistics from the epilogue)."""
     OH, OW = spec.out_hw(d.H, d.W)
-    y = empty((d.B, OH, OW, c4(spec.cout)), x)
+    if is16(x) != d.x_bf16:
+        x = cast(x, torch.bfloat16 if d.x_bf16 else torch.float32)
+    y = empty((d.B, OH, OW, c4(spec.cout)), x, torch.bfloat16 if d.y_bf16 else torch.float32)
     nws = query('iprgan_conv_fwd_ws_floats', C.byref(d))
     ws = empty((nws,), x) if nws else None
     p0, p1 = (ptr(pair[0]), ptr(pair[1])) if pair is not None else (None, None)
@@ -122,7 +159,11 @@ def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_sl
                   residual=None):
     """colsums=True: also returns (partials, rows): per-tile column sums of dx (after the fused activation derivative),
     i.e. the bias gradient of the layer that produced this layer's input, up to ``colsum_partials``."""
-    dx = empty((d.B, d.H, d.W, c4(spec.cin)), dy)
+    if is16(dy) != d.y_bf16:
+        dy = cast(dy, torch.bfloat16 if d.y_bf16 else torch.float32)
+    dx = empty((d.B, d.H, d.W, c4(spec.cin)), dy, torch.bfloat16 if d.x_bf16 else torch.float32)
+    if prev_out is not None and is16(prev_out) != d.x_bf16:
+        raise RuntimeError('conv_bwd_data: prev_out must have the storage type of the layer input')
     nws = query('iprgan_conv_bwd_data_ws_floats', C.byref(d))
     ws = empty((nws,), dy) if nws else None
     p0, p1 = (ptr(pair[0]), ptr(pair[1])) if pair is not None else (None, None)
@@ -146,12 +187,18 @@ def colsum(x2d_like, channels, out=None, beta=0.0):
     M = x2d_like.numel() // C_
     res = empty((channels,), x2d_like) if out is None else out
     ws = empty((query('iprgan_colsum_ws_floats', M, C_),), x2d_like)
-    call('iprgan_colsum', ptr(x2d_like), ptr(res), ptr(ws), M, C_, channels, float(beta), stream())
+    call('iprgan_colsum', ptr(x2d_like), ptr(res), ptr(ws), M, C_, channels, float(beta), is16(x2d_like), stream())
     return res
 
 
 def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0.0):
-    """dw, db given (gradient-bucket views): ``dw = beta*dw + grad`` written in place, no temporary."""
+    """dw, db given (gradient-bucket views): ``dw = beta*dw + grad`` written in place, no temporary.
+    bf16 x / dy are consumed directly where the 128x128 bf16 tile applies, through fp32 copies elsewhere."""
+    d = ConvDesc(*[getattr(d, f) for f, _ in ConvDesc._fields_])
+    d.x_bf16, d.y_bf16 = is16(x), is16(dy)            # the kernels read either storage type (include/iprgan.h)
+    if d.x_bf16 and not query('iprgan_conv_wgrad_takes_bf16', C.byref(d)):
+        x = cast(x, torch.float32)
+        d.x_bf16 = 0
     if dw is None:
         dw = empty(tuple(w_shape), x)
     if db is None and want_bias:
@@ -166,7 +213,7 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
 def gemv_fwd(x2d, w, bias, sigma, out=None):
     B, K = x2d.shape
     y = empty((B,), x2d) if out is None else out
-    call('iprgan_gemv_fwd', ptr(x2d), ptr(w), ptr(bias), ptr(sigma), ptr(y), B, K, stream())
+    call('iprgan_gemv_fwd', ptr(x2d), ptr(w), ptr(bias), ptr(sigma), ptr(y), B, K, is16(x2d), stream())
     return y
 
 
@@ -176,7 +223,7 @@ def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_
     dw = empty((K,), x2d) if need_dw else None
     db = empty((1,), x2d) if need_dw else None
     call('iprgan_gemv_bwd', ptr(x2d), ptr(w), ptr(dy), ptr(sigma), ptr(dx), ptr(dw), ptr(db),
-         ptr(prev_out), prev_act, float(prev_slope), B, K, stream())
+         ptr(prev_out), prev_act, float(prev_slope), B, K, is16(x2d), stream())
     return dx, dw, db
 
 
@@ -194,7 +241,7 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, a
     call('iprgan_bn_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
          ptr(mean), ptr(invstd), ptr(ws), M, C_, float(eps), float(momentum), 0 if training else 1,
          act, float(slope), ptr(part), int(rows), ptr(conv_bias) if part is not None else None,
-         counter.data_ptr() if counter is not None else None, ptr(residual), stream())
+         counter.data_ptr() if counter is not None else None, ptr(residual), is16(x), stream())
     return y, mean, invstd
 
 
@@ -203,12 +250,14 @@ def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None,
     that produced x."""
     C_ = x.shape[-1]
     M = x.numel() // C_
+    if dy.dtype != x.dtype:
+        dy = cast(dy, x.dtype)
     dx = torch.empty_like(x)
     dgamma, dbeta = empty((C_,), x), empty((C_,), x)
     ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
     call('iprgan_bn_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
          ptr(dgamma), ptr(dbeta), ptr(ws), M, C_, act, float(slope), ptr(dbias), dbias.numel() if dbias is not None else 0,
-         float(dbias_beta), stream())
+         float(dbias_beta), is16(x), stream())
     return dx, dgamma, dbeta
 
 
@@ -403,7 +452,7 @@ def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias
     ws = None if part is not None else empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
     call('iprgan_instnorm_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(ws),
          B, H * W, C_, float(eps), act, float(slope), ptr(part), int(rows),
-         ptr(conv_bias) if part is not None else None, ptr(residual), stream())
+         ptr(conv_bias) if part is not None else None, ptr(residual), is16(x), stream())
     return y, mean, invstd
 
 
@@ -415,17 +464,19 @@ def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias
     ws = empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
     call('iprgan_instnorm_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
          ptr(dgamma), ptr(dbeta), ptr(ws), B, H * W, C_, act, float(slope), ptr(dbias),
-         dbias.numel() if dbias is not None else 0, float(dbias_beta), stream())
+         dbias.numel() if dbias is not None else 0, float(dbias_beta), is16(x), stream())
     return dx, dgamma, dbeta
 
 
 def prelu_fwd(x, alpha):
+    _f32(x)
     y = torch.empty_like(x)
     call('iprgan_prelu_fwd', ptr(x), ptr(alpha), ptr(y), x.numel(), stream())
     return y
 
 
 def prelu_bwd(x, dy, alpha):
+    _f32(x, dy)
     dx = torch.empty_like(x)
     dalpha = empty((1,), x)
     ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
@@ -435,6 +486,7 @@ def prelu_bwd(x, dy, alpha):
 
 def pixel_shuffle2(x, inverse=False):
     """forward: [B,H,W,4C] -> [B,2H,2W,C]; inverse: [B,2H,2W,C] -> [B,H,W,4C]."""
+    _f32(x)
     if not inverse:
         B, H, W, C4_ = x.shape
         Cc = C4_ // 4
@@ -448,6 +500,7 @@ def pixel_shuffle2(x, inverse=False):
 
 
 def maxpool2_fwd(x):
+    _f32(x)
     B, H, W, C_ = x.shape
     y = empty((B, H // 2, W // 2, C_), x)
     call('iprgan_maxpool2_fwd', ptr(x), ptr(y), B, H, W, C_, stream())
@@ -455,6 +508,7 @@ def maxpool2_fwd(x):
 
 
 def maxpool2_bwd(x, dy):
+    _f32(x, dy)
     B, H, W, C_ = x.shape
     dx = torch.empty_like(x)
     call('iprgan_maxpool2_bwd', ptr(x), ptr(dy), ptr(dx), B, H, W, C_, stream())
@@ -462,6 +516,7 @@ def maxpool2_bwd(x, dy):
 
 
 def add(a, b):
+    _f32(a, b)
     out = torch.empty_like(a)
     call('iprgan_add', ptr(a), ptr(b), ptr(out), a.numel(), stream())
     return out

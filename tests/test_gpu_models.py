@@ -345,15 +345,17 @@ def test_conv_linearity_at_full_size(dev):
         assert float((lhs - rhs).abs().max()) <= 5e-5 * float(rhs.abs().max())
 
 
-def test_dcgan_bf16_math_vs_reference_golden(golden, dev):
+@pytest.mark.parametrize('mode', ['bf16', 'bf16act'])
+def test_dcgan_bf16_math_vs_reference_golden(golden, dev, mode):
     """BASELINE config 5 asks for bf16 MFMA conv tiles: IPRGAN_MATH_BF16 rounds the conv operands to bf16 in LDS
     (fp32 accumulation, fp32 tensors / master weights / norms / Adam).  Tolerance: operand rounding is 2^-9
     relative per element, so after three training steps the losses must agree with the fp32 reference to 3e-2
     absolute (they are O(1)), the generated images to 3 % in L2, and the sign bits / BER exactly."""
     from iprgan import Config, _lib, models
     ref = golden('dcgan_steps_wbox')
+    # 'bf16act': activations with >= 64 channels additionally LIVE as bf16 in HBM (every producer rounds its output once)
     try:
-        _lib.set_math('bf16')
+        _lib.set_math(mode)
         res = cases.run_dcgan_steps(Config, models, [dev], n_steps=3, wbox=True)
     finally:
         _lib.set_math('fp32')
@@ -392,7 +394,8 @@ def test_dcgan128_steps_vs_reference_golden(golden, dev):
     compare(res, golden('dcgan128_steps_wbox'), policy=policy)
 
 
-def test_dcgan128_bf16_steps_vs_reference_golden(golden, dev):
+@pytest.mark.parametrize('mode', ['bf16', 'bf16act'])
+def test_dcgan128_bf16_steps_vs_reference_golden(golden, dev, mode):
     """The same two 128x128 steps with IPRGAN_MATH_BF16 (bf16 MFMA tiles, fp32 accumulation / master weights / norms /
     Adam).  Tolerance as for the 64x64 bf16 test: operand rounding is 2^-9 relative per element, so the O(1) losses
     must agree with the fp32 reference to 3e-2 absolute, the generated images to 3 % in L2, the first Adam moments of
@@ -400,7 +403,7 @@ def test_dcgan128_bf16_steps_vs_reference_golden(golden, dev):
     from iprgan import Config, _lib, models
     ref = golden('dcgan128_steps_wbox')
     try:
-        _lib.set_math('bf16')
+        _lib.set_math(mode)
         res = cases.run_dcgan_steps(Config, models, [dev], n_steps=2, batch=8, seed=91, cfg=cases.DCGAN128_CFG, size=128)
     finally:
         _lib.set_math('fp32')
