@@ -36,6 +36,7 @@ static ProfSlot g_slots[] = {
     {"gconv_bf16_kernel", 0, 0, 0},     {"wgrad_bf16_kernel", 0, 0, 0},
     {"wgrad_t_kernel<128x128>", 0, 0, 0}, {"wgrad_t_kernel<128x64>", 0, 0, 0},
     {"wgrad_t_kernel<64x64>", 0, 0, 0},   {"wgrad_t_kernel<128x128,8w>", 0, 0, 0},
+    {"fewin_conv_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; };
@@ -51,16 +52,16 @@ static hipEvent_t prof_event() {
 // Launch a conv-family kernel, timed when profiling is on.  The start/stop events ride on the dispatch packet
 // itself (hipExtLaunchKernelGGL): bracketing every launch with two hipEventRecord calls instead put two extra
 // packets per launch on the queue and cost 0.45 ms of a 13 ms step - a measurement that slowed what it measured.
-template <class Kern, class Args>
+template <class Kern, class... Args>
 static void prof_launch(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream_t st, int slot, double flops,
-                        const Args& a) {
+                        const Args&... a) {
   if (g_prof_on && g_recs.size() < 65536) {
     ProfRec r;
     r.a = prof_event(); r.b = prof_event(); r.slot = slot; r.flops = flops;
-    hipExtLaunchKernelGGL(kern, grid, block, (unsigned)smem, st, r.a, r.b, 0, a);
+    hipExtLaunchKernelGGL(kern, grid, block, (unsigned)smem, st, r.a, r.b, 0, a...);
     g_recs.push_back(r);
   } else {
-    hipLaunchKernelGGL(kern, grid, block, (unsigned)smem, st, a);
+    hipLaunchKernelGGL(kern, grid, block, (unsigned)smem, st, a...);
   }
 }
 
@@ -558,6 +559,100 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
         a.stat_part[((size_t)lq * 2 + 1) * a.Ns + n0 + c] = s2;
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Few-INPUT-channel convolutions (RGB stems 3 -> 64: Conv2d forward; and the backward-data of RGB heads, which has the
+// same form): K = taps * 4 is far too short for the MFMA tiles (36 padded to 64: two K steps, the launch is all
+// prologue and epilogue) and the layer is bound by WRITING its 64-channel output.  Direct form on the vector ALU:
+// a block owns a 16 x 16 tile of output pixels and 64 output channels; the input halo (4 channels = 16 bytes per
+// pixel) and the block's weights [tap][n][c] sit in LDS; lane = (channel quad q, pixel column): every thread
+// accumulates 16 pixels (one column of the tile) x 4 channels, reading one 16-byte input vector per (pixel, tap)
+// and four 16-byte weight vectors per tap.  Stores: a wave writes 4 pixels x 256 contiguous bytes per instruction.
+// ------------------------------------------------------------------------------------------
+#define FEWIN_T 16
+__global__ __launch_bounds__(256) void fewin_conv_kernel(const GConvArgs a, int lds_w, int lds_h) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 flds[];
+  const Phase& ph = a.ph[0];
+  const int ntap = ph.ntap, tw = ph.tw, th = ph.th;
+  f32x4* X = flds;                                   // [lds_h][lds_w] input pixels (4 channels each)
+  f32x4* Wl = flds + lds_h * lds_w;                  // [ntap][4 input channels][16 quads]: weights of 4 output channels
+  const int tiles_x = (a.OW + FEWIN_T - 1) / FEWIN_T, tiles_y = (a.OH + FEWIN_T - 1) / FEWIN_T;
+  const int tile = blockIdx.x, b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
+  const int y0 = (tr / tiles_x) * FEWIN_T, x0 = (tr % tiles_x) * FEWIN_T;
+  const int n0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, q = tid & 15, pg = tid >> 4;
+  // input window of the tile: rows iy = y * isy + dy0 + t * dys for y in [y0, y0 + 15], t in [0, th)
+  const int dyl = ph.dys < 0 ? (th - 1) * ph.dys : 0, dxl = ph.dxs < 0 ? (tw - 1) * ph.dxs : 0;
+  const int iy_lo = y0 * a.isy + ph.dy0 + dyl, ix_lo = x0 * a.isx + ph.dx0 + dxl;
+  const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
+  for (int i = tid; i < lds_h * lds_w; i += 256) {
+    const int r = i / lds_w, c = i - r * lds_w;
+    int iy = iy_lo + r, ix = ix_lo + c;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    bool ok = true;
+    if (reflect) { iy = reflect_idx(iy, a.IH); ix = reflect_idx(ix, a.IW); ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW; }
+    else ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+    if (ok) v = *(const f32x4*)(a.in + ((size_t)(b * a.IH + iy) * a.IW + ix) * 4);
+    X[i] = v;
+  }
+  for (int i = tid; i < ntap * 64; i += 256) {       // transposed while staged: Wl[t][c][quad] = (W[4 quad + k][t][c])_k
+    const int t = i >> 6, n = i & 63;
+    const int ty = t / tw, tx = t - ty * tw;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n0 + n < a.Ns) v = *(const f32x4*)(a.wt + (size_t)(n0 + n) * a.Kp + (size_t)(ph.wbase + ty * ph.wsy + tx * ph.wsx) * 4);
+    float* wf = (float*)Wl;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wf[((t * 4 + c) * 16 + (n >> 2)) * 4 + (n & 3)] = v[c];
+  }
+  __syncthreads();
+  f32x4 acc[FEWIN_T];
+#pragma unroll
+  for (int i = 0; i < FEWIN_T; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int cx = pg * a.isx - dxl;                  // LDS column of this thread's pixel for tap offset 0
+  for (int t = 0; t < ntap; ++t) {
+    const int ty = t / tw, tx = t - ty * tw;
+    // wc: this thread's 4 output channels for input channel c (vector x scalar FMAs: v_pk_fma_f32 pairs)
+    const f32x4 w0 = Wl[(t * 4 + 0) * 16 + q], w1 = Wl[(t * 4 + 1) * 16 + q], w2 = Wl[(t * 4 + 2) * 16 + q], w3 = Wl[(t * 4 + 3) * 16 + q];
+    const f32x4* xp = X + (ty * ph.dys - dyl) * lds_w + cx + tx * ph.dxs;
+    const int xstep = a.isy * lds_w;
+#pragma unroll
+    for (int i = 0; i < FEWIN_T; ++i) {
+      const f32x4 xin = xp[i * xstep];
+      acc[i] += w0 * xin.x;
+      acc[i] += w1 * xin.y;
+      acc[i] += w2 * xin.z;
+      acc[i] += w3 * xin.w;
+    }
+  }
+  // epilogue: same order of operations as gconv_kernel's (pair scale, bias, activation, fused derivative, residual)
+  const int n = n0 + 4 * q, ox = x0 + pg;
+  if (n >= a.Ns || ox >= a.OW) return;
+  float rsc0 = 1.f, rsc1 = 1.f;
+  if (a.rs0) { rsc0 = 1.f / *a.rs0; rsc1 = 1.f / *a.rs1; }
+  const float rs = b < (a.B >> 1) ? rsc0 : rsc1;
+#pragma unroll
+  for (int i = 0; i < FEWIN_T; ++i) {
+    const int oy = y0 + i;
+    if (oy >= a.OH) break;
+    f32x4 v = acc[i];
+    if (a.rs0) v *= rs;
+    if (a.bias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (n + k < a.N) v[k] += a.bias[n + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], a.act, a.slope);
+    const size_t idx = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Ns + n;
+    if (a.aux) {
+      const f32x4 o = a.aux16 ? ld_bf16x4(a.aux, idx) : *(const f32x4*)(a.aux + idx);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= act_grad_from_out(o[k], a.aux_act, a.aux_slope);
+    }
+    if (a.res) v += a.out16 ? ld_bf16x4(a.res, idx) : *(const f32x4*)(a.res + idx);
+    if (a.out16) *(bf16x4*)((__bf16*)a.out + idx) = to_bf16x4(v);
+    else *(f32x4*)(a.out + idx) = v;
   }
 }
 
@@ -1472,6 +1567,7 @@ static void tune_store(const TuneKey& k, int v) {
 static int g_force_tile = -1, g_force_wgrad = -1;     // test hook: iprgan_debug_force_tiles
 static int g_autotune = getenv("IPRGAN_AUTOTUNE") ? atoi(getenv("IPRGAN_AUTOTUNE")) : 1;
 static int g_smalln = getenv("IPRGAN_SMALLN") ? atoi(getenv("IPRGAN_SMALLN")) : 1;
+static int g_fewin = getenv("IPRGAN_FEWIN") ? atoi(getenv("IPRGAN_FEWIN")) : 1;      // A/B switch: direct few-input-channel kernel
 static int g_math = IPRGAN_MATH_FP32;                 // iprgan_set_math_mode
 static int g_bf16_bk = getenv("IPRGAN_BF16_BK") ? atoi(getenv("IPRGAN_BF16_BK")) : 64;   // K step of the bf16 gconv tiles
 static int g_nbuf = getenv("IPRGAN_LDS_BUFS") ? atoi(getenv("IPRGAN_LDS_BUFS")) : 1;  // wgrad_kernel only: 1 = single LDS buffer (measured faster: 3-4 blocks/CU)
@@ -1622,6 +1718,25 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
     a.linear_out = (a.nphase == 1 && a.osy == 1 && a.osx == 1 && a.ph[0].ooy == 0 && a.ph[0].oox == 0) ? 1 : 0;
   }
   IPR_CHECK(a.nphase >= 1 && a.nphase <= 4, "conv: stride %d unsupported (max 2)", a.osy);
+  if (g_fewin && a.Cs == 4 && a.nphase == 1 && a.osy == 1 && a.osx == 1 && a.ph[0].ooy == 0 && a.ph[0].oox == 0 &&
+      !a.stat_part && a.ksplit <= 1 && !a.planar_M && !a.wmod && !a.in16 && a.Ns >= 32) {
+    // few input channels (RGB stems; backward-data of RGB heads): direct form on the vector ALU (fewin_conv_kernel)
+    const Phase& p = a.ph[0];
+    const int lw = (FEWIN_T - 1) * a.isx + (p.tw - 1) * (p.dxs < 0 ? -p.dxs : p.dxs) + 1;
+    const int lh = (FEWIN_T - 1) * a.isy + (p.th - 1) * (p.dys < 0 ? -p.dys : p.dys) + 1;
+    const size_t smem = ((size_t)lw * lh + (size_t)p.ntap * 64) * sizeof(f32x4);
+    if (smem <= 150 * 1024) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)fewin_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+      }
+      dim3 grid((unsigned)(a.B * cdiv(a.OH, FEWIN_T) * cdiv(a.OW, FEWIN_T)), (unsigned)cdiv(a.Ns, 64));
+      prof_launch(fewin_conv_kernel, grid, dim3(256), smem, st, 18, a.flops, a, lw, lh);
+      IPR_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (smalln_eligible(a) && a.ws && a.ws_floats >= smalln_ws_floats(a)) return launch_smalln(a, st);
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
