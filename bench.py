@@ -285,6 +285,13 @@ def main():
         log('per-step host ms: ' + ' '.join(f'{(b - a) * 1e3:.1f}' for a, b in zip([t0] + stamps[:-1], stamps)) +
             f' | final sync {(t0 + elapsed - stamps[-1]) * 1e3:.1f}')
     kernels = [k for k in _lib.prof_results() if k['launches']]
+    if os.environ.get('IPRGAN_BENCH_LAYERS') and rank == 0:     # per-layer table of the sampled steps, to stderr
+        rows = sorted(_lib.prof_layers(), key=lambda r: -r['ms'])
+        tot = sum(r['ms'] for r in rows)
+        log(f'conv-family layers, {prof_steps} sampled step(s), {tot / prof_steps:.3f} ms/step:')
+        for r in rows:
+            log(f"  {r['name']:58s} n/step={r['launches'] / prof_steps:5.1f} us={r['ms'] / r['launches'] * 1e3:8.1f} "
+                f"ms/step={r['ms'] / prof_steps:7.3f} TF={r['flops'] / r['ms'] / 1e9 if r['ms'] else 0:6.1f}")
     metrics = model.get_metrics()
     assert all(v == v for v in metrics.values()), f'non-finite metrics {metrics}'
 

@@ -305,6 +305,9 @@ int iprgan_prof_enable(int on);
 int iprgan_prof_collect(void);
 int iprgan_prof_num_kernels(void);
 int iprgan_prof_get(int i, char* name, int name_len, long long* launches, double* ms, double* flops);
+/* the same records grouped by layer: name = pass (fwd / dgrad / wgrad) + descriptor geometry */
+int iprgan_prof_num_layers(void);
+int iprgan_prof_get_layer(int i, char* name, int name_len, long long* launches, double* ms, double* flops);
 
 /* ---- math mode of the conv family (process-wide).  FP32 (default): v_mfma_f32_32x32x2_f32 on fp32 tiles.
  * BF16 (BASELINE config "DCGAN 128x128 bs256 bf16"): tensors and master weights stay fp32 in HBM, tiles are
@@ -318,6 +321,9 @@ int iprgan_get_math_mode(void);
 /* test hook: force one tile configuration (gconv 0..5, wgrad candidate 0..19 = 4 * block target + tile shape; -1 = autotune / heuristic) so that
  * the parity tests can exercise every variant, not only the one the autotuner picks. */
 int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand);
+/* test hook: force the split count (1..4) of the split-K path that convolutions with few output tiles take when their
+ * workspace is passed (iprgan_conv_fwd_ws_floats / iprgan_conv_bwd_data_ws_floats); -1 = autotuned. */
+int iprgan_debug_force_splitk(int splits);
 
 /* ---- misc elementwise ----------------------------------------------------------------------- */
 int iprgan_fill(float* p, float v, size_t n, void* stream);

@@ -39,8 +39,30 @@ static ProfSlot g_slots[] = {
     {"fewin_conv_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
-struct ProfRec { hipEvent_t a, b; int slot; double flops; };
+struct ProfRec { hipEvent_t a, b; int slot; double flops; int tag; };
 static bool g_prof_on = false;
+// per-layer view of the same records: the entry points name the layer (pass + geometry) before they launch
+struct LayerAgg { long long launches; double ms, flops; };
+static std::vector<std::string> g_tag_names;
+static std::map<std::string, int> g_tag_index;
+static std::vector<LayerAgg> g_tag_agg;
+static int g_cur_tag = -1;
+static void prof_tag(const char* pass, const iprgan_conv_desc* d) {
+  if (!g_prof_on) return;
+  char buf[160];
+  snprintf(buf, sizeof(buf), "%-5s B%d %dx%d %d->%d k%dx%d s%d p%d%s%s%s", pass, d->B, d->H, d->W, d->Cin, d->Cout, d->KH,
+           d->KW, d->stride, d->pad, d->transposed ? " T" : "", d->pad_mode ? " reflect" : "",
+           d->x_bf16 || d->y_bf16 ? " b16" : "");
+  auto it = g_tag_index.find(buf);
+  if (it == g_tag_index.end()) {
+    g_cur_tag = (int)g_tag_names.size();
+    g_tag_index[buf] = g_cur_tag;
+    g_tag_names.push_back(buf);
+    g_tag_agg.push_back(LayerAgg{0, 0, 0});
+  } else {
+    g_cur_tag = it->second;
+  }
+}
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_free_events;
 static hipEvent_t prof_event() {
@@ -57,7 +79,7 @@ static void prof_launch(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream
                         const Args&... a) {
   if (g_prof_on && g_recs.size() < 65536) {
     ProfRec r;
-    r.a = prof_event(); r.b = prof_event(); r.slot = slot; r.flops = flops;
+    r.a = prof_event(); r.b = prof_event(); r.slot = slot; r.flops = flops; r.tag = g_cur_tag;
     hipExtLaunchKernelGGL(kern, grid, block, (unsigned)smem, st, r.a, r.b, 0, a...);
     g_recs.push_back(r);
   } else {
@@ -1256,21 +1278,27 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_t_kernel(const WGradArgs
     }
 }
 
-// out[m][n] = act(sum_z slab[z][m][n] + bias[n]) in fixed split order (deterministic); pad channels stay zero
+// out[m][n] = act(sum_z slab[z][m][n] + bias[n]) * act'(aux[m][n]) + res[m][n] in fixed split order (deterministic);
+// pad channels stay zero.  The same epilogue as gconv_kernel's, applied once to the reduced tile.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restrict__ slab, const float* __restrict__ bias,
                                                             f32x4* __restrict__ out, unsigned n4, unsigned Ns4, int N,
-                                                            int ksplit, int act, float slope) {
+                                                            int ksplit, int act, float slope, const f32x4* __restrict__ aux,
+                                                            int aux_act, float aux_slope, const f32x4* __restrict__ res) {
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
     f32x4 v = slab[i];
     for (int z = 1; z < ksplit; ++z) v += slab[(size_t)z * n4 + i];
     const int n = (int)(i % Ns4) * 4;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (aux) o = aux[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float t = v[k];
       if (bias && n + k < N) t += bias[n + k];
       t = act_apply(t, act, slope);
+      if (aux) t *= act_grad_from_out(o[k], aux_act, aux_slope);
       v[k] = n + k < N ? t : 0.f;
     }
+    if (res) v += res[i];
     out[i] = v;
   }
 }
@@ -1790,6 +1818,65 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   return run(best);
 }
 
+// ---- split-K for regular convolutions with few output tiles.  A 3x3 512->512 layer on a 6x6 map at batch 64 (VGG
+// block 5 of the SRGAN content loss, networks/vgg.py) has 2304 output rows: 288 tiles of 64x64 for 256 CUs, a round and
+// an eighth, at 62 TFLOP/s, while its reduction is 4608 long.  Such layers split the K loop over blockIdx.z like the
+// full-map path below (slabs of M*Ns partial sums, fixed-order reduce that applies the whole epilogue once); the split
+// count 1..4 is autotuned per geometry together with the tile.
+#define SPLITK_MAX 4
+static int g_force_splitk = -1;
+static bool splitk_geom_ok(const GConvArgs& a) {
+  if (a.nphase != 1 || a.osy != 1 || a.osx != 1 || a.ph[0].ooy || a.ph[0].oox) return false;
+  const long long M = a.ph[0].M, blocks = (long long)cdiv((int)M, 64) * cdiv(a.Ns, 64);
+  return a.Ns >= 64 && (a.Cs % 32) == 0 && blocks <= 1280 && a.ph[0].steps >= 32 && M * a.Ns <= (4ll << 20);
+}
+static size_t splitk_ws_floats(const GConvArgs& a) {
+  return splitk_geom_ok(a) ? (size_t)SPLITK_MAX * (size_t)a.ph[0].M * a.Ns : 0;
+}
+static bool splitk_eligible(const GConvArgs& a, const float* ws) {
+  return ws && splitk_geom_ok(a) && !a.stat_part && !a.rs0 && !a.in16 && !a.out16 && !a.aux16 && !a.planar_M && !a.wmod &&
+         a.ksplit <= 1 && a.res != a.out && a.aux != a.out && g_force_tile < 0;
+}
+static int gconv_splitk(const GConvArgs& a0, float* ws, hipStream_t st) {
+  const int M = a0.ph[0].M;
+  auto run = [&](int cand) -> int {
+    const int ks = cand + 1;
+    if (ks == 1) return launch_gconv(a0, st);
+    GConvArgs a = a0;
+    a.ksplit = ks; a.out = ws; a.bias = nullptr; a.act = IPRGAN_ACT_NONE; a.aux = nullptr; a.res = nullptr;
+    const int rc = launch_gconv(a, st);
+    if (rc) return rc;
+    const unsigned n4 = (unsigned)((size_t)M * a0.Ns / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int)n4, 256) < 2048 ? cdiv((int)n4, 256) : 2048), dim3(256), 0, st,
+                       (const f32x4*)ws, a0.bias, (f32x4*)a0.out, n4, (unsigned)(a0.Ns / 4), a0.N, ks, a0.act, a0.slope,
+                       (const f32x4*)a0.aux, a0.aux_act, a0.aux_slope, (const f32x4*)a0.res);
+    IPR_LAUNCH_CHECK();
+    return 0;
+  };
+  const long long blocks = (long long)cdiv(M, 64) * cdiv(a0.Ns, 64);
+  int guess = blocks <= 384 ? (int)((768 + blocks / 2) / blocks) : 1;        // ~3 blocks of 4 waves per CU
+  guess = guess > SPLITK_MAX ? SPLITK_MAX : guess < 1 ? 1 : guess;
+  if (g_force_splitk >= 1) return run((g_force_splitk > SPLITK_MAX ? SPLITK_MAX : g_force_splitk) - 1);
+  if (!g_autotune) return run(guess - 1);
+  TuneKey key = {{a0.B, a0.IH, a0.IW, a0.Cs, a0.OH, a0.OW, a0.Ns, a0.isy, a0.osy, a0.nphase, a0.ph[0].th, a0.ph[0].tw,
+                  a0.ph[0].ohg, a0.ph[0].owg, a0.pad_mode + 16 * g_math + (1 << 20) + (1 << 21) * (a0.aux != nullptr) +
+                      (1 << 22) * (a0.res != nullptr), a0.Kp}};
+  int cached;
+  if (tune_lookup(key, &cached)) return run(cached);
+  const bool prof_was = g_prof_on;
+  g_prof_on = false;
+  float best_us = 0.f;
+  int err = 0;
+  const int best = tune_pick(SPLITK_MAX, run, st, guess - 1, &best_us, &err);
+  g_prof_on = prof_was;
+  if (err) return err;
+  tune_store(key, best);
+  if (getenv("IPRGAN_TUNE_LOG"))
+    fprintf(stderr, "[iprgan tune] split-K B%d in %dx%dx%d out %dx%dx%d taps %dx%d -> %d split(s) (%.1f us)\n", a0.B, a0.IH,
+            a0.IW, a0.Cs, a0.OH, a0.OW, a0.Ns, a0.ph[0].th, a0.ph[0].tw, best + 1, best_us);
+  return run(best);
+}
+
 // ---- full-map convolutions (kernel = whole input map, output 1x1: the "FC" layer of networks/discriminator_96.py:20)
 // are skinny GEMMs, M = batch rows: Y[B][Cout] = X[B][H*W*Cin] W^T.  As a convolution they fill 1/16 of the GPU
 // (B = 64: one 64-row tile per 64 output channels) and their backward-data multiplies 35 of 36 taps by zero.  Here the
@@ -2048,12 +2135,34 @@ static size_t smalln_ws_for(const iprgan_conv_desc* d, bool fwd) {
   const int ntap = d->KH * d->KW;
   return (size_t)rup(ntap * 4, 128) * c4(c_red) + (size_t)ntap * pix * 4;
 }
+// geometry of the regular (not full-map) forward / backward-data pass of a layer
+static GConvArgs conv_fwd_geom(const iprgan_conv_desc* d) {
+  GConvArgs a;
+  memset(&a, 0, sizeof(a));
+  const Shape s = out_shape(d);
+  if (!d->transposed) {
+    geom_forward_form(a, d->B, d->H, d->W, d->Cin, s.OH, s.OW, d->Cout, d->KH, d->KW, d->stride, d->pad);
+    a.pad_mode = d->pad_mode;
+  } else {
+    geom_bwd_form(a, d->B, d->H, d->W, d->Cin, s.OH, s.OW, d->Cout, d->KH, d->KW, d->stride, d->pad);
+  }
+  return a;
+}
+static GConvArgs conv_bwd_geom(const iprgan_conv_desc* d) {          // zero-padded layers only
+  GConvArgs a;
+  memset(&a, 0, sizeof(a));
+  const Shape s = out_shape(d);
+  if (!d->transposed) geom_bwd_form(a, d->B, s.OH, s.OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad);
+  else geom_forward_form(a, d->B, s.OH, s.OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad);
+  return a;
+}
 size_t iprgan_conv_fwd_ws_floats(const iprgan_conv_desc* d) {
   if (fullmap_conv(d)) {
     const int ks = fullmap_ksplit(d);
     return ks > 1 ? (size_t)ks * d->B * c4(d->Cout) : 0;
   }
-  return smalln_ws_for(d, true);
+  const size_t sk = splitk_ws_floats(conv_fwd_geom(d)), sn = smalln_ws_for(d, true);
+  return sk > sn ? sk : sn;
 }
 
 
@@ -2102,6 +2211,7 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
   IPR_CHECK(!pair_sigma0 == !pair_sigma1 && (!pair_sigma0 || ((d->B & 1) == 0 && !fullmap_conv(d))),
             "conv_fwd: a paired pass needs both sigmas, an even batch and a regular convolution");
   IPR_CHECK(d->stride >= 1 && d->stride <= 2, "conv_fwd: stride %d unsupported", d->stride);
+  prof_tag("fwd", d);
   GConvArgs a;
   memset(&a, 0, sizeof(a));
   const Shape s = out_shape(d);
@@ -2117,7 +2227,7 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
       const unsigned n4 = (unsigned)d->B * (unsigned)(c4(d->Cout) / 4);
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int)n4, 256) < 1024 ? cdiv((int)n4, 256) : 1024), dim3(256), 0,
                          (hipStream_t)stream, (const f32x4*)ws, bias, (f32x4*)y, n4, (unsigned)(c4(d->Cout) / 4), d->Cout,
-                         ks, d->act, d->slope);
+                         ks, d->act, d->slope, (const f32x4*)nullptr, 0, 0.f, (const f32x4*)nullptr);
       IPR_LAUNCH_CHECK();
       return 0;
     }
@@ -2138,14 +2248,22 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
   a.act = d->act; a.slope = d->slope;
   a.ws = ws; a.ws_floats = ws ? iprgan_conv_fwd_ws_floats(d) : 0;
   a.stat_part = stat_part; a.stat_mode = 1;
+  if (splitk_eligible(a, ws)) return gconv_splitk(a, ws, (hipStream_t)stream);
   const int rc = launch_gconv(a, (hipStream_t)stream);
   if (stat_part && !rc) *stat_rows = stat_rows_of(a);
   return rc;
 }
 
+static size_t reflect_padded_floats(const iprgan_conv_desc* d) {
+  return rup4((size_t)d->B * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * c4(d->Cin));
+}
 size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d) {
-  if (d->pad_mode != IPRGAN_PAD_REFLECT) return smalln_ws_for(d, false);
-  return (size_t)d->B * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * c4(d->Cin);
+  if (d->pad_mode != IPRGAN_PAD_REFLECT) {
+    const size_t sk = fullmap_conv(d) ? 0 : splitk_ws_floats(conv_bwd_geom(d)), sn = smalln_ws_for(d, false);
+    return sk > sn ? sk : sn;
+  }
+  // [gradient w.r.t. the reflection-padded image | workspace of the few-channel path on that padded grid]
+  return reflect_padded_floats(d) + smalln_ws_for(d, false);
 }
 
 int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
@@ -2158,6 +2276,7 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
             (!pair_sigma0 || ((d->B & 1) == 0 && !fullmap_conv(d) && d->pad_mode != IPRGAN_PAD_REFLECT)),
             "conv_bwd_data: a paired pass needs both sigmas, an even batch and a zero-padded regular convolution");
   IPR_CHECK(d->stride >= 1 && d->stride <= 2, "conv_bwd_data: stride %d unsupported", d->stride);
+  prof_tag("dgrad", d);
   GConvArgs a;
   memset(&a, 0, sizeof(a));
   const Shape s = out_shape(d);
@@ -2190,9 +2309,11 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = IPRGAN_ACT_NONE; a.slope = 0.f;
   if (!reflect) { a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.ws = ws; a.ws_floats = ws ? smalln_ws_for(d, false) : 0; }
+  else { a.ws = ws + reflect_padded_floats(d); a.ws_floats = smalln_ws_for(d, false); }    // RGB stems: few-channel path
   a.stat_part = stat_part; a.stat_mode = 2;
   if (!reflect) a.res = residual;
   IPR_CHECK(!residual || reflect || !(smalln_eligible(a) && ws), "conv_bwd_data: no residual input on the few-channel path");
+  if (!reflect && splitk_eligible(a, ws)) return gconv_splitk(a, ws, (hipStream_t)stream);
   const int rc = launch_gconv(a, (hipStream_t)stream);
   if (stat_part && !rc) *stat_rows = stat_rows_of(a);
   if (rc || !reflect) return rc;
@@ -2219,6 +2340,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
                            float* db, float* ws, float beta, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   IPR_CHECK(iprgan_conv_wgrad_takes_bf16(d), "conv_bwd_weight: this layer needs an fp32 x (iprgan_conv_wgrad_takes_bf16)");
+  prof_tag("wgrad", d);
   const Shape s = out_shape(d);
   const WGeom g = wgrad_geom(d);
   const float* xin = x;
@@ -2349,9 +2471,15 @@ int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand) {
   return 0;
 }
 
+int iprgan_debug_force_splitk(int splits) {
+  g_force_splitk = splits;
+  return 0;
+}
+
 int iprgan_prof_enable(int on) {
   if (on) {
     for (int i = 0; i < g_nslots; ++i) { g_slots[i].launches = 0; g_slots[i].ms = 0; g_slots[i].flops = 0; }
+    for (auto& t : g_tag_agg) t = LayerAgg{0, 0, 0};
   }
   g_prof_on = on != 0;
   return 0;
@@ -2361,6 +2489,9 @@ int iprgan_prof_collect(void) {
     float ms = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       g_slots[r.slot].launches += 1; g_slots[r.slot].ms += ms; g_slots[r.slot].flops += r.flops;
+      if (r.tag >= 0 && r.tag < (int)g_tag_agg.size()) {
+        g_tag_agg[r.tag].launches += 1; g_tag_agg[r.tag].ms += ms; g_tag_agg[r.tag].flops += r.flops;
+      }
     }
     g_free_events.push_back(r.a); g_free_events.push_back(r.b);
   }
@@ -2368,6 +2499,13 @@ int iprgan_prof_collect(void) {
   return 0;
 }
 int iprgan_prof_num_kernels(void) { return g_nslots; }
+int iprgan_prof_num_layers(void) { return (int)g_tag_names.size(); }
+int iprgan_prof_get_layer(int i, char* name, int name_len, long long* launches, double* ms, double* flops) {
+  IPR_CHECK(i >= 0 && i < (int)g_tag_names.size(), "prof_get_layer: bad index %d", i);
+  snprintf(name, name_len, "%s", g_tag_names[i].c_str());
+  *launches = g_tag_agg[i].launches; *ms = g_tag_agg[i].ms; *flops = g_tag_agg[i].flops;
+  return 0;
+}
 int iprgan_prof_get(int i, char* name, int name_len, long long* launches, double* ms, double* flops) {
   IPR_CHECK(i >= 0 && i < g_nslots, "prof_get: bad index %d", i);
   snprintf(name, name_len, "%s", g_slots[i].name);

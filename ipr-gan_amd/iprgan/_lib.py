@@ -94,12 +94,15 @@ SIGNATURES = {
     'iprgan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I,
                          C.c_double, _P]),
     'iprgan_debug_force_tiles': (_I, [_I, _I]),
+    'iprgan_debug_force_splitk': (_I, [_I]),
     'iprgan_set_math_mode': (_I, [_I]),
     'iprgan_get_math_mode': (_I, []),
     'iprgan_prof_enable': (_I, [_I]),
     'iprgan_prof_collect': (_I, []),
     'iprgan_prof_num_kernels': (_I, []),
     'iprgan_prof_get': (_I, [_I, C.c_char_p, _I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'iprgan_prof_num_layers': (_I, []),
+    'iprgan_prof_get_layer': (_I, [_I, C.c_char_p, _I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'iprgan_fill': (_I, [_P, _F, _Z, _P]),
     'iprgan_axpy': (_I, [_P, _P, _F, _Z, _P]),
     'iprgan_axpy_multi': (_I, [_P, _P, _P, _I, _F, _P]),
@@ -185,6 +188,18 @@ def prof_results():
         n, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
         call('iprgan_prof_get', i, name, 96, C.byref(n), C.byref(ms), C.byref(fl))
         out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value))
+    return out
+
+
+def prof_layers():
+    """prof_results() grouped by layer (pass + geometry); call after prof_results() (which collects)."""
+    out = []
+    for i in range(query('iprgan_prof_num_layers')):
+        name = C.create_string_buffer(160)
+        n, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
+        call('iprgan_prof_get_layer', i, name, 160, C.byref(n), C.byref(ms), C.byref(fl))
+        if n.value:
+            out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value))
     return out
 
 

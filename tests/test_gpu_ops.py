@@ -361,7 +361,7 @@ def test_cpu_tensor_is_refused(dev):
 
 
 REFLECT_CONVS = [(64, 64, 3, 1, 1, 8, 9, 2), (3, 32, 7, 1, 3, 12, 10, 2), (64, 3, 7, 1, 3, 9, 9, 1), (256, 256, 3, 1, 1, 6, 6, 2),
-                 (64, 3, 7, 1, 3, 14, 11, 2)]         # RGB head, ragged: swapped-role wgrad on the reflect-padded copy
+                 (64, 3, 7, 1, 3, 14, 11, 2), (3, 64, 7, 1, 3, 13, 16, 2)]         # RGB head, ragged: swapped-role wgrad on the reflect-padded copy
 
 
 @pytest.mark.parametrize('cfg', REFLECT_CONVS, ids=lambda c: '-'.join(map(str, c)))
@@ -609,6 +609,7 @@ def test_conv_epilogue_column_sums(dev, shape, tile):
     d = spec.desc(B, H, W)
     try:
         _lib.call('iprgan_debug_force_tiles', tile, -1)
+        _lib.call('iprgan_debug_force_splitk', 1)       # bit-equality below: the plain pass must not take the split-K path
         wf, wb = ops.conv_prep(spec, d, w.to(dev), None, True, True)
         xd = to_nhwc(x).to(dev)
         y0 = ops.conv_fwd(spec, d, xd, wf, b.to(dev))
@@ -633,6 +634,56 @@ def test_conv_epilogue_column_sums(dev, shape, tile):
         assert float((cs - refc).abs().max()) <= 2e-4 * float(want.abs().max()) * want[:, 0].numel() ** 0.5
     finally:
         _lib.call('iprgan_debug_force_tiles', -1, -1)
+        _lib.call('iprgan_debug_force_splitk', -1)
+
+
+SPLITK_SHAPES = [   # cin, cout, k, stride, pad, transposed, H, W, B, pad_mode: few output tiles, long reductions
+    (512, 512, 3, 1, 1, False, 6, 6, 16, 0),      # VGG block 5 of the SRGAN content loss (networks/vgg.py) at a small batch
+    (256, 128, 3, 2, 1, False, 12, 10, 8, 0),     # strided: still one phase in the forward pass; backward is 4 phases
+    (128, 192, 3, 1, 1, False, 9, 7, 6, 1),       # reflect padding forward (backward goes through the fold, not split)
+    (256, 64, 4, 2, 1, True, 5, 6, 8, 0),         # transposed: the backward-data pass is the single-phase one
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('splits', [1, 2, 3, 4])
+@pytest.mark.parametrize('shape', SPLITK_SHAPES, ids=lambda c: '-'.join(map(str, c)))
+def test_conv_splitk(dev, shape, splits):
+    """Split-K path of regular convolutions with few output tiles (forced split counts): forward with bias + LeakyReLU
+    and backward-data with the fused activation derivative and a residual input against torch; every split count must
+    agree with the unsplit kernel to fp32 rounding."""
+    from iprgan import _lib, ops
+    cin, cout, k, s, p, tr, H, W, B, pm = shape
+    x = rnd(B, cin, H, W, seed=1)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w, b = rnd(*wshape, seed=2, scale=(cin * k * k) ** -0.5), rnd(cout, seed=3, scale=0.3)
+    if tr:
+        conv = lambda t: F.conv_transpose2d(t, w, b, stride=s, padding=p)
+    elif pm:
+        conv = lambda t: F.conv2d(F.pad(t, (p, p, p, p), mode='reflect'), w, b, stride=s)
+    else:
+        conv = lambda t: F.conv2d(t, w, b, stride=s, padding=p)
+    xin = F.leaky_relu(x, 0.2).requires_grad_()
+    y_ref = F.leaky_relu(conv(xin), 0.1)
+    g = rnd(*y_ref.shape, seed=4)
+    res = rnd(*x.shape, seed=5)
+    conv(xin).backward(g)
+    dx_ref = xin.grad * torch.where(xin > 0, 1.0, 0.2) + res
+    spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr, pad_mode=pm, act=2, slope=0.1)
+    d = spec.desc(B, H, W)
+    import ctypes as C
+    assert _lib.query('iprgan_conv_fwd_ws_floats', C.byref(d)) > 0 or _lib.query('iprgan_conv_bwd_data_ws_floats', C.byref(d)) > 0
+    try:
+        _lib.call('iprgan_debug_force_splitk', splits)
+        wf, wb = ops.conv_prep(spec, d, w.to(dev), None, True, True)
+        xd = to_nhwc(xin.detach()).to(dev)
+        y = ops.conv_fwd(spec, d, xd, wf, b.to(dev))
+        close(from_nhwc(y.cpu(), cout), y_ref.detach(), what='split-K forward')
+        dspec = ops.ConvSpec(cin, cout, k, s, p, 0, tr, pad_mode=pm)
+        dx = ops.conv_bwd_data(dspec, dspec.desc(B, H, W), to_nhwc(g).to(dev), wb, xd, 2, 0.2, residual=to_nhwc(res).to(dev))
+        close(from_nhwc(dx.cpu(), cin), dx_ref, what='split-K backward-data')
+    finally:
+        _lib.call('iprgan_debug_force_splitk', -1)
 
 
 @pytest.mark.parametrize('shape,denorm', [((2, 3, 176, 193), False), ((1, 3, 256, 256), True), ((2, 1, 161, 200), False)])
