@@ -1651,6 +1651,20 @@ static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
               : launch_gconv_tfnk<WGM, WGN, WM, WN, false, 1, 32, false, false>(a, st);
 }
 
+// bf16 tiles with 128x64 / 128x128 per wave.  A 64x64 wave tile reads 4 operand fragments from LDS per 4 MFMAs of 32
+// cycles: with one wave per SIMD that is 4 x 32 LDS cycles per 128 MFMA cycles - the LDS port is as busy as the matrix
+// core, and the staging stores come on top.  128x64 per wave reads 6 fragments per 8 MFMAs (75 %), 128x128 reads 8 per
+// 16 (50 %).  (The fp32 MFMA is 4x slower per fragment, so the fp32 tiles are nowhere near this limit.)
+template <int WGM, int WGN, int WM, int WN>
+static int launch_gconv_bf16big(const GConvArgs& a, hipStream_t st) {
+  if (g_math != IPRGAN_MATH_BF16 || (a.Cs % 64) != 0 || a.Ns < WGN * WN * 32) return -1;
+  if (a.in16)
+    return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, true, true>(a, st)
+                       : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, false, true>(a, st);
+  return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, true>(a, st)
+                     : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, false>(a, st);
+}
+
 static int launch_gconv(const GConvArgs& ain, hipStream_t st);
 
 static bool smalln_eligible(const GConvArgs& a) {
@@ -1777,6 +1791,8 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
       case 3: return launch_gconv_t<2, 2, 1, 2>(a, st);
       case 4: return launch_gconv_t<2, 4, 2, 1>(a, st);      // 128x128, 8 waves of 64x32
       case 5: return launch_gconv_t<4, 2, 1, 1>(a, st);      // 128x64, 8 waves of 32x32
+      case 6: return launch_gconv_bf16big<2, 2, 4, 2>(a, st);   // bf16 only: 256x128, 4 waves of 128x64
+      case 7: return launch_gconv_bf16big<2, 2, 4, 4>(a, st);   // bf16 only: 256x256, 4 waves of 128x128
       default: return launch_gconv_t<2, 2, 1, 1>(a, st);
     }
   };
@@ -1787,7 +1803,8 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   else if (blocks(128, 64) >= 384) tile = 1;
   if (g_force_tile >= 0) {
     if ((g_force_tile == 0 || g_force_tile == 3 || g_force_tile == 4) && N < 128) return run(2);
-    return run(g_force_tile);
+    const int rc = run(g_force_tile);
+    return rc == -1 ? run(2) : rc;          // a bf16-only tile forced on an fp32 launch
   }
   if (!g_autotune) return run(tile);
 
@@ -1805,8 +1822,9 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   g_prof_on = false;
   float best_us = 0.f;
   int err = 0;
-  const int best = tune_pick(6, [&](int cand) -> int {
+  const int best = tune_pick(8, [&](int cand) -> int {
     if ((cand == 0 || cand == 3 || cand == 4) && N < 128) return -1;
+    if (cand >= 6 && (long long)cdiv(maxM, 256) * cdiv(N, 128) * a.nphase < 256) return -1;    // not even one block per CU
     return run(cand);
   }, st, tile, &best_us, &err);
   g_prof_on = prof_was;

@@ -164,7 +164,16 @@ def ptr32(t):
     return ptr(t)
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream():
+    """Raw hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream
+    object through several Python layers (11 us per call, measured: a third of the host time of a DCGAN-64 step, which
+    launches ~150 kernels); the two C accessors below return the same handle in well under a microsecond."""
+    if _raw_stream is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -4,7 +4,8 @@ import cProfile, gc, io, os, pstats, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'ipr-gan_amd')]
 import bench
-from iprgan import Config, models
+from iprgan import Config, models, _lib
+_lib.set_math(os.environ.get('HOST_PROF_MATH', 'fp32'))
 name = sys.argv[1] if len(sys.argv) > 1 else 'srgan'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device('cuda:0')
@@ -21,6 +22,7 @@ th = time.perf_counter() - t0
 torch.cuda.synchronize()
 t = time.perf_counter() - t0
 print(f'{name}: wall {t / steps * 1e3:.3f} ms/step, host loop {th / steps * 1e3:.3f} ms/step')
+torch.autograd.set_multithreading_enabled(False)      # backward on this thread: visible to cProfile
 pr = cProfile.Profile()
 pr.enable()
 for i in range(steps):

@@ -537,6 +537,39 @@ def test_conv_bf16_math_mode(dev, shape):
         _lib.set_math('fp32')
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['bf16', 'bf16act'])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4, 5, 6, 7])
+def test_bf16_gconv_tiles(dev, tile, mode):
+    """Every bf16 tile of the forward / backward-data kernel, including the 128x64 and 128x128 per-wave tiles that only
+    the bf16 modes build (6, 7), on bf16-representable inputs (products exact: only the summation order differs), with
+    fp32 and with bf16 activations in HBM; ragged M (not a multiple of 256) and N = 256 so that 256-wide tiles apply."""
+    from iprgan import _lib, ops
+    cin, cout, k, s, p, H, W, B = 64, 256, 3, 1, 1, 15, 13, 5
+    x, w = rnd(B, cin, H, W, seed=1).bfloat16().float(), rnd(cout, cin, k, k, seed=2, scale=0.05).bfloat16().float()
+    b = rnd(cout, seed=5, scale=0.3)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, b, stride=s, padding=p)
+    g = rnd(*yr.shape, seed=3).bfloat16().float()
+    yr.backward(g)
+    try:
+        _lib.set_math(mode)
+        _lib.call('iprgan_debug_force_tiles', tile, -1)
+        spec = ops.ConvSpec(cin, cout, k, s, p)
+        d = spec.desc(B, H, W)
+        assert bool(d.x_bf16) == (mode == 'bf16act')
+        wf, wb = ops.conv_prep(spec, d, w.to(dev), None, True, True)
+        y = ops.conv_fwd(spec, d, to_nhwc(x).to(dev), wf, b.to(dev))
+        dx = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb)
+        # outputs stored as bf16 carry one more rounding (2^-9 relative)
+        tol = 2e-4 if mode == 'bf16' else 6e-3
+        close(from_nhwc(y.float().cpu(), cout), yr, tol, f'{mode} fwd tile {tile}')
+        close(from_nhwc(dx.float().cpu(), cin), xr.grad, tol, f'{mode} dgrad tile {tile}')
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
+        _lib.set_math('fp32')
+
+
 NORTH_STAR = [
     # SURVEY 8d "conv microbench (north-star)": the 3x3 convs Resnet9Blocks runs on a 64x3x256x256 batch
     # cin, cout, stride, pad_mode, H
