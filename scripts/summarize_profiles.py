@@ -15,13 +15,13 @@ import sys
 
 def short(k):
     """rocprof kernel name -> the name bench.py reports (iprgan_prof_get slots)."""
-    m = re.match(r'void iprgan::gconv_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)(?:, (true|false))?(?:, (true|false))?>', k)
+    m = re.match(r'void iprgan::gconv_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)(?:, (true|false))?(?:, (true|false))?(?:, (true|false))?>', k)
     if m:
         if m.group(8) == 'true':
             return 'gconv_bf16_kernel'
         wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
         return f'gconv_kernel<{wgm * wm * 32}x{wgn * wn * 32}' + (',8w>' if wgm * wgn == 8 else '>')
-    m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?>', k)
+    m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?(?:, (true|false))?>', k)
     if m:
         if m.group(7) == 'true':
             return 'wgrad_bf16_kernel'
