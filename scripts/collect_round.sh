@@ -2,12 +2,14 @@
 # After `gpurun -- 'bash scripts/gpu_round.sh <tag>'`: copy the judged summaries from gpurun_out/ into profiles/.
 TAG=${1:-r02}
 cd "$(dirname "$0")/.."
-for t in $TAG ${TAG}_srgan ${TAG}_cyclegan; do
+for t in $TAG ${TAG}_srgan ${TAG}_cyclegan ${TAG}_dcgan128_bf16act; do
   python scripts/summarize_profiles.py gpurun_out/prof $t profiles/$t
   cp gpurun_out/${t}_bench_under_rocprof.json profiles/ 2>/dev/null
 done
 for f in ${TAG}_bench.json ${TAG}_bench_srgan.json ${TAG}_bench_cyclegan.json ${TAG}_bench_dcgan128.json \
-         ${TAG}_bench_dcgan128_bf16.json ${TAG}_bench_dcgan64_bf16.json ${TAG}_conv_bench.jsonl; do
+         ${TAG}_bench_dcgan128_bf16.json ${TAG}_bench_dcgan64_bf16.json ${TAG}_bench_dcgan128_bf16act.json \
+         ${TAG}_bench_dcgan64_bf16act.json ${TAG}_conv_bench.jsonl ${TAG}_northstar_conv_pmc.json ${TAG}_layers_dcgan64.txt \
+         ${TAG}_layers_srgan.txt ${TAG}_layers_cyclegan.txt ${TAG}_layers_dcgan128_bf16act.txt; do
   cp gpurun_out/$f profiles/ 2>/dev/null
 done
 ls -la profiles | grep $TAG

@@ -34,10 +34,12 @@ prof_workload () {   # $1 = workload, $2 = file tag, $3.. = bench args for the p
 prof_workload dcgan64 ${TAG} --steps 20 --warmup 8
 prof_workload srgan ${TAG}_srgan --steps 8 --warmup 4
 prof_workload cyclegan ${TAG}_cyclegan --steps 4 --warmup 2
+prof_workload dcgan128 ${TAG}_dcgan128_bf16act --math bf16act --steps 8 --warmup 4
 # the counters of THIS build first, so that the bench line's roofline.traffic (read from profiles/) matches it
 python scripts/summarize_profiles.py $O/prof $TAG $R/profiles/$TAG > /dev/null
 python scripts/summarize_profiles.py $O/prof ${TAG}_srgan $R/profiles/${TAG}_srgan > /dev/null
 python scripts/summarize_profiles.py $O/prof ${TAG}_cyclegan $R/profiles/${TAG}_cyclegan > /dev/null
+python scripts/summarize_profiles.py $O/prof ${TAG}_dcgan128_bf16act $R/profiles/${TAG}_dcgan128_bf16act > /dev/null
 cp $R/profiles/${TAG}*_pmc_traffic.json $R/profiles/${TAG}*_mfma_util.json $R/profiles/${TAG}*_bench_kernel_stats.csv $O/ 2>/dev/null
 timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err; cut -c1-400 $O/${TAG}_bench.json
 for w in srgan cyclegan dcgan128; do
@@ -45,7 +47,25 @@ for w in srgan cyclegan dcgan128; do
 done
 timeout 900 python bench.py --workload dcgan128 --math bf16 --no-cpu-baseline > $O/${TAG}_bench_dcgan128_bf16.json 2>> $O/bench_dcgan128.err
 timeout 900 python bench.py --math bf16 --no-cpu-baseline > $O/${TAG}_bench_dcgan64_bf16.json 2>> $O/bench.err
+timeout 900 python bench.py --workload dcgan128 --math bf16act --no-cpu-baseline > $O/${TAG}_bench_dcgan128_bf16act.json 2>> $O/bench_dcgan128.err
+timeout 900 python bench.py --math bf16act --no-cpu-baseline > $O/${TAG}_bench_dcgan64_bf16act.json 2>> $O/bench.err
 timeout 600 python scripts/conv_bench.py > $O/${TAG}_conv_bench.jsonl 2> $O/conv_bench.err
+# per-layer tables (conv-family launches by pass + geometry) of the four workloads
+for w in dcgan64 srgan cyclegan; do
+  IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload $w --no-cpu-baseline 2>&1 >/dev/null | grep -A200 "conv-family layers" | cut -c18- > $O/${TAG}_layers_$w.txt
+done
+IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload dcgan128 --math bf16act --no-cpu-baseline 2>&1 >/dev/null | grep -A200 "conv-family layers" | cut -c18- > $O/${TAG}_layers_dcgan128_bf16act.txt
+# north-star conv shape (3x3 256->256 @64x64, batch 64): counter passes for the per-kernel MFMA / LDS / VALU picture
+export IPRGAN_TUNE_CACHE=$O/tune_cache_ns.txt
+rm -f $IPRGAN_TUNE_CACHE
+timeout 300 python scripts/conv_bench.py "256->256 k3" > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU -d $O/prof -o ns1 --output-format csv -- python3 $R/scripts/conv_bench.py "256->256 k3" > /dev/null 2> $O/prof_ns1.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY -d $O/prof -o ns2 --output-format csv -- python3 $R/scripts/conv_bench.py "256->256 k3" > /dev/null 2> $O/prof_ns2.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/prof -o ns3 --output-format csv -- python3 $R/scripts/conv_bench.py "256->256 k3" > /dev/null 2> $O/prof_ns3.err
+cd $R
+unset IPRGAN_TUNE_CACHE
+python scripts/summarize_ns_pmc.py $O/prof $O/${TAG} > /dev/null 2> $O/ns_pmc.err
 # the raw per-dispatch traces are large; only the stats and counter CSVs are needed back
 find $O/prof -name '*kernel_trace.csv' -size +20M -delete
 find $O/prof -name '*counter_collection.csv' -size +30M -delete

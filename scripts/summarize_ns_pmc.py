@@ -1,5 +1,5 @@
 """profiles/<out>_northstar_conv_pmc.json from the counter passes of scripts/conv_bench.py NS
-(3x3 256->256 @64x64, batch 64), collected as
+(3x3 256->256 @64x64, batch 64, zero- and reflect-padded), collected as
     rocprofv3 --kernel-trace --pmc <set i> -d gpurun_out/prof -o ns<i> --output-format csv -- python3 scripts/conv_bench.py NS
 with the sets  1: SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU
                2: SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY
@@ -18,7 +18,7 @@ def main():
     for i in (1, 2, 3):
         for r in csv.DictReader(open(f'{prof}/ns{i}_counter_collection.csv')):
             k = r['Kernel_Name']
-            if 'gconv_kernel' in k or 'wgrad_kernel' in k:
+            if 'gconv_kernel' in k or 'wgrad_kernel' in k or 'wgrad_t_kernel' in k:
                 k = re.sub(r'\(.*', '', k).replace('void iprgan::', '')
                 e = tot[k][r['Counter_Name']]
                 e[0] += 1
