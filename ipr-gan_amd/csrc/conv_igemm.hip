@@ -501,6 +501,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 #pragma unroll
       for (int k = 0; k < 4; ++k) cs1[j][k] = cs2[j][k] = 0.f;
   }
+  // Per-store work is kept minimal: the bias of this lane's channel quads is loaded once, and the common activations
+  // (none / ReLU / LeakyReLU, also as the fused derivative) are a compare-select instead of the general switch, whose
+  // inlined tanh / sigmoid branches made each of the 16-64 stores of a wave several hundred instructions of code.  On
+  // the layers with short reductions (K = 576: 18 steps) the epilogue is a fifth of a wave's life.
+  const bool aux_simple = a.aux_act == IPRGAN_ACT_NONE || a.aux_act == IPRGAN_ACT_RELU || a.aux_act == IPRGAN_ACT_LRELU;
+  const float neg_aux = a.aux_act == IPRGAN_ACT_NONE ? 1.f : a.aux_act == IPRGAN_ACT_RELU ? 0.f : a.aux_slope;
+  const size_t slab_off = a.ksplit > 1 ? (size_t)zi * pM * a.Ns : 0;
+  f32x4 bias4[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n = n0 + (wn * WN + j) * 32 + qcol;
+    if (a.bias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (n + k < a.N) bias4[j][k] = a.bias[n + k];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -529,18 +546,27 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 #pragma unroll
           for (int k = 0; k < 4; ++k) { cs1[j][k] += v[k]; cs2[j][k] += v[k] * v[k]; }
         }
-        if (a.bias) {
+        v += bias4[j];
+        if (a.act == IPRGAN_ACT_LRELU) {        // the common activations without the general switch (uniform branches)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if (n + k < a.N) v[k] += a.bias[n + k];
+          for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * a.slope;
+        } else if (a.act == IPRGAN_ACT_RELU) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        } else if (a.act != IPRGAN_ACT_NONE) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], a.act, a.slope);
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], a.act, a.slope);
-        const size_t idx = (a.planar_M ? ((size_t)(n >> 2) * a.planar_M + opix) * 4 : opix * a.Ns + n) +
-                           (a.ksplit > 1 ? (size_t)zi * pM * a.Ns : 0);
+        const size_t idx = (a.planar_M ? ((size_t)(n >> 2) * a.planar_M + opix) * 4 : opix * a.Ns + n) + slab_off;
         if (a.aux) {
           const f32x4 o = a.aux16 ? ld_bf16x4(a.aux, idx) : *(const f32x4*)(a.aux + idx);
+          if (aux_simple) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] *= act_grad_from_out(o[k], a.aux_act, a.aux_slope);
+            for (int k = 0; k < 4; ++k) v[k] *= o[k] > 0.f ? 1.f : neg_aux;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] *= act_grad_from_out(o[k], a.aux_act, a.aux_slope);
+          }
         }
         if (a.res) v += a.out16 ? ld_bf16x4(a.res, idx) : *(const f32x4*)(a.res + idx);
         if (STATS && a.stat_mode == 2) {
@@ -593,8 +619,54 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 // accumulates 16 pixels (one column of the tile) x 4 channels, reading one 16-byte input vector per (pixel, tap)
 // and four 16-byte weight vectors per tap.  Stores: a wave writes 4 pixels x 256 contiguous bytes per instruction.
 // ------------------------------------------------------------------------------------------
+// Epilogue of one 4-channel group of the few-input-channel kernels (same order of operations as gconv_kernel's: pair
+// scale, bias, activation, fused derivative, residual).  SIMPLE: activation and fused derivative are none / ReLU /
+// LeakyReLU, folded into one select-and-multiply each (neg = factor of the non-positive side); the general form inlines
+// tanh / sigmoid per element, and 64 copies of that made these short kernels 11 k instructions long (94 KB of code,
+// more than the instruction cache) - their K loop is 27..196 deep, so the epilogue IS the kernel.
+template <bool SIMPLE>
+__device__ __forceinline__ void fewin_store(const GConvArgs& a, f32x4 v, const f32x4 bias4, float rs, float neg_act,
+                                            float neg_aux, size_t idx, int n) {
+  if (a.rs0) v *= rs;
+  v += bias4;
+  if (SIMPLE) {                  // neg_act = 1 (none), 0 (ReLU: select, so that -inf and NaN behave as in act_apply) or the slope
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : (neg_act == 0.f ? 0.f : v[k] * neg_act);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], a.act, a.slope);
+  }
+  if (a.aux) {
+    const f32x4 o = a.aux16 ? ld_bf16x4(a.aux, idx) : *(const f32x4*)(a.aux + idx);
+    if (SIMPLE) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= o[k] > 0.f ? 1.f : neg_aux;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= act_grad_from_out(o[k], a.aux_act, a.aux_slope);
+    }
+  }
+  if (a.res) v += a.out16 ? ld_bf16x4(a.res, idx) : *(const f32x4*)(a.res + idx);
+  if (a.out16) *(bf16x4*)((__bf16*)a.out + idx) = to_bf16x4(v);
+  else *(f32x4*)(a.out + idx) = v;
+}
+__device__ __forceinline__ f32x4 fewin_bias4(const GConvArgs& a, int n) {
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (n + k < a.N) b[k] = a.bias[n + k];
+  }
+  return b;
+}
+static bool fewin_simple_act(int act) { return act == IPRGAN_ACT_NONE || act == IPRGAN_ACT_RELU || act == IPRGAN_ACT_LRELU; }
+static float fewin_neg(int act, float slope) { return act == IPRGAN_ACT_NONE ? 1.f : act == IPRGAN_ACT_RELU ? 0.f : slope; }
+
 #define FEWIN_T 16
-__global__ __launch_bounds__(256) void fewin_conv_kernel(const GConvArgs a, int lds_w, int lds_h) {
+#ifndef FEWIN_WAVES
+#define FEWIN_WAVES 5          // waves per SIMD the register allocation of fewin_mfma_kernel must allow
+#endif
+template <bool SIMPLE>
+__global__ __launch_bounds__(256) void fewin_conv_kernel(const GConvArgs a, int lds_w, int lds_h, float neg_act, float neg_aux) {
   extern __shared__ __attribute__((aligned(16))) f32x4 flds[];
   const Phase& ph = a.ph[0];
   const int ntap = ph.ntap, tw = ph.tw, th = ph.th;
@@ -648,33 +720,142 @@ __global__ __launch_bounds__(256) void fewin_conv_kernel(const GConvArgs a, int 
       acc[i] += w3 * xin.w;
     }
   }
-  // epilogue: same order of operations as gconv_kernel's (pair scale, bias, activation, fused derivative, residual)
   const int n = n0 + 4 * q, ox = x0 + pg;
   if (n >= a.Ns || ox >= a.OW) return;
   float rsc0 = 1.f, rsc1 = 1.f;
   if (a.rs0) { rsc0 = 1.f / *a.rs0; rsc1 = 1.f / *a.rs1; }
   const float rs = b < (a.B >> 1) ? rsc0 : rsc1;
+  const f32x4 bias4 = fewin_bias4(a, n);
 #pragma unroll
   for (int i = 0; i < FEWIN_T; ++i) {
     const int oy = y0 + i;
     if (oy >= a.OH) break;
-    f32x4 v = acc[i];
-    if (a.rs0) v *= rs;
-    if (a.bias) {
+    fewin_store<SIMPLE>(a, acc[i], bias4, rs, neg_act, neg_aux, ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Ns + n, n);
+  }
+}
+
+// The same layers under IPRGAN_MATH_BF16: the 16x16 pixel tile is a 256-row M tile, (tap, channel) is the K index
+// (4 channels per tap, K padded to 16), 64 output channels are two 32-column N tiles: 4 waves x (2 x 2) tiles of
+// v_mfma_f32_32x32x16_bf16.  A fragments come straight out of the halo image in LDS (8 consecutive k = two taps x 4
+// channels = two 8-byte reads at the taps' pixel offsets), so the gather costs no address arithmetic in HBM space and
+// the layer runs at its output-write bound instead of the fp32 vector-ALU bound of fewin_conv_kernel.
+template <bool SIMPLE>
+__global__ __launch_bounds__(256, FEWIN_WAVES) void fewin_mfma_kernel(const GConvArgs a, int lds_w, int lds_h, int kpad, float neg_act, float neg_aux) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 flds[];
+  const Phase& ph = a.ph[0];
+  const int ntap = ph.ntap, tw = ph.tw, th = ph.th;
+  const int ksteps = (ntap * 4 + 15) / 16;
+  bf16x4* X = (bf16x4*)flds;                                        // [lds_h][lds_w] halo pixels, 4 channels each
+  __bf16* Wl = (__bf16*)(X + ((lds_h * lds_w + 1) & ~1));             // [64][kpad] weights, k = tap * 4 + c, zero past ntap * 4
+  int* toff = (int*)(Wl + 64 * kpad);                               // [ksteps * 4] LDS pixel offset of every tap (clamped)
+  const int tiles_x = (a.OW + FEWIN_T - 1) / FEWIN_T, tiles_y = (a.OH + FEWIN_T - 1) / FEWIN_T;
+  const int tile = blockIdx.x, b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
+  const int y0 = (tr / tiles_x) * FEWIN_T, x0 = (tr % tiles_x) * FEWIN_T;
+  const int n0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dyl = ph.dys < 0 ? (th - 1) * ph.dys : 0, dxl = ph.dxs < 0 ? (tw - 1) * ph.dxs : 0;
+  const int iy_lo = y0 * a.isy + ph.dy0 + dyl, ix_lo = x0 * a.isx + ph.dx0 + dxl;
+  const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
+  for (int i = tid; i < lds_h * lds_w; i += 256) {
+    const int r = i / lds_w, c = i - r * lds_w;
+    int iy = iy_lo + r, ix = ix_lo + c;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    bool ok = true;
+    if (reflect) { iy = reflect_idx(iy, a.IH); ix = reflect_idx(ix, a.IW); ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW; }
+    else ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+    if (ok) v = *(const f32x4*)(a.in + ((size_t)(b * a.IH + iy) * a.IW + ix) * 4);
+    X[i] = to_bf16x4(v);
+  }
+  for (int i = tid; i < 64 * (kpad / 4); i += 256) {
+    const int n = i / (kpad / 4), t = i - n * (kpad / 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t < ntap && n0 + n < a.Ns) {
+      const int ty = t / tw, tx = t - ty * tw;
+      v = *(const f32x4*)(a.wt + (size_t)(n0 + n) * a.Kp + (size_t)(ph.wbase + ty * ph.wsy + tx * ph.wsx) * 4);
+    }
+    *(bf16x4*)(Wl + n * kpad + t * 4) = to_bf16x4(v);
+  }
+  for (int t = tid; t < ksteps * 4; t += 256) {
+    const int tc = t < ntap ? t : ntap - 1;                         // padding taps read a valid pixel against zero weights
+    const int ty = tc / tw, tx = tc - ty * tw;
+    toff[t] = (ty * ph.dys - dyl) * lds_w + tx * ph.dxs - dxl;
+  }
+  __syncthreads();
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[2][2];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if (n + k < a.N) v[k] += a.bias[n + k];
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // row l31 of M tile i of this wave = pixel (4 * wave + 2 * i + (l31 >> 4), l31 & 15) of the 16 x 16 tile
+  int pbase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) pbase[i] = (4 * wave + 2 * i + (l31 >> 4)) * a.isy * lds_w + (l31 & 15) * a.isx;
+  for (int kk = 0; kk < ksteps; ++kk) {
+    const int o0 = toff[kk * 4 + 2 * half], o1 = toff[kk * 4 + 2 * half + 1];
+    bf16x8 af[2], bf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16x4 lo = X[pbase[i] + o0], hi = X[pbase[i] + o1];
+      af[i] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], a.act, a.slope);
-    const size_t idx = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Ns + n;
-    if (a.aux) {
-      const f32x4 o = a.aux16 ? ld_bf16x4(a.aux, idx) : *(const f32x4*)(a.aux + idx);
+    for (int j = 0; j < 2; ++j) bf[j] = *(const bf16x8*)(Wl + (j * 32 + l31) * kpad + kk * 16 + half * 8);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] *= act_grad_from_out(o[k], a.aux_act, a.aux_slope);
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  }
+  // epilogue: quad transpose to 4 consecutive channels per lane (as in gconv_kernel), then fewin_store.  Row
+  // ml = 8 g + 4 half + qp of M tile i is pixel (4 wave + 2 i + (g >> 1), 8 (g & 1) + 4 half + qp) of the 16 x 16 tile.
+  const int qp = lane & 3, qcol = l31 & ~3;
+  float rsc0 = 1.f, rsc1 = 1.f;
+  if (a.rs0) { rsc0 = 1.f / *a.rs0; rsc1 = 1.f / *a.rs1; }
+  const float rs = b < (a.B >> 1) ? rsc0 : rsc1;
+  f32x4 bias4[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bias4[j] = fewin_bias4(a, n0 + j * 32 + qcol);
+  const int oyb = y0 + 4 * wave, oxb = x0 + 4 * half + qp;
+  const size_t base = ((size_t)(b * a.OH + oyb) * a.OW + oxb) * a.Ns + n0 + qcol;
+  if (SIMPLE && y0 + FEWIN_T <= a.OH && x0 + FEWIN_T <= a.OW && n0 + 64 <= a.Ns && !a.aux && !a.res) {
+    // whole tile, plain epilogue (every stem forward of the four workloads): no bounds, no per-store flag tests; this
+    // kernel retires ~40 instructions per 4-channel store, and at 64 stores of 8 bytes per wave-lane that IS its time
+    const int rstep = a.OW * a.Ns;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float c0 = acc[i][j][4 * g], c1 = acc[i][j][4 * g + 1], c2 = acc[i][j][4 * g + 2], c3 = acc[i][j][4 * g + 3];
+          quad_transpose(c0, c1, c2, c3, qp);
+          f32x4 v = f32x4{c0, c1, c2, c3} * rs + bias4[j];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : (neg_act == 0.f ? 0.f : v[k] * neg_act);
+          const size_t idx = base + (size_t)((2 * i + (g >> 1)) * rstep + 8 * (g & 1) * a.Ns + j * 32);
+          if (a.out16) *(bf16x4*)((__bf16*)a.out + idx) = to_bf16x4(v);
+          else *(f32x4*)(a.out + idx) = v;
+        }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int oy = oyb + 2 * i + (g >> 1), ox = oxb + 8 * (g & 1);
+      const bool mok = oy < a.OH && ox < a.OW;
+      const size_t pix = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Ns;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float c0 = acc[i][j][4 * g], c1 = acc[i][j][4 * g + 1], c2 = acc[i][j][4 * g + 2], c3 = acc[i][j][4 * g + 3];
+        quad_transpose(c0, c1, c2, c3, qp);
+        const int n = n0 + j * 32 + qcol;
+        if (!mok || n >= a.Ns) continue;
+        fewin_store<SIMPLE>(a, f32x4{c0, c1, c2, c3}, bias4[j], rs, neg_act, neg_aux, pix + n, n);
+      }
     }
-    if (a.res) v += a.out16 ? ld_bf16x4(a.res, idx) : *(const f32x4*)(a.res + idx);
-    if (a.out16) *(bf16x4*)((__bf16*)a.out + idx) = to_bf16x4(v);
-    else *(f32x4*)(a.out + idx) = v;
   }
 }
 
@@ -1766,15 +1947,36 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
     const Phase& p = a.ph[0];
     const int lw = (FEWIN_T - 1) * a.isx + (p.tw - 1) * (p.dxs < 0 ? -p.dxs : p.dxs) + 1;
     const int lh = (FEWIN_T - 1) * a.isy + (p.th - 1) * (p.dys < 0 ? -p.dys : p.dys) + 1;
+    const bool simple = fewin_simple_act(a.act) && (!a.aux || fewin_simple_act(a.aux_act));
+    const float neg_act = fewin_neg(a.act, a.slope), neg_aux = fewin_neg(a.aux_act, a.aux_slope);
+    if (g_math == IPRGAN_MATH_BF16) {          // bf16 math: the same tile on the matrix cores (fewin_mfma_kernel)
+      const int ksteps = cdiv(p.ntap * 4, 16), kpad = ksteps * 16 + 8;
+      const size_t smem16 = (size_t)((lw * lh + 1) & ~1) * 8 + (size_t)64 * kpad * 2 + (size_t)ksteps * 4 * sizeof(int);
+      if (smem16 <= 150 * 1024) {
+        static bool attr16_set = false;
+        if (!attr16_set) {
+          (void)hipFuncSetAttribute((const void*)fewin_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+          (void)hipFuncSetAttribute((const void*)fewin_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+          attr16_set = true;
+        }
+        dim3 grid((unsigned)(a.B * cdiv(a.OH, FEWIN_T) * cdiv(a.OW, FEWIN_T)), (unsigned)cdiv(a.Ns, 64));
+        if (simple) prof_launch(fewin_mfma_kernel<true>, grid, dim3(256), smem16, st, 18, a.flops, a, lw, lh, kpad, neg_act, neg_aux);
+        else prof_launch(fewin_mfma_kernel<false>, grid, dim3(256), smem16, st, 18, a.flops, a, lw, lh, kpad, neg_act, neg_aux);
+        IPR_LAUNCH_CHECK();
+        return 0;
+      }
+    }
     const size_t smem = ((size_t)lw * lh + (size_t)p.ntap * 64) * sizeof(f32x4);
     if (smem <= 150 * 1024) {
       static bool attr_set = false;
       if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)fewin_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)fewin_conv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)fewin_conv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
       }
       dim3 grid((unsigned)(a.B * cdiv(a.OH, FEWIN_T) * cdiv(a.OW, FEWIN_T)), (unsigned)cdiv(a.Ns, 64));
-      prof_launch(fewin_conv_kernel, grid, dim3(256), smem, st, 18, a.flops, a, lw, lh);
+      if (simple) prof_launch(fewin_conv_kernel<true>, grid, dim3(256), smem, st, 18, a.flops, a, lw, lh, neg_act, neg_aux);
+      else prof_launch(fewin_conv_kernel<false>, grid, dim3(256), smem, st, 18, a.flops, a, lw, lh, neg_act, neg_aux);
       IPR_LAUNCH_CHECK();
       return 0;
     }

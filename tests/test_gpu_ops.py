@@ -496,7 +496,9 @@ def test_every_wgrad_candidate(dev, cand):
 
 BF16_SHAPES = [  # cin, cout, k, s, p, transposed, H, B
     (64, 128, 3, 1, 1, False, 16, 4), (128, 64, 4, 2, 1, False, 16, 4), (256, 128, 4, 2, 1, True, 8, 4),
-    (32, 96, 3, 1, 1, False, 9, 3), (64, 64, 3, 2, 1, False, 17, 2)]
+    (32, 96, 3, 1, 1, False, 9, 3), (64, 64, 3, 2, 1, False, 17, 2),
+    # RGB stems / heads: the few-input-channel MFMA kernel (forward of 3->C, backward-data of C->3), ragged tiles
+    (3, 64, 3, 1, 1, False, 19, 3), (3, 96, 4, 2, 1, False, 18, 2), (64, 3, 3, 1, 1, True, 13, 2), (3, 64, 7, 1, 3, False, 20, 2)]
 
 
 @pytest.mark.parametrize('shape', BF16_SHAPES)
