@@ -127,7 +127,7 @@ struct GConvArgs {
   float slope;
   int aux_act;
   float aux_slope;
-  unsigned in_bytes, wt_bytes;
+  unsigned in_bytes, wt_bytes, out_bytes, aux_bytes;   // buffer descriptor ranges (out_bytes also bounds the residual)
   int linear_out;
   int planar_M;        // > 0: store output channel n at plane n>>2 (tap-planar T of the small-N path)
   float* ws;           // host-side only: workspace for the small-N path (may be null)
@@ -154,13 +154,19 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define OOB_OFFSET 0x80000000u     // buffer voffset beyond any tensor (< 2 GiB): the load returns 0
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
 }
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t rs, unsigned voff, f32x4 v) {      // out-of-range: dropped
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store_bf16x4(__amdgpu_buffer_rsrc_t rs, unsigned voff, bf16x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, 0, 0);
+}
 // 4 consecutive bf16 elements (8 bytes) widened to fp32; out-of-range offsets give zeros like buf_load4
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 buf_load4_bf16(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
   const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
   const f32x4 v = {__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
@@ -501,13 +507,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 #pragma unroll
       for (int k = 0; k < 4; ++k) cs1[j][k] = cs2[j][k] = 0.f;
   }
-  // Per-store work is kept minimal: the bias of this lane's channel quads is loaded once, and the common activations
-  // (none / ReLU / LeakyReLU, also as the fused derivative) are a compare-select instead of the general switch, whose
-  // inlined tanh / sigmoid branches made each of the 16-64 stores of a wave several hundred instructions of code.  On
-  // the layers with short reductions (K = 576: 18 steps) the epilogue is a fifth of a wave's life.
+  // The epilogue runs in two passes per 32-row tile so that its memory operations overlap: pass 1 turns the accumulators
+  // into final pre-derivative values (transpose, pair scale, bias, activation) and computes one byte offset per 4-channel
+  // store, with invalid rows / columns mapped to an out-of-range offset; pass 2 issues ALL loads of the fused derivative
+  // and residual operands of the tile as buffer loads (out-of-range lanes read zeros, no exec-mask branches, so the
+  // compiler keeps them in flight together instead of load - wait - store per store), then multiplies, adds and stores
+  // through the buffer descriptor (out-of-range lanes are dropped).  The bias of this lane's channel quads is loaded
+  // once; the common activations avoid the general switch, whose inlined tanh / sigmoid made each store several hundred
+  // instructions of code.  On layers with short reductions (K = 576: 18 steps) the epilogue was a fifth of a wave's life.
   const bool aux_simple = a.aux_act == IPRGAN_ACT_NONE || a.aux_act == IPRGAN_ACT_RELU || a.aux_act == IPRGAN_ACT_LRELU;
   const float neg_aux = a.aux_act == IPRGAN_ACT_NONE ? 1.f : a.aux_act == IPRGAN_ACT_RELU ? 0.f : a.aux_slope;
-  const size_t slab_off = a.ksplit > 1 ? (size_t)zi * pM * a.Ns : 0;
+  const unsigned esz_out = a.out16 ? 2u : 4u;
+  const unsigned slab_off = a.ksplit > 1 ? (unsigned)zi * (unsigned)pM * (unsigned)a.Ns : 0u;     // elements (< 2^31: checked)
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux ? a.aux_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? a.out_bytes : 0, 0x00020000);
   f32x4 bias4[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
@@ -518,36 +532,42 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
       for (int k = 0; k < 4; ++k) if (n + k < a.N) bias4[j][k] = a.bias[n + k];
     }
   }
+  constexpr int GC = WN >= 2 ? 2 : 4;     // row groups per pass (4 stores in flight per lane: registers stay at the K loop's level)
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
+  for (int ig = 0; ig < WM * (4 / GC); ++ig) {
+    const int i = ig / (4 / GC), g0 = (ig % (4 / GC)) * GC;
+    f32x4 val[GC][WN];
+    unsigned eoff[GC][WN];            // element index of the store, or OOB_OFFSET
+    // ---- pass 1: values and offsets
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int gg = 0; gg < GC; ++gg) {
+      const int g = g0 + gg;
       const int m = m0 + (wm * WM + i) * 32 + 8 * g + 4 * half + qp;
       const bool mok = m < pM;
-      size_t opix = 0;
-      if (a.linear_out) {
-        opix = (size_t)m;
-      } else if (mok) {
-        const int b = fdiv(m, d_plane);
-        const int rem = m - b * plane;
+      unsigned opix = (unsigned)m;
+      if (!a.linear_out) {
+        const int mm = mok ? m : 0;
+        const int b = fdiv(mm, d_plane);
+        const int rem = mm - b * plane;
         const int y = fdiv(rem, d_owg);
         const int x = rem - y * p_owg;
-        opix = (size_t)(b * a.OH + y * a.osy + ooy) * a.OW + x * a.osx + oox;
+        opix = (unsigned)((b * a.OH + y * a.osy + ooy) * a.OW + x * a.osx + oox);
       }
+      const float rsm = a.rs0 ? (m < halfM ? rsc0 : rsc1) : 1.f;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         float c0 = acc[i][j][4 * g], c1 = acc[i][j][4 * g + 1], c2 = acc[i][j][4 * g + 2], c3 = acc[i][j][4 * g + 3];
         quad_transpose(c0, c1, c2, c3, qp);
         const int n = n0 + (wn * WN + j) * 32 + qcol;
-        if (!mok || n >= a.Ns) continue;
+        const bool ok = mok && n < a.Ns;
         f32x4 v = {c0, c1, c2, c3};
-        if (a.rs0) v *= (m < halfM ? rsc0 : rsc1);
-        if (STATS && a.stat_mode == 1) {
+        if (a.rs0) v *= rsm;
+        if (STATS && a.stat_mode == 1) {        // rows past M and columns past N accumulate zeros (zero-filled operands)
 #pragma unroll
           for (int k = 0; k < 4; ++k) { cs1[j][k] += v[k]; cs2[j][k] += v[k] * v[k]; }
         }
         v += bias4[j];
-        if (a.act == IPRGAN_ACT_LRELU) {        // the common activations without the general switch (uniform branches)
+        if (a.act == IPRGAN_ACT_LRELU) {        // uniform branches
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * a.slope;
         } else if (a.act == IPRGAN_ACT_RELU) {
@@ -557,26 +577,59 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = act_apply(v[k], a.act, a.slope);
         }
-        const size_t idx = (a.planar_M ? ((size_t)(n >> 2) * a.planar_M + opix) * 4 : opix * a.Ns + n) + slab_off;
-        if (a.aux) {
-          const f32x4 o = a.aux16 ? ld_bf16x4(a.aux, idx) : *(const f32x4*)(a.aux + idx);
-          if (aux_simple) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] *= o[k] > 0.f ? 1.f : neg_aux;
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] *= act_grad_from_out(o[k], a.aux_act, a.aux_slope);
-          }
-        }
-        if (a.res) v += a.out16 ? ld_bf16x4(a.res, idx) : *(const f32x4*)(a.res + idx);
-        if (STATS && a.stat_mode == 2) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { cs1[j][k] += v[k]; cs2[j][k] += v[k] * v[k]; }
-        }
-        if (a.out16) *(bf16x4*)((__bf16*)a.out + idx) = to_bf16x4(v);        // mode 2: this tensor lives as bf16
-        else *(f32x4*)(a.out + idx) = v;
+        val[gg][j] = v;
+        const unsigned e = (a.planar_M ? ((unsigned)(n >> 2) * (unsigned)a.planar_M + opix) * 4u : opix * (unsigned)a.Ns + (unsigned)n) + slab_off;
+        eoff[gg][j] = ok ? e : OOB_OFFSET;
       }
     }
+    // ---- pass 2: fused derivative, residual (all loads of the tile in flight together), statistics, stores
+    if (a.aux) {
+      f32x4 o[GC][WN];
+#pragma unroll
+      for (int g = 0; g < GC; ++g)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          o[g][j] = a.aux16 ? buf_load4_bf16(rs_aux, eoff[g][j] == OOB_OFFSET ? OOB_OFFSET : eoff[g][j] * 2u)
+                            : buf_load4(rs_aux, eoff[g][j] == OOB_OFFSET ? OOB_OFFSET : eoff[g][j] * 4u);
+#pragma unroll
+      for (int g = 0; g < GC; ++g)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          if (aux_simple) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) val[g][j][k] *= o[g][j][k] > 0.f ? 1.f : neg_aux;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) val[g][j][k] *= act_grad_from_out(o[g][j][k], a.aux_act, a.aux_slope);
+          }
+        }
+    }
+    if (a.res) {
+      f32x4 r[GC][WN];
+#pragma unroll
+      for (int g = 0; g < GC; ++g)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          r[g][j] = a.out16 ? buf_load4_bf16(rs_res, eoff[g][j] == OOB_OFFSET ? OOB_OFFSET : eoff[g][j] * 2u)
+                            : buf_load4(rs_res, eoff[g][j] == OOB_OFFSET ? OOB_OFFSET : eoff[g][j] * 4u);
+#pragma unroll
+      for (int g = 0; g < GC; ++g)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) val[g][j] += r[g][j];
+    }
+#pragma unroll
+    for (int g = 0; g < GC; ++g)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const bool ok = eoff[g][j] != OOB_OFFSET;
+        if (STATS && a.stat_mode == 2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const float t = ok ? val[g][j][k] : 0.f; cs1[j][k] += t; cs2[j][k] += t * t; }
+        }
+        const unsigned boff = ok ? eoff[g][j] * esz_out : OOB_OFFSET;
+        if (a.out16) buf_store_bf16x4(rs_out, boff, to_bf16x4(val[g][j]));     // this tensor lives as bf16
+        else buf_store4(rs_out, boff, val[g][j]);
+      }
   }
   if (STATS) {
     // rows of one column quad live in the 8 lanes that differ in lane bits 0, 1 (row inside the transposed quad) and 5
@@ -1938,6 +1991,13 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
               "conv: bf16 activations need IPRGAN_MATH_BF16, a channel count that is a multiple of 64 and a regular convolution");
     IPR_CHECK(inb < 0x7fffffffull && wtb < 0x7fffffffull, "conv: tensor larger than 2 GiB (%llu / %llu bytes)", inb, wtb);
     a.in_bytes = (unsigned)inb; a.wt_bytes = (unsigned)wtb;
+    // output (and the same-shaped fused-derivative / residual operands): addressed through buffer descriptors too
+    const unsigned long long oel = a.planar_M ? (unsigned long long)a.Ns * a.planar_M
+                                   : a.ksplit > 1 ? (unsigned long long)a.ksplit * a.ph[0].M * a.Ns
+                                                  : (unsigned long long)a.B * a.OH * a.OW * a.Ns;
+    const unsigned long long outb = oel * (a.out16 ? 2ull : 4ull), auxb = oel * (a.aux16 ? 2ull : 4ull);
+    IPR_CHECK(outb < 0x7fffffffull && auxb < 0x7fffffffull, "conv: output tensor larger than 2 GiB (%llu bytes)", outb);
+    a.out_bytes = (unsigned)outb; a.aux_bytes = (unsigned)auxb;
     a.linear_out = (a.nphase == 1 && a.osy == 1 && a.osx == 1 && a.ph[0].ooy == 0 && a.ph[0].oox == 0) ? 1 : 0;
   }
   IPR_CHECK(a.nphase >= 1 && a.nphase <= 4, "conv: stride %d unsupported (max 2)", a.osy);
