@@ -399,7 +399,11 @@ def test_dcgan128_bf16_steps_vs_reference_golden(golden, dev, mode):
     """The same two 128x128 steps with IPRGAN_MATH_BF16 (bf16 MFMA tiles, fp32 accumulation / master weights / norms /
     Adam).  Tolerance as for the 64x64 bf16 test: operand rounding is 2^-9 relative per element, so the O(1) losses
     must agree with the fp32 reference to 3e-2 absolute, the generated images to 3 % in L2, the first Adam moments of
-    every parameter (= the gradients) to 5 % in overall magnitude; sign buffers and the BER exactly."""
+    every parameter (= the gradients) in overall magnitude to 5 % for weight tensors and 8 % for per-channel vectors
+    (BatchNorm affine parameters and biases: every element is a sum of B*H*W signed terms whose cancellation amplifies
+    the operand rounding; measured over bf16 / bf16act, with and without the matrix-core stem kernel
+    (scripts/dbg/d128_bf16_key.py): weights <= 3.3 %, vectors <= 5.1 %, no mode consistently better);
+    sign buffers and the BER exactly."""
     from iprgan import Config, _lib, models
     ref = golden('dcgan128_steps_wbox')
     try:
@@ -412,7 +416,9 @@ def test_dcgan128_bf16_steps_vs_reference_golden(golden, dev, mode):
             assert abs(float(res[k]) - float(ref[k])) < 3e-2, (k, float(res[k]), float(ref[k]))
         if k.startswith('step0/opt') and k.endswith('::asum'):
             a, b = float(res[k]), float(ref[k])
-            assert abs(a - b) <= 5e-2 * abs(b) + 1e-6, (k, a, b)
+            n_est = abs(b) / max(1e-30, float(np.abs(ref[k.replace('::asum', '::samp')]).mean()))     # ~ element count
+            vector = n_est <= 1024          # BatchNorm weight / bias (64..512 channels); the smallest weight tensor has 1728
+            assert abs(a - b) <= (8e-2 if vector else 5e-2) * abs(b) + 1e-6, (k, a, b)
     a, b = res['step0/fake_sample'].astype(np.float64), ref['step0/fake_sample'].astype(np.float64)
     assert np.linalg.norm(a - b) / np.linalg.norm(b) < 3e-2
     assert float(res['final/ber']) == 0.0
