@@ -93,23 +93,45 @@ __global__ void axpy_multi_kernel(const AxpyTable t, float a) {
 }
 
 // ---- GEMV head -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias,
-                                                       const float* __restrict__ inv_scale,
-                                                       float* __restrict__ y, int K, int x16) {
+// 4 consecutive elements of a tensor stored as fp32 or bf16
+__device__ __forceinline__ float4 ld4e(const float* p, size_t i, int b16) {
+  if (b16) {
+    typedef __bf16 h4 __attribute__((ext_vector_type(4)));
+    const h4 h = *(const h4*)((const __bf16*)p + i);
+    return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+  }
+  return *(const float4*)(p + i);
+}
+__device__ __forceinline__ void st4e(float* p, size_t i, float4 v, int b16) {
+  if (b16) {
+    typedef __bf16 h4 __attribute__((ext_vector_type(4)));
+    const h4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *(h4*)((__bf16*)p + i) = h;
+  } else {
+    *(float4*)(p + i) = v;
+  }
+}
+
+// y[b] = <x[b, :], w> / sigma + bias: one block per sample; the K loop runs four 16-byte loads per thread per trip
+// (K = 32768 .. 131072: at one load per trip a 256-thread block per row moved 0.8 TB/s)
+__global__ __launch_bounds__(1024) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ inv_scale,
+                                                        float* __restrict__ y, int K, int x16) {
   __shared__ float sh[16];
   const size_t row = (size_t)blockIdx.x * K;
+  const int stride = blockDim.x * 4;
   float s = 0.f;
-  for (int k = threadIdx.x * 4; k < K; k += blockDim.x * 4) {
-    float4 a;
-    if (x16) {
-      typedef __bf16 h4 __attribute__((ext_vector_type(4)));
-      const h4 h = *(const h4*)((const __bf16*)x + row + k);
-      a = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
-    } else {
-      a = *(const float4*)(x + row + k);
-    }
-    const float4 b = *(const float4*)(w + k);
+  int k = threadIdx.x * 4;
+  for (; k + 3 * stride < K; k += 4 * stride) {
+    float4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = ld4e(x, row + k + u * stride, x16); b[u] = *(const float4*)(w + k + u * stride); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += a[u].x * b[u].x + a[u].y * b[u].y + a[u].z * b[u].z + a[u].w * b[u].w;
+  }
+  for (; k < K; k += stride) {
+    const float4 a = ld4e(x, row + k, x16), b = *(const float4*)(w + k);
     s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
   }
   s = block_sum(s, sh);
@@ -118,28 +140,57 @@ __global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__
     y[blockIdx.x] = s / sc + (bias ? bias[0] : 0.f);
   }
 }
-__global__ void gemv_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+// dx[b, k] = dy[b] * w[k] / sigma * act'(prev_out[b, k]): grid (k quads, samples), 16-byte accesses, no index division
+__global__ __launch_bounds__(256) void gemv_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
                                    const float* __restrict__ inv_scale, float* __restrict__ dx,
                                    const float* __restrict__ prev_out, int prev_act, float prev_slope,
                                    int B, int K, int x16) {
   const float sc = inv_scale ? *inv_scale : 1.f;
-  const size_t total = (size_t)B * K;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i % K);
-    const int b = (int)(i / K);
-    float v = dy[b] * (w[k] / sc);
-    if (prev_out) v *= act_grad_from_out(lde(prev_out, i, x16), prev_act, prev_slope);
-    ste(dx, i, v, x16);
+  const int b = blockIdx.y;
+  const float g = dy[b];
+  for (int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k < K; k += gridDim.x * blockDim.x * 4) {
+    const float4 wv = *(const float4*)(w + k);
+    float4 v = make_float4(g * (wv.x / sc), g * (wv.y / sc), g * (wv.z / sc), g * (wv.w / sc));
+    const size_t i = (size_t)b * K + k;
+    if (prev_out) {
+      const float4 o = ld4e(prev_out, i, x16);
+      v.x *= act_grad_from_out(o.x, prev_act, prev_slope); v.y *= act_grad_from_out(o.y, prev_act, prev_slope);
+      v.z *= act_grad_from_out(o.z, prev_act, prev_slope); v.w *= act_grad_from_out(o.w, prev_act, prev_slope);
+    }
+    st4e(dx, i, v, x16);
   }
 }
-__global__ void gemv_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// dw[k] = sum_b dy[b] x[b, k] (sample order: deterministic), two columns per thread, eight samples' loads in flight
+__global__ __launch_bounds__(256) void gemv_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                    float* __restrict__ dw, float* __restrict__ db, int B, int K, int x16) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
   if (k < K && dw) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dy[b] * lde(x, (size_t)b * K + k, x16);
-    dw[k] = s;
+    float s0 = 0.f, s1 = 0.f;
+    auto ld2 = [&](int b, float& v0, float& v1) {
+      const size_t i = (size_t)b * K + k;
+      if (x16) {
+        const unsigned r = *(const unsigned*)((const __bf16*)x + i);
+        v0 = __builtin_bit_cast(float, r << 16); v1 = __builtin_bit_cast(float, r & 0xffff0000u);
+      } else {
+        const float2 t = *(const float2*)(x + i);
+        v0 = t.x; v1 = t.y;
+      }
+    };
+    int b = 0;
+    for (; b + 7 < B; b += 8) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ld2(b + u, v0[u], v1[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const float g = dy[b + u]; s0 += g * v0[u]; s1 += g * v1[u]; }
+    }
+    for (; b < B; ++b) {
+      float v0, v1;
+      ld2(b, v0, v1);
+      const float g = dy[b];
+      s0 += g * v0; s1 += g * v1;
+    }
+    dw[k] = s0; dw[k + 1] = s1;
   }
   if (db && blockIdx.x == 0 && threadIdx.x == 0) {
     float s = 0.f;
@@ -578,7 +629,7 @@ int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const flo
                     int B, int K, int x_bf16, void* stream) {
   IPR_CHECK(K % 4 == 0, "gemv_fwd: K=%d must be a multiple of 4", K);
   if (B == 0) return 0;
-  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, w, bias, inv_scale, y, K, x_bf16);
+  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(B), dim3(K >= 16384 ? 1024 : 256), 0, (hipStream_t)stream, x, w, bias, inv_scale, y, K, x_bf16);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -588,12 +639,14 @@ int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) return 0;
   if (dx) {
-    hipLaunchKernelGGL(gemv_bwd_dx_kernel, dim3(grid_for((size_t)B * K, 4096)), dim3(256), 0, st, w, dy,
+    IPR_CHECK(K % 4 == 0, "gemv_bwd: K=%d must be a multiple of 4", K);
+    const int gx = cdiv(K / 4, 256) < 64 ? cdiv(K / 4, 256) : 64;
+    hipLaunchKernelGGL(gemv_bwd_dx_kernel, dim3(gx, B), dim3(256), 0, st, w, dy,
                        inv_scale, dx, prev_out, prev_act, prev_slope, B, K, x_bf16);
     IPR_LAUNCH_CHECK();
   }
   if (dw || db) {
-    hipLaunchKernelGGL(gemv_bwd_dw_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, x, dy, dw, db, B, K, x_bf16);
+    hipLaunchKernelGGL(gemv_bwd_dw_kernel, dim3(cdiv(K, 512)), dim3(256), 0, st, x, dy, dw, db, B, K, x_bf16);
     IPR_LAUNCH_CHECK();
   }
   return 0;

@@ -98,28 +98,48 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
       if (beta) pb = *(const f32x4*)(beta + cq * 4);
     }
     const bool from_x = MODE == 2 && act_from_x(act), no_act = MODE == 2 && act == IPRGAN_ACT_NONE;
-    for (int r = r0 + tr; r < r1; r += TR) {
-      const size_t off = gofs + (size_t)r * C + cq * 4;
+    auto accumulate = [&](const f32x4 xv, const f32x4 gv, const f32x4 yv) {
       if (MODE == 0) {
-        a0 += ldv<B16>(x, off);
+        a0 += xv;
       } else if (MODE == 1) {
-        const f32x4 d = ldv<B16>(x, off) - p0;
+        const f32x4 d = xv - p0;
         a0 += d;
         a1 += d * d;
       } else {
-        const f32x4 xv = ldv<B16>(x, off), gv = ldv<B16>(dy, off);
         f32x4 dz = gv;
         if (from_x) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) dz[k] = gv[k] * act_grad_from_out((xv[k] - p0[k]) * p1[k] * pg[k] + pb[k], act, slope);
         } else if (!no_act) {
-          const f32x4 yv = ldv<B16>(y, off);
 #pragma unroll
           for (int k = 0; k < 4; ++k) dz[k] = gv[k] * act_grad_from_out(yv[k], act, slope);
         }
         a0 += dz;
         a1 += dz * ((xv - p0) * p1);
       }
+    };
+    const bool need_y = MODE == 2 && !from_x && !no_act;
+    int r = r0 + tr;
+    // four rows per trip: all their loads are issued before the first is consumed (a thread streams 2-3 tensors with
+    // nothing else to hide the latency behind; one row per trip ran the bf16 tensors of DCGAN-128 at 3 TB/s)
+    for (; r + 3 * TR < r1; r += 4 * TR) {
+      f32x4 xv[4], gv[4], yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t off = gofs + (size_t)(r + u * TR) * C + cq * 4;
+        xv[u] = ldv<B16>(x, off);
+        if (MODE == 2) gv[u] = ldv<B16>(dy, off);
+        if (need_y) yv[u] = ldv<B16>(y, off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accumulate(xv[u], MODE == 2 ? gv[u] : xv[u], need_y ? yv[u] : xv[u]);   // same row order as below
+    }
+    for (; r < r1; r += TR) {
+      const size_t off = gofs + (size_t)r * C + cq * 4;
+      const f32x4 xv = ldv<B16>(x, off);
+      const f32x4 gv = MODE == 2 ? ldv<B16>(dy, off) : xv;
+      const f32x4 yv = need_y ? ldv<B16>(y, off) : xv;
+      accumulate(xv, gv, yv);
     }
   }
   sh[0][threadIdx.x] = a0;

@@ -2,9 +2,10 @@
 # After `gpurun -- 'bash scripts/gpu_round.sh <tag>'`: copy the judged summaries from gpurun_out/ into profiles/.
 TAG=${1:-r02}
 cd "$(dirname "$0")/.."
-for t in $TAG ${TAG}_srgan ${TAG}_cyclegan ${TAG}_dcgan128_bf16act; do
-  python scripts/summarize_profiles.py gpurun_out/prof $t profiles/$t
-  cp gpurun_out/${t}_bench_under_rocprof.json profiles/ 2>/dev/null
+for t in $TAG ${TAG}_srgan ${TAG}_cyclegan ${TAG}_dcgan128_bf16act; do     # summarised on the GPU box by gpu_round.sh
+  for sfx in bench_kernel_stats.csv pmc_traffic.json mfma_util.json bench_under_rocprof.json; do
+    cp gpurun_out/${t}_$sfx profiles/ 2>/dev/null
+  done
 done
 for f in ${TAG}_bench.json ${TAG}_bench_srgan.json ${TAG}_bench_cyclegan.json ${TAG}_bench_dcgan128.json \
          ${TAG}_bench_dcgan128_bf16.json ${TAG}_bench_dcgan64_bf16.json ${TAG}_bench_dcgan128_bf16act.json \

@@ -66,7 +66,12 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
 cd $R
 unset IPRGAN_TUNE_CACHE
 python scripts/summarize_ns_pmc.py $O/prof $O/${TAG} > /dev/null 2> $O/ns_pmc.err
-# the raw per-dispatch traces are large; only the stats and counter CSVs are needed back
-find $O/prof -name '*kernel_trace.csv' -size +20M -delete
-find $O/prof -name '*counter_collection.csv' -size +30M -delete
-ls -la $O/prof | head -30
+# Everything judged is summarised HERE (gpurun merges at most 64 MiB back): per-workload kernel stats, HBM traffic and
+# MFMA-busy summaries into $O, then the raw per-dispatch traces and counter dumps are dropped.
+for t in $TAG ${TAG}_srgan ${TAG}_cyclegan ${TAG}_dcgan128_bf16act; do
+  python scripts/summarize_profiles.py $O/prof $t $O/$t > /dev/null 2>> $O/summarize.err
+done
+find $O/prof -name '*kernel_trace.csv' -delete
+find $O/prof -name '*counter_collection.csv' -delete
+find $O/prof -name '*agent_info.csv' -delete
+du -sh $O; ls $O | head -80
