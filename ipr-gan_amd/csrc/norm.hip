@@ -297,17 +297,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   // layer (networks/sr_resnet.py:37-38, resnet_generator.py:52-53), folded into this pass
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (FIXED) {
+  if (FIXED) {               // 256 % C4n == 0: a thread keeps its channel quad; blockIdx.y = group (InstanceNorm: sample)
     const int c = (int)(threadIdx.x % (unsigned)C4n) * 4;
-    const f32x4 g = ld4(gamma, c, 1.f), b = ld4(beta, c, 0.f), m = ld4(mean, c, 0.f), is = ld4(invstd, c, 1.f);
+    const size_t go = (size_t)blockIdx.y * (size_t)C4n * 4;
+    const f32x4 g = ld4(gamma, c, 1.f), b = ld4(beta, c, 0.f), m = ld4(mean + go, c, 0.f), is = ld4(invstd + go, c, 1.f);
+    const size_t base = (size_t)blockIdx.y * n4;        // n4 = 16-byte quads per group here
 #pragma unroll 4
     for (; i < n4; i += stride) {
-      const f32x4 v = ldv<B16>(x, (size_t)i * 4);
+      const f32x4 v = ldv<B16>(x, (base + i) * 4);
       f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = act_apply((v[k] - m[k]) * is[k] * g[k] + b[k], act, slope);
-      if (residual) o += ldv<B16>(residual, (size_t)i * 4);
-      stv<B16>(y, (size_t)i * 4, o);
+      if (residual) o += ldv<B16>(residual, (base + i) * 4);
+      stv<B16>(y, (base + i) * 4, o);
     }
     return;
   }
@@ -357,11 +359,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool from_x = act_from_x(act), no_act = act == IPRGAN_ACT_NONE;
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-  auto body = [&](unsigned idx, const f32x4& g, const f32x4& b, const f32x4& m, const f32x4& is, const f32x4& s1,
+  auto body = [&](size_t idx, const f32x4& g, const f32x4& b, const f32x4& m, const f32x4& is, const f32x4& s1,
                   const f32x4& s2) {
-    const f32x4 xv = ldv<B16>(x, (size_t)idx * 4), gv = ldv<B16>(dy, (size_t)idx * 4);
+    const f32x4 xv = ldv<B16>(x, idx * 4), gv = ldv<B16>(dy, idx * 4);
     f32x4 yv = {0.f, 0.f, 0.f, 0.f};
-    if (!from_x && !no_act) yv = ldv<B16>(y, (size_t)idx * 4);
+    if (!from_x && !no_act) yv = ldv<B16>(y, idx * 4);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -369,15 +371,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       const float dz = no_act ? gv[k] : gv[k] * act_grad_from_out(from_x ? t * g[k] + b[k] : yv[k], act, slope);
       o[k] = g[k] * is[k] * (dz - s1[k] * invM - t * s2[k] * invM);
     }
-    stv<B16>(dx, (size_t)idx * 4, o);
+    stv<B16>(dx, idx * 4, o);
     csum += o;
   };
-  if (FIXED) {               // see bn_apply_kernel
+  if (FIXED) {               // see bn_apply_kernel: blockIdx.y = group, n4 = quads per group
     const int c = (int)(threadIdx.x % (unsigned)C4n) * 4;
-    const f32x4 g = ld4(gamma, c, 1.f), b = ld4(beta, c, 0.f), m = ld4(mean, c, 0.f), is = ld4(invstd, c, 1.f);
-    const f32x4 s1 = ld4(sums, c, 0.f), s2 = ld4(sums + C, c, 0.f);
+    const size_t grp = blockIdx.y;
+    const f32x4 g = ld4(gamma, c, 1.f), b = ld4(beta, c, 0.f), m = ld4(mean + grp * C, c, 0.f), is = ld4(invstd + grp * C, c, 1.f);
+    const f32x4 s1 = ld4(sums + grp * 2 * C, c, 0.f), s2 = ld4(sums + grp * 2 * C + C, c, 0.f);
+    const size_t base = grp * n4;
 #pragma unroll 2
-    for (; i < n4; i += stride) body(i, g, b, m, is, s1, s2);
+    for (; i < n4; i += stride) body(base + i, g, b, m, is, s1, s2);
   } else {
     for (; i < n4; i += stride) {
       const int c = (int)(i - fdiv(i, d_c4n) * (unsigned)C4n) * 4;
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if ((int)threadIdx.x < C4n) {
       f32x4 t = sh[threadIdx.x];
       for (int k = threadIdx.x + C4n; k < 256; k += C4n) t += sh[k];
-      *(f32x4*)(colpart + ((size_t)blockIdx.x * 2) * C + threadIdx.x * 4) = t;
+      *(f32x4*)(colpart + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2) * C + threadIdx.x * 4) = t;
     }
   }
 }
@@ -461,12 +465,15 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
   IPR_LAUNCH_CHECK();
   const size_t n4 = (size_t)G * M * C / 4;
   IPR_CHECK(n4 < 0x7fffffffull, "norm_fwd: tensor of %zu elements is too large", n4 * 4);
-  const int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
-  const bool fixed = G == 1 && 256 % (C / 4) == 0;
+  int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
+  const bool fixed = 256 % (C / 4) == 0 && G <= 65535;
   auto kern = b16 ? (fixed ? bn_apply_kernel<true, true> : bn_apply_kernel<false, true>)
                   : (fixed ? bn_apply_kernel<true, false> : bn_apply_kernel<false, false>);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_invstd, (unsigned)n4, C / 4,
-                     make_fastdiv(C / 4), make_fastdiv((uint32_t)((size_t)M * C / 4)), act, slope, residual);
+  const size_t n4g = (size_t)M * C / 4;              // quads per group
+  if (fixed) blocks = (int)(cdivz(n4g, 256) < (size_t)cdiv(4096, G) ? cdivz(n4g, 256) : (size_t)cdiv(4096, G));
+  hipLaunchKernelGGL(kern, dim3(blocks, fixed ? G : 1), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_invstd,
+                     (unsigned)(fixed ? n4g : n4), C / 4,
+                     make_fastdiv(C / 4), make_fastdiv((uint32_t)n4g), act, slope, residual);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -494,25 +501,29 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
   const size_t n4 = (size_t)G * M * C / 4;
   IPR_CHECK(n4 < 0x7fffffffull, "norm_bwd: tensor of %zu elements is too large", n4 * 4);
   int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
-  const bool fixed = G == 1 && 256 % (C / 4) == 0;
+  const bool fixed = 256 % (C / 4) == 0 && G <= 1024;
+  const size_t n4g = (size_t)M * C / 4;              // quads per group
+  int gy = 1;
+  if (fixed) { gy = G; blocks = (int)(cdivz(n4g, 256) < (size_t)cdiv(4096, G) ? cdivz(n4g, 256) : (size_t)cdiv(4096, G)); }
   // column sums of dx (bias gradient of the producing convolution) ride on the apply pass when a thread keeps its
-  // channel chunk; the per-block partials live behind the reduction workspace
+  // channel chunk; the per-block partials (at most 1024 rows) live behind the reduction workspace
   float* colpart = nullptr;
   if (dbias_prev && 256 % (C / 4) == 0) {
-    if (blocks > 1024) blocks = 1024;
+    const int cap = fixed ? (1024 / G > 0 ? 1024 / G : 1) : 1024;
+    if (blocks > cap) blocks = cap;
     colpart = sums + (size_t)G * 2 * C;
   }
   auto kern = b16 ? (fixed ? bn_bwd_apply_kernel<true, true> : bn_bwd_apply_kernel<false, true>)
                   : (fixed ? bn_bwd_apply_kernel<true, false> : bn_bwd_apply_kernel<false, false>);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st, x, y, dy, dx, gamma, beta, save_mean, save_invstd, sums,
-                     (unsigned)n4, C / 4, C,
-                     make_fastdiv(C / 4), make_fastdiv((uint32_t)((size_t)M * C / 4)), 1.0f / (float)M, act, slope,
+  hipLaunchKernelGGL(kern, dim3(blocks, gy), dim3(256), 0, st, x, y, dy, dx, gamma, beta, save_mean, save_invstd, sums,
+                     (unsigned)(fixed ? n4g : n4), C / 4, C,
+                     make_fastdiv(C / 4), make_fastdiv((uint32_t)n4g), 1.0f / (float)M, act, slope,
                      colpart);
   IPR_LAUNCH_CHECK();
   if (dbias_prev) {
     if (colpart) {
       const float* pp = colpart;
-      int rows = blocks;
+      int rows = blocks * gy;
       if (compact_partials(pp, rows, 1, C, st)) return 2;
       hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(dbias_n, 64)), dim3(64 * FL), 0, st, pp, rows, C, dbias_n,
                          dbias_prev, dbias_beta);

@@ -15,26 +15,26 @@ timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo 
 tail -3 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 fi
-prof_workload () {   # $1 = workload, $2 = file tag, $3.. = bench args for the profiled runs
-  local W=$1 T=$2; shift 2
+prof_workload () {   # $1 = workload, $2 = file tag, $3 = math mode, $4.. = step counts of the kernel-stats run
+  local W=$1 T=$2 MATH=$3; shift 3
   # one un-profiled pass records the autotuner's choices; the profiler runs replay them (IPRGAN_TUNE_CACHE), so their
   # per-kernel averages contain the launches of the training step only, like the bench line's own HIP-event figures
   export IPRGAN_TUNE_CACHE=$O/tune_cache_$T.txt
   rm -f $IPRGAN_TUNE_CACHE
   cd $R
-  timeout 600 python bench.py --workload $W --no-cpu-baseline "$@" > /dev/null 2> $O/tune_pass_$T.err
+  timeout 600 python bench.py --workload $W --math $MATH --no-cpu-baseline "$@" > /dev/null 2> $O/tune_pass_$T.err
   cd /tmp && export TMPDIR=/tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o $T --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline "$@" > $O/${T}_bench_under_rocprof.json 2> $O/prof_$T.err
-  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof -o ${T}_fetch --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_fetch.err
-  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof -o ${T}_write --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_write.err
-  timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/prof -o ${T}_mfma --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_mfma.err
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o $T --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --no-cpu-baseline "$@" > $O/${T}_bench_under_rocprof.json 2> $O/prof_$T.err
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof -o ${T}_fetch --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_fetch.err
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof -o ${T}_write --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_write.err
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/prof -o ${T}_mfma --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_mfma.err
   cd $R
   unset IPRGAN_TUNE_CACHE
 }
-prof_workload dcgan64 ${TAG} --steps 20 --warmup 8
-prof_workload srgan ${TAG}_srgan --steps 8 --warmup 4
-prof_workload cyclegan ${TAG}_cyclegan --steps 4 --warmup 2
-prof_workload dcgan128 ${TAG}_dcgan128_bf16act --math bf16act --steps 8 --warmup 4
+prof_workload dcgan64 ${TAG} fp32 --steps 20 --warmup 8
+prof_workload srgan ${TAG}_srgan fp32 --steps 8 --warmup 4
+prof_workload cyclegan ${TAG}_cyclegan fp32 --steps 4 --warmup 2
+prof_workload dcgan128 ${TAG}_dcgan128_bf16act bf16act --steps 8 --warmup 4
 # the counters of THIS build first, so that the bench line's roofline.traffic (read from profiles/) matches it
 python scripts/summarize_profiles.py $O/prof $TAG $R/profiles/$TAG > /dev/null
 python scripts/summarize_profiles.py $O/prof ${TAG}_srgan $R/profiles/${TAG}_srgan > /dev/null
