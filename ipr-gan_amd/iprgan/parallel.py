@@ -105,11 +105,51 @@ class TorchDistTransport:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
 
+def _all_ranks_ok(ok, device):
+    """Collective AND of a per-rank success flag (so that every rank takes the same transport)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def _rccl_or_torch(rank, nranks, device):
+    """The library's own RCCL communicator, verified before it is trusted with gradients: every rank must be able to
+    bind RCCL (iprgan_comm_unique_id exercises the dlopen + symbol lookup without any communication), the communicator
+    must come up on every rank, and a one-element all-reduce must return the rank count.  If any rank fails any of the
+    three, ALL ranks fall back - loudly - to torch.distributed's all_reduce on the same side stream (backend 'nccl' is RCCL
+    too: same wire, one communicator more in the process).  IPRGAN_COMM=torch selects that path outright."""
+    import sys
+    if os.environ.get('IPRGAN_COMM') == 'torch':
+        return TorchDistTransport
+    from . import _lib as L
+    why = None
+    try:
+        L.call('iprgan_comm_unique_id', C.create_string_buffer(128))
+    except Exception as e:                                  # noqa: BLE001 - any failure means "cannot bind"
+        why = f'binding RCCL failed: {e}'
+    if _all_ranks_ok(why is None, device):
+        try:
+            RcclTransport.ensure(rank, nranks)
+            probe = torch.ones(4, device=device)
+            RcclTransport.all_reduce(probe, torch.cuda.current_stream())
+            torch.cuda.current_stream().synchronize()
+            if float(probe[0].item()) != float(nranks):
+                why = f'probe all-reduce returned {float(probe[0].item())}, expected {nranks}'
+        except Exception as e:                              # noqa: BLE001
+            why = f'communicator: {e}'
+        if _all_ranks_ok(why is None, device):
+            return RcclTransport
+        RcclTransport.destroy()
+    print(f'[iprgan rank {rank}] iprgan_comm_* unavailable on at least one rank ({why or "another rank failed"}); gradient '
+          f'buckets go through torch.distributed all_reduce instead', file=sys.stderr, flush=True)
+    return TorchDistTransport
+
+
 def _pick_transport(device):
     rank, nranks = world()
     if nranks > 1:
         if device.type == 'cuda' and dist.get_backend() == 'nccl':
-            return RcclTransport.ensure(rank, nranks)
+            return _rccl_or_torch(rank, nranks, device)
         return TorchDistTransport
     if device.type == 'cuda' and os.environ.get('IPRGAN_FORCE_COMM') == '1':
         return RcclTransport.ensure(0, 1)          # single-rank communicator: exercises the RCCL path on one GPU
