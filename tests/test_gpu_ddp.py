@@ -195,3 +195,33 @@ def test_rccl_bucket_exchange_is_enqueued_before_the_first_layers_wgrad(tmp_path
         # device time between the moment bucket 0 was ready and the moment the last bucket was: backward kernels ran
         # in between, i.e. the first exchange had that long to hide
         assert info['gap_ms'] > 0.0, info
+
+def _probe_worker(rank, out):
+    """World of ONE rank over the nccl (= RCCL) backend: the start-up path every rank of an N-GPU job takes."""
+    _paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    from iprgan import parallel
+    dev = torch.device('cuda:0')
+    t = parallel._rccl_or_torch(0, 1, dev)
+    res = {'picked': t.__name__}
+    buf = torch.arange(8, dtype=torch.float32, device=dev)
+    t.all_reduce(buf, torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    res['buf'] = buf.cpu()
+    os.environ['IPRGAN_COMM'] = 'torch'
+    res['forced'] = parallel._rccl_or_torch(0, 1, dev).__name__
+    parallel.RcclTransport.destroy()
+    dist.destroy_process_group()
+    torch.save(res, out)
+
+
+def test_comm_startup_probe_over_nccl_backend(tmp_path):
+    """parallel._rccl_or_torch: bind, communicator, probe all-reduce and the collective verdict over a real nccl (RCCL)
+    process group of one rank; IPRGAN_COMM=torch selects the torch.distributed transport."""
+    out = str(tmp_path / 'probe.pt')
+    mp.spawn(_probe_worker, args=(out,), nprocs=1, join=True)
+    res = torch.load(out)
+    assert res['picked'] == 'RcclTransport' and res['forced'] == 'TorchDistTransport'
+    assert torch.equal(res['buf'], torch.arange(8, dtype=torch.float32))
