@@ -715,6 +715,7 @@ static bool fewin_simple_act(int act) { return act == IPRGAN_ACT_NONE || act == 
 static float fewin_neg(int act, float slope) { return act == IPRGAN_ACT_NONE ? 1.f : act == IPRGAN_ACT_RELU ? 0.f : slope; }
 
 #define FEWIN_T 16
+#define FEWIN_TAPS 16          // taps of weights resident in LDS at a time (fewin_conv_kernel): 16 KB
 #ifndef FEWIN_WAVES
 #define FEWIN_WAVES 5          // waves per SIMD the register allocation of fewin_mfma_kernel must allow
 #endif
@@ -744,33 +745,40 @@ __global__ __launch_bounds__(256) void fewin_conv_kernel(const GConvArgs a, int 
     if (ok) v = *(const f32x4*)(a.in + ((size_t)(b * a.IH + iy) * a.IW + ix) * 4);
     X[i] = v;
   }
-  for (int i = tid; i < ntap * 64; i += 256) {       // transposed while staged: Wl[t][c][quad] = (W[4 quad + k][t][c])_k
-    const int t = i >> 6, n = i & 63;
-    const int ty = t / tw, tx = t - ty * tw;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (n0 + n < a.Ns) v = *(const f32x4*)(a.wt + (size_t)(n0 + n) * a.Kp + (size_t)(ph.wbase + ty * ph.wsy + tx * ph.wsx) * 4);
-    float* wf = (float*)Wl;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) wf[((t * 4 + c) * 16 + (n >> 2)) * 4 + (n & 3)] = v[c];
-  }
-  __syncthreads();
   f32x4 acc[FEWIN_T];
 #pragma unroll
   for (int i = 0; i < FEWIN_T; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int cx = pg * a.isx - dxl;                  // LDS column of this thread's pixel for tap offset 0
-  for (int t = 0; t < ntap; ++t) {
-    const int ty = t / tw, tx = t - ty * tw;
-    // wc: this thread's 4 output channels for input channel c (vector x scalar FMAs: v_pk_fma_f32 pairs)
-    const f32x4 w0 = Wl[(t * 4 + 0) * 16 + q], w1 = Wl[(t * 4 + 1) * 16 + q], w2 = Wl[(t * 4 + 2) * 16 + q], w3 = Wl[(t * 4 + 3) * 16 + q];
-    const f32x4* xp = X + (ty * ph.dys - dyl) * lds_w + cx + tx * ph.dxs;
-    const int xstep = a.isy * lds_w;
+  // The weights pass through LDS in chunks of FEWIN_TAPS taps (k7 / k9 stems: 49 / 81 taps x 1 KB would leave one block
+  // per CU - one wave per SIMD and nothing to hide a latency behind; the k9 backward-data of SRGAN ran at 26 TFLOP/s).
+  for (int t0 = 0; t0 < ntap; t0 += FEWIN_TAPS) {
+    const int tn = ntap - t0 < FEWIN_TAPS ? ntap - t0 : FEWIN_TAPS;
+    if (t0) __syncthreads();                          // everyone is done with the previous chunk
+    for (int i = tid; i < tn * 64; i += 256) {        // transposed while staged: Wl[t][c][quad] = (W[4 quad + k][t][c])_k
+      const int tl = i >> 6, n = i & 63, t = t0 + tl;
+      const int ty = t / tw, tx = t - ty * tw;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + n < a.Ns) v = *(const f32x4*)(a.wt + (size_t)(n0 + n) * a.Kp + (size_t)(ph.wbase + ty * ph.wsy + tx * ph.wsx) * 4);
+      float* wf = (float*)Wl;
 #pragma unroll
-    for (int i = 0; i < FEWIN_T; ++i) {
-      const f32x4 xin = xp[i * xstep];
-      acc[i] += w0 * xin.x;
-      acc[i] += w1 * xin.y;
-      acc[i] += w2 * xin.z;
-      acc[i] += w3 * xin.w;
+      for (int c = 0; c < 4; ++c) wf[((tl * 4 + c) * 16 + (n >> 2)) * 4 + (n & 3)] = v[c];
+    }
+    __syncthreads();                                  // (also covers the input window on the first trip)
+    for (int tl = 0; tl < tn; ++tl) {
+      const int t = t0 + tl;
+      const int ty = t / tw, tx = t - ty * tw;
+      // wc: this thread's 4 output channels for input channel c (vector x scalar FMAs: v_pk_fma_f32 pairs)
+      const f32x4 w0 = Wl[(tl * 4 + 0) * 16 + q], w1 = Wl[(tl * 4 + 1) * 16 + q], w2 = Wl[(tl * 4 + 2) * 16 + q], w3 = Wl[(tl * 4 + 3) * 16 + q];
+      const f32x4* xp = X + (ty * ph.dys - dyl) * lds_w + cx + tx * ph.dxs;
+      const int xstep = a.isy * lds_w;
+#pragma unroll
+      for (int i = 0; i < FEWIN_T; ++i) {
+        const f32x4 xin = xp[i * xstep];
+        acc[i] += w0 * xin.x;
+        acc[i] += w1 * xin.y;
+        acc[i] += w2 * xin.z;
+        acc[i] += w3 * xin.w;
+      }
     }
   }
   const int n = n0 + 4 * q, ox = x0 + pg;
@@ -2026,7 +2034,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
         return 0;
       }
     }
-    const size_t smem = ((size_t)lw * lh + (size_t)p.ntap * 64) * sizeof(f32x4);
+    const size_t smem = ((size_t)lw * lh + (size_t)(p.ntap < FEWIN_TAPS ? p.ntap : FEWIN_TAPS) * 64) * sizeof(f32x4);
     if (smem <= 150 * 1024) {
       static bool attr_set = false;
       if (!attr_set) {
