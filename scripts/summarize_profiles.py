@@ -68,7 +68,7 @@ def main():
                         '"all_conv" weighs every gconv / wgrad launch of the step by its cycles.', 'kernels': {}}
         tb = tg = 0.0
         for k in sorted(busy):
-            if 'gconv' not in k and 'wgrad_kernel' not in k and 'wgrad_t_kernel' not in k:
+            if ('gconv' not in k and 'wgrad' not in k and 'fewin_mfma' not in k) or 'wgrad_reduce' in k:
                 continue
             b, g = busy[k][1], gui[k][1]
             tb += b
