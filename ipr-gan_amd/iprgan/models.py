@@ -19,6 +19,9 @@ from .tools import loss_sum, loss_value
 
 import os
 
+# CycleGAN: passes of one network over inputs that are all known up front run as one pass over the concatenated batch
+# (exact: its norm layers are per sample).  A/B switch.
+_BATCH_PASSES = os.environ.get('IPRGAN_BATCH_PASSES', '1') != '0'
 _PAIR_D = os.environ.get('IPRGAN_PAIR_D', '1') != '0'       # A/B switch for the paired discriminator pass
 
 __all__ = ['Model', 'Wrapper', 'DCGAN', 'SRGAN', 'CycleGAN', 'VAE', 'ImagePool', 'BlackBoxWrapper',
@@ -348,6 +351,10 @@ class CycleGAN(Model):
         fn_g, fn_d = getattr(networks, config.G), getattr(networks, config.D)
         self.GA, self.GB = Replica(fn_g(), dev), Replica(fn_g(), dev)
         self.DA, self.DB = Replica(fn_d(), dev), Replica(fn_d(), dev)
+        # batching two passes of a network into one is exact only without batch statistics
+        per_sample = lambda net: not any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in net.modules())
+        self._batch_g = _BATCH_PASSES and per_sample(self.GA) and per_sample(self.GB)
+        self._batch_d = _BATCH_PASSES and per_sample(self.DA) and per_sample(self.DB)
         self.poolA, self.poolB = ImagePool(config.pool_size), ImagePool(config.pool_size)
         for net in (self.GA, self.GB, self.DA, self.DB):
             net.train()
@@ -385,12 +392,25 @@ class CycleGAN(Model):
     def forward_g(self, data):
         self.real_A = self._dev(data['real_A'])
         self.real_B = self._dev(data['real_B'])
-        self.fake_B = self.GA(self.real_A)
-        self.fake_A = self.GB(self.real_B)
-        self.rec_A = self.GB(self.fake_B)
-        self.rec_B = self.GA(self.fake_A)
-        self.idt_A = self.GA(self.real_B)
-        self.idt_B = self.GB(self.real_A)
+        if self._batch_g:
+            # GA(real_A) and GA(real_B) (the identity term, models/cyclegan.py:109-110) are two passes of the same network
+            # whose inputs are both known here, and InstanceNorm statistics are per sample: ONE pass over the
+            # concatenated batch computes the same values (launches of twice the size: the 256->256 layers have 1024
+            # tiles instead of 512, four blocks per CU instead of two) and its backward the same weight gradients.
+            n = self.real_A.shape[0]
+            out = self.GA(torch.cat([self.real_A, self.real_B]))
+            self.fake_B, self.idt_A = out[:n], out[n:]
+            out = self.GB(torch.cat([self.real_B, self.real_A]))
+            self.fake_A, self.idt_B = out[:n], out[n:]
+            self.rec_A = self.GB(self.fake_B)
+            self.rec_B = self.GA(self.fake_A)
+        else:
+            self.fake_B = self.GA(self.real_A)
+            self.fake_A = self.GB(self.real_B)
+            self.rec_A = self.GB(self.fake_B)
+            self.rec_B = self.GA(self.fake_A)
+            self.idt_A = self.GA(self.real_B)
+            self.idt_B = self.GB(self.real_A)
         with _no_param_grads(self.DA, self.DB):
             self.GA_logits = self.DA(self.fake_B)
             self.GB_logits = self.DB(self.fake_A)
@@ -400,10 +420,17 @@ class CycleGAN(Model):
         self.real_B = self._dev(data['real_B'])
         self.fake_A = self.poolA(data['fake_A'])
         self.fake_B = self.poolB(data['fake_B'])
-        self.RA_logits = self.DB(self.real_A)
-        self.FA_logits = self.DB(self.fake_A.detach())
-        self.RB_logits = self.DA(self.real_B)
-        self.FB_logits = self.DA(self.fake_B.detach())
+        if self._batch_d:       # same argument for the two passes of each discriminator (InstanceNorm or no norm at all)
+            n = self.real_A.shape[0]
+            out = self.DB(torch.cat([self.real_A, self.fake_A.detach()]))
+            self.RA_logits, self.FA_logits = out[:n], out[n:]
+            out = self.DA(torch.cat([self.real_B, self.fake_B.detach()]))
+            self.RB_logits, self.FB_logits = out[:n], out[n:]
+        else:
+            self.RA_logits = self.DB(self.real_A)
+            self.FA_logits = self.DB(self.fake_A.detach())
+            self.RB_logits = self.DA(self.real_B)
+            self.FB_logits = self.DA(self.fake_B.detach())
 
     def compute_g_loss(self):
         self.LossGA = loss_value(L.LOSS_MSE_ONES, self.GA_logits)

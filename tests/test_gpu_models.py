@@ -80,8 +80,12 @@ def step_policy(steps, lr=2e-4):
             return (2e-2, 1e-2)
         if k.startswith(('final/optG', 'final/optD')):
             return (0.1, 1e-3, 'scale')
-        if k.startswith(('final/G/', 'final/D/')) and leaf not in cases.BUFFER_LEAVES:
-            return (2e-3, 2 * lr * steps)
+        net = k.split('/')[1] if k.count('/') >= 2 else ''
+        if k.startswith('final/') and net in ('G', 'D', 'GA', 'GB', 'DA', 'DB') and leaf not in cases.BUFFER_LEAVES:
+            # (CycleGAN's four networks included: the bias of a convolution that feeds an InstanceNorm has a zero true
+            # gradient, Adam turns its rounding noise into +-lr moves - up to 1.05 lr on the second step - and the two
+            # implementations need not agree on the sign: observed up to 5.5 lr apart after two steps)
+            return (2e-3, 3 * lr * steps)
         return (1e-2, 1e-3)
     return policy
 
@@ -445,7 +449,10 @@ def test_cyclegan_pool_swap_and_lr_decay_vs_reference_golden(golden, dev):
             # first conv rounds to the other side of zero (one output channel of DA.conv0 moves by 0.4 % of the
             # tensor's scale); G moments to 3-5e-3 in L2 (sign() gradient of the L1 cycle terms).  The biases of convs
             # feeding a norm layer have a zero true gradient (1e-9 noise on both sides, under the 1e-6 floor).
-            return (2e-2, 2e-2, 'relmax')
+            # Which elements flip depends on the summation order, i.e. on the tile the autotuner picked for this batch
+            # size (the two passes of each discriminator run as one pass of twice the batch): observed single-element
+            # deviations up to 2.5 % of the tensor's largest sampled entry -> 2 % relative + 4 % of that entry.
+            return (2e-2, 4e-2, 'relmax')
         if k.startswith('final/pool'):
             # images generated after up to three Adam steps (+-lr moves on noise-level gradients, see step_policy):
             # a wrongly swapped pool slot differs by O(1), rounding drift stays below 5e-2
