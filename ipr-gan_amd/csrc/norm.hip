@@ -154,41 +154,48 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   }
 }
 
-// sums the NB slice partials of 64 channels with FL lanes each (slice order within a lane, then lanes)
+// Sums the NB partial rows of the 64 channels of a 1024-thread block: 64 row lanes x 16 channel quads, 16-byte loads (a
+// lane walks rows lane, lane + 64, ... with two independent accumulators), then the row lanes are added in lane order by
+// the first 64 threads.  Results are valid in the threads with lane (= threadIdx.x >> 6) == 0; thread t there owns
+// channel blockIdx.x * 64 + t.  Deterministic: fixed row -> lane assignment, fixed addition order.  (The first version
+// gave every channel 16 scalar lanes: beyond ~150 rows it was latency-bound and needed the compaction pre-pass below;
+// this one takes 2048 rows directly - every norm layer of SRGAN and CycleGAN.)
 #define FL 16
 __device__ __forceinline__ void final_sums(const float* __restrict__ part, int NB, int C, int c, int lane,
                                            float (*sh)[FL][64], float& s0, float& s1, bool two) {
-  float a0 = 0.f, a1 = 0.f;
-  if (c < C) {
-    // four independent partial sums per lane: the loads overlap instead of queueing behind one accumulator
-    float p0[4] = {0.f, 0.f, 0.f, 0.f}, p1[4] = {0.f, 0.f, 0.f, 0.f};
-    int b = lane;
-    for (; b + 3 * FL < NB; b += 4 * FL) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        p0[u] += part[((size_t)(b + u * FL) * 2) * C + c];
-        if (two) p1[u] += part[((size_t)(b + u * FL) * 2 + 1) * C + c];
+  (void)sh;
+  __shared__ f32x4 shq[2][64][16];
+  const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int cq = (c & ~63) + 4 * q;                 // first channel of this thread's quad (c & ~63 = blockIdx.x * 64)
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+  if (cq < C) {
+    int r = rl;
+    for (; r + 64 < NB; r += 128) {
+      a0 += *(const f32x4*)(part + ((size_t)r * 2) * C + cq);
+      b0 += *(const f32x4*)(part + ((size_t)(r + 64) * 2) * C + cq);
+      if (two) {
+        a1 += *(const f32x4*)(part + ((size_t)r * 2 + 1) * C + cq);
+        b1 += *(const f32x4*)(part + ((size_t)(r + 64) * 2 + 1) * C + cq);
       }
     }
-    for (; b < NB; b += FL) {
-      p0[0] += part[((size_t)b * 2) * C + c];
-      if (two) p1[0] += part[((size_t)b * 2 + 1) * C + c];
+    if (r < NB) {
+      a0 += *(const f32x4*)(part + ((size_t)r * 2) * C + cq);
+      if (two) a1 += *(const f32x4*)(part + ((size_t)r * 2 + 1) * C + cq);
     }
-    a0 = (p0[0] + p0[1]) + (p0[2] + p0[3]);
-    a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
   }
-  const int cl = threadIdx.x & 63;
-  sh[0][lane][cl] = a0;
-  sh[1][lane][cl] = a1;
+  shq[0][rl][q] = a0 + b0;
+  shq[1][rl][q] = a1 + b1;
   __syncthreads();
   s0 = s1 = 0.f;
-#pragma unroll
-  for (int l = 0; l < FL; ++l) { s0 += sh[0][l][cl]; s1 += sh[1][l][cl]; }
+  if (lane == 0) {
+    const int cl = threadIdx.x & 63;
+    for (int l = 0; l < 64; ++l) { s0 += shq[0][l][cl >> 2][cl & 3]; s1 += shq[1][l][cl >> 2][cl & 3]; }
+  }
 }
 
-// Convolution epilogues emit one row of column sums per OUTPUT TILE (thousands of rows for the large layers); the
-// final kernels walk their partial rows with 16 lanes per channel, which is latency-bound beyond a few hundred rows.
-// This pre-pass folds part[G][rows][W] (W = 2*Cs floats per row) down to out[G][NBC][W], slice by slice in row order.
+// Convolution epilogues emit one row of column sums per OUTPUT TILE (thousands of rows for the largest layers); beyond
+// COMPACT_ABOVE rows this pre-pass folds part[G][rows][W] (W = 2*Cs floats per row) down to out[G][NBC][W], slice by slice in row order.
+#define COMPACT_ABOVE 2048
 #define NBC 32
 __global__ __launch_bounds__(256) void part_compact_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ out,
                                                            int rows, int W4, int rps) {
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256) void part_compact_kernel(const f32x4* __restri
 // returns the partial pointer / row count the final kernel should read (compacted into the spare room behind the rows
 // when there are many: iprgan_conv_stat_floats reserves it)
 static int compact_partials(const float*& part, int& rows_per_group, int G, int Cs, hipStream_t st) {
-  if (rows_per_group <= 4 * NBC) return 0;
+  if (rows_per_group <= COMPACT_ABOVE) return 0;
   float* out = const_cast<float*>(part) + (size_t)G * rows_per_group * 2 * Cs;
   const int W4 = 2 * Cs / 4, rps = cdiv(rows_per_group, NBC), nb = cdiv(rows_per_group, rps);
   hipLaunchKernelGGL(part_compact_kernel, dim3(nb, cdiv(W4, 64), G), dim3(256), 0, st, (const f32x4*)part, (f32x4*)out,
