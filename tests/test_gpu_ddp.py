@@ -70,6 +70,46 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _cyclegan_worker(rank, world, port, out):
+    _paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from iprgan import Config, models
+    from oracle import cases, recipe
+    dev = torch.device('cuda:0')
+    torch.manual_seed(20 + rank)
+    m = models.CycleGAN(Config(dict(cases.CYCLEGAN_CFG, G='Resnet6Blocks')), device=[dev])
+    assert m._batch_g and m._batch_d
+    wcfg = dict(cases.WBOX_CFG)
+    wcfg['target'] = 'GB'
+    m = models.WhiteBoxWrapper(m, Config(wcfg))
+    for s in range(2):
+        a = torch.tanh(recipe.tensor(70 + rank, s, (2, 3, 32, 32)))
+        b = torch.tanh(recipe.tensor(80 + rank, s, (2, 3, 32, 32)))
+        m.update_g({'real_A': a, 'real_B': b})
+        m.update_d({'real_A': m.real_A, 'real_B': m.real_B, 'fake_A': m.fake_A.detach(), 'fake_B': m.fake_B.detach()})
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().flatten() for n in (m.GA, m.GB, m.DA, m.DB) for p in n.parameters()]).cpu()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save({'same_params': all(torch.equal(gathered[0], g) for g in gathered),
+                    'finite': bool(torch.isfinite(flat).all()),
+                    'ber': float(m.loss_model.compute_ber(m.GB))}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cyclegan_steps_two_ranks_on_one_gpu(tmp_path):
+    """Two ranks through CycleGAN's step with its batched same-network passes (two recorded passes per generator instead
+    of three): the reducers' last-pass detection must still send every bucket exactly once - replicas stay bit-identical."""
+    out = str(tmp_path / 'res.pt')
+    mp.spawn(_cyclegan_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res['finite'] and res['ber'] == 0.0
+    assert res['same_params'], 'replicas diverged'
+
+
 def test_dcgan_steps_two_ranks_on_one_gpu(tmp_path):
     out = str(tmp_path / 'res.pt')
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
