@@ -400,9 +400,9 @@ class CycleGAN(Model):
             n = self.real_A.shape[0]
             out = self.GA(torch.cat([self.real_A, self.real_B]))
             self.fake_B, self.idt_A = out[:n], out[n:]
-            out = self.GB(torch.cat([self.real_B, self.real_A]))
-            self.fake_A, self.idt_B = out[:n], out[n:]
-            self.rec_A = self.GB(self.fake_B)
+            # ... and G_B's cycle pass over fake_B, known by now, joins G_B's other two (one pass of three batches)
+            out = self.GB(torch.cat([self.real_B, self.real_A, self.fake_B]))
+            self.fake_A, self.idt_B, self.rec_A = out[:n], out[n:2 * n], out[2 * n:]
             self.rec_B = self.GA(self.fake_A)
         else:
             self.fake_B = self.GA(self.real_A)
