@@ -742,3 +742,25 @@ def test_ms_ssim_loss_vs_oracle(dev, shape, denorm):
     assert float((ga - gb).abs().max()) <= 2e-3 * float(ga.abs().max()), float((ga - gb).abs().max()) / float(ga.abs().max())
     # MS-SSIM(x, x) = 1 -> loss 0
     assert abs(float(tools.ms_ssim(normalized=denorm)(xb.detach(), xb.detach()))) < 2e-6
+
+
+@pytest.mark.gpu
+def test_integration_md_ctypes_stub(dev):
+    """The ctypes stub INTEGRATION.md shows a reference maintainer (SN conv 3x3 + LeakyReLU through the C ABI only) is
+    executed as written and compared with torch's spectral_norm + conv2d + leaky_relu on the CPU."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", text, re.S) if 'def sn_conv3x3_lrelu' in b)
+    ns = {}
+    exec(block.replace('<repo>', root), ns)
+    conv = torch.nn.utils.spectral_norm(torch.nn.Conv2d(8, 16, 3, 1, 1))
+    x = rnd(2, 8, 9, 7, seed=3)
+    with torch.no_grad():
+        w0, u0, v0 = conv.weight_orig.clone(), conv.weight_u.clone(), conv.weight_v.clone()
+        conv.train()
+        ref = F.leaky_relu(conv(x), 0.1)                      # one power iteration, then W / sigma
+    y = ns['sn_conv3x3_lrelu'](x.to(dev), w0.to(dev), u0.to(dev), v0.to(dev), conv.bias.detach().to(dev))
+    torch.cuda.synchronize()
+    close(from_nhwc(y.cpu(), 16), ref, what='INTEGRATION.md stub')
