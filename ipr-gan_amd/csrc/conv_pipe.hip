@@ -1,0 +1,235 @@
+// bf16 gather-GEMM tiles staged by LDS-DMA through a multi-stage ring (math mode "bf16 activations", BASELINE config 5:
+// DCGAN 128x128 batch 256; layers networks/conv_generator.py:8,21 and networks/sn_discriminator.py:9-18 at mg = md = 16).
+//
+// Same contraction, geometry (GConvArgs / Phase) and epilogue as gconv_kernel<.., IN16> of conv_igemm.hip:
+//     out[b, y*osy+ooy, x*osx+oox, n] = sum_{tap,c} in[b, y*isy+dy(tap), x*isx+dx(tap), c] * Wt[n][tap*Cs+c]
+// with both operands bf16 in HBM, Cs % 64 == 0 and zero padding, so that one 64-deep K step lies inside one tap.
+// What differs is how the operand tiles reach LDS and how the K loop is synchronised:
+//   * `buffer_load_dwordx4 ... lds` (LDS-DMA): a wave-instruction moves 8 tile rows x 128 bytes straight from L2/HBM
+//     into LDS - no staging VGPRs, no ds_write pass.  The LDS destination is lane-linear (base + 16 * lane), so the
+//     bank-conflict swizzle is applied to the per-lane SOURCE address: LDS position p of row r holds source chunk
+//     p ^ ((r >> 1) & 7); the fragment reads apply the same XOR.  Rows outside the image (zero padding, ragged M) use an
+//     out-of-range buffer offset: the DMA writes zeros.
+//   * NSTAGE stage buffers form a ring; NSTAGE-1 K steps of loads are in flight behind the MFMAs.  Per K step: one
+//     counted `s_waitcnt vmcnt(N)` (this wave's part of the oldest stage has landed), ONE raw `s_barrier` (everybody's
+//     part has; everybody is done reading the stage that is about to be refilled), issue the loads of step t+NSTAGE-1,
+//     then the fragment reads and MFMAs of step t.  hipcc's own `__syncthreads()` would drain vmcnt to 0.
+//   * block tiles of 256 rows (8 waves, 64x64 / 64x32 / 128x64 per wave): half the L2 -> LDS bytes per FLOP of the
+//     128-row tiles.
+#include "conv_shared.h"
+
+namespace iprgan {
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+// One LDS-DMA wave-instruction: lane l copies the 16 bytes at buffer offset voff (out of range: zeros) to LDS byte
+// address lds_addr + 16 * l (lds_addr wave-uniform: it travels in M0).  Device pass only: in the host pass the builtin
+// is an error that clang defers silently and then drops the kernel's host stub.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(uintptr_t)lds_addr, 16, voff, 0, 0, 0);
+#endif
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until at most `stages` x L of this wave's LDS-DMA instructions are outstanding (stages: wave-uniform, 0..3)
+template <int L>
+__device__ __forceinline__ void wait_stages(int stages) {
+  static_assert(3 * L <= 63, "vmcnt is a 6-bit field");
+  if (stages >= 3) wait_vmcnt<3 * L>();
+  else if (stages == 2) wait_vmcnt<2 * L>();
+  else if (stages == 1) wait_vmcnt<L>();
+  else wait_vmcnt<0>();
+}
+
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS>
+__global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvArgs a) {
+  constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NW = WGM * WGN;
+  constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW, L = LA + LB;          // LDS-DMA instructions per wave and stage
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;        // 64 bf16 = 128 bytes per tile row
+  static_assert(LA >= 1 && LB >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave stages whole 8-row pieces");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+
+  // logical tile order as in gconv_kernel: n tiles fastest, then the sub-pixel phases, then m tiles
+  const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                gridDim.x * gridDim.y * gridDim.z);
+  const unsigned lq = lt / gridDim.y;
+  const int pz = (int)(lq % gridDim.z);
+  const int pM = a.ph[pz].M;
+  const int m0 = (int)(lq / gridDim.z) * BM, n0 = (int)(lt % gridDim.y) * BN;
+  if (m0 >= pM) {
+    if (STATS) {
+      for (int c = threadIdx.x; c < BN; c += NW * 64)
+        if (n0 + c < a.Ns) { a.stat_part[((size_t)lq * 2) * a.Ns + n0 + c] = 0.f; a.stat_part[((size_t)lq * 2 + 1) * a.Ns + n0 + c] = 0.f; }
+    }
+    return;
+  }
+  const int p_tw = a.ph[pz].tw;
+  const int nt = a.ph[pz].steps / 2;                      // steps counts 32-deep K steps; Cs % 64 == 0
+  const int p_dy0 = a.ph[pz].dy0, p_dx0 = a.ph[pz].dx0, p_dys = a.ph[pz].dys, p_dxs = a.ph[pz].dxs;
+  const int p_wbase = a.ph[pz].wbase, p_wsy = a.ph[pz].wsy, p_wsx = a.ph[pz].wsx;
+  const int p_owg = a.ph[pz].owg, plane = a.ph[pz].ohg * a.ph[pz].owg;
+  const FastDiv d_plane = a.ph[pz].d_plane, d_owg = a.ph[pz].d_owg;
+  const int IH = a.IH, IW = a.IW, Cs = a.Cs;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform (LDS-DMA base, M0)
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lrow = lane >> 3, lchunk = lane & 7;
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+
+  // rows this lane stages: piece (i * NW + wave) = tile rows 8 * piece .. 8 * piece + 7, this lane row 8 * piece + lrow,
+  // LDS position lchunk <- source chunk lchunk ^ swz(row)
+  int aiy[LA], aix[LA];
+  unsigned arow[LA], wrow[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    const int r = (i * NW + wave) * 8 + lrow;
+    const int m = m0 + r;
+    const unsigned sc = (unsigned)(lchunk ^ ((r >> 1) & 7)) * 16u;
+    if (m < pM) {
+      const int b = fdiv(m, d_plane);
+      const int rem = m - b * plane;
+      const int y = fdiv(rem, d_owg);
+      const int x = rem - y * p_owg;
+      aiy[i] = y * a.isy;
+      aix[i] = x * a.isx;
+      arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * 2u + sc;
+    } else {
+      aiy[i] = ROW_INVALID; aix[i] = 0; arow[i] = 0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int r = (i * NW + wave) * 8 + lrow;
+    wrow[i] = (unsigned)((n0 + r) * a.Kp) * 2u + (unsigned)(lchunk ^ ((r >> 1) & 7)) * 16u;
+  }
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;                  // LDS byte address of the ring
+  int u_c = 0, u_ty = 0, u_tx = 0;                                     // wave-uniform tap walk (channel offset, tap)
+  // issue the LDS-DMA of the next K step of the walk into stage buffer `buf`
+  auto issue = [&](int buf) {
+    const int dy = p_dy0 + u_ty * p_dys, dx = p_dx0 + u_tx * p_dxs;
+    const int tapoff = ((dy * IW + dx) * Cs + u_c) * 2;
+    const unsigned wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c) * 2u;
+    const unsigned sbase = lds_base + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int iy = aiy[i] + dy, ix = aix[i] + dx;
+      const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+      dma16(rs_in, sbase + (unsigned)(i * NW) * 1024u, ok ? arow[i] + (unsigned)tapoff : OOB_OFFSET);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
+      dma16(rs_wt, sbase + A_BYTES + (unsigned)(i * NW) * 1024u, wrow[i] + wk);
+    u_c += 64;
+    if (u_c >= Cs) { u_c = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
+  };
+
+  // fragment read offsets: row (wm*WM+i)*32 + l31 of A / (wn*WN+j)*32 + l31 of B, chunk (2 kk + half) ^ swz(l31)
+  const int half = lane >> 5, l31 = lane & 31;
+  unsigned foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) foff[kk] = (unsigned)l31 * 128u + (unsigned)((2 * kk + half) ^ ((l31 >> 1) & 7)) * 16u;
+  const unsigned a_wave = (unsigned)(wm * WM) * 4096u, b_wave = A_BYTES + (unsigned)(wn * WN) * 4096u;
+  const char* ldsc = (const char*)lds;
+  auto compute = [&](int buf) {
+    const char* sb = ldsc + buf * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[WM], bf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8*)(sb + a_wave + i * 4096 + foff[kk]);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[j] = *(const bf16x8*)(sb + b_wave + j * 4096 + foff[kk]);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- the ring
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nt) issue(s);
+  int cur = 0, nxt = NSTAGE - 1;                 // stage read at step t, stage refilled at step t (= read at t-1)
+  for (int t = 0; t < nt; ++t) {
+    const int rem = nt - 1 - t;                  // K steps after this one
+    wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads of step t-1 are complete
+    __builtin_amdgcn_s_barrier();
+    if (rem >= NSTAGE - 1) issue(nxt);
+    compute(cur);
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                  // STATS reuses the ring as scratch
+
+  gconv_epilogue<WGM, WGN, WM, WN, STATS>(a, acc, lds, pz, pz, lq, m0, n0);
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------
+bool gconv_pipe_eligible(const GConvArgs& a) {
+  if (!a.in16 || (a.Cs % 64) != 0 || a.pad_mode != IPRGAN_PAD_ZERO || a.ksplit > 1 || a.wmod > 0 || a.planar_M) return false;
+  for (int i = 0; i < a.nphase; ++i)
+    if (a.ph[i].M > 0 && ((a.ph[i].steps & 1) || a.ph[i].steps < 2)) return false;
+  return true;
+}
+
+template <int WGM, int WGN, int WM, int WN, int NSTAGE>
+static int launch_pipe_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
+  constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+  int maxM = 0;
+  for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
+  if (maxM == 0) return 0;
+  const size_t smem = (size_t)NSTAGE * (BM + BN) * 128;
+  dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.nphase);
+  *bm_out = BM;
+  if (a.stat_part) {
+    auto kern = gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+    prof_launch(kern, grid, dim3(WGM * WGN * 64), smem, st, BN >= 128 ? 19 : 20, a.flops, a);
+  } else {
+    auto kern = gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, false>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+    prof_launch(kern, grid, dim3(WGM * WGN * 64), smem, st, BN >= 128 ? 19 : 20, a.flops, a);
+  }
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+// variant: 0 = 256x128 (8 waves of 64x64, 3 stages), 1 = 256x64 (8 waves of 64x32, 3 stages),
+//          2 = 256x256 (8 waves of 128x64, 2 stages), 3 = 128x128 (4 waves of 64x64, 2 stages: two blocks per CU)
+// returns -1 when the variant does not apply to the geometry
+int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_out) {
+  if (!gconv_pipe_eligible(a)) return -1;
+  switch (variant) {
+    case 0: return a.Ns >= 128 ? launch_pipe_t<4, 2, 2, 2, 3>(a, st, bm_out) : -1;
+    case 1: return launch_pipe_t<4, 2, 2, 1, 3>(a, st, bm_out);
+    case 2: return a.Ns >= 256 ? launch_pipe_t<2, 4, 4, 2, 2>(a, st, bm_out) : -1;
+    case 3: return a.Ns >= 128 ? launch_pipe_t<2, 2, 2, 2, 2>(a, st, bm_out) : -1;
+    default: return -1;
+  }
+}
+
+}  // namespace iprgan

@@ -541,12 +541,15 @@ def test_conv_bf16_math_mode(dev, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('mode', ['bf16', 'bf16act'])
-@pytest.mark.parametrize('tile', [0, 1, 2, 4, 5, 6, 7])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_bf16_gconv_tiles(dev, tile, mode):
     """Every bf16 tile of the forward / backward-data kernel, including the 128x64 and 128x128 per-wave tiles that only
     the bf16 modes build (6, 7), on bf16-representable inputs (products exact: only the summation order differs), with
-    fp32 and with bf16 activations in HBM; ragged M (not a multiple of 256) and N = 256 so that 256-wide tiles apply."""
+    fp32 and with bf16 activations in HBM; ragged M (not a multiple of 256) and N = 256 so that 256-wide tiles apply.
+    Tiles 8-11 are the LDS-DMA ring tiles of conv_pipe.hip (bf16 operands in HBM only)."""
     from iprgan import _lib, ops
+    if tile >= 8 and mode != 'bf16act':
+        pytest.skip('the LDS-DMA ring tiles read bf16 operands from HBM')
     cin, cout, k, s, p, H, W, B = 64, 256, 3, 1, 1, 15, 13, 5
     x, w = rnd(B, cin, H, W, seed=1).bfloat16().float(), rnd(cout, cin, k, k, seed=2, scale=0.05).bfloat16().float()
     b = rnd(cout, seed=5, scale=0.3)
@@ -567,6 +570,73 @@ def test_bf16_gconv_tiles(dev, tile, mode):
         tol = 2e-4 if mode == 'bf16' else 6e-3
         close(from_nhwc(y.float().cpu(), cout), yr, tol, f'{mode} fwd tile {tile}')
         close(from_nhwc(dx.float().cpu(), cin), xr.grad, tol, f'{mode} dgrad tile {tile}')
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
+        _lib.set_math('fp32')
+
+
+PIPE_SHAPES = [  # cin, cout, k, s, p, outpad, transposed, H, W, B
+    (64, 128, 3, 1, 1, 0, False, 15, 13, 5),      # k3: 9 taps x one 64-deep step; ragged M
+    (64, 64, 4, 2, 1, 0, False, 18, 14, 3),       # D.conv1 form: forward one phase of 16 steps, backward-data four phases of 4
+    (128, 64, 4, 2, 1, 0, True, 8, 8, 6),         # ConvT k4s2 (generator): forward = four sub-pixel phases
+    (64, 64, 3, 2, 1, 1, True, 6, 5, 2),          # ConvT k3s2 with output_padding: phases of 1, 2, 2, 4 taps (one-step rings)
+    (256, 256, 4, 2, 1, 0, False, 8, 8, 4),       # two channel steps per tap, N = 256 (the 256x256 tile applies)
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tile', [8, 9, 10, 11])
+@pytest.mark.parametrize('shape', PIPE_SHAPES, ids=lambda c: '-'.join(map(str, c)))
+def test_pipe_tiles(dev, shape, tile):
+    """The LDS-DMA ring tiles (conv_pipe.hip) on bf16-representable operands (products exact, fp32 accumulation: only the
+    summation order differs from torch) through every geometry form they serve: strided forward, sub-pixel phases of the
+    transposed / backward-data forms incl. phases shorter than the ring, zero padding by out-of-range DMA offsets, ragged
+    M; with bias + LeakyReLU, the fused activation derivative, epilogue column sums and the paired pass.  A tile that does
+    not apply to a geometry (N below its width) falls back to the register-staged kernel, which keeps the check valid."""
+    from iprgan import _lib, ops
+    cin, cout, k, s, p, op, tr, H, W, B = shape
+    x = rnd(B, cin, H, W, seed=1).bfloat16().float()
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = rnd(*wshape, seed=2, scale=(cin * k * k) ** -0.5).bfloat16().float()
+    b = rnd(cout, seed=3, scale=0.3)
+    conv = (lambda t: F.conv_transpose2d(t, w, None, stride=s, padding=p, output_padding=op)) if tr else \
+           (lambda t: F.conv2d(t, w, None, stride=s, padding=p))
+    xin = F.leaky_relu(x, 0.25).bfloat16().float().requires_grad_()       # slope 1/4: stays bf16-representable
+    acc = conv(xin)
+    y_ref = F.leaky_relu(acc + b.view(1, -1, 1, 1), 0.1)
+    g = rnd(*acc.shape, seed=4).bfloat16().float()
+    acc.backward(g)
+    dx_ref = xin.grad * torch.where(xin > 0, 1.0, 0.25)
+    try:
+        _lib.set_math('bf16act')
+        _lib.call('iprgan_debug_force_tiles', tile, -1)
+        spec = ops.ConvSpec(cin, cout, k, s, p, op, tr, act=2, slope=0.1)
+        d = spec.desc(B, H, W)
+        assert d.x_bf16 and d.y_bf16
+        wf, wb = ops.conv_prep(spec, d, w.to(dev), None, True, True)
+        xd = to_nhwc(xin.detach()).to(dev).bfloat16()
+        y, (part, rows) = ops.conv_fwd(spec, d, xd, wf, b.to(dev), stats=True)
+        close(from_nhwc(y.float().cpu(), cout), y_ref.detach(), 6e-3, f'pipe fwd tile {tile}')
+        Cs = ops.c4(cout)
+        pr = part[:rows * 2 * Cs].view(rows, 2, Cs).double().sum(0).cpu()
+        a64 = acc.detach().double()
+        assert float((pr[0, :cout] - a64.sum((0, 2, 3))).abs().max()) <= 2e-4 * float(acc.abs().max()) * acc[:, 0].numel() ** 0.5
+        assert float((pr[1, :cout] - (a64 ** 2).sum((0, 2, 3))).abs().max()) <= 2e-4 * float((a64 ** 2).sum((0, 2, 3)).max())
+        dspec = ops.ConvSpec(cin, cout, k, s, p, op, tr)
+        dd = dspec.desc(B, H, W)
+        gd = to_nhwc(g).to(dev).bfloat16()
+        dx, (part, rows) = ops.conv_bwd_data(dspec, dd, gd, wb, xd, 2, 0.25, colsums=True)
+        close(from_nhwc(dx.float().cpu(), cin), dx_ref, 6e-3, f'pipe dgrad tile {tile}')
+        cs = ops.colsum_partials(part, rows, ops.c4(cin), cin).cpu().double()
+        # the sums are taken over the fp32 values before they are rounded to bf16 for the store
+        assert float((cs - dx_ref.double().sum((0, 2, 3))).abs().max()) <= 2e-4 * float(dx_ref.abs().max()) * dx_ref[:, 0].numel() ** 0.5
+        if B % 2 == 0:          # paired pass: rows of each half-batch divided by its own sigma before the bias
+            s0, s1 = torch.tensor([1.5], device=dev), torch.tensor([0.75], device=dev)
+            yp = ops.conv_fwd(spec, d, xd, wf, b.to(dev), pair=(s0, s1))
+            accp = acc.detach().clone()
+            accp[:B // 2] /= 1.5
+            accp[B // 2:] /= 0.75
+            close(from_nhwc(yp.float().cpu(), cout), F.leaky_relu(accp + b.view(1, -1, 1, 1), 0.1), 6e-3, f'pipe pair tile {tile}')
     finally:
         _lib.call('iprgan_debug_force_tiles', -1, -1)
         _lib.set_math('fp32')
