@@ -16,6 +16,13 @@
 //     then the fragment reads and MFMAs of step t.  hipcc's own `__syncthreads()` would drain vmcnt to 0.
 //   * block tiles of 256 rows (8 waves, 64x64 / 64x32 / 128x64 per wave): half the L2 -> LDS bytes per FLOP of the
 //     128-row tiles.
+//   * the epilogue goes through LDS (pipe_epilogue): the common register-layout epilogue of conv_shared.h costs ~1400
+//     vector instructions per wave (quad transposes, per-row-group pixel arithmetic, the general activation switch) -
+//     with the bf16 MFMA 16x faster than the fp32 one that was 2.7x the matrix time of a short-K layer (D.conv1
+//     backward-data: 46 VALU per MFMA measured).  Here the accumulators are written to the (now free) ring as an fp32
+//     [rows][columns] tile and every thread then owns 8 consecutive channels of one pixel per pass: no transposes, one
+//     pixel address per 8 values, 16-byte loads of the fused-derivative operand (issued before the K loop, so they
+//     cost no latency) and 16-byte stores of whole contiguous rows.
 #include "conv_shared.h"
 
 namespace iprgan {
@@ -46,7 +53,180 @@ __device__ __forceinline__ void wait_stages(int stages) {
   else wait_vmcnt<0>();
 }
 
-template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS>
+// ---- row-major epilogue through LDS ---------------------------------------------------------------------------
+template <int WGM, int WGN, int WM, int WN, int RING_BYTES>
+struct EpiGeom {
+  static constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NT = WGM * WGN * 64;
+  static constexpr int NH = (BM * BN * 4 > RING_BYTES) ? 2 : 1;     // column halves (256x256: two rounds of 128 columns)
+  static constexpr int CN = BN / NH;        // columns per round
+  static constexpr int OCT = CN / 8;        // threads per tile row (8 channels each)
+  static constexpr int RPI = NT / OCT;      // rows per pass of the block
+  static constexpr int NIT = BM / RPI;      // passes
+  static constexpr bool PF_FIRST = NH * NIT <= 8;    // registers for the operand prefetched ahead of the K loop
+  static_assert(BM * CN * 4 <= RING_BYTES && WGN % NH == 0 && NT % OCT == 0 && BM % RPI == 0, "epilogue tile geometry");
+};
+
+// element offset (pixel * Ns; add the channel) of tile row m of phase pz, or OOB_OFFSET when the row is past the phase
+__device__ __forceinline__ unsigned pipe_row_elem(const GConvArgs& a, int pz, int m) {
+  if (m >= a.ph[pz].M) return OOB_OFFSET;
+  unsigned opix = (unsigned)m;
+  if (!a.linear_out) {
+    const int plane = a.ph[pz].ohg * a.ph[pz].owg;
+    const int b = fdiv(m, a.ph[pz].d_plane);
+    const int rem = m - b * plane;
+    const int y = fdiv(rem, a.ph[pz].d_owg);
+    const int x = rem - y * a.ph[pz].owg;
+    opix = (unsigned)((b * a.OH + y * a.osy + a.ph[pz].ooy) * a.OW + x * a.osx + a.ph[pz].oox);
+  }
+  return opix * (unsigned)a.Ns;
+}
+
+__device__ __forceinline__ void unpack_bf16x8(u32x4 r, f32x4& lo, f32x4& hi) {
+  lo = f32x4{__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+             __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u)};
+  hi = f32x4{__builtin_bit_cast(float, r.z << 16), __builtin_bit_cast(float, r.z & 0xffff0000u),
+             __builtin_bit_cast(float, r.w << 16), __builtin_bit_cast(float, r.w & 0xffff0000u)};
+}
+
+// the fused-derivative operand (bf16 storage) of this thread's stores of column half h: NIT 16-byte loads
+template <class G>
+__device__ __forceinline__ void pipe_aux_load(const GConvArgs& a, int pz, int m0, int n0, int h, u32x4 (&v)[G::NIT]) {
+  const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux_bytes, 0x00020000);
+  const int tid = threadIdx.x, n = n0 + h * G::CN + (tid % G::OCT) * 8;
+#pragma unroll
+  for (int it = 0; it < G::NIT; ++it) {
+    const unsigned e = pipe_row_elem(a, pz, m0 + it * G::RPI + tid / G::OCT);
+    v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, (e != OOB_OFFSET && n < a.Ns) ? (e + (unsigned)n) * 2u : OOB_OFFSET, 0, 0);
+  }
+}
+
+// Same order of operations as gconv_epilogue (conv_shared.h): pair scale, [column sums of the accumulator], bias,
+// activation, fused derivative, residual, [column sums of the stored value], store.  Activations: none / ReLU /
+// LeakyReLU only (the launcher refuses the others).  T: the ring, free by now (all DMA landed, all fragment reads done).
+template <int WGM, int WGN, int WM, int WN, int RING_BYTES, bool STATS, bool PF>
+__device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[WM][WN], float* T, int pz, unsigned lq,
+                                              int m0, int n0, u32x4 (&auxpf)[EpiGeom<WGM, WGN, WM, WN, RING_BYTES>::NIT]) {
+  using G = EpiGeom<WGM, WGN, WM, WN, RING_BYTES>;
+  constexpr int CN = G::CN, OCT = G::OCT, RPI = G::RPI, NIT = G::NIT, NW = WGM * WGN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN, half = lane >> 5, l31 = lane & 31;
+  const int oct = tid % OCT, r0 = tid / OCT;
+  const int halfM = a.ph[pz].M >> 1;
+  float rsc0 = 1.f, rsc1 = 1.f;
+  if (a.rs0) { rsc0 = 1.f / *a.rs0; rsc1 = 1.f / *a.rs1; }
+  const float neg_act = a.act == IPRGAN_ACT_NONE ? 1.f : a.act == IPRGAN_ACT_RELU ? 0.f : a.slope;
+  const float neg_aux = a.aux_act == IPRGAN_ACT_NONE ? 1.f : a.aux_act == IPRGAN_ACT_RELU ? 0.f : a.aux_slope;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux ? a.aux_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? a.out_bytes : 0, 0x00020000);
+  constexpr int WGN_H = WGN / G::NH;
+#pragma unroll
+  for (int h = 0; h < G::NH; ++h) {
+    const int n = n0 + h * CN + oct * 8;
+    const bool nok = n < a.Ns;                        // Ns % 8 == 0 (launcher)
+    u32x4 auxl[NIT];
+    if (!PF && a.aux && a.aux16) pipe_aux_load<G>(a, pz, m0, n0, h, auxl);      // in flight across the LDS round trip
+    if (h > 0) __syncthreads();                       // everybody is done reading the previous half
+    if (wn / WGN_H == h) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            T[((wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CN + ((wn % WGN_H) * WN + j) * 32 + l31] = acc[i][j][r];
+    }
+    __syncthreads();
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { if (n + k < a.N) b0[k] = a.bias[n + k]; if (n + 4 + k < a.N) b1[k] = a.bias[n + 4 + k]; }
+    }
+    float cs1[8], cs2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cs1[k] = cs2[k] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int r = it * RPI + r0, m = m0 + r;
+      const unsigned e0 = pipe_row_elem(a, pz, m);
+      const bool ok = e0 != OOB_OFFSET && nok;
+      const unsigned e = e0 + (unsigned)n;
+      f32x4 v0 = *(const f32x4*)(T + r * CN + oct * 8), v1 = *(const f32x4*)(T + r * CN + oct * 8 + 4);
+      if (a.rs0) { const float rsm = m < halfM ? rsc0 : rsc1; v0 *= rsm; v1 *= rsm; }
+      if (STATS && a.stat_mode == 1) {     // rows past M and columns past N hold zeros (zero-filled operands)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cs1[k] += v0[k]; cs2[k] += v0[k] * v0[k]; cs1[4 + k] += v1[k]; cs2[4 + k] += v1[k] * v1[k]; }
+      }
+      v0 += b0; v1 += b1;
+      if (a.act != IPRGAN_ACT_NONE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v0[k] = v0[k] > 0.f ? v0[k] : (neg_act == 0.f ? 0.f : v0[k] * neg_act);
+          v1[k] = v1[k] > 0.f ? v1[k] : (neg_act == 0.f ? 0.f : v1[k] * neg_act);
+        }
+      }
+      if (a.aux) {
+        f32x4 o0, o1;
+        if (a.aux16) {
+          unpack_bf16x8(PF ? auxpf[it] : auxl[it], o0, o1);
+        } else {
+          o0 = buf_load4(rs_aux, ok ? e * 4u : OOB_OFFSET);
+          o1 = buf_load4(rs_aux, ok ? e * 4u + 16u : OOB_OFFSET);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v0[k] *= o0[k] > 0.f ? 1.f : neg_aux; v1[k] *= o1[k] > 0.f ? 1.f : neg_aux; }
+      }
+      if (a.res) {
+        if (a.out16) {
+          f32x4 q0, q1;
+          unpack_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? e * 2u : OOB_OFFSET, 0, 0), q0, q1);
+          v0 += q0; v1 += q1;
+        } else {
+          v0 += buf_load4(rs_res, ok ? e * 4u : OOB_OFFSET);
+          v1 += buf_load4(rs_res, ok ? e * 4u + 16u : OOB_OFFSET);
+        }
+      }
+      if (STATS && a.stat_mode == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float t0 = ok ? v0[k] : 0.f, t1 = ok ? v1[k] : 0.f;
+          cs1[k] += t0; cs2[k] += t0 * t0; cs1[4 + k] += t1; cs2[4 + k] += t1 * t1;
+        }
+      }
+      if (a.out16) {
+        const bf16x4 p0 = to_bf16x4(v0), p1 = to_bf16x4(v1);
+        const u32x2 w0 = __builtin_bit_cast(u32x2, p0), w1 = __builtin_bit_cast(u32x2, p1);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0.x, w0.y, w1.x, w1.y}, rs_out, ok ? e * 2u : OOB_OFFSET, 0, 0);
+      } else {
+        buf_store4(rs_out, ok ? e * 4u : OOB_OFFSET, v0);
+        buf_store4(rs_out, ok ? e * 4u + 16u : OOB_OFFSET, v1);
+      }
+    }
+    if (STATS) {
+      // this thread: 8 channels x its NIT rows; the lanes of a wave with the same channel octet (lane % OCT) are combined
+      // by butterflies, the NW waves through LDS in wave order: fixed order, deterministic
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int o = OCT; o < 64; o <<= 1) { cs1[k] += __shfl_xor(cs1[k], o, 64); cs2[k] += __shfl_xor(cs2[k], o, 64); }
+      __syncthreads();                               // the tile has been consumed
+      if (lane < OCT) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { T[(wave * CN + lane * 8 + k) * 2] = cs1[k]; T[(wave * CN + lane * 8 + k) * 2 + 1] = cs2[k]; }
+      }
+      __syncthreads();
+      for (int c = tid; c < CN; c += G::NT) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { s1 += T[(w * CN + c) * 2]; s2 += T[(w * CN + c) * 2 + 1]; }
+        const int nn = n0 + h * CN + c;
+        if (nn < a.Ns) { a.stat_part[((size_t)lq * 2) * a.Ns + nn] = s1; a.stat_part[((size_t)lq * 2 + 1) * a.Ns + nn] = s2; }
+      }
+    }
+  }
+}
+
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF>
 __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvArgs a) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NW = WGM * WGN;
   constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW, L = LA + LB;          // LDS-DMA instructions per wave and stage
@@ -165,6 +345,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
     }
   };
 
+  // PREF: the fused-derivative operand of this thread's stores, loaded FIRST: vmcnt retires in order, so the wait for
+  // stage 0 covers these loads (the same latency, once per tile) and every later counted wait is unaffected
+  using G = EpiGeom<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES>;
+  u32x4 auxpf[G::NIT];
+  if constexpr (PREF) pipe_aux_load<G>(a, pz, m0, n0, 0, auxpf);
+
   // ---- the ring
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
@@ -181,17 +367,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
     nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                  // STATS reuses the ring as scratch
+  __builtin_amdgcn_s_barrier();                  // the epilogue reuses the ring
 
-  gconv_epilogue<WGM, WGN, WM, WN, STATS>(a, acc, lds, pz, pz, lq, m0, n0);
+  pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------
 bool gconv_pipe_eligible(const GConvArgs& a) {
   if (!a.in16 || (a.Cs % 64) != 0 || a.pad_mode != IPRGAN_PAD_ZERO || a.ksplit > 1 || a.wmod > 0 || a.planar_M) return false;
+  auto simple = [](int act) { return act == IPRGAN_ACT_NONE || act == IPRGAN_ACT_RELU || act == IPRGAN_ACT_LRELU; };
+  if ((a.Ns % 8) != 0 || !simple(a.act) || (a.aux && !simple(a.aux_act))) return false;       // pipe_epilogue
   for (int i = 0; i < a.nphase; ++i)
     if (a.ph[i].M > 0 && ((a.ph[i].steps & 1) || a.ph[i].steps < 2)) return false;
   return true;
+}
+
+template <void (*KERN)(const GConvArgs)>
+static void pipe_go(const GConvArgs& a, dim3 grid, dim3 block, size_t smem, int slot, hipStream_t st) {
+  static bool attr_set = false;            // per kernel instantiation
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+  prof_launch(KERN, grid, block, smem, st, slot, a.flops, a);
 }
 
 template <int WGM, int WGN, int WM, int WN, int NSTAGE>
@@ -203,23 +398,25 @@ static int launch_pipe_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   const size_t smem = (size_t)NSTAGE * (BM + BN) * 128;
   dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.nphase);
   *bm_out = BM;
+  // (the 256x256 tile has no registers left for a prefetch ahead of the K loop: its epilogue loads per column half)
+  constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * (BM + BN) * 128>::PF_FIRST;
+  const bool pref = a.aux && a.aux16 && can_pf;
+  const dim3 block(WGM * WGN * 64);
+  const int slot = BN >= 128 ? 19 : 20;
   if (a.stat_part) {
-    auto kern = gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
-    prof_launch(kern, grid, dim3(WGM * WGN * 64), smem, st, BN >= 128 ? 19 : 20, a.flops, a);
+    if constexpr (can_pf) { if (pref) { pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true, true>>(a, grid, block, smem, slot, st); IPR_LAUNCH_CHECK(); return 0; } }
+    pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true, false>>(a, grid, block, smem, slot, st);
   } else {
-    auto kern = gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, false>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
-    prof_launch(kern, grid, dim3(WGM * WGN * 64), smem, st, BN >= 128 ? 19 : 20, a.flops, a);
+    if constexpr (can_pf) { if (pref) { pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, false, true>>(a, grid, block, smem, slot, st); IPR_LAUNCH_CHECK(); return 0; } }
+    pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, false, false>>(a, grid, block, smem, slot, st);
   }
   IPR_LAUNCH_CHECK();
   return 0;
 }
 
 // variant: 0 = 256x128 (8 waves of 64x64, 3 stages), 1 = 256x64 (8 waves of 64x32, 3 stages),
-//          2 = 256x256 (8 waves of 128x64, 2 stages), 3 = 128x128 (4 waves of 64x64, 2 stages: two blocks per CU)
+//          2 = 256x256 (8 waves of 128x64, 2 stages), 3 = 128x128 (4 waves of 64x64, 2 stages: two blocks per CU),
+//          4 = 256x64 with 2 stages (80 KB: two blocks per CU), 5 = 128x64 (4 waves of 64x32, 3 stages, two blocks per CU)
 // returns -1 when the variant does not apply to the geometry
 int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_out) {
   if (!gconv_pipe_eligible(a)) return -1;
@@ -228,6 +425,8 @@ int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_o
     case 1: return launch_pipe_t<4, 2, 2, 1, 3>(a, st, bm_out);
     case 2: return a.Ns >= 256 ? launch_pipe_t<2, 4, 4, 2, 2>(a, st, bm_out) : -1;
     case 3: return a.Ns >= 128 ? launch_pipe_t<2, 2, 2, 2, 2>(a, st, bm_out) : -1;
+    case 4: return launch_pipe_t<4, 2, 2, 1, 2>(a, st, bm_out);
+    case 5: return launch_pipe_t<2, 2, 2, 1, 3>(a, st, bm_out);
     default: return -1;
   }
 }

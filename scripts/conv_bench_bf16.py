@@ -41,7 +41,7 @@ def main():
     dev = torch.device('cuda:0')
     _lib.set_math('bf16act')
     only = sys.argv[1] if len(sys.argv) > 1 else None
-    tiles = [int(t) for t in os.environ.get('CONV_BENCH_TILES', '-1,0,4,8,9,10,11').split(',')]
+    tiles = [int(t) for t in os.environ.get('CONV_BENCH_TILES', '-1,0,4,5,8,9,10,11,12,13').split(',')]
     for name, cin, cout, k, s, p, tr, H in LAYERS:
         if only and only not in name:
             continue
@@ -57,8 +57,9 @@ def main():
         row = dict(layer=name, gflop=round(flops / 1e9, 1))
         for t in tiles:
             _lib.call('iprgan_debug_force_tiles', t, -1)
-            t_f = timeit(lambda: ops.conv_fwd(spec, d, x, wf, None))
-            t_d = timeit(lambda: ops.conv_bwd_data(spec, d, dy, wb))
+            t_f = timeit(lambda: ops.conv_fwd(spec, d, x, wf, None, stats=True))
+            # as inside a training step: fused activation derivative of the producer (reads the layer input) + column sums
+            t_d = timeit(lambda: ops.conv_bwd_data(spec, d, dy, wb, x, 2, 0.1, colsums=True))
             row[f'fwd[{t}]'] = f'{t_f * 1e3:.0f}us {flops / t_f / 1e9:.0f}TF'
             row[f'dgrad[{t}]'] = f'{t_d * 1e3:.0f}us {flops / t_d / 1e9:.0f}TF'
         _lib.call('iprgan_debug_force_tiles', -1, -1)
