@@ -63,8 +63,11 @@ def main():
             row[f'fwd[{t}]'] = f'{t_f * 1e3:.0f}us {flops / t_f / 1e9:.0f}TF'
             row[f'dgrad[{t}]'] = f'{t_d * 1e3:.0f}us {flops / t_d / 1e9:.0f}TF'
         _lib.call('iprgan_debug_force_tiles', -1, -1)
-        t_w = timeit(lambda: ops.conv_bwd_weight(spec, d, x, dy, wshape, False))
-        row['wgrad'] = f'{t_w * 1e3:.0f}us {flops / t_w / 1e9:.0f}TF'
+        for c in [int(t) for t in os.environ.get('CONV_BENCH_WGRAD', '-1,0,60,61,63,64,66,67').split(',')]:
+            _lib.call('iprgan_debug_force_tiles', -1, c)
+            t_w = timeit(lambda: ops.conv_bwd_weight(spec, d, x, dy, wshape, False))
+            row[f'wgrad[{c}]'] = f'{t_w * 1e3:.0f}us {flops / t_w / 1e9:.0f}TF'
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
         print(json.dumps(row), flush=True)
 
 

@@ -13,7 +13,7 @@ def main():
     for f in sorted(glob.glob(f'{prof}/{tag}_*_counter_collection.csv')):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            if not re.search(r'gconv|wgrad|fewin', k):
+            if not re.search(r"gconv|wgrad_halo|fewin", k):
                 continue
             k = re.sub(r'\(.*', '', k).replace('void iprgan::', '')
             e = tot[k][r['Counter_Name']]

@@ -494,6 +494,49 @@ def test_every_wgrad_candidate(dev, cand):
         _lib.call('iprgan_debug_force_tiles', -1, -1)
 
 
+HALO_SHAPES = [  # cin, cout, k, s, p, outpad, transposed, H, W, B
+    (64, 64, 3, 1, 1, 0, False, 16, 16, 3),       # k3 s1: one 64x64 tile pair, zero padding on every border patch
+    (64, 128, 3, 1, 1, 0, False, 13, 11, 2),      # ragged maps: patches that hang over the right / bottom edge
+    (128, 64, 4, 2, 1, 0, False, 16, 16, 4),      # k4 s2 Conv2d (D.conv1 form): two channel chunks of the gathered tensor
+    (64, 64, 4, 2, 1, 0, False, 18, 14, 2),       # k4 s2, ragged output grid 9 x 7
+    (128, 64, 4, 2, 1, 0, True, 8, 8, 5),         # ConvT k4 s2 (generator): S = x on the input grid, L = dy
+    (64, 128, 4, 2, 1, 0, True, 5, 6, 3),         # ConvT, small ragged grid
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cand', [60, 61, 62, 63, 64, 65, 66, 67, 68])
+@pytest.mark.parametrize('shape', HALO_SHAPES, ids=lambda c: '-'.join(map(str, c)))
+def test_wgrad_halo(dev, shape, cand):
+    """Backward-weight in the halo form (wgrad_halo.hip; candidates 60-68 = 3 variants x block targets 128 / 256 / 512) on
+    bf16-representable tensors (products exact, fp32 accumulation): every tap, stride residue, zero-padded border and
+    ragged patch against torch, for Conv2d and ConvTranspose2d; accumulate-into-bucket form (beta = 1) as well."""
+    from iprgan import _lib, ops
+    cin, cout, k, s, p, op, tr, H, W, B = shape
+    x = rnd(B, cin, H, W, seed=1).bfloat16().float()
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = torch.zeros(*wshape, requires_grad=True)
+    conv = (lambda t: F.conv_transpose2d(t, w, None, stride=s, padding=p, output_padding=op)) if tr else \
+           (lambda t: F.conv2d(t, w, None, stride=s, padding=p))
+    y = conv(x)
+    g = rnd(*y.shape, seed=4).bfloat16().float()
+    y.backward(g)
+    try:
+        _lib.set_math('bf16act')
+        _lib.call('iprgan_debug_force_tiles', -1, cand)
+        spec = ops.ConvSpec(cin, cout, k, s, p, op, tr)
+        d = spec.desc(B, H, W)
+        xd, gd = to_nhwc(x).to(dev).bfloat16(), to_nhwc(g).to(dev).bfloat16()
+        dw, _ = ops.conv_bwd_weight(spec, d, xd, gd, wshape, False)
+        close(dw, w.grad, 2e-4, f'halo wgrad cand {cand}')
+        acc = torch.full(wshape, 0.5, device=dev)
+        ops.conv_bwd_weight(spec, d, xd, gd, wshape, False, dw=acc, beta=1.0)
+        close(acc.cpu(), w.grad + 0.5, 2e-4, f'halo wgrad beta=1 cand {cand}')
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
+        _lib.set_math('fp32')
+
+
 BF16_SHAPES = [  # cin, cout, k, s, p, transposed, H, B
     (64, 128, 3, 1, 1, False, 16, 4), (128, 64, 4, 2, 1, False, 16, 4), (256, 128, 4, 2, 1, True, 8, 4),
     (32, 96, 3, 1, 1, False, 9, 3), (64, 64, 3, 2, 1, False, 17, 2),
