@@ -69,7 +69,12 @@ class RcclTransport:
     _ready = False
 
     @classmethod
-    def ensure(cls, rank, nranks):
+    def ensure(cls, rank, nranks, probe_device=None):
+        """Bring the communicator up.  With several ranks ``ncclCommInitRank`` is a rendezvous: if one rank cannot enter it
+        (RCCL not loadable, a bad id) its peers block inside the bootstrap with no timeout.  So the blocking part - init and
+        a one-element probe all-reduce - runs in a helper thread that this thread abandons after IPRGAN_COMM_TIMEOUT
+        seconds (default 90; ctypes releases the GIL).  Raises on failure or timeout; the caller turns that into a
+        collective decision (``_rccl_or_torch``), so that no rank keeps waiting for one that gave up."""
         from . import _lib as L
         if cls._ready:
             return cls
@@ -80,7 +85,37 @@ class RcclTransport:
             box = [bytes(ident.raw)]
             dist.broadcast_object_list(box, src=0)
             ident = C.create_string_buffer(box[0], 128)
-        L.call('iprgan_comm_init', rank, nranks, ident)
+        if nranks == 1:
+            L.call('iprgan_comm_init', rank, nranks, ident)
+            cls._ready = True
+            return cls
+        import threading
+        result = {}
+
+        def bring_up():
+            try:
+                if probe_device is not None:
+                    torch.cuda.set_device(probe_device)
+                L.call('iprgan_comm_init', rank, nranks, ident)
+                if probe_device is not None:
+                    probe = torch.ones(4, device=probe_device)
+                    st = torch.cuda.current_stream(probe_device)
+                    L.call('iprgan_allreduce_bucket', probe.data_ptr(), probe.numel(), 0, st.cuda_stream)
+                    st.synchronize()
+                    result['probe'] = float(probe[0].item())
+                result['ok'] = True
+            except Exception as e:                          # noqa: BLE001
+                result['error'] = e
+
+        t = threading.Thread(target=bring_up, daemon=True, name='iprgan-comm-init')
+        t.start()
+        t.join(float(os.environ.get('IPRGAN_COMM_TIMEOUT', '90')))
+        if t.is_alive():
+            raise TimeoutError('iprgan_comm_init did not return (a peer never entered the RCCL rendezvous?)')
+        if 'error' in result:
+            raise result['error']
+        if probe_device is not None and result.get('probe') != float(nranks):
+            raise RuntimeError(f'probe all-reduce returned {result.get("probe")}, expected {nranks}')
         cls._ready = True
         return cls
 
@@ -115,9 +150,13 @@ def _all_ranks_ok(ok, device):
 def _rccl_or_torch(rank, nranks, device):
     """The library's own RCCL communicator, verified before it is trusted with gradients: every rank must be able to
     bind RCCL (iprgan_comm_unique_id exercises the dlopen + symbol lookup without any communication), the communicator
-    must come up on every rank, and a one-element all-reduce must return the rank count.  If any rank fails any of the
-    three, ALL ranks fall back - loudly - to torch.distributed's all_reduce on the same side stream (backend 'nccl' is RCCL
-    too: same wire, one communicator more in the process).  IPRGAN_COMM=torch selects that path outright."""
+    must come up on every rank, and a one-element all-reduce must return the rank count.  The three results are AND-ed
+    across ranks over torch.distributed; if any rank failed - or did not get out of the RCCL rendezvous within
+    IPRGAN_COMM_TIMEOUT seconds (``RcclTransport.ensure``: the blocking calls run in an abandonable thread, so a rank
+    whose peer never arrives does not hang the job) - ALL ranks fall back, loudly, to torch.distributed's all_reduce on
+    the same side stream (backend 'nccl' is RCCL too: same wire, one communicator more in the process).
+    IPRGAN_COMM=torch selects that path outright.  Which transport carries the gradients is reported by
+    ``transport_name()`` (bench.py prints it)."""
     import sys
     if os.environ.get('IPRGAN_COMM') == 'torch':
         return TorchDistTransport
@@ -129,23 +168,41 @@ def _rccl_or_torch(rank, nranks, device):
         why = f'binding RCCL failed: {e}'
     if _all_ranks_ok(why is None, device):
         try:
-            RcclTransport.ensure(rank, nranks)
-            probe = torch.ones(4, device=device)
-            RcclTransport.all_reduce(probe, torch.cuda.current_stream())
-            torch.cuda.current_stream().synchronize()
-            if float(probe[0].item()) != float(nranks):
-                why = f'probe all-reduce returned {float(probe[0].item())}, expected {nranks}'
+            RcclTransport.ensure(rank, nranks, probe_device=device)
         except Exception as e:                              # noqa: BLE001
             why = f'communicator: {e}'
         if _all_ranks_ok(why is None, device):
             return RcclTransport
-        RcclTransport.destroy()
+        if why is None:
+            RcclTransport.destroy()
     print(f'[iprgan rank {rank}] iprgan_comm_* unavailable on at least one rank ({why or "another rank failed"}); gradient '
           f'buckets go through torch.distributed all_reduce instead', file=sys.stderr, flush=True)
     return TorchDistTransport
 
 
+_chosen = {'name': 'none'}        # the transport the last GradReducer layout picked (bench.py reports it)
+
+
+def transport_name():
+    return _chosen['name']
+
+
+def comm_nranks():
+    """Ranks of the library's own communicator (0 = not initialised)."""
+    from . import _lib as L
+    try:
+        return int(L.query('iprgan_comm_nranks'))
+    except Exception:                                       # noqa: BLE001
+        return 0
+
+
 def _pick_transport(device):
+    t = _pick_transport_impl(device)
+    _chosen['name'] = {None: 'none', RcclTransport: 'rccl-abi', TorchDistTransport: 'torch.distributed'}[t]
+    return t
+
+
+def _pick_transport_impl(device):
     rank, nranks = world()
     if nranks > 1:
         if device.type == 'cuda' and dist.get_backend() == 'nccl':
@@ -174,6 +231,7 @@ class GradReducer:
         self.pending = 0                            # recorded forward passes whose backward has not run yet
         self.in_final = False
         self.trace = None                           # list of (kind, index, seq) when tracing (tests)
+        self.exposed_log = []                       # (event at wait(), bucket completion events) of the last steps
         self._handles = []
         for p in self.params:
             _owner[id(p)] = (weakref.ref(p), self)
@@ -291,7 +349,7 @@ class GradReducer:
             self.stream.wait_event(ready)
             with torch.cuda.stream(self.stream):
                 self.transport.all_reduce(b['flat'], self.stream)
-                b['done'] = torch.cuda.Event(enable_timing=self.trace is not None)
+                b['done'] = torch.cuda.Event(enable_timing=self.trace is not None or self.world > 1)
                 b['done'].record(self.stream)
             if self.trace is not None:
                 b['ready'] = ready
@@ -319,18 +377,38 @@ class GradReducer:
             self._launch(b)
 
     def wait(self):
-        """Before the optimizer step: the compute stream waits for the exchanged buckets.  Parameters nobody produced
-        a gradient for get ``.grad = None`` (so Adam skips them exactly as on a single GPU)."""
+        """Before the optimizer step: the compute stream waits for the exchanged buckets.  Afterwards ``p.grad`` holds the
+        SUM over ranks (Adam multiplies by 1/world as it reads: ``opt.grad_scale``), not the mean.  On one rank,
+        parameters nobody produced a gradient for get ``.grad = None`` (Adam skips them, as the reference's would)."""
         if not self.armed:
             return
         self.armed = False
         self.pending = 0
-        for b in self.buckets:
-            if b['done'] is not None:
-                torch.cuda.current_stream().wait_event(b['done'])
+        dones = [b['done'] for b in self.buckets if b['done'] is not None]
+        if dones and self.world > 1:                # where the compute stream stands when it starts to wait
+            here = torch.cuda.Event(enable_timing=True)
+            here.record()
+            self.exposed_log.append((here, dones))
+            del self.exposed_log[:-64]
+        for d in dones:
+            torch.cuda.current_stream().wait_event(d)
+        if self.world > 1:
+            # every rank steps every parameter: a parameter that only SOME ranks produced a gradient for keeps its view
+            # (zeros on the ranks that did not) - skipping it locally would let weights and Adam state diverge
+            return
         for p in self.params:
             if p not in self.touched:
                 p.grad = None
+
+    def exposed_ms(self):
+        """Mean time per step the compute stream had to wait for the exchange (completion of the last bucket after the
+        stream reached ``wait()``); call after a device synchronize."""
+        if not self.exposed_log:
+            return 0.0
+        tot = 0.0
+        for here, dones in self.exposed_log:
+            tot += max([0.0] + [here.elapsed_time(d) for d in dones])
+        return tot / len(self.exposed_log)
 
     def close(self):
         for h in self._handles:
@@ -346,5 +424,8 @@ def broadcast_module(module, src=0):
     _, w = world()
     if w == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    # in place on the tensors themselves (not through .data): the write bumps their version counters, which key the
+    # engine's cached conv operands (engine.py) - a later re-broadcast can then never leave stale operands behind
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src)

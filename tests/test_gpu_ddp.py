@@ -265,3 +265,60 @@ def test_comm_startup_probe_over_nccl_backend(tmp_path):
     res = torch.load(out)
     assert res['picked'] == 'RcclTransport' and res['forced'] == 'TorchDistTransport'
     assert torch.equal(res['buf'], torch.arange(8, dtype=torch.float32))
+
+
+def _rccl2_worker(rank, port, out):
+    """Two ranks, two GPUs, the library's OWN communicator (iprgan_comm_*): SUM of a bucket against torch.distributed."""
+    _paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=2, device_id=dev)
+    from iprgan import parallel
+    t = parallel._rccl_or_torch(rank, 2, dev)
+    g = torch.Generator().manual_seed(7 + rank)
+    mine = torch.randn(1 << 20, generator=g).to(dev)
+    ref = mine.clone()
+    dist.all_reduce(ref)
+    buf = mine.clone()
+    t.all_reduce(buf, torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({'picked': t.__name__, 'equal': bool(torch.equal(buf, ref)), 'nranks': parallel.comm_nranks(),
+                    'name': parallel.transport_name()}, out)
+    parallel.RcclTransport.destroy()
+    dist.destroy_process_group()
+
+
+def test_rccl_transport_two_gpus(tmp_path):
+    """The N > 1 branch of iprgan_comm_init on real hardware: rank 0's unique id travels over torch.distributed, both
+    ranks join the communicator, the verified probe passes, and a 4 MB bucket summed by iprgan_allreduce_bucket equals
+    torch.distributed's all_reduce bit for bit (two addends: one order).  Skipped on boxes with fewer than two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    out = str(tmp_path / 'rccl2.pt')
+    mp.spawn(_rccl2_worker, args=(_free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res['picked'] == 'RcclTransport' and res['nranks'] == 2 and res['equal'], res
+
+
+def test_bench_self_launch_two_ranks_one_gpu():
+    """``python bench.py --gpus 2`` WITHOUT a launcher (the shape of the driver's N = 1 command): bench.py starts
+    torch.distributed.run itself as a child, relays rank 0's JSON line and reports which transport carried the gradients
+    (two ranks share this box's GPU over gloo here; on a multi-GPU node the same command runs one rank per GPU on RCCL)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(IPRGAN_SHARE_DEVICE='1', IPRGAN_DIST_BACKEND='gloo')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['config']['parallelism'] == 'dp2' and r['config']['global_batch'] == 256
+    assert r['transport'] == 'torch.distributed' and r['comm_nranks'] == 0 and r['allreduce_exposed_ms_per_step'] >= 0.0
+    assert r['value'] > 0 and r['scaling'] == 'weak'
