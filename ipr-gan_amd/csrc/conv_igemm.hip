@@ -37,7 +37,7 @@ static ProfSlot g_slots[] = {
     {"wgrad_t_kernel<64x64>", 0, 0, 0},   {"wgrad_t_kernel<128x128,8w>", 0, 0, 0},
     {"fewin_conv_kernel", 0, 0, 0},
     {"gconv_pipe_kernel", 0, 0, 0},     {"gconv_pipe_kernel<256x64>", 0, 0, 0},
-    {"wgrad_halo_kernel", 0, 0, 0},
+    {"wgrad_halo_kernel", 0, 0, 0},     {"wgrad_rgb_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; int tag; };
@@ -2003,9 +2003,16 @@ bool wgrad_halo_eligible(const iprgan_conv_desc* d);
 int wgrad_halo_nsplit(const iprgan_conv_desc* d, int variant, int target_blocks);
 int launch_wgrad_halo(const iprgan_conv_desc* d, const void* x, const void* dy, float* ws, int variant, int target_blocks,
                       hipStream_t st, int* nsplit_out, int* Nrows_out, int* Kw_out);
+bool wgrad_rgb_eligible(const iprgan_conv_desc* d);
+int wgrad_rgb_nsplit(const iprgan_conv_desc* d, int target_blocks);
+int launch_wgrad_rgb(const iprgan_conv_desc* d, const void* x, const void* dy, float* ws, int target_blocks, hipStream_t st,
+                     int* nsplit_out, int* Nrows_out, int* Kw_out);
+#define WGRAD_NRGB 2                        // candidates WGRAD_NCAND + WGRAD_NHALO + {0, 1}: 256 / 512 blocks
+static const int g_rgb_targets[WGRAD_NRGB] = {256, 512};
 #define WGRAD_NHALO 9                       // candidate WGRAD_NCAND + 3 * variant + target index
 static const int g_halo_targets[3] = {128, 256, 512};
 static bool wgrad_halo_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_BF16 && wgrad_halo_eligible(d); }
+static bool wgrad_rgb_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_BF16 && wgrad_rgb_eligible(d); }
 
 static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that fits every candidate
   size_t m = 0;
@@ -2013,6 +2020,13 @@ static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that
     const WGeom g = wgrad_geom(d);
     for (int i = 0; i < WGRAD_NHALO; ++i) {
       const size_t n = (size_t)wgrad_halo_nsplit(d, i / 3, g_halo_targets[i % 3]) * c4(g.N) * d->KH * d->KW * c4(g.Cq);
+      if (n > m) m = n;
+    }
+  }
+  if (wgrad_rgb_ok(d)) {
+    const WGeom g = wgrad_geom(d);
+    for (int i = 0; i < WGRAD_NRGB; ++i) {
+      const size_t n = (size_t)wgrad_rgb_nsplit(d, g_rgb_targets[i]) * c4(g.N) * 64;
       if (n > m) m = n;
     }
   }
@@ -2371,10 +2385,15 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   float* dw_trial = ws + rup4(wgrad_slab_floats(d) + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout))) +
                     rup4(wgrad_padded_floats(d));
   auto run_to = [&](int cand, float* dw_out, float beta_out) -> int {
-    if (cand >= WGRAD_NCAND) {           // halo form: same slabs, same fixed-order reduce
-      if (cand >= WGRAD_NCAND + WGRAD_NHALO || !wgrad_halo_ok(d)) return -1;
-      int nsplit = 0, Nrows = 0, Kw = 0;
-      const int rc = launch_wgrad_halo(d, x, dy, ws, (cand - WGRAD_NCAND) / 3, g_halo_targets[(cand - WGRAD_NCAND) % 3], st, &nsplit, &Nrows, &Kw);
+    if (cand >= WGRAD_NCAND) {           // halo / RGB forms: same slabs, same fixed-order reduce
+      int nsplit = 0, Nrows = 0, Kw = 0, rc;
+      if (cand >= WGRAD_NCAND + WGRAD_NHALO) {
+        if (cand >= WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB || !wgrad_rgb_ok(d)) return -1;
+        rc = launch_wgrad_rgb(d, x, dy, ws, g_rgb_targets[cand - WGRAD_NCAND - WGRAD_NHALO], st, &nsplit, &Nrows, &Kw);
+      } else {
+        if (!wgrad_halo_ok(d)) return -1;
+        rc = launch_wgrad_halo(d, x, dy, ws, (cand - WGRAD_NCAND) / 3, g_halo_targets[(cand - WGRAD_NCAND) % 3], st, &nsplit, &Nrows, &Kw);
+      }
       if (rc) return rc;
       const int ntap = d->KH * d->KW, Qs = c4(g.Cq);
       const long long total = (long long)g.N * ntap * Qs;
@@ -2453,11 +2472,12 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   }
   if (g_force_wgrad >= 0) {
     WGradPlan pf;
-    if (g_force_wgrad >= WGRAD_NCAND ? (g_force_wgrad < WGRAD_NCAND + WGRAD_NHALO && wgrad_halo_ok(d)) : wgrad_plan_c(d, g_force_wgrad, pf))
+    if (g_force_wgrad >= WGRAD_NCAND + WGRAD_NHALO ? (g_force_wgrad < WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB && wgrad_rgb_ok(d))
+        : g_force_wgrad >= WGRAD_NCAND ? wgrad_halo_ok(d) : wgrad_plan_c(d, g_force_wgrad, pf))
       cand = g_force_wgrad;
   } else if (g_autotune) {     // same scheme as the forward/backward-data tiles: time every candidate once per geometry
     TuneKey key = {{d->B, d->H, d->W, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->outpad,
-                    d->transposed, d->pad_mode, -7, g_math, d->x_bf16, 0}};
+                    d->transposed, d->pad_mode, -7, g_math, d->x_bf16, d->y_bf16}};
     int cached;
     if (tune_lookup(key, &cached)) {
       cand = cached;
@@ -2466,7 +2486,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
       g_prof_on = false;
       float best_us = 0.f;
       int err = 0;
-      cand = tune_pick(WGRAD_NCAND + WGRAD_NHALO, run, st, cand, &best_us, &err);
+      cand = tune_pick(WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB, run, st, cand, &best_us, &err);
       g_prof_on = prof_was;
       if (err) return err;
       if (getenv("IPRGAN_TUNE_LOG"))

@@ -245,6 +245,205 @@ __global__ __launch_bounds__(wh_threads(KH * KW, TPW)) void wgrad_halo_kernel(co
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Backward-weight of the RGB layers (3 -> C stems, C -> 3 heads; k3 s1 p1): dW[n][c][tap] = sum_p T64[p][n] T4[p+tap-1][c]
+// with T64 the bf16 tensor with many channels (Conv2d 3->C: dy; ConvTranspose2d C->3: x) and T4 the fp32 NHWC4 image
+// (x / dy).  19 GFLOP over 0.6 GB at DCGAN-128 batch 256: bound by READING T64 once.  The split-M GEMM spent 330 us on it
+// (1.8 TB/s: 64x64 tiles whose K = 36 columns fill one MFMA column block in two).  Here a block streams tiles of 256
+// pixels (whole image rows): T64 by LDS-DMA into two [pixel][32 channel] planes (64-byte rows: the transposed reads of
+// 4 consecutive pixels are conflict-free), the fp32 halo rows of T4 by LDS-DMA as well (zero padding = out-of-range
+// offsets); B fragments [pixel][(tap, c)] are assembled from the halo with eight 4-byte LDS reads at the tap's shift and
+// rounded to bf16 (the math mode's operand rounding).  Every wave reduces its 64 pixels of the tile into all 64 x 64
+// (36 used) accumulators; waves and blocks are combined in fixed order (LDS, then the slab reduce).
+// Layers: networks/sn_discriminator.py:9 (3 -> 64), networks/conv_generator.py:21 (64 -> 3).
+struct WRgbArgs {
+  const void* T64;      // [B][H][W][Cs] bf16
+  const float* T4;      // [B][H][W][4] fp32
+  float* ws;            // slabs [nsplit][Nrows][64]
+  int B, H, W, Cs, R;   // R = image rows per tile (R * W = 256)
+  int tpi, ntile, tps;  // tiles per image, tiles in all, tiles per split
+  FastDiv d_tpi, d_w;
+  int Nrows;
+  unsigned t64_bytes, t4_bytes;
+  double flops;
+};
+
+#define WRGB_TPIX 256
+#define WRGB_NSTAGE 3
+
+__global__ __launch_bounds__(256) void wgrad_rgb_kernel(const WRgbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  constexpr int A_BYTES = 2 * WRGB_TPIX * 64;                         // two 32-channel planes
+  const int HROW = a.W + 2, HPIX = (a.R + 2) * HROW;                  // halo: R + 2 rows of W + 2 pixels, 16 bytes each
+  const int HINST = (HPIX + 63) / 64;                                 // DMA instructions (64 pixels each)
+  const int STAGE = A_BYTES + (HINST + 1) * 1024;                     // + one kilobyte that swallows the dummy instructions
+  const int zero_off = WRGB_NSTAGE * STAGE;                           // 128 bytes of zeros behind the ring
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x, n0 = blockIdx.y * 64;
+  char* ldsc = (char*)lds;
+  if (tid < 32) *(float*)(ldsc + zero_off + tid * 4) = 0.f;
+
+  int tbeg = split * a.tps, tend = tbeg + a.tps;
+  if (tend > a.ntile) tend = a.ntile;
+  const int nt = tend - tbeg;
+  const wh_u32x4 rs64 = wh_make_rsrc(a.T64, a.t64_bytes), rs4 = wh_make_rsrc(a.T4, a.t4_bytes);
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+
+  // DMA slots of this wave per stage: 8 for T64 (32 instructions of 16 pixel rows x 64 B over 4 waves), then its share
+  // of the halo instructions.  All waves issue the same count (dummies read out of range into the stage's pad).
+  auto issue = [&](int tile, int buf) {
+    const int b = fdiv(tile, a.d_tpi);
+    const int r0 = (tile - b * a.tpi) * a.R;
+    const unsigned sb = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)buf * STAGE);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int inst = i * 4 + wave;                                  // 0..31: plane = inst / 16, pixels 16 * (inst % 16) ..
+      const int plane = inst >> 4, m = (inst & 15) * 16 + (lane >> 2), piece = lane & 3;
+      const int r = fdiv(m, a.d_w), x = m - r * a.W;
+      const bool ok = r0 + r < a.H;
+      const unsigned off = ok ? (unsigned)((((b * a.H + r0 + r) * a.W + x) * a.Cs + n0 + plane * 32) * 2 + piece * 16) : OOB_OFFSET;
+      wh_dma16(rs64, __builtin_amdgcn_readfirstlane(sb + (unsigned)inst * 1024u), off);
+    }
+    for (int i = 0; i < 6; ++i) {                                     // fixed trip count: the counted vmcnt needs it
+      const int inst = i * 4 + wave, hp = inst * 64 + lane;           // halo pixel of this lane (16 bytes)
+      const int hr = hp / HROW, hx = hp - hr * HROW;
+      const int y = r0 - 1 + hr, x = hx - 1;
+      const bool ok = inst < HINST && hp < HPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+      const unsigned off = ok ? (unsigned)(((b * a.H + y) * a.W + x) * 16) : OOB_OFFSET;
+      // instructions past the halo (every wave issues six) write zeros into the stage's spare kilobyte
+      const unsigned dst = sb + A_BYTES + (unsigned)(inst < HINST ? inst : HINST) * 1024u;
+      wh_dma16(rs4, __builtin_amdgcn_readfirstlane(dst), off);
+    }
+  };
+  constexpr int LPW = 8 + 6;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int half = lane >> 5, gq = (lane & 15) >> 2, gp = lane & 3, gcol = (lane >> 4) & 1, l31 = lane & 31;
+  const unsigned a_lane = (unsigned)((wave * 64 + 8 * half + gq) * 64 + gcol * 32 + gp * 8);     // + plane*16384 + ks*1024 + rd*256
+  // B column of this lane in column block cf: col = cf * 32 + l31 = tap * 4 + c
+  unsigned b_lane[2];
+  bool b_ok[2];
+#pragma unroll
+  for (int cf = 0; cf < 2; ++cf) {
+    const int col = cf * 32 + l31, tap = col >> 2, c = col & 3, ty = tap / 3, tx = tap - ty * 3;
+    b_ok[cf] = col < 36;
+    b_lane[cf] = (unsigned)(A_BYTES + ((ty * HROW + tx + 8 * half) * 16 + c * 4));
+  }
+
+  auto compute = [&](int buf) {
+    const char* sb = ldsc + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i] = wh_tr_read8(sb + a_lane + i * 16384 + ks * 1024, sb + a_lane + i * 16384 + ks * 1024 + 256);
+      const int m0 = wave * 64 + ks * 16;                             // first pixel of this k step: 16 pixels in one image row
+      const int r = fdiv(m0, a.d_w), x0 = m0 - r * a.W;
+      const unsigned srow = (unsigned)((r * HROW + x0) * 16);
+#pragma unroll
+      for (int cf = 0; cf < 2; ++cf) {
+        const char* bp = b_ok[cf] ? sb + b_lane[cf] + srow : ldsc + zero_off;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *(const float*)(bp + i * 16);
+        bfr[cf] = bf16x8{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf)
+          acc[i][cf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[cf], acc[i][cf], 0, 0, 0);
+    }
+  };
+
+  __syncthreads();                                                   // the zero area is written
+#pragma unroll
+  for (int s = 0; s < WRGB_NSTAGE - 1; ++s)
+    if (s < nt) issue(tbeg + s, s);
+  int cur = 0, nxt = WRGB_NSTAGE - 1;
+  for (int t = 0; t < nt; ++t) {
+    const int rem = nt - 1 - t;
+    if (rem >= 1) wh_wait_vmcnt<LPW>();
+    else wh_wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (rem >= WRGB_NSTAGE - 1) issue(tbeg + t + WRGB_NSTAGE - 1, nxt);
+    compute(cur);
+    cur = cur + 1 == WRGB_NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == WRGB_NSTAGE ? 0 : nxt + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // combine the four waves (each reduced its own 64 pixels of every tile) in wave order, then one slab per block
+  float* red = (float*)lds;                                           // [wave][64 n][64 col]: 64 KB of the ring
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        red[(wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + cf * 32 + l31] = acc[i][cf][r];
+  __syncthreads();
+  float* slab = a.ws + ((size_t)split * a.Nrows + n0) * 64;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const float s = ((red[e] + red[4096 + e]) + red[8192 + e]) + red[12288 + e];
+    slab[e] = s;
+  }
+}
+
+bool wgrad_rgb_eligible(const iprgan_conv_desc* d) {
+  // T64 = dy (Conv2d 3->C) or x (ConvT C->3) must be bf16, the 3-channel side fp32 NHWC4
+  if (d->pad_mode != IPRGAN_PAD_ZERO || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->outpad != 0) return false;
+  const int n64 = d->transposed ? d->Cin : d->Cout, n4 = d->transposed ? d->Cout : d->Cin;
+  const bool t64_16 = d->transposed ? d->x_bf16 : d->y_bf16, t4_16 = d->transposed ? d->y_bf16 : d->x_bf16;
+  if (n4 > 4 || (n64 % 64) != 0 || !t64_16 || t4_16) return false;
+  return (d->W % 16) == 0 && d->W <= 256 && (WRGB_TPIX % d->W) == 0;
+}
+int wgrad_rgb_nsplit(const iprgan_conv_desc* d, int target_blocks) {
+  const int R = WRGB_TPIX / d->W, ntile = d->B * cdiv(d->H, R);
+  const int n64 = d->transposed ? d->Cin : d->Cout;
+  int want = cdiv(target_blocks, n64 / 64);
+  if (want > ntile) want = ntile;
+  if (want < 1) want = 1;
+  return cdiv(ntile, cdiv(ntile, want));
+}
+int launch_wgrad_rgb(const iprgan_conv_desc* d, const void* x, const void* dy, float* ws, int target_blocks, hipStream_t st,
+                     int* nsplit_out, int* Nrows_out, int* Kw_out) {
+  if (!wgrad_rgb_eligible(d)) return -1;
+  WRgbArgs a;
+  memset(&a, 0, sizeof(a));
+  a.T64 = d->transposed ? x : dy; a.T4 = (const float*)(d->transposed ? dy : x);
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cs = d->transposed ? d->Cin : d->Cout;
+  a.R = WRGB_TPIX / d->W; a.tpi = cdiv(d->H, a.R); a.ntile = a.B * a.tpi;
+  const int nsplit = wgrad_rgb_nsplit(d, target_blocks);
+  a.tps = cdiv(a.ntile, nsplit);
+  a.d_tpi = make_fastdiv(a.tpi); a.d_w = make_fastdiv(a.W);
+  a.Nrows = a.Cs; a.ws = ws;
+  const unsigned long long b64 = (unsigned long long)a.B * a.H * a.W * a.Cs * 2, b4 = (unsigned long long)a.B * a.H * a.W * 16;
+  IPR_CHECK(b64 < 0x7fffffffull && b4 < 0x7fffffffull, "conv_bwd_weight: tensor larger than 2 GiB");
+  a.t64_bytes = (unsigned)b64; a.t4_bytes = (unsigned)b4;
+  a.flops = 2.0 * a.B * (double)a.H * a.W * d->Cout * d->Cin * 9;
+  const int HINST = cdiv((a.R + 2) * (a.W + 2), 64);
+  IPR_CHECK(HINST <= 24, "conv_bwd_weight: halo too large for the RGB kernel");
+  const size_t smem = (size_t)WRGB_NSTAGE * (2 * WRGB_TPIX * 64 + (HINST + 1) * 1024) + 128;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)wgrad_rgb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  *nsplit_out = nsplit; *Nrows_out = a.Nrows; *Kw_out = 64;
+  prof_launch(wgrad_rgb_kernel, dim3(nsplit, a.Cs / 64), dim3(256), smem, st, 22, a.flops, a);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------
 bool wgrad_halo_eligible(const iprgan_conv_desc* d) {
   if (!d->x_bf16 || !d->y_bf16 || d->pad_mode != IPRGAN_PAD_ZERO) return false;

@@ -196,6 +196,26 @@ def run_bbox_transforms(tools, make_cfg):
     return res
 
 
+def run_loss_factories(loss_ns):
+    """tools.l1 / tools.mse (tools/loss.py:10-20,72-76) with and without ``normalized``: value and gradient w.r.t. x on
+    a seeded image pair in [-1, 1] with a block of exact ties (sign(0) = 0 in the L1 gradient).  ``loss_ns``: anything
+    with ``l1`` / ``mse`` factories (the real tools/loss.py, oracle.bbox, iprgan.tools)."""
+    x = torch.tanh(recipe.tensor(5, 1, (3, 3, 20, 24)))
+    y = torch.tanh(recipe.tensor(5, 2, (3, 3, 20, 24)))
+    y[0, 0, :2] = x[0, 0, :2]
+    res = {}
+    for name in ('l1', 'mse'):
+        for normalized in (False, True):
+            dev = getattr(loss_ns, 'DEVICE', None)
+            xa = (x.to(dev) if dev is not None else x.clone()).requires_grad_()
+            loss = getattr(loss_ns, name)(normalized=normalized)(xa, y.to(dev) if dev is not None else y)
+            loss.backward()
+            key = f'{name}/{"norm" if normalized else "raw"}'
+            res[key + '/value'] = np.float64(float(loss.detach()))
+            res[key + '/grad'] = xa.grad.detach().cpu().numpy()
+    return res
+
+
 def run_dcgan_complete_steps(make_cfg, models, device, n_steps=2, batch=4, seed=81):
     """The 'complete' protection (configs/DCGAN/complete/*.yaml): BlackBoxWrapper (TransformDist trigger ->
     noise-patch target, SSIM) inside WhiteBoxWrapper, in the order of experiments/image_generation.py:56-101."""

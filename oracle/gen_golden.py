@@ -54,6 +54,7 @@ def main():
     save('cyclegan_pool_steps', lambda: cases.run_cyclegan_pool_steps(ref_loader.Config, models, dev))
     save('vgg_layer_names', lambda: {'names': np.array(cases.vgg_layer_names_from_source(
         os.path.join(ref_loader.REF, 'networks', 'vgg.py')))})
+    save('loss_factories', lambda: cases.run_loss_factories(ref_loader.load_loss()))
     save('dcgan_steps_complete', lambda: cases.run_dcgan_complete_steps(ref_loader.Config, models, dev))
 
 

@@ -76,6 +76,28 @@ def load():
     return networks, tools, models
 
 
+def load_loss():
+    """The REAL ``tools/loss.py`` (``Loss``, ``l1``, ``mse``: tools/loss.py:10-20,72-76).  Its module-level imports of
+    torchvision.transforms.Normalize and pytorch_msssim.SSIM / MS_SSIM (both absent from this image, neither used by
+    ``Loss`` / ``l1`` / ``mse``) are satisfied by empty stand-in modules that exist only while the file is loaded."""
+    sys.dont_write_bytecode = True
+    stubs = {'torchvision': types.ModuleType('torchvision'), 'torchvision.transforms': types.ModuleType('torchvision.transforms'),
+             'pytorch_msssim': types.ModuleType('pytorch_msssim')}
+    stubs['torchvision'].transforms = stubs['torchvision.transforms']
+    stubs['torchvision.transforms'].Normalize = object
+    stubs['pytorch_msssim'].SSIM = stubs['pytorch_msssim'].MS_SSIM = object
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    try:
+        return _load('_ref_tools_loss', 'tools/loss.py')
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def Config(entries):
     load()
     return sys.modules['ref_models_loaded'].Config(entries)

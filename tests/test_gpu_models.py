@@ -323,6 +323,24 @@ def test_full_size_step_is_deterministic_and_keeps_watermark(dev):
         assert np.isfinite(runs[0][f'step{s}/metric/D/Sum']) and np.isfinite(runs[0][f'step{s}/metric/G/Sum'])
 
 
+def test_dcgan128_bf16act_full_size_step_is_deterministic_and_keeps_watermark(dev):
+    """BASELINE config 5 at its FULL size (DCGAN 128x128, batch 256, bf16 MFMA tiles, bf16 activations in HBM): the
+    LDS-DMA ring tiles, the halo backward-weight kernels and the slab reductions are fixed-order, so two runs from the
+    same seeds agree BIT FOR BIT (the tile / candidate choice is per process: the second run replays the first one's);
+    everything stays finite, the sign loss is >= 0 and the embedded signature survives (BER 0, sign_model.py:51-60)."""
+    from iprgan import Config, _lib, models
+    try:
+        _lib.set_math('bf16act')
+        r = _bitwise_equal_runs(lambda: cases.run_dcgan_steps(Config, models, [dev], n_steps=2, batch=256, seed=7,
+                                                                 cfg=cases.DCGAN128_CFG, size=128))
+    finally:
+        _lib.set_math('fp32')
+    assert r['final/ber'] == 0.0
+    for s in range(2):
+        assert r[f'step{s}/metric/P/SignLoss'] >= 0.0
+        assert np.isfinite(r[f'step{s}/metric/D/Sum']) and np.isfinite(r[f'step{s}/metric/G/Sum'])
+
+
 def test_conv_linearity_at_full_size(dev):
     """conv(a*x + b*y) == a*conv(x) + b*conv(y) for the largest DCGAN-64 layer shapes at batch 128 (forward,
     strided backward-data phases and backward-weight), to fp32 rounding."""
@@ -406,7 +424,7 @@ def test_dcgan128_bf16_steps_vs_reference_golden(golden, dev, mode):
     every parameter (= the gradients) in overall magnitude to 5 % for weight tensors and 8 % for per-channel vectors
     (BatchNorm affine parameters and biases: every element is a sum of B*H*W signed terms whose cancellation amplifies
     the operand rounding; measured over bf16 / bf16act, with and without the matrix-core stem kernel
-    (scripts/dbg/d128_bf16_key.py): weights <= 3.3 %, vectors <= 5.1 %, no mode consistently better);
+    (measured in round 2): weights <= 3.3 %, vectors <= 5.1 %, no mode consistently better);
     sign buffers and the BER exactly."""
     from iprgan import Config, _lib, models
     ref = golden('dcgan128_steps_wbox')
@@ -478,6 +496,22 @@ def test_loss_factories_vs_oracle(name, normalized, dev):
     np.testing.assert_allclose(float(lb.detach()), float(la.detach()), rtol=2e-6)
     la.backward(); lb.backward()
     np.testing.assert_allclose(xb.grad.cpu().numpy(), xa.grad.numpy(), rtol=1e-6, atol=1e-10)
+
+
+def test_loss_factories_vs_reference_golden(dev, golden):
+    """iprgan.tools.l1 / mse on the GPU against values and gradients produced by the REAL tools/loss.py
+    (tests/golden/loss_factories.npz): the mean is an fp32 tree sum here and torch's CPU sum there - 2e-6 relative."""
+    from iprgan import tools
+
+    class NS:
+        DEVICE = dev
+        l1, mse = staticmethod(tools.l1), staticmethod(tools.mse)
+    res, ref = cases.run_loss_factories(NS), golden('loss_factories')
+    for k in res:
+        if k.endswith('/value'):
+            np.testing.assert_allclose(res[k], ref[k], rtol=2e-6, err_msg=k)
+        else:
+            np.testing.assert_allclose(res[k], ref[k], rtol=1e-6, atol=1e-10, err_msg=k)
 
 
 def _bitwise_equal_runs(fn):

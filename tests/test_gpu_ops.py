@@ -537,6 +537,47 @@ def test_wgrad_halo(dev, shape, cand):
         _lib.set_math('fp32')
 
 
+RGB_WGRAD_SHAPES = [  # cin, cout, transposed, H, W, B
+    (3, 64, False, 16, 16, 3),        # stem 3 -> 64: tiles of 16 rows, halo rows above / below the image are zero padding
+    (3, 128, False, 12, 32, 2),       # two 64-channel tiles of dy; H not a multiple of the tile's rows (ragged last tile)
+    (64, 3, True, 8, 64, 2),          # head 64 -> 3 (ConvTranspose2d): T64 = x, T4 = dy
+    (3, 64, False, 6, 128, 2),        # full-width rows of config 5 (two rows per tile)
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cand', [69, 70])
+@pytest.mark.parametrize('shape', RGB_WGRAD_SHAPES, ids=lambda c: '-'.join(map(str, c)))
+def test_wgrad_rgb(dev, shape, cand):
+    """Backward-weight of the RGB layers in the streaming form (wgrad_rgb_kernel; candidates 69 / 70) with the
+    many-channel tensor stored as bf16 and the 3-channel side fp32: the kernel rounds the fp32 side to bf16 (math-mode
+    operand rounding), so the reference is computed from the rounded image and the products are exact."""
+    from iprgan import _lib, ops
+    cin, cout, tr, H, W, B = shape
+    k, s, p = 3, 1, 1
+    x = rnd(B, cin, H, W, seed=1).bfloat16().float()
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = torch.zeros(*wshape, requires_grad=True)
+    y = F.conv_transpose2d(x, w, None, stride=s, padding=p) if tr else F.conv2d(x, w, None, stride=s, padding=p)
+    g = rnd(*y.shape, seed=4).bfloat16().float()
+    y.backward(g)
+    try:
+        _lib.set_math('bf16act')
+        _lib.call('iprgan_debug_force_tiles', -1, cand)
+        spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr)
+        d = spec.desc(B, H, W)
+        xd, gd = to_nhwc(x).to(dev), to_nhwc(g).to(dev)
+        if tr:
+            xd = xd.bfloat16()
+        else:
+            gd = gd.bfloat16()
+        dw, _ = ops.conv_bwd_weight(spec, d, xd, gd, wshape, False)
+        close(dw, w.grad, 2e-4, f'rgb wgrad cand {cand}')
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
+        _lib.set_math('fp32')
+
+
 BF16_SHAPES = [  # cin, cout, k, s, p, transposed, H, B
     (64, 128, 3, 1, 1, False, 16, 4), (128, 64, 4, 2, 1, False, 16, 4), (256, 128, 4, 2, 1, True, 8, 4),
     (32, 96, 3, 1, 1, False, 9, 3), (64, 64, 3, 2, 1, False, 17, 2),

@@ -137,6 +137,15 @@ def test_vae_steps_match_reference(golden):
     compare(cases.run_vae_steps(gan.Cfg, gan, gan.CPU), golden('vae_steps_wbox'), rtol=5e-4, atol=5e-5)
 
 
+def test_loss_factories_match_reference(golden):
+    """oracle.bbox.l1 / mse against the fixture generated by the REAL tools/loss.py (Loss, l1, mse): bit-exact values and
+    gradients, both ``normalized`` settings (the CPU arithmetic is the same torch ops in the same order)."""
+    res, ref = cases.run_loss_factories(bbox), golden('loss_factories')
+    assert sorted(res) == sorted(ref.files)
+    for k in res:
+        assert np.array_equal(np.asarray(res[k]), ref[k]), k
+
+
 def test_bbox_transforms_match_reference(golden):
     """TransformDist / RandomBitMask / TransformVar restatements vs the reference's own classes (seeded)."""
     compare(cases.run_bbox_transforms(bbox, gan.Cfg), golden('bbox_transforms'), rtol=1e-6, atol=1e-7)
