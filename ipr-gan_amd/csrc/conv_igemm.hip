@@ -575,7 +575,109 @@ __global__ __launch_bounds__(256, FEWIN_WAVES) void fewin_mfma_kernel(const GCon
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j)           // SIMPLE: operand roles swapped (weights as A): the tile comes out transposed
+        acc[i][j] = SIMPLE ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  }
+  if constexpr (SIMPLE) {
+    // Transposed accumulators (rows = channels, columns = pixels): lane (l31, half) holds pixel l31 of M tile i and, in
+    // registers 4g..4g+3, channels 8g + 4 half + 0..3 of column block j.  One v_permlane32_swap per register pairs group
+    // g of the lower half-wave with group g of the upper one: afterwards a lane owns 8 CONSECUTIVE channels of its pixel
+    // (lower half: 16 gp .. +7, upper half: 16 gp + 8 .. +15) - no quad transposes, one pixel address per M tile, 16-byte
+    // stores and 16-byte loads of the fused-derivative operand.  (The row-per-lane form retired ~35 vector instructions
+    // per 4-channel store and ran at 2.7 TB/s of output; this form about half of that.)
+    float rsc0 = 1.f, rsc1 = 1.f;
+    if (a.rs0) { rsc0 = 1.f / *a.rs0; rsc1 = 1.f / *a.rs1; }
+    const float rs = b < (a.B >> 1) ? rsc0 : rsc1;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux ? a.aux_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? a.out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oy = y0 + 4 * wave + 2 * i + (l31 >> 4), ox = x0 + (l31 & 15);
+      const bool mok = oy < a.OH && ox < a.OW;
+      const unsigned pix = (unsigned)((b * a.OH + oy) * a.OW + ox) * (unsigned)a.Ns;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          f32x4 v0, v1;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            // (inline asm: with __builtin_amdgcn_permlane32_swap hipcc 7.2 produced a tile whose 32 channels all carried
+            // channel 0 here - the two v_nop are the VALU-write -> permlane wait states the compiler would have added)
+            float lo = acc[i][j][8 * gp + k], hi = acc[i][j][8 * gp + 4 + k];
+            asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+            v0[k] = lo;
+            v1[k] = hi;
+          }
+#ifdef FEWIN_DBG_NOSWAP
+          {
+            const int nA = n0 + j * 32 + 16 * gp + 4 * half, nB = nA + 8;
+            f32x4 qa, qb;
+            for (int k = 0; k < 4; ++k) { qa[k] = acc[i][j][8 * gp + k]; qb[k] = acc[i][j][8 * gp + 4 + k]; }
+            buf_store4(rs_out, mok ? (pix + nA) * 4u : OOB_OFFSET, qa);
+            buf_store4(rs_out, mok ? (pix + nB) * 4u : OOB_OFFSET, qb);
+            continue;
+          }
+#endif
+          const int n = n0 + j * 32 + 16 * gp + 8 * half;
+          const bool ok = mok && n < a.Ns;                      // Ns % 8 == 0 (launcher)
+          const unsigned e = pix + (unsigned)n;
+          if (a.rs0) { v0 *= rs; v1 *= rs; }
+          if (a.bias) {      // the bias vector has N floats: dword loads through a descriptor of exactly that size (zeros past it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v0[k] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bias, (unsigned)(n + k) * 4u, 0, 0));
+              v1[k] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bias, (unsigned)(n + 4 + k) * 4u, 0, 0));
+            }
+          }
+          if (a.act != IPRGAN_ACT_NONE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v0[k] = v0[k] > 0.f ? v0[k] : (neg_act == 0.f ? 0.f : v0[k] * neg_act);
+              v1[k] = v1[k] > 0.f ? v1[k] : (neg_act == 0.f ? 0.f : v1[k] * neg_act);
+            }
+          }
+          if (a.aux) {
+            f32x4 o0, o1;
+            if (a.aux16) {
+              const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, ok ? e * 2u : OOB_OFFSET, 0, 0);
+              o0 = f32x4{__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                         __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u)};
+              o1 = f32x4{__builtin_bit_cast(float, r.z << 16), __builtin_bit_cast(float, r.z & 0xffff0000u),
+                         __builtin_bit_cast(float, r.w << 16), __builtin_bit_cast(float, r.w & 0xffff0000u)};
+            } else {
+              o0 = buf_load4(rs_aux, ok ? e * 4u : OOB_OFFSET);
+              o1 = buf_load4(rs_aux, ok ? e * 4u + 16u : OOB_OFFSET);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v0[k] *= o0[k] > 0.f ? 1.f : neg_aux; v1[k] *= o1[k] > 0.f ? 1.f : neg_aux; }
+          }
+          if (a.res) {
+            if (a.out16) {
+              const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? e * 2u : OOB_OFFSET, 0, 0);
+              v0 += f32x4{__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                          __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u)};
+              v1 += f32x4{__builtin_bit_cast(float, r.z << 16), __builtin_bit_cast(float, r.z & 0xffff0000u),
+                          __builtin_bit_cast(float, r.w << 16), __builtin_bit_cast(float, r.w & 0xffff0000u)};
+            } else {
+              v0 += buf_load4(rs_res, ok ? e * 4u : OOB_OFFSET);
+              v1 += buf_load4(rs_res, ok ? e * 4u + 16u : OOB_OFFSET);
+            }
+          }
+          if (a.out16) {
+            const bf16x4 p0 = to_bf16x4(v0), p1 = to_bf16x4(v1);
+            const u32x2 w0 = __builtin_bit_cast(u32x2, p0), w1 = __builtin_bit_cast(u32x2, p1);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0.x, w0.y, w1.x, w1.y}, rs_out, ok ? e * 2u : OOB_OFFSET, 0, 0);
+          } else {
+            buf_store4(rs_out, ok ? e * 4u : OOB_OFFSET, v0);
+            buf_store4(rs_out, ok ? e * 4u + 16u : OOB_OFFSET, v1);
+          }
+        }
+    }
+    return;
   }
   // epilogue: quad transpose to 4 consecutive channels per lane (as in gconv_kernel), then fewin_store.  Row
   // ml = 8 g + 4 half + qp of M tile i is pixel (4 wave + 2 i + (g >> 1), 8 (g & 1) + 4 half + qp) of the 16 x 16 tile.
@@ -1737,7 +1839,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
           attr16_set = true;
         }
         dim3 grid((unsigned)(a.B * cdiv(a.OH, FEWIN_T) * cdiv(a.OW, FEWIN_T)), (unsigned)cdiv(a.Ns, 64));
-        if (simple) prof_launch(fewin_mfma_kernel<true>, grid, dim3(256), smem16, st, 18, a.flops, a, lw, lh, kpad, neg_act, neg_aux);
+        if (simple && (a.Ns % 8) == 0) prof_launch(fewin_mfma_kernel<true>, grid, dim3(256), smem16, st, 18, a.flops, a, lw, lh, kpad, neg_act, neg_aux);
         else prof_launch(fewin_mfma_kernel<false>, grid, dim3(256), smem16, st, 18, a.flops, a, lw, lh, kpad, neg_act, neg_aux);
         IPR_LAUNCH_CHECK();
         return 0;
