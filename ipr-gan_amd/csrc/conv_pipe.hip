@@ -29,6 +29,13 @@ namespace iprgan {
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// Cache policy of the epilogue's streams (the tile's output, the operand of the fused derivative): each byte is touched
+// once, while the operand rows of the K loop are re-read tap after tap and by the neighbouring tiles of the same XCD.
+// aux bit 1 = nt: the streams pass through L2 without displacing those rows.
+#ifndef PIPE_NT
+#define PIPE_NT 0          // measured: nt on these streams is neutral to -5 % (DCGAN-128 layers), so the default policy stays
+#endif
+
 // One LDS-DMA wave-instruction: lane l copies the 16 bytes at buffer offset voff (out of range: zeros) to LDS byte
 // address lds_addr + 16 * l (lds_addr wave-uniform: it travels in M0).  Device pass only: in the host pass the builtin
 // is an error that clang defers silently and then drops the kernel's host stub.
@@ -62,7 +69,7 @@ struct EpiGeom {
   static constexpr int OCT = CN / 8;        // threads per tile row (8 channels each)
   static constexpr int RPI = NT / OCT;      // rows per pass of the block
   static constexpr int NIT = BM / RPI;      // passes
-  static constexpr bool PF_FIRST = NH * NIT <= 8;    // registers for the operand prefetched ahead of the K loop
+  static constexpr bool PF_FIRST = NH == 1 && NIT <= 8;    // registers for the operand prefetched ahead of the K loop
   static_assert(BM * CN * 4 <= RING_BYTES && WGN % NH == 0 && NT % OCT == 0 && BM % RPI == 0, "epilogue tile geometry");
 };
 
@@ -96,7 +103,7 @@ __device__ __forceinline__ void pipe_aux_load(const GConvArgs& a, int pz, int m0
 #pragma unroll
   for (int it = 0; it < G::NIT; ++it) {
     const unsigned e = pipe_row_elem(a, pz, m0 + it * G::RPI + tid / G::OCT);
-    v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, (e != OOB_OFFSET && n < a.Ns) ? (e + (unsigned)n) * 2u : OOB_OFFSET, 0, 0);
+    v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, (e != OOB_OFFSET && n < a.Ns) ? (e + (unsigned)n) * 2u : OOB_OFFSET, 0, PIPE_NT);
   }
 }
 
@@ -105,7 +112,7 @@ __device__ __forceinline__ void pipe_aux_load(const GConvArgs& a, int pz, int m0
 // LeakyReLU only (the launcher refuses the others).  T: the ring, free by now (all DMA landed, all fragment reads done).
 template <int WGM, int WGN, int WM, int WN, int RING_BYTES, bool STATS, bool PF>
 __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[WM][WN], float* T, int pz, unsigned lq,
-                                              int m0, int n0, u32x4 (&auxpf)[EpiGeom<WGM, WGN, WM, WN, RING_BYTES>::NIT]) {
+                                              int m0, int n0, const u32x4* auxpf) {      // PF: [NH][NIT] prefetched
   using G = EpiGeom<WGM, WGN, WM, WN, RING_BYTES>;
   constexpr int CN = G::CN, OCT = G::OCT, RPI = G::RPI, NIT = G::NIT, NW = WGM * WGN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,7 +175,7 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
       if (a.aux) {
         f32x4 o0, o1;
         if (a.aux16) {
-          unpack_bf16x8(PF ? auxpf[it] : auxl[it], o0, o1);
+          unpack_bf16x8(PF ? auxpf[h * NIT + it] : auxl[it], o0, o1);
         } else {
           o0 = buf_load4(rs_aux, ok ? e * 4u : OOB_OFFSET);
           o1 = buf_load4(rs_aux, ok ? e * 4u + 16u : OOB_OFFSET);
@@ -196,7 +203,7 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
       if (a.out16) {
         const bf16x4 p0 = to_bf16x4(v0), p1 = to_bf16x4(v1);
         const u32x2 w0 = __builtin_bit_cast(u32x2, p0), w1 = __builtin_bit_cast(u32x2, p1);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0.x, w0.y, w1.x, w1.y}, rs_out, ok ? e * 2u : OOB_OFFSET, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0.x, w0.y, w1.x, w1.y}, rs_out, ok ? e * 2u : OOB_OFFSET, 0, PIPE_NT);
       } else {
         buf_store4(rs_out, ok ? e * 4u : OOB_OFFSET, v0);
         buf_store4(rs_out, ok ? e * 4u + 16u : OOB_OFFSET, v1);
@@ -372,6 +379,264 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf);
 }
 
+// ---- persistent form -------------------------------------------------------------------------------------------
+// One block per CU walks a list of tiles.  What it buys over one-tile blocks (measured on the 9-step 64 -> 128 k3 layer,
+// 256x128 tile, one block per CU: the block lived 34 k cycles for 9.2 k cycles of MFMA; 39 % of its wave cycles were
+// parked in s_waitcnt / s_barrier): the first stages of the NEXT tile are issued before the epilogue of the current one
+// (the ring is free by then; the epilogue works in its own LDS region), so the DMA latency of a tile's prologue and
+// the HBM / L2 idle time of an epilogue disappear behind each other.
+//   FWD (no fused derivative, no residual, bf16 output - every forward pass): bias, activation and the column sums
+//   are applied in the accumulator layout, where a lane owns ONE channel (one bias value, two running sums per column
+//   block); the tile goes to LDS as bf16 and leaves as a plain copy: 16-byte LDS read -> 16-byte store of whole rows.
+//   !FWD: pipe_epilogue on a 64 KB fp32 region (256x128 tiles in two column halves), operand of the fused derivative
+//   prefetched for the next tile while the current one is stored.
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool FWD>
+__global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConvArgs a, int ntn, int nphz, int total) {
+  constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NW = WGM * WGN, NT = NW * 64;
+  constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW, L = LA + LB;
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128, RING = NSTAGE * STAGE_BYTES;
+  constexpr int T_BYTES = 64 * 1024;
+  static_assert(RING + T_BYTES <= 160 * 1024 && BM * BN * 2 <= T_BYTES, "LDS budget");
+  using G = EpiGeom<WGM, WGN, WM, WN, T_BYTES>;
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  char* ldsc = (char*)lds;
+  float* T = (float*)(ldsc + RING);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lrow = lane >> 3, lchunk = lane & 7, half = lane >> 5, l31 = lane & 31;
+  const int IH = a.IH, IW = a.IW, Cs = a.Cs;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+  const int myslot = (int)xcd_remap(blockIdx.x, gridDim.x);           // blocks of one XCD take neighbouring tiles of a round
+
+  // ---- state of the tile whose operands are being loaded
+  int l_pz = 0, l_m0 = 0, l_n0 = 0, l_nt = 0;
+  unsigned l_lq = 0;
+  int p_tw = 1, p_dy0 = 0, p_dx0 = 0, p_dys = 0, p_dxs = 0, p_wbase = 0, p_wsy = 0, p_wsx = 0;
+  int aiy[LA], aix[LA];
+  unsigned arow[LA], wrow[LB];
+  int u_c = 0, u_ty = 0, u_tx = 0;
+  // next tile of this block at or after round `it` that has rows (tiles past the end of a short phase only owe a row of
+  // zero partials); returns false when the list is exhausted
+  auto next_tile = [&](int& it) -> bool {
+    for (;; ++it) {
+      const long long lt = (long long)it * gridDim.x + myslot;
+      if (lt >= total) return false;
+      const unsigned lq = (unsigned)(lt / ntn);
+      const int pz = (int)(lq % (unsigned)nphz), m0 = (int)(lq / (unsigned)nphz) * BM, n0 = (int)(lt % ntn) * BN;
+      if (m0 >= a.ph[pz].M) {
+        if (STATS)
+          for (int c = tid; c < BN; c += NT)
+            if (n0 + c < a.Ns) { a.stat_part[((size_t)lq * 2) * a.Ns + n0 + c] = 0.f; a.stat_part[((size_t)lq * 2 + 1) * a.Ns + n0 + c] = 0.f; }
+        continue;
+      }
+      l_pz = pz; l_m0 = m0; l_n0 = n0; l_lq = lq; l_nt = a.ph[pz].steps / 2;
+      return true;
+    }
+  };
+  auto setup_rows = [&]() {
+    const Phase& ph = a.ph[l_pz];
+    p_tw = ph.tw; p_dy0 = ph.dy0; p_dx0 = ph.dx0; p_dys = ph.dys; p_dxs = ph.dxs;
+    p_wbase = ph.wbase; p_wsy = ph.wsy; p_wsx = ph.wsx;
+    const int plane = ph.ohg * ph.owg;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int r = (i * NW + wave) * 8 + lrow;
+      const int m = l_m0 + r;
+      const unsigned sc = (unsigned)(lchunk ^ ((r >> 1) & 7)) * 16u;
+      if (m < ph.M) {
+        const int b = fdiv(m, ph.d_plane);
+        const int rem = m - b * plane;
+        const int y = fdiv(rem, ph.d_owg);
+        const int x = rem - y * ph.owg;
+        aiy[i] = y * a.isy;
+        aix[i] = x * a.isx;
+        arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * 2u + sc;
+      } else {
+        aiy[i] = ROW_INVALID; aix[i] = 0; arow[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int r = (i * NW + wave) * 8 + lrow;
+      wrow[i] = (unsigned)((l_n0 + r) * a.Kp) * 2u + (unsigned)(lchunk ^ ((r >> 1) & 7)) * 16u;
+    }
+    u_c = 0; u_ty = 0; u_tx = 0;
+  };
+  auto issue = [&](int buf) {
+    const int dy = p_dy0 + u_ty * p_dys, dx = p_dx0 + u_tx * p_dxs;
+    const int tapoff = ((dy * IW + dx) * Cs + u_c) * 2;
+    const unsigned wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c) * 2u;
+    const unsigned sbase = lds_base + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int iy = aiy[i] + dy, ix = aix[i] + dx;
+      const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+      dma16(rs_in, sbase + (unsigned)(i * NW) * 1024u, ok ? arow[i] + (unsigned)tapoff : OOB_OFFSET);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
+      dma16(rs_wt, sbase + A_BYTES + (unsigned)(i * NW) * 1024u, wrow[i] + wk);
+    u_c += 64;
+    if (u_c >= Cs) { u_c = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
+  };
+  auto prologue = [&]() {            // first NSTAGE - 1 stages of the loading tile into ring slots 0 ..
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < l_nt) issue(s);
+  };
+
+  unsigned foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) foff[kk] = (unsigned)l31 * 128u + (unsigned)((2 * kk + half) ^ ((l31 >> 1) & 7)) * 16u;
+  const unsigned a_wave = (unsigned)(wm * WM) * 4096u, b_wave = A_BYTES + (unsigned)(wn * WN) * 4096u;
+  f32x16 acc[WM][WN];
+  auto compute = [&](int buf) {
+    const char* sb = ldsc + buf * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 af[WM], bf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8*)(sb + a_wave + i * 4096 + foff[kk]);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[j] = *(const bf16x8*)(sb + b_wave + j * 4096 + foff[kk]);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  int it = 0;
+  if (!next_tile(it)) return;
+  setup_rows();
+  // fused-derivative operand of the loading tile, prefetched a tile ahead when one column half covers the tile (the
+  // 256x128 tile would need 64 more registers for two halves in flight twice: its epilogue loads per half instead)
+  constexpr bool PFN = !FWD && G::NH == 1;
+  u32x4 auxn[PFN ? G::NIT : 1];
+  const bool use_aux = PFN && a.aux && a.aux16;
+  if constexpr (PFN) {
+    if (use_aux) pipe_aux_load<G>(a, l_pz, l_m0, l_n0, 0, auxn);
+  }
+  prologue();
+  for (;;) {
+    // ---- K loop of the current tile (its first stages are in flight)
+    const int c_pz = l_pz, c_m0 = l_m0, c_n0 = l_n0, nt = l_nt;
+    const unsigned c_lq = l_lq;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int cur = 0, nxt = NSTAGE - 1;
+    for (int t = 0; t < nt; ++t) {
+      const int rem = nt - 1 - t;
+      // the first wait of a tile also retires the previous tile's stores (they were issued after this tile's first
+      // stages, so a counted wait cannot skip them): vmcnt(0) there, counted waits afterwards
+      if (t == 0) wait_stages<L>(0); else wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (rem >= NSTAGE - 1) issue(nxt);
+      compute(cur);
+      cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+      nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // every wave is done with the ring
+    // ---- operands of the next tile: rows, prologue DMA, (operand of the fused derivative: after the current one is consumed)
+    u32x4 auxc[PFN ? G::NIT : 1];
+    if constexpr (PFN) {
+#pragma unroll
+      for (int i = 0; i < G::NIT; ++i) auxc[i] = auxn[i];
+    }
+    ++it;
+    const bool more = next_tile(it);
+    if (more) {
+      setup_rows();
+      if constexpr (PFN) {
+        if (use_aux) pipe_aux_load<G>(a, l_pz, l_m0, l_n0, 0, auxn);
+      }
+      prologue();
+    }
+    // ---- epilogue of the current tile
+    if constexpr (!FWD) {
+      if (use_aux) pipe_epilogue<WGM, WGN, WM, WN, T_BYTES, STATS, true>(a, acc, T, c_pz, c_lq, c_m0, c_n0, auxc);
+      else pipe_epilogue<WGM, WGN, WM, WN, T_BYTES, STATS, false>(a, acc, T, c_pz, c_lq, c_m0, c_n0, auxc);
+      __syncthreads();                           // T is read out before the next tile's epilogue writes it (vmcnt drained too)
+    } else {
+      const int pM = a.ph[c_pz].M, halfM = pM >> 1;
+      float rsc0 = 1.f, rsc1 = 1.f;
+      if (a.rs0) { rsc0 = 1.f / *a.rs0; rsc1 = 1.f / *a.rs1; }
+      const float neg_act = a.act == IPRGAN_ACT_NONE ? 1.f : a.act == IPRGAN_ACT_RELU ? 0.f : a.slope;
+      __bf16* T16 = (__bf16*)T;
+      float cs1[WN], cs2[WN], bias_l[WN];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int n = c_n0 + (wn * WN + j) * 32 + l31;
+        cs1[j] = cs2[j] = 0.f;
+        bias_l[j] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float rsm = a.rs0 ? (c_m0 + row < halfM ? rsc0 : rsc1) : 1.f;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            float v = acc[i][j][r];
+            if (a.rs0) v *= rsm;
+            if (STATS) { cs1[j] += v; cs2[j] += v * v; }         // stat_mode 1: the accumulator before the bias (rows past M are zero)
+            v += bias_l[j];
+            if (a.act != IPRGAN_ACT_NONE) v = v > 0.f ? v : (neg_act == 0.f ? 0.f : v * neg_act);
+            T16[row * BN + (wn * WN + j) * 32 + l31] = (__bf16)v;
+          }
+        }
+      __syncthreads();
+      {                                          // copy-out: 8 channels (16 bytes) of one pixel per thread and pass
+        constexpr int OCT = BN / 8, RPI = NT / OCT, NIT = BM / RPI;
+        const int oct = tid % OCT, r0 = tid / OCT, n = c_n0 + oct * 8;
+        const bool nok = n < a.Ns;
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+          const int row = q * RPI + r0;
+          const unsigned e0 = pipe_row_elem(a, c_pz, c_m0 + row);
+          const u32x4 w = *(const u32x4*)(T16 + row * BN + oct * 8);
+          __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, (e0 != OOB_OFFSET && nok) ? (e0 + (unsigned)n) * 2u : OOB_OFFSET, 0, PIPE_NT);
+        }
+      }
+      if (STATS) {
+        // this lane: column (wn*WN+j)*32 + l31 over its 16 * WM rows; + the other half-wave; the WGM waves of a column through LDS
+#pragma unroll
+        for (int j = 0; j < WN; ++j) { cs1[j] += __shfl_xor(cs1[j], 32, 64); cs2[j] += __shfl_xor(cs2[j], 32, 64); }
+        __syncthreads();                         // the tile has been copied out
+        if (half == 0) {
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const int c = (wn * WN + j) * 32 + l31;
+            T[(wm * BN + c) * 2] = cs1[j]; T[(wm * BN + c) * 2 + 1] = cs2[j];
+          }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < WGM; ++w) { s1 += T[(w * BN + c) * 2]; s2 += T[(w * BN + c) * 2 + 1]; }
+          if (c_n0 + c < a.Ns) { a.stat_part[((size_t)c_lq * 2) * a.Ns + c_n0 + c] = s1; a.stat_part[((size_t)c_lq * 2 + 1) * a.Ns + c_n0 + c] = s2; }
+        }
+      }
+      __syncthreads();                           // T is free for the next tile
+    }
+    if (!more) break;
+  }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------
 bool gconv_pipe_eligible(const GConvArgs& a) {
   if (!a.in16 || (a.Cs % 64) != 0 || a.pad_mode != IPRGAN_PAD_ZERO || a.ksplit > 1 || a.wmod > 0 || a.planar_M) return false;
@@ -414,9 +679,40 @@ static int launch_pipe_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   return 0;
 }
 
+template <int WGM, int WGN, int WM, int WN, int NSTAGE>
+static int launch_pipe2_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
+  constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+  int maxM = 0;
+  for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
+  if (maxM == 0) return 0;
+  const size_t smem = (size_t)NSTAGE * (BM + BN) * 128 + 64 * 1024;
+  const int ntn = cdiv(a.Ns, BN), total = cdiv(maxM, BM) * a.nphase * ntn;
+  int ncu = 256;
+  static int s_ncu = 0;
+  if (!s_ncu) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) s_ncu = pr.multiProcessorCount; else s_ncu = 256; }
+  ncu = s_ncu;
+  dim3 grid(total < ncu ? total : ncu), block(WGM * WGN * 64);
+  *bm_out = BM;
+  const bool fwd = !a.aux && !a.res && a.out16;
+  const int slot = BN >= 128 ? 19 : 20;
+  auto go = [&](auto kern) { prof_launch(kern, grid, block, smem, st, slot, a.flops, a, ntn, a.nphase, total); };
+#define PIPE2_ATTR(K) { static bool s = false; if (!s) { (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); s = true; } }
+  if (a.stat_part) {
+    if (fwd) { auto k = gconv_pipe2_kernel<WGM, WGN, WM, WN, NSTAGE, true, true>; PIPE2_ATTR(k) go(k); }
+    else { auto k = gconv_pipe2_kernel<WGM, WGN, WM, WN, NSTAGE, true, false>; PIPE2_ATTR(k) go(k); }
+  } else {
+    if (fwd) { auto k = gconv_pipe2_kernel<WGM, WGN, WM, WN, NSTAGE, false, true>; PIPE2_ATTR(k) go(k); }
+    else { auto k = gconv_pipe2_kernel<WGM, WGN, WM, WN, NSTAGE, false, false>; PIPE2_ATTR(k) go(k); }
+  }
+#undef PIPE2_ATTR
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
 // variant: 0 = 256x128 (8 waves of 64x64, 3 stages), 1 = 256x64 (8 waves of 64x32, 3 stages),
 //          2 = 256x256 (8 waves of 128x64, 2 stages), 3 = 128x128 (4 waves of 64x64, 2 stages: two blocks per CU),
-//          4 = 256x64 with 2 stages (80 KB: two blocks per CU), 5 = 128x64 (4 waves of 64x32, 3 stages, two blocks per CU)
+//          4 = 256x64 with 2 stages (80 KB: two blocks per CU), 5 = 128x64 (4 waves of 64x32, 3 stages, two blocks per CU),
+//          6 / 7 = persistent 256x128 / 256x64 (gconv_pipe2_kernel: one block per CU walks the tile list)
 // returns -1 when the variant does not apply to the geometry
 int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_out) {
   if (!gconv_pipe_eligible(a)) return -1;
@@ -427,6 +723,8 @@ int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_o
     case 3: return a.Ns >= 128 ? launch_pipe_t<2, 2, 2, 2, 2>(a, st, bm_out) : -1;
     case 4: return launch_pipe_t<4, 2, 2, 1, 2>(a, st, bm_out);
     case 5: return launch_pipe_t<2, 2, 2, 1, 3>(a, st, bm_out);
+    case 6: return a.Ns >= 128 ? launch_pipe2_t<4, 2, 2, 2, 2>(a, st, bm_out) : -1;       // persistent 256x128, 2 stages + 64 KB
+    case 7: return launch_pipe2_t<4, 2, 2, 1, 2>(a, st, bm_out);                          // persistent 256x64, 2 stages + 64 KB
     default: return -1;
   }
 }

@@ -625,12 +625,12 @@ def test_conv_bf16_math_mode(dev, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('mode', ['bf16', 'bf16act'])
-@pytest.mark.parametrize('tile', [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 def test_bf16_gconv_tiles(dev, tile, mode):
     """Every bf16 tile of the forward / backward-data kernel, including the 128x64 and 128x128 per-wave tiles that only
     the bf16 modes build (6, 7), on bf16-representable inputs (products exact: only the summation order differs), with
     fp32 and with bf16 activations in HBM; ragged M (not a multiple of 256) and N = 256 so that 256-wide tiles apply.
-    Tiles 8-13 are the LDS-DMA ring tiles of conv_pipe.hip (bf16 operands in HBM only)."""
+    Tiles 8-15 are the LDS-DMA ring tiles (14, 15: the persistent form) of conv_pipe.hip (bf16 operands in HBM only)."""
     from iprgan import _lib, ops
     if tile >= 8 and mode != 'bf16act':
         pytest.skip('the LDS-DMA ring tiles read bf16 operands from HBM')
@@ -669,7 +669,7 @@ PIPE_SHAPES = [  # cin, cout, k, s, p, outpad, transposed, H, W, B
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tile', [8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize('tile', [8, 9, 10, 11, 12, 13, 14, 15])
 @pytest.mark.parametrize('shape', PIPE_SHAPES, ids=lambda c: '-'.join(map(str, c)))
 def test_pipe_tiles(dev, shape, tile):
     """The LDS-DMA ring tiles (conv_pipe.hip) on bf16-representable operands (products exact, fp32 accumulation: only the
