@@ -38,6 +38,7 @@ static ProfSlot g_slots[] = {
     {"fewin_conv_kernel", 0, 0, 0},
     {"gconv_pipe_kernel", 0, 0, 0},     {"gconv_pipe_kernel<256x64>", 0, 0, 0},
     {"wgrad_halo_kernel", 0, 0, 0},     {"wgrad_rgb_kernel", 0, 0, 0},
+    {"gconv_pipe_f32_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; int tag; };

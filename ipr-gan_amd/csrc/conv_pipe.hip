@@ -233,9 +233,15 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
   }
 }
 
-template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF>
+// F32: fp32 operands in HBM and the exact fp32 MFMA (v_mfma_f32_32x32x2_f32): a tile row is 32 channels x 4 bytes - the
+// same 128-byte rows, the same LDS image and chunk swizzle, a 32-deep K step.  The fp32 MFMA is 16x slower per
+// fragment, so a K step is 4096 cycles of matrix work per wave against the same 48 KB of DMA: the ring hides it entirely
+// and the kernel's job is to keep the matrix pipe issuing (no staging registers, no ds_write pass, one barrier per step).
+// ReflectionPad2d (fp32 workloads: CycleGAN) is folded into the DMA source offsets.
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF, bool F32 = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvArgs a) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NW = WGM * WGN;
+  constexpr int ESZ = F32 ? 4 : 2, KSTEP = F32 ? 32 : 64;             // bytes per operand element, channels per K step
   constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW, L = LA + LB;          // LDS-DMA instructions per wave and stage
   constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;        // 64 bf16 = 128 bytes per tile row
   static_assert(LA >= 1 && LB >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "every wave stages whole 8-row pieces");
@@ -257,7 +263,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
     return;
   }
   const int p_tw = a.ph[pz].tw;
-  const int nt = a.ph[pz].steps / 2;                      // steps counts 32-deep K steps; Cs % 64 == 0
+  const int nt = F32 ? a.ph[pz].steps : a.ph[pz].steps / 2;          // steps counts 32-deep K steps (bf16: Cs % 64 == 0)
+  const bool reflect = F32 && a.pad_mode == IPRGAN_PAD_REFLECT;
   const int p_dy0 = a.ph[pz].dy0, p_dx0 = a.ph[pz].dx0, p_dys = a.ph[pz].dys, p_dxs = a.ph[pz].dxs;
   const int p_wbase = a.ph[pz].wbase, p_wsy = a.ph[pz].wsy, p_wsx = a.ph[pz].wsx;
   const int p_owg = a.ph[pz].owg, plane = a.ph[pz].ohg * a.ph[pz].owg;
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
       const int x = rem - y * p_owg;
       aiy[i] = y * a.isy;
       aix[i] = x * a.isx;
-      arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * 2u + sc;
+      arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * (unsigned)ESZ + sc;
     } else {
       aiy[i] = ROW_INVALID; aix[i] = 0; arow[i] = 0;
     }
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
 #pragma unroll
   for (int i = 0; i < LB; ++i) {
     const int r = (i * NW + wave) * 8 + lrow;
-    wrow[i] = (unsigned)((n0 + r) * a.Kp) * 2u + (unsigned)(lchunk ^ ((r >> 1) & 7)) * 16u;
+    wrow[i] = (unsigned)((n0 + r) * a.Kp) * (unsigned)ESZ + (unsigned)(lchunk ^ ((r >> 1) & 7)) * 16u;
   }
 
   f32x16 acc[WM][WN];
@@ -312,19 +319,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   // issue the LDS-DMA of the next K step of the walk into stage buffer `buf`
   auto issue = [&](int buf) {
     const int dy = p_dy0 + u_ty * p_dys, dx = p_dx0 + u_tx * p_dxs;
-    const int tapoff = ((dy * IW + dx) * Cs + u_c) * 2;
-    const unsigned wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c) * 2u;
+    const int tapoff = ((dy * IW + dx) * Cs + u_c) * ESZ;
+    const unsigned wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c) * (unsigned)ESZ;
     const unsigned sbase = lds_base + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int iy = aiy[i] + dy, ix = aix[i] + dx;
-      const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
-      dma16(rs_in, sbase + (unsigned)(i * NW) * 1024u, ok ? arow[i] + (unsigned)tapoff : OOB_OFFSET);
+      bool ok;
+      unsigned off;
+      if (reflect) {              // wave-uniform branch: the mirrored pixel instead of a zero
+        ok = aiy[i] != ROW_INVALID;
+        const int ry = reflect_idx(iy, IH), rx = reflect_idx(ix, IW);
+        off = arow[i] + (unsigned)((((ry - aiy[i]) * IW + (rx - aix[i])) * Cs + u_c) * ESZ);
+      } else {
+        ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+        off = arow[i] + (unsigned)tapoff;
+      }
+      dma16(rs_in, sbase + (unsigned)(i * NW) * 1024u, ok ? off : OOB_OFFSET);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i)
       dma16(rs_wt, sbase + A_BYTES + (unsigned)(i * NW) * 1024u, wrow[i] + wk);
-    u_c += 64;
+    u_c += KSTEP;
     if (u_c >= Cs) { u_c = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
   };
 
@@ -337,6 +353,27 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   const char* ldsc = (const char*)lds;
   auto compute = [&](int buf) {
     const char* sb = ldsc + buf * STAGE_BYTES;
+    if constexpr (F32) {
+      // chunk 2 kq + half = four consecutive k of this lane's row; MFMA e of the group takes element e of both halves
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        f32x4 af[WM], bf[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = *(const f32x4*)(sb + a_wave + i * 4096 + foff[kq]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[j] = *(const f32x4*)(sb + b_wave + j * 4096 + foff[kq]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 af[WM], bf[WN];
@@ -638,10 +675,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------
+static int g_pipe_f32 = getenv("IPRGAN_PIPE_F32") ? atoi(getenv("IPRGAN_PIPE_F32")) : 1;     // A/B switch: LDS-DMA ring tiles for fp32 layers
 bool gconv_pipe_eligible(const GConvArgs& a) {
-  if (!a.in16 || (a.Cs % 64) != 0 || a.pad_mode != IPRGAN_PAD_ZERO || a.ksplit > 1 || a.wmod > 0 || a.planar_M) return false;
+  if (a.ksplit > 1 || a.wmod > 0 || a.planar_M) return false;
   auto simple = [](int act) { return act == IPRGAN_ACT_NONE || act == IPRGAN_ACT_RELU || act == IPRGAN_ACT_LRELU; };
   if ((a.Ns % 8) != 0 || !simple(a.act) || (a.aux && !simple(a.aux_act))) return false;       // pipe_epilogue
+  if (!a.in16) {          // fp32 operands and the fp32 MFMA (F32 instantiations): fp32 tensors throughout
+    return g_pipe_f32 && (a.Cs % 32) == 0 && !a.out16 && !a.aux16;
+  }
+  if ((a.Cs % 64) != 0 || a.pad_mode != IPRGAN_PAD_ZERO) return false;
   for (int i = 0; i < a.nphase; ++i)
     if (a.ph[i].M > 0 && ((a.ph[i].steps & 1) || a.ph[i].steps < 2)) return false;
   return true;
@@ -667,6 +709,12 @@ static int launch_pipe_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * (BM + BN) * 128>::PF_FIRST;
   const bool pref = a.aux && a.aux16 && can_pf;
   const dim3 block(WGM * WGN * 64);
+  if (!a.in16) {            // fp32 operands, exact fp32 MFMA
+    if (a.stat_part) pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, true>>(a, grid, block, smem, 23, st);
+    else pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, false, false, true>>(a, grid, block, smem, 23, st);
+    IPR_LAUNCH_CHECK();
+    return 0;
+  }
   const int slot = BN >= 128 ? 19 : 20;
   if (a.stat_part) {
     if constexpr (can_pf) { if (pref) { pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true, true>>(a, grid, block, smem, slot, st); IPR_LAUNCH_CHECK(); return 0; } }
@@ -723,8 +771,8 @@ int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_o
     case 3: return a.Ns >= 128 ? launch_pipe_t<2, 2, 2, 2, 2>(a, st, bm_out) : -1;
     case 4: return launch_pipe_t<4, 2, 2, 1, 2>(a, st, bm_out);
     case 5: return launch_pipe_t<2, 2, 2, 1, 3>(a, st, bm_out);
-    case 6: return a.Ns >= 128 ? launch_pipe2_t<4, 2, 2, 2, 2>(a, st, bm_out) : -1;       // persistent 256x128, 2 stages + 64 KB
-    case 7: return launch_pipe2_t<4, 2, 2, 1, 2>(a, st, bm_out);                          // persistent 256x64, 2 stages + 64 KB
+    case 6: return a.in16 && a.Ns >= 128 ? launch_pipe2_t<4, 2, 2, 2, 2>(a, st, bm_out) : -1;   // persistent 256x128, 2 stages + 64 KB
+    case 7: return a.in16 ? launch_pipe2_t<4, 2, 2, 1, 2>(a, st, bm_out) : -1;                  // persistent 256x64, 2 stages + 64 KB
     default: return -1;
   }
 }

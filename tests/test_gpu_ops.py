@@ -442,10 +442,11 @@ TILE_SHAPES = [(256, 512, 3, 1, 1, False, 16, 2), (64, 64, 4, 2, 1, False, 16, 3
                (64, 128, 3, 1, 1, False, 9, 1)]
 
 
-@pytest.mark.parametrize('tile', range(6))
+@pytest.mark.parametrize('tile', list(range(6)) + [8, 9, 10, 11, 12, 13])
 def test_every_gconv_tile_variant(dev, tile):
-    """The autotuner picks ONE tile per geometry; this forces each of the six forward/backward-data tile
-    variants in turn (including shapes with few rows) so that none ships untested."""
+    """The autotuner picks ONE tile per geometry; this forces each of the forward/backward-data tile variants in turn
+    (including shapes with few rows) so that none ships untested.  8-13: the LDS-DMA ring tiles of conv_pipe.hip in their
+    fp32 form (fp32 operands in HBM, exact fp32 MFMA)."""
     from iprgan import _lib, ops
     try:
         _lib.call('iprgan_debug_force_tiles', tile, -1)
@@ -657,6 +658,57 @@ def test_bf16_gconv_tiles(dev, tile, mode):
     finally:
         _lib.call('iprgan_debug_force_tiles', -1, -1)
         _lib.set_math('fp32')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tile', [8, 9, 11, 13])
+def test_pipe_tiles_fp32_reflect_and_epilogue(dev, tile):
+    """fp32 form of the LDS-DMA ring tiles: ReflectionPad2d folded into the DMA offsets (CycleGAN's residual convolutions,
+    networks/resnet_generator.py:26-29), bias + LeakyReLU, epilogue column sums, the fused activation derivative with a
+    residual input, and the paired pass - against torch, fp32 tolerance."""
+    from iprgan import _lib, ops
+    cin, cout, k, p, H, W, B = 64, 128, 3, 1, 13, 11, 4
+    x = rnd(B, cin, H, W, seed=1)
+    w, b = rnd(cout, cin, k, k, seed=2, scale=(cin * k * k) ** -0.5), rnd(cout, seed=3, scale=0.3)
+    try:
+        _lib.call('iprgan_debug_force_tiles', tile, -1)
+        _lib.call('iprgan_debug_force_splitk', 1)
+        for pm in (1, 0):
+            conv = (lambda t: F.conv2d(F.pad(t, (p, p, p, p), mode='reflect'), w, None)) if pm else \
+                   (lambda t: F.conv2d(t, w, None, padding=p))
+            xin = F.leaky_relu(x, 0.2).requires_grad_()
+            acc = conv(xin)
+            y_ref = F.leaky_relu(acc + b.view(1, -1, 1, 1), 0.1)
+            spec = ops.ConvSpec(cin, cout, k, 1, p, 0, False, pad_mode=pm, act=2, slope=0.1)
+            d = spec.desc(B, H, W)
+            wf, wb = ops.conv_prep(spec, d, w.to(dev), None, True, True)
+            xd = to_nhwc(xin.detach()).to(dev)
+            y, (part, rows) = ops.conv_fwd(spec, d, xd, wf, b.to(dev), stats=True)
+            close(from_nhwc(y.cpu(), cout), y_ref.detach(), what=f'fp32 pipe fwd tile {tile} pad_mode {pm}')
+            Cs = ops.c4(cout)
+            pr = part[:rows * 2 * Cs].view(rows, 2, Cs).double().sum(0).cpu()
+            a64 = acc.detach().double()
+            assert float((pr[0, :cout] - a64.sum((0, 2, 3))).abs().max()) <= 2e-4 * float(acc.abs().max()) * acc[:, 0].numel() ** 0.5
+            s0, s1 = torch.tensor([1.5], device=dev), torch.tensor([0.75], device=dev)
+            yp = ops.conv_fwd(spec, d, xd, wf, b.to(dev), pair=(s0, s1))
+            accp = acc.detach().clone()
+            accp[:B // 2] /= 1.5
+            accp[B // 2:] /= 0.75
+            close(from_nhwc(yp.cpu(), cout), F.leaky_relu(accp + b.view(1, -1, 1, 1), 0.1), what=f'fp32 pipe pair tile {tile}')
+            if not pm:          # backward-data of the zero-padded layer through the same tiles (reflect goes through the fold)
+                g = rnd(*acc.shape, seed=4)
+                res = rnd(*x.shape, seed=5)
+                acc.backward(g)
+                dx_ref = xin.grad * torch.where(xin > 0, 1.0, 0.2) + res
+                dspec = ops.ConvSpec(cin, cout, k, 1, p, 0, False)
+                dx, (part, rows) = ops.conv_bwd_data(dspec, dspec.desc(B, H, W), to_nhwc(g).to(dev), wb, xd, 2, 0.2,
+                                                     colsums=True, residual=to_nhwc(res).to(dev))
+                close(from_nhwc(dx.cpu(), cin), dx_ref, what=f'fp32 pipe dgrad tile {tile}')
+                cs = ops.colsum_partials(part, rows, ops.c4(cin), cin).cpu().double()
+                assert float((cs - dx_ref.double().sum((0, 2, 3))).abs().max()) <= 2e-4 * float(dx_ref.abs().max()) * dx_ref[:, 0].numel() ** 0.5
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
+        _lib.call('iprgan_debug_force_splitk', -1)
 
 
 PIPE_SHAPES = [  # cin, cout, k, s, p, outpad, transposed, H, W, B
