@@ -152,10 +152,18 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
     float cs1[8], cs2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) cs1[k] = cs2[k] = 0.f;
+    // Rows of one thread are RPI apart.  When a pass covers whole grid rows (RPI % width == 0) inside one image and the
+    // tile is full, the pixel offset advances by a constant per pass: one division chain per tile instead of one per row.
+    const Phase& ph = a.ph[pz];
+    const bool lin = !a.linear_out && (RPI % ph.owg) == 0 && ((ph.ohg * ph.owg) % G::BM) == 0 && m0 + G::BM <= ph.M;
+    const unsigned e_first = pipe_row_elem(a, pz, m0 + r0 < ph.M ? m0 + r0 : 0);
+    const unsigned e_step = a.linear_out ? (unsigned)(RPI * a.Ns) : (unsigned)((RPI / (ph.owg > 0 ? ph.owg : 1)) * a.osy * a.OW * a.Ns);
+    const bool fast_rows = a.linear_out ? m0 + G::BM <= ph.M : lin;
+    const bool full = fast_rows && n0 + h * CN + CN <= a.Ns;         // no row or column of this tile is clipped
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int r = it * RPI + r0, m = m0 + r;
-      const unsigned e0 = pipe_row_elem(a, pz, m);
+      const unsigned e0 = fast_rows ? e_first + (unsigned)it * e_step : pipe_row_elem(a, pz, m);
       const bool ok = e0 != OOB_OFFSET && nok;
       const unsigned e = e0 + (unsigned)n;
       f32x4 v0 = *(const f32x4*)(T + r * CN + oct * 8), v1 = *(const f32x4*)(T + r * CN + oct * 8 + 4);
@@ -193,11 +201,13 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
           v1 += buf_load4(rs_res, ok ? e * 4u + 16u : OOB_OFFSET);
         }
       }
-      if (STATS && a.stat_mode == 2) {
+      if (STATS && a.stat_mode == 2) {     // column sums of what is stored (the bias gradient of the layer below): sums only
+        if (full) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float t0 = ok ? v0[k] : 0.f, t1 = ok ? v1[k] : 0.f;
-          cs1[k] += t0; cs2[k] += t0 * t0; cs1[4 + k] += t1; cs2[4 + k] += t1 * t1;
+          for (int k = 0; k < 4; ++k) { cs1[k] += v0[k]; cs1[4 + k] += v1[k]; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { cs1[k] += ok ? v0[k] : 0.f; cs1[4 + k] += ok ? v1[k] : 0.f; }
         }
       }
       if (a.out16) {
@@ -215,7 +225,13 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
 #pragma unroll
       for (int k = 0; k < 8; ++k)
 #pragma unroll
-        for (int o = OCT; o < 64; o <<= 1) { cs1[k] += __shfl_xor(cs1[k], o, 64); cs2[k] += __shfl_xor(cs2[k], o, 64); }
+        for (int o = OCT; o < 64; o <<= 1) cs1[k] += __shfl_xor(cs1[k], o, 64);
+      if (a.stat_mode == 1) {                        // sums of squares: forward statistics only
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+          for (int o = OCT; o < 64; o <<= 1) cs2[k] += __shfl_xor(cs2[k], o, 64);
+      }
       __syncthreads();                               // the tile has been consumed
       if (lane < OCT) {
 #pragma unroll
@@ -674,6 +690,187 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
   }
 }
 
+// ---- four sub-pixel phases in one block ------------------------------------------------------------------------
+// Backward-data of a k4 s2 p1 Conv2d and forward of the matching ConvTranspose2d (geom_bwd_form: four phases of 2x2 taps
+// each).  As four independent tile sets (one per phase) every input pixel row crosses L2 -> LDS sixteen times (4 phases x
+// 4 taps) for a K of only 4 x C per tile: at 64 channels the launch moved 160 KB of LDS-DMA per 256x64 tile and sat at
+// the per-CU DMA rate (D.conv1 backward-data of DCGAN-128: 333 TFLOP/s).  Here a block owns 256 grid positions (whole
+// rows of the small grid) x 64 output channels x ALL FOUR phases:
+//   * the (R + 2) x (W + 2) halo of input pixels is staged ONCE per 64-channel chunk (LDS-DMA, zero padding = out of
+//     range); the nine taps of the 3x3 neighbourhood are row shifts of that image (A fragments: ds_read_b128 at the
+//     tap's halo row, XOR swizzle recomputed per tap);
+//   * tap (dy, dx) feeds the phases that use it (corner 1, edge 2, centre 4): its A fragments are read once and
+//     multiplied with one 64 x 64 weight tile per phase; weight tiles stream through an 8-slot ring two stages ahead;
+//   * 4 phases x 256 x 64 accumulators = 128 registers per lane; each phase leaves through pipe_epilogue.
+// L2 -> LDS bytes per output drop 3.6x (C = 64).  Same GConvArgs, same partial-row accounting as the phase tiles.
+template <int HPW, bool DB, bool STATS>
+__global__ __launch_bounds__(512) void gconv_phase4_kernel(const GConvArgs a) {
+  constexpr int HALO_BYTES = HPW * 8 * 1024, RING_OFF = (DB ? 2 : 1) * HALO_BYTES, T_BYTES = 64 * 1024;
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  char* ldsc = (char*)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;                    // this wave: tile rows 64 wr .., columns 32 wc ..
+  const int half = lane >> 5, l31 = lane & 31, lrow = lane >> 3, lchunk = lane & 7;
+  const int W = a.ph[0].owg, Hg = a.ph[0].ohg, R = 256 / W, HW = W + 2, HR = (R + 2) * HW;     // grid of every phase (even sizes)
+  // logical tile order: n tiles fastest, then m tiles (the four phases are inside the block)
+  const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int mt = (int)(lt / gridDim.y), n0 = (int)(lt % gridDim.y) * 64, m0 = mt * 256;
+  const int b = m0 / (Hg * W), y0 = (m0 - b * Hg * W) / W;   // tile = rows y0 .. y0 + R - 1 of image b
+  const int Cs = a.Cs, NC = Cs / 64;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+
+  // halo slots of this lane: instruction j = i * 8 + wave covers halo pixels 8 j .. 8 j + 7, this lane pixel 8 j + lrow
+  unsigned hoff[HPW];
+#pragma unroll
+  for (int i = 0; i < HPW; ++i) {
+    const int h = (i * 8 + wave) * 8 + lrow;
+    const int hr = h / HW, hx = h - hr * HW, y = y0 - 1 + hr, x = hx - 1;
+    const bool ok = h < HR && (unsigned)y < (unsigned)a.IH && (unsigned)x < (unsigned)a.IW;
+    hoff[i] = ok ? (unsigned)(((b * a.IH + y) * a.IW + x) * Cs) * 2u + (unsigned)(lchunk ^ ((h >> 1) & 7)) * 16u : OOB_OFFSET;
+  }
+  auto issue_halo = [&](int c) {
+    const unsigned dst = lds_base + (unsigned)((DB ? (c & 1) : 0) * HALO_BYTES) + (unsigned)wave * 1024u;
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) dma16(rs_in, dst + (unsigned)i * 8192u, hoff[i] == OOB_OFFSET ? OOB_OFFSET : hoff[i] + (unsigned)c * 128u);
+  };
+  // weight tile of (tap t of the 3x3 neighbourhood, phase index q of that tap's list) for chunk c into ring slot `slot`
+  const unsigned wrow = (unsigned)((n0 + wave * 8 + lrow) * a.Kp) * 2u + (unsigned)(lchunk ^ (((wave * 8 + lrow) >> 1) & 7)) * 16u;
+  auto issue_w = [&](int c, int dyi, int dxi, int py, int px, int slot) {
+    const Phase& ph = a.ph[py * 2 + px];
+    const int ty = ph.dy0 - dyi, tx = ph.dx0 - dxi;                     // dys = dxs = -1
+    const unsigned wk = (unsigned)((ph.wbase + ty * ph.wsy + tx * ph.wsx) * Cs + c * 64) * 2u;
+    dma16(rs_wt, lds_base + RING_OFF + (unsigned)slot * 8192u + (unsigned)wave * 1024u, wrow + wk);
+  };
+  // stage t (tap) of chunk c: its NP weight tiles, compile-time slot list (prefix sums of 1,2,1,2,4,2,1,2,1 mod 8)
+  auto issue_stage = [&](int c, auto TC) {
+    constexpr int t = decltype(TC)::value;
+    constexpr int dyi = t / 3 - 1, dxi = t % 3 - 1;
+    constexpr int pre[9] = {0, 1, 3, 4, 6, 10, 12, 13, 15};
+    int q = 0;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const bool uy = (dyi == -1 && py == 0) || dyi == 0 || (dyi == 1 && py == 1);
+        const bool ux = (dxi == -1 && px == 0) || dxi == 0 || (dxi == 1 && px == 1);
+        if (uy && ux) { issue_w(c, dyi, dxi, py, px, (pre[t] + q) & 7); ++q; }
+      }
+  };
+
+  f32x16 acc[4][2][1];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][i][0][r] = 0.f;
+
+  // halo row index of this lane's A rows for tap (0, 0): row m = 64 wr + 32 i + l31 of the tile = (m / W, m % W)
+  int hidx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = wr * 64 + i * 32 + l31, r = m / W, x = m - r * W;
+    hidx[i] = (r + 1) * HW + x + 1;
+  }
+  const unsigned b_lane = (unsigned)(wc * 32 + l31) * 128u;
+  const unsigned b_sw = (unsigned)((l31 >> 1) & 7);
+
+  auto compute = [&](int c, auto TC) {
+    constexpr int t = decltype(TC)::value;
+    constexpr int dyi = t / 3 - 1, dxi = t % 3 - 1;
+    constexpr int pre[9] = {0, 1, 3, 4, 6, 10, 12, 13, 15};
+    const char* hb = ldsc + (DB ? (c & 1) : 0) * HALO_BYTES;
+    unsigned aoff[2], asw[2];
+    // (opaque to the optimiser: otherwise the nine taps' addresses are hoisted out of the chunk loop - 36 registers that
+    // the 128 accumulators do not leave, reloaded from scratch in every step)
+    asm volatile("" : "+v"(hidx[0]), "+v"(hidx[1]));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = hidx[i] + dyi * HW + dxi;
+      aoff[i] = (unsigned)idx * 128u;
+      asw[i] = (unsigned)((idx >> 1) & 7);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {             // k outermost: two A fragments live at a time (128 accumulators leave little room)
+      bf16x8 af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(hb + aoff[i] + (((unsigned)(2 * kk + half)) ^ asw[i]) * 16u);
+      int q = 0;
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const bool uy = (dyi == -1 && py == 0) || dyi == 0 || (dyi == 1 && py == 1);
+          const bool ux = (dxi == -1 && px == 0) || dxi == 0 || (dxi == 1 && px == 1);
+          if (uy && ux) {
+            const bf16x8 bf = *(const bf16x8*)(ldsc + RING_OFF + ((pre[t] + q) & 7) * 8192 + b_lane + (((unsigned)(2 * kk + half)) ^ b_sw) * 16u);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[py * 2 + px][i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf, acc[py * 2 + px][i][0], 0, 0, 0);
+            ++q;
+          }
+        }
+    }
+  };
+
+  using G = EpiGeom<4, 2, 2, 1, T_BYTES>;
+  const bool use_aux = a.aux && a.aux16;
+
+  issue_halo(0);
+  issue_stage(0, std::integral_constant<int, 0>{});
+  issue_stage(0, std::integral_constant<int, 1>{});
+  for (int c = 0; c < NC; ++c) {
+    const bool more_c = c + 1 < NC;
+    // one tap per step: wait for its weight tiles (and, in-order, everything older), barrier, issue two stages ahead
+    // (+ the next chunk's halo right behind stage 2), multiply
+    auto step = [&](auto TC) {
+      constexpr int t = decltype(TC)::value;
+      constexpr int NPv[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
+      constexpr int nxt1 = t < 8 ? NPv[t + 1] : NPv[0];                 // instructions of the stage after this one
+      const bool has1 = t < 8 || more_c;
+      if (t == 1 || t == 2) {                    // the next chunk's halo (issued at t = 0, after stage 2) is younger than this stage
+        if (more_c && DB) wait_vmcnt<nxt1 + HPW>(); else wait_vmcnt<nxt1>();
+      } else if (has1) {
+        wait_vmcnt<nxt1>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 <= 8) issue_stage(c, std::integral_constant<int, (t + 2 <= 8 ? t + 2 : 0)>{});
+      else if (more_c) issue_stage(c + 1, std::integral_constant<int, (t + 2 > 8 ? t + 2 - 9 : 0)>{});
+      if (t == 0 && more_c && DB) issue_halo(c + 1);
+      compute(c, TC);
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- four epilogues (phase p: rows m0 .. of its grid, partial row lq = 4 mt + p), next phase's operand loaded a phase ahead
+  float* T = (float*)lds;
+  auto epi = [&](int p, const u32x4* aux) {
+    if (use_aux) pipe_epilogue<4, 2, 2, 1, T_BYTES, STATS, true>(a, acc[p], T, p, (unsigned)(mt * 4 + p), m0, n0, aux);
+    else pipe_epilogue<4, 2, 2, 1, T_BYTES, STATS, false>(a, acc[p], T, p, (unsigned)(mt * 4 + p), m0, n0, aux);
+    __syncthreads();
+  };
+  // (the fused-derivative operand of a phase is loaded one phase ahead; phase 0's here: 128 accumulators + the K loop's
+  // working set leave no registers to carry it through the loop, and its latency is paid once per 4 x 256 x 64 outputs)
+  u32x4 auxA[G::NIT], auxB[G::NIT];
+  if (use_aux) { pipe_aux_load<G>(a, 0, m0, n0, 0, auxA); pipe_aux_load<G>(a, 1, m0, n0, 0, auxB); }
+  epi(0, auxA);
+  if (use_aux) pipe_aux_load<G>(a, 2, m0, n0, 0, auxA);
+  epi(1, auxB);
+  if (use_aux) pipe_aux_load<G>(a, 3, m0, n0, 0, auxB);
+  epi(2, auxA);
+  epi(3, auxB);
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------
 static int g_pipe_f32 = getenv("IPRGAN_PIPE_F32") ? atoi(getenv("IPRGAN_PIPE_F32")) : 1;     // A/B switch: LDS-DMA ring tiles for fp32 layers
 bool gconv_pipe_eligible(const GConvArgs& a) {
@@ -757,10 +954,51 @@ static int launch_pipe2_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   return 0;
 }
 
+// the canonical k4 s2 p1 backward-data form: four phases of 2x2 taps on equal even grids whose rows tile 256 positions
+static bool phase4_eligible(const GConvArgs& a) {
+  if (!a.in16 || a.nphase != 4 || a.osy != 2 || a.osx != 2 || a.isy != 1 || a.isx != 1 || (a.Cs % 64) != 0) return false;
+  if (a.pad_mode != IPRGAN_PAD_ZERO || a.ksplit > 1 || a.wmod > 0 || a.planar_M || (a.Ns % 64) != 0) return false;
+  auto simple = [](int act) { return act == IPRGAN_ACT_NONE || act == IPRGAN_ACT_RELU || act == IPRGAN_ACT_LRELU; };
+  if (!simple(a.act) || (a.aux && !simple(a.aux_act))) return false;
+  const int W = a.ph[0].owg, H = a.ph[0].ohg;
+  for (int p = 0; p < 4; ++p) {
+    const Phase& ph = a.ph[p];
+    if (ph.th != 2 || ph.tw != 2 || ph.dys != -1 || ph.dxs != -1 || ph.owg != W || ph.ohg != H) return false;
+    if (ph.dy0 != p / 2 || ph.dx0 != p % 2 || ph.ooy != p / 2 || ph.oox != p % 2) return false;
+  }
+  if (W != a.IW || H != a.IH || W > 64 || W < 16 || (256 % W) != 0 || (H % (256 / W)) != 0) return false;
+  if (W == 64 && a.Cs > 64) return false;          // two 56 KB halo buffers + the weight ring do not fit
+  return true;
+}
+
+static int launch_phase4(const GConvArgs& a, hipStream_t st, int* bm_out) {
+  if (!phase4_eligible(a)) return -1;
+  const int W = a.ph[0].owg, mtiles = a.ph[0].M / 256;
+  dim3 grid(mtiles, a.Ns / 64), block(512);
+  *bm_out = 256;
+  auto go = [&](auto kern, size_t smem) {
+    prof_launch(kern, grid, block, smem, st, 24, a.flops, a);
+  };
+#define PH4_ATTR(K, S) { static bool s = false; if (!s) { (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S)); s = true; } }
+  if (W == 64) {
+    const size_t smem = 7 * 8192 + 65536;          // one halo buffer (single channel chunk) + 8 weight slots; the epilogue's 64 KB alias them
+    if (a.stat_part) { auto k = gconv_phase4_kernel<7, false, true>; PH4_ATTR(k, smem) go(k, smem); }
+    else { auto k = gconv_phase4_kernel<7, false, false>; PH4_ATTR(k, smem) go(k, smem); }
+  } else {
+    const size_t smem = 2 * 6 * 8192 + 65536;
+    if (a.stat_part) { auto k = gconv_phase4_kernel<6, true, true>; PH4_ATTR(k, smem) go(k, smem); }
+    else { auto k = gconv_phase4_kernel<6, true, false>; PH4_ATTR(k, smem) go(k, smem); }
+  }
+#undef PH4_ATTR
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
 // variant: 0 = 256x128 (8 waves of 64x64, 3 stages), 1 = 256x64 (8 waves of 64x32, 3 stages),
 //          2 = 256x256 (8 waves of 128x64, 2 stages), 3 = 128x128 (4 waves of 64x64, 2 stages: two blocks per CU),
 //          4 = 256x64 with 2 stages (80 KB: two blocks per CU), 5 = 128x64 (4 waves of 64x32, 3 stages, two blocks per CU),
-//          6 / 7 = persistent 256x128 / 256x64 (gconv_pipe2_kernel: one block per CU walks the tile list)
+//          6 / 7 = persistent 256x128 / 256x64 (gconv_pipe2_kernel: one block per CU walks the tile list),
+//          8 = gconv_phase4_kernel (the four sub-pixel phases of a k4 s2 p1 backward-data form in one block)
 // returns -1 when the variant does not apply to the geometry
 int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_out) {
   if (!gconv_pipe_eligible(a)) return -1;
@@ -773,6 +1011,7 @@ int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_o
     case 5: return launch_pipe_t<2, 2, 2, 1, 3>(a, st, bm_out);
     case 6: return a.in16 && a.Ns >= 128 ? launch_pipe2_t<4, 2, 2, 2, 2>(a, st, bm_out) : -1;   // persistent 256x128, 2 stages + 64 KB
     case 7: return a.in16 ? launch_pipe2_t<4, 2, 2, 1, 2>(a, st, bm_out) : -1;                  // persistent 256x64, 2 stages + 64 KB
+    case 8: return launch_phase4(a, st, bm_out);                                                // four phases per block (k4 s2 p1)
     default: return -1;
   }
 }

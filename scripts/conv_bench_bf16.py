@@ -41,7 +41,7 @@ def main():
     dev = torch.device('cuda:0')
     _lib.set_math('bf16act')
     only = sys.argv[1] if len(sys.argv) > 1 else None
-    tiles = [int(t) for t in os.environ.get('CONV_BENCH_TILES', '-1,8,9,10,11,12,14,15').split(',')]
+    tiles = [int(t) for t in os.environ.get('CONV_BENCH_TILES', '-1,8,11,12,16').split(',')]
     for name, cin, cout, k, s, p, tr, H in LAYERS:
         if only and only not in name:
             continue

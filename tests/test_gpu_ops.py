@@ -717,11 +717,15 @@ PIPE_SHAPES = [  # cin, cout, k, s, p, outpad, transposed, H, W, B
     (128, 64, 4, 2, 1, 0, True, 8, 8, 6),         # ConvT k4s2 (generator): forward = four sub-pixel phases
     (64, 64, 3, 2, 1, 1, True, 6, 5, 2),          # ConvT k3s2 with output_padding: phases of 1, 2, 2, 4 taps (one-step rings)
     (256, 256, 4, 2, 1, 0, False, 8, 8, 4),       # two channel steps per tap, N = 256 (the 256x256 tile applies)
+    # the four-phases-per-block tile (16): whole grid rows x 256 positions; halo rows above / below the image are padding
+    (64, 64, 4, 2, 1, 0, False, 128, 128, 1),     # backward-data: 64 x 64 grid, one channel chunk (single halo buffer)
+    (128, 64, 4, 2, 1, 0, True, 32, 32, 2),       # ConvT forward: 32 x 32 grid, two chunks (double-buffered halo), Cout 64
+    (64, 128, 4, 2, 1, 0, False, 32, 32, 2),      # backward-data with Cout = 128 reduced in two chunks, 16 x 16 grid
 ]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tile', [8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize('tile', [8, 9, 10, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize('shape', PIPE_SHAPES, ids=lambda c: '-'.join(map(str, c)))
 def test_pipe_tiles(dev, shape, tile):
     """The LDS-DMA ring tiles (conv_pipe.hip) on bf16-representable operands (products exact, fp32 accumulation: only the
