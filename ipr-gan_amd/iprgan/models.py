@@ -323,13 +323,20 @@ class ImagePool(torch.nn.Module):
     def load_state_dict(self, *args, **kwargs):
         self.images = torch.empty_like(args[0]['images'])
         super().load_state_dict(*args, **kwargs)
+        self._host_counts = None                    # re-read from the loaded buffer at the next call
 
     def __call__(self, images):
         if self.pool_size <= 0:
             return images.detach()
-        if self.counts < self.pool_size:
+        # ``counts`` is a registered buffer (it lives on the model's device and is part of the checkpoint, as in the
+        # reference); the branch below is taken on a HOST mirror of it, so that update_d does not drain the GPU queue
+        # once per step to compare a device scalar (it cost one full synchronisation per CycleGAN step)
+        if getattr(self, '_host_counts', None) is None:
+            self._host_counts = float(self.counts)
+        if self._host_counts < self.pool_size:
             self.images = torch.cat([self.images.to(images.device), images.detach()], dim=0)[:self.pool_size, ...]
             self.counts += images.size(0)
+            self._host_counts += images.size(0)
             return images.detach()
         images = images.detach()
         prob = torch.rand(images.size(0)) > 0.5

@@ -430,6 +430,12 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_
          float(weight_decay), int(step), float(grad_scale), stream())
 
 
+def adam_step_tables(ptab, grads, mtab, vtab, sizes, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """adam_step with the parameter / moment pointer tables and sizes built once by the caller (optim.Adam)."""
+    call('iprgan_adam_step', ptab, L.ptr_table(grads), mtab, vtab, sizes, n, float(lr), float(beta1), float(beta2),
+         float(eps), float(weight_decay), int(step), float(grad_scale), stream())
+
+
 def axpy_multi(dsts, srcs, alpha=1.0):
     """dsts[i] += alpha * srcs[i] for a list of tensors in one launch."""
     n = len(dsts)

@@ -39,21 +39,62 @@ class Adam(Optimizer):
                 v = st['step']
                 st['step'] = torch.tensor(float(v), dtype=torch.float32)       # int (torch 1.8) or any-device tensor
 
+    # ---- fast path: every parameter of a group has a gradient and all share one step count (every step of the three
+    # GANs).  The pointer / size tables of parameters and moments are built once, the step count is ONE host tensor
+    # that every state entry references, and a step costs a list comprehension over the gradients' pointers instead of
+    # ~5 us of per-parameter bookkeeping (CPU-tensor add, int(), dict lookups: 1.4 ms for CycleGAN's 280 tensors).
+    def _shared(self, group):
+        import ctypes as C
+        from . import _lib as L
+        params = group['params']
+        sh = self._fast.get(id(group))
+        if sh is not None and sh['n'] == len(params) and self.state[params[0]].get('step') is sh['step_t'] \
+                and self.state[params[-1]].get('step') is sh['step_t']:
+            return sh
+        states = [self._init_state(p) for p in params]
+        steps = {float(st['step']) for st in states}
+        if len(steps) != 1:
+            return None
+        step_t = torch.tensor(steps.pop(), dtype=torch.float32)
+        for st in states:
+            st['step'] = step_t
+        sh = {'n': len(params), 'step_t': step_t, 'step': int(step_t),
+              'ptab': L.ptr_table(params), 'mtab': L.ptr_table([st['exp_avg'] for st in states]),
+              'vtab': L.ptr_table([st['exp_avg_sq'] for st in states]),
+              'sizes': (C.c_longlong * len(params))(*[p.numel() for p in params]),
+              'ptrs': [p.data_ptr() for p in params]}
+        self._fast[id(group)] = sh
+        return sh
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if not hasattr(self, '_fast'):
+            self._fast = {}
         for group in self.param_groups:
+            params = group['params']
+            grads = [p.grad for p in params]
+            if params and all(g is not None and g.is_contiguous() for g in grads):
+                sh = self._shared(group)
+                if sh is not None and sh['ptrs'][0] == params[0].data_ptr() and sh['ptrs'][-1] == params[-1].data_ptr():
+                    sh['step'] += 1
+                    sh['step_t'].fill_(sh['step'])
+                    beta1, beta2 = group['betas']
+                    ops.adam_step_tables(sh['ptab'], grads, sh['mtab'], sh['vtab'], sh['sizes'], sh['n'], group['lr'],
+                                         beta1, beta2, group['eps'], group['weight_decay'], sh['step'], self.grad_scale)
+                    torch.autograd.graph.increment_version(params)
+                    continue
+                self._fast.pop(id(group), None)          # parameters were replaced (.to(), load): rebuild next time
             buckets = {}
             for p in group['params']:
                 if p.grad is None:
                     continue
                 st = self._init_state(p)
-                if not torch.is_tensor(st['step']) or st['step'].is_cuda:
-                    st['step'] = torch.tensor(float(st['step']), dtype=torch.float32)
-                st['step'] += 1
+                # (a fresh tensor: the fast path shares one step tensor between the entries of a group)
+                st['step'] = torch.tensor(float(st['step']) + 1.0, dtype=torch.float32)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 buckets.setdefault(int(st['step']), []).append((p, g, st['exp_avg'], st['exp_avg_sq']))
             beta1, beta2 = group['betas']

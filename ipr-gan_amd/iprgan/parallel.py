@@ -232,6 +232,7 @@ class GradReducer:
         self.in_final = False
         self.trace = None                           # list of (kind, index, seq) when tracing (tests)
         self.exposed_log = []                       # (event at wait(), bucket completion events) of the last steps
+        self._touched_checked = False
         self._handles = []
         for p in self.params:
             _owner[id(p)] = (weakref.ref(p), self)
@@ -378,8 +379,8 @@ class GradReducer:
 
     def wait(self):
         """Before the optimizer step: the compute stream waits for the exchanged buckets.  Afterwards ``p.grad`` holds the
-        SUM over ranks (Adam multiplies by 1/world as it reads: ``opt.grad_scale``), not the mean.  On one rank,
-        parameters nobody produced a gradient for get ``.grad = None`` (Adam skips them, as the reference's would)."""
+        SUM over ranks (Adam multiplies by 1/world as it reads: ``opt.grad_scale``), not the mean.  Parameters nobody
+        produced a gradient for get ``.grad = None`` (Adam skips them, as the reference's would)."""
         if not self.armed:
             return
         self.armed = False
@@ -392,10 +393,18 @@ class GradReducer:
             del self.exposed_log[:-64]
         for d in dones:
             torch.cuda.current_stream().wait_event(d)
-        if self.world > 1:
-            # every rank steps every parameter: a parameter that only SOME ranks produced a gradient for keeps its view
-            # (zeros on the ranks that did not) - skipping it locally would let weights and Adam state diverge
-            return
+        if self.world > 1 and not self._touched_checked:
+            # Adam skips parameters without a gradient; if the ranks disagreed on WHICH parameters those are, weights and
+            # moments would diverge silently.  Every rank runs the same graph in the three GANs, so the sets are equal by
+            # construction - verified once, collectively, at the first step (one small all-reduce and a host read).
+            self._touched_checked = True
+            mask = torch.tensor([1.0 if p in self.touched else 0.0 for p in self.params], device=self.flat.device)
+            lo, hi = mask.clone(), mask.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                raise RuntimeError('data-parallel ranks disagree on which parameters received gradients: the replicas '
+                                   'would diverge (every rank must run the same passes)')
         for p in self.params:
             if p not in self.touched:
                 p.grad = None
