@@ -509,8 +509,13 @@ __global__ __launch_bounds__(256) void fewin_conv_kernel(const GConvArgs a, int 
 // v_mfma_f32_32x32x16_bf16.  A fragments come straight out of the halo image in LDS (8 consecutive k = two taps x 4
 // channels = two 8-byte reads at the taps' pixel offsets), so the gather costs no address arithmetic in HBM space and
 // the layer runs at its output-write bound instead of the fp32 vector-ALU bound of fewin_conv_kernel.
+// SIMPLE instantiation (every stem / head of the GANs): PERSISTENT - a block walks tiles blockIdx.x, + gridDim.x, ...:
+// the 64 x K weights are converted and laid out once per block instead of once per 16 x 16 tile (704 16-byte loads per
+// tile before), and the halo pixels of the next tile are loaded into registers while the current tile is multiplied and
+// stored (a tile's life was 23 k cycles, 55 % of them parked behind two dependent rounds of global loads).
+constexpr int fewin_waves(bool simple) { return simple ? 3 : FEWIN_WAVES; }      // persistent form: ~41 KB of LDS, three blocks per CU
 template <bool SIMPLE>
-__global__ __launch_bounds__(256, FEWIN_WAVES) void fewin_mfma_kernel(const GConvArgs a, int lds_w, int lds_h, int kpad, float neg_act, float neg_aux) {
+__global__ __launch_bounds__(256, fewin_waves(SIMPLE)) void fewin_mfma_kernel(const GConvArgs a, int lds_w, int lds_h, int kpad, float neg_act, float neg_aux, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) f32x4 flds[];
   const Phase& ph = a.ph[0];
   const int ntap = ph.ntap, tw = ph.tw, th = ph.th;
@@ -518,24 +523,12 @@ __global__ __launch_bounds__(256, FEWIN_WAVES) void fewin_mfma_kernel(const GCon
   bf16x4* X = (bf16x4*)flds;                                        // [lds_h][lds_w] halo pixels, 4 channels each
   __bf16* Wl = (__bf16*)(X + ((lds_h * lds_w + 1) & ~1));             // [64][kpad] weights, k = tap * 4 + c, zero past ntap * 4
   int* toff = (int*)(Wl + 64 * kpad);                               // [ksteps * 4] LDS pixel offset of every tap (clamped)
+  u32x4* Tst = (u32x4*)(((uintptr_t)(toff + ksteps * 4) + 15) & ~(uintptr_t)15);      // [256 pixels][8 pieces]: staged bf16 output
   const int tiles_x = (a.OW + FEWIN_T - 1) / FEWIN_T, tiles_y = (a.OH + FEWIN_T - 1) / FEWIN_T;
-  const int tile = blockIdx.x, b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
-  const int y0 = (tr / tiles_x) * FEWIN_T, x0 = (tr % tiles_x) * FEWIN_T;
   const int n0 = blockIdx.y * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dyl = ph.dys < 0 ? (th - 1) * ph.dys : 0, dxl = ph.dxs < 0 ? (tw - 1) * ph.dxs : 0;
-  const int iy_lo = y0 * a.isy + ph.dy0 + dyl, ix_lo = x0 * a.isx + ph.dx0 + dxl;
   const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
-  for (int i = tid; i < lds_h * lds_w; i += 256) {
-    const int r = i / lds_w, c = i - r * lds_w;
-    int iy = iy_lo + r, ix = ix_lo + c;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    bool ok = true;
-    if (reflect) { iy = reflect_idx(iy, a.IH); ix = reflect_idx(ix, a.IW); ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW; }
-    else ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-    if (ok) v = *(const f32x4*)(a.in + ((size_t)(b * a.IH + iy) * a.IW + ix) * 4);
-    X[i] = to_bf16x4(v);
-  }
   for (int i = tid; i < 64 * (kpad / 4); i += 256) {
     const int n = i / (kpad / 4), t = i - n * (kpad / 4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -550,7 +543,44 @@ __global__ __launch_bounds__(256, FEWIN_WAVES) void fewin_mfma_kernel(const GCon
     const int ty = tc / tw, tx = tc - ty * tw;
     toff[t] = (ty * ph.dys - dyl) * lds_w + tx * ph.dxs - dxl;
   }
-  __syncthreads();
+  // halo pixels of this thread (i = tid + 256 q): position inside the halo, fixed for every tile
+  constexpr int HQ = 3;                                             // up to 768 halo pixels (k9: 24 x 24)
+  int hr[HQ], hc[HQ];
+#pragma unroll
+  for (int q = 0; q < HQ; ++q) {
+    const int i = tid + 256 * q;
+    hr[q] = i < lds_h * lds_w ? i / lds_w : -(1 << 20);
+    hc[q] = i - (i / lds_w) * lds_w;
+  }
+  f32x4 hv[HQ];
+  auto load_halo = [&](int tile) {
+    const int b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
+    const int y0 = (tr / tiles_x) * FEWIN_T, x0 = (tr % tiles_x) * FEWIN_T;
+    const int iy_lo = y0 * a.isy + ph.dy0 + dyl, ix_lo = x0 * a.isx + ph.dx0 + dxl;
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+      int iy = iy_lo + hr[q], ix = ix_lo + hc[q];
+      bool ok;
+      if (reflect) { iy = reflect_idx(iy, a.IH); ix = reflect_idx(ix, a.IW); ok = hr[q] >= 0 && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW; }
+      else ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;          // (hr < 0: iy hugely negative)
+      hv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok) hv[q] = *(const f32x4*)(a.in + ((size_t)(b * a.IH + iy) * a.IW + ix) * 4);
+    }
+  };
+  int tile = blockIdx.x;
+  load_halo(tile);
+  for (;;) {
+  const int b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
+  const int y0 = (tr / tiles_x) * FEWIN_T, x0 = (tr % tiles_x) * FEWIN_T;
+#pragma unroll
+  for (int q = 0; q < HQ; ++q)
+    if (hr[q] >= 0) X[tid + 256 * q] = to_bf16x4(hv[q]);
+  // LDS-only barriers in this loop: __syncthreads() would also drain vmcnt, i.e. wait for the previous tile's output
+  // stores to COMPLETE (microseconds per tile, which a one-tile block never pays: it simply exits)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int nxt = tile + gridDim.x;
+  if (SIMPLE && nxt < ntiles) load_halo(nxt);                       // in flight behind this tile's MFMAs and stores
   const int half = lane >> 5, l31 = lane & 31;
   f32x16 acc[2][2];
 #pragma unroll
@@ -594,6 +624,10 @@ __global__ __launch_bounds__(256, FEWIN_WAVES) void fewin_mfma_kernel(const GCon
     const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux ? a.aux_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? a.out_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
+    // bf16 output: the 16-byte pieces go through LDS ([pixel][8 pieces], piece slot XOR pixel & 7) and leave as whole
+    // 128-byte pixel rows (8 consecutive lanes = one pixel): a lane-per-pixel store touched 32 lines per instruction
+    // with 32 bytes each and ran at 2.7 TB/s of output.  (fp32 output would need 64 KB of LDS per block: stored directly.)
+    const bool staged = a.out16 != 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int oy = y0 + 4 * wave + 2 * i + (l31 >> 4), ox = x0 + (l31 & 15);
@@ -671,14 +705,31 @@ __global__ __launch_bounds__(256, FEWIN_WAVES) void fewin_mfma_kernel(const GCon
           if (a.out16) {
             const bf16x4 p0 = to_bf16x4(v0), p1 = to_bf16x4(v1);
             const u32x2 w0 = __builtin_bit_cast(u32x2, p0), w1 = __builtin_bit_cast(u32x2, p1);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0.x, w0.y, w1.x, w1.y}, rs_out, ok ? e * 2u : OOB_OFFSET, 0, 0);
+            const int pl = (4 * wave + 2 * i + (l31 >> 4)) * 16 + (l31 & 15), piece = j * 4 + gp * 2 + half;
+            Tst[pl * 8 + (piece ^ (pl & 7))] = u32x4{w0.x, w0.y, w1.x, w1.y};
           } else {
             buf_store4(rs_out, ok ? e * 4u : OOB_OFFSET, v0);
             buf_store4(rs_out, ok ? e * 4u + 16u : OOB_OFFSET, v1);
           }
         }
     }
-    return;
+    if (staged) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int idx = q * 256 + tid, pl = idx >> 3, piece = idx & 7;
+        const int oy = y0 + (pl >> 4), ox = x0 + (pl & 15), n = n0 + piece * 8;
+        const bool ok = oy < a.OH && ox < a.OW && n < a.Ns;
+        const u32x4 w = Tst[pl * 8 + (piece ^ (pl & 7))];
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, ok ? ((unsigned)((b * a.OH + oy) * a.OW + ox) * (unsigned)a.Ns + (unsigned)n) * 2u : OOB_OFFSET, 0, 0);
+      }
+    }
+    if (nxt >= ntiles) return;
+    tile = nxt;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // the halo image and the staged tile are free for the next tile
+    continue;
   }
   // epilogue: quad transpose to 4 consecutive channels per lane (as in gconv_kernel), then fewin_store.  Row
   // ml = 8 g + 4 half + qp of M tile i is pixel (4 wave + 2 i + (g >> 1), 8 (g & 1) + 4 half + qp) of the 16 x 16 tile.
@@ -728,6 +779,8 @@ __global__ __launch_bounds__(256, FEWIN_WAVES) void fewin_mfma_kernel(const GCon
         fewin_store<SIMPLE>(a, f32x4{c0, c1, c2, c3}, bias4[j], rs, neg_act, neg_aux, pix + n, n);
       }
     }
+  }
+  return;                                        // (general epilogue: one tile per block)
   }
 }
 
@@ -1831,7 +1884,8 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
     const float neg_act = fewin_neg(a.act, a.slope), neg_aux = fewin_neg(a.aux_act, a.aux_slope);
     if (g_math == IPRGAN_MATH_BF16) {          // bf16 math: the same tile on the matrix cores (fewin_mfma_kernel)
       const int ksteps = cdiv(p.ntap * 4, 16), kpad = ksteps * 16 + 8;
-      const size_t smem16 = (size_t)((lw * lh + 1) & ~1) * 8 + (size_t)64 * kpad * 2 + (size_t)ksteps * 4 * sizeof(int);
+      size_t smem16 = (size_t)((lw * lh + 1) & ~1) * 8 + (size_t)64 * kpad * 2 + (size_t)ksteps * 4 * sizeof(int) + 16;
+      if (a.out16) smem16 += 32768;                          // + the staged bf16 tile (its own region: the weights persist)
       if (smem16 <= 150 * 1024) {
         static bool attr16_set = false;
         if (!attr16_set) {
@@ -1839,9 +1893,15 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
           (void)hipFuncSetAttribute((const void*)fewin_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
           attr16_set = true;
         }
-        dim3 grid((unsigned)(a.B * cdiv(a.OH, FEWIN_T) * cdiv(a.OW, FEWIN_T)), (unsigned)cdiv(a.Ns, 64));
-        if (simple && (a.Ns % 8) == 0) prof_launch(fewin_mfma_kernel<true>, grid, dim3(256), smem16, st, 18, a.flops, a, lw, lh, kpad, neg_act, neg_aux);
-        else prof_launch(fewin_mfma_kernel<false>, grid, dim3(256), smem16, st, 18, a.flops, a, lw, lh, kpad, neg_act, neg_aux);
+        const int ntiles = a.B * cdiv(a.OH, FEWIN_T) * cdiv(a.OW, FEWIN_T);
+        dim3 grid((unsigned)ntiles, (unsigned)cdiv(a.Ns, 64));
+        if (simple && (a.Ns % 8) == 0 && lw * lh <= 768) {       // persistent: ~4 blocks per CU walk the tiles
+          const int per_cu = 3;
+          if (ntiles > 256 * per_cu) grid.x = 256 * per_cu;
+          prof_launch(fewin_mfma_kernel<true>, grid, dim3(256), smem16, st, 18, a.flops, a, lw, lh, kpad, neg_act, neg_aux, ntiles);
+        } else {
+          prof_launch(fewin_mfma_kernel<false>, grid, dim3(256), smem16, st, 18, a.flops, a, lw, lh, kpad, neg_act, neg_aux, ntiles);
+        }
         IPR_LAUNCH_CHECK();
         return 0;
       }

@@ -45,6 +45,14 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_ad
 #endif
 }
 
+// Workgroup barrier for LDS hand-offs only: this wave's LDS operations are complete, then s_barrier.  __syncthreads()
+// additionally drains vmcnt - in the epilogues below that is a wait for the tile's own output stores (or the next tile's
+// prefetch) to COMPLETE, paid once per phase / tile for nothing.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -133,7 +141,7 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
     const bool nok = n < a.Ns;                        // Ns % 8 == 0 (launcher)
     u32x4 auxl[NIT];
     if (!PF && a.aux && a.aux16) pipe_aux_load<G>(a, pz, m0, n0, h, auxl);      // in flight across the LDS round trip
-    if (h > 0) __syncthreads();                       // everybody is done reading the previous half
+    if (h > 0) lds_barrier();                         // everybody is done reading the previous half
     if (wn / WGN_H == h) {
 #pragma unroll
       for (int i = 0; i < WM; ++i)
@@ -143,7 +151,7 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
           for (int r = 0; r < 16; ++r)
             T[((wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CN + ((wn % WGN_H) * WN + j) * 32 + l31] = acc[i][j][r];
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
 #pragma unroll
@@ -232,12 +240,12 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
 #pragma unroll
           for (int o = OCT; o < 64; o <<= 1) cs2[k] += __shfl_xor(cs2[k], o, 64);
       }
-      __syncthreads();                               // the tile has been consumed
+      lds_barrier();                                 // the tile has been consumed
       if (lane < OCT) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { T[(wave * CN + lane * 8 + k) * 2] = cs1[k]; T[(wave * CN + lane * 8 + k) * 2 + 1] = cs2[k]; }
       }
-      __syncthreads();
+      lds_barrier();
       for (int c = tid; c < CN; c += G::NT) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -565,6 +573,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
     }
   };
 
+  constexpr int FWD_STORES = BM / (NT / (BN / 8));           // 16-byte output stores per lane and tile (FWD copy-out)
+  bool first_tile = true;
   int it = 0;
   if (!next_tile(it)) return;
   setup_rows();
@@ -590,9 +600,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
     int cur = 0, nxt = NSTAGE - 1;
     for (int t = 0; t < nt; ++t) {
       const int rem = nt - 1 - t;
-      // the first wait of a tile also retires the previous tile's stores (they were issued after this tile's first
-      // stages, so a counted wait cannot skip them): vmcnt(0) there, counted waits afterwards
-      if (t == 0) wait_stages<L>(0); else wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+      // the previous tile's output stores were issued AFTER this tile's first stages: a counted wait for stage 0 has to
+      // allow for them (FWD: exactly FWD_STORES per lane, + column-sum stores on some waves - a lower bound is safe), or
+      // the tile would wait for its predecessor's stores to complete
+      if (t == 0 && !first_tile) {
+        if constexpr (FWD) {
+          if (rem >= NSTAGE - 2) wait_vmcnt<(NSTAGE - 2) * L + FWD_STORES>(); else wait_stages<L>(0);
+        } else {          // pipe_epilogue: >= NH * NIT stores per lane (+ the operand prefetched for this tile when one half covers it)
+          if (rem < NSTAGE - 2) wait_stages<L>(0);
+          else if (use_aux) wait_vmcnt<(NSTAGE - 2) * L + G::NH * G::NIT + G::NIT>();
+          else wait_vmcnt<(NSTAGE - 2) * L + G::NH * G::NIT>();
+        }
+      } else {
+        wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (rem >= NSTAGE - 1) issue(nxt);
@@ -621,7 +642,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
     if constexpr (!FWD) {
       if (use_aux) pipe_epilogue<WGM, WGN, WM, WN, T_BYTES, STATS, true>(a, acc, T, c_pz, c_lq, c_m0, c_n0, auxc);
       else pipe_epilogue<WGM, WGN, WM, WN, T_BYTES, STATS, false>(a, acc, T, c_pz, c_lq, c_m0, c_n0, auxc);
-      __syncthreads();                           // T is read out before the next tile's epilogue writes it (vmcnt drained too)
+      lds_barrier();                             // T is read out before the next tile's epilogue writes it
     } else {
       const int pM = a.ph[c_pz].M, halfM = pM >> 1;
       float rsc0 = 1.f, rsc1 = 1.f;
@@ -651,7 +672,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
             T16[row * BN + (wn * WN + j) * 32 + l31] = (__bf16)v;
           }
         }
-      __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();              // (LDS-only barriers: __syncthreads() would wait for the output stores too)
       {                                          // copy-out: 8 channels (16 bytes) of one pixel per thread and pass
         constexpr int OCT = BN / 8, RPI = NT / OCT, NIT = BM / RPI;
         const int oct = tid % OCT, r0 = tid / OCT, n = c_n0 + oct * 8;
@@ -668,7 +690,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
         // this lane: column (wn*WN+j)*32 + l31 over its 16 * WM rows; + the other half-wave; the WGM waves of a column through LDS
 #pragma unroll
         for (int j = 0; j < WN; ++j) { cs1[j] += __shfl_xor(cs1[j], 32, 64); cs2[j] += __shfl_xor(cs2[j], 32, 64); }
-        __syncthreads();                         // the tile has been copied out
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // the tile has been copied out
         if (half == 0) {
 #pragma unroll
           for (int j = 0; j < WN; ++j) {
@@ -676,7 +699,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
             T[(wm * BN + c) * 2] = cs1[j]; T[(wm * BN + c) * 2 + 1] = cs2[j];
           }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         for (int c = tid; c < BN; c += NT) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -684,9 +708,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
           if (c_n0 + c < a.Ns) { a.stat_part[((size_t)c_lq * 2) * a.Ns + c_n0 + c] = s1; a.stat_part[((size_t)c_lq * 2 + 1) * a.Ns + c_n0 + c] = s2; }
         }
       }
-      __syncthreads();                           // T is free for the next tile
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();              // T is free for the next tile
     }
     if (!more) break;
+    first_tile = false;
   }
 }
 
@@ -857,7 +883,7 @@ __global__ __launch_bounds__(512) void gconv_phase4_kernel(const GConvArgs a) {
   auto epi = [&](int p, const u32x4* aux) {
     if (use_aux) pipe_epilogue<4, 2, 2, 1, T_BYTES, STATS, true>(a, acc[p], T, p, (unsigned)(mt * 4 + p), m0, n0, aux);
     else pipe_epilogue<4, 2, 2, 1, T_BYTES, STATS, false>(a, acc[p], T, p, (unsigned)(mt * 4 + p), m0, n0, aux);
-    __syncthreads();
+    lds_barrier();
   };
   // (the fused-derivative operand of a phase is loaded one phase ahead; phase 0's here: 128 accumulators + the K loop's
   // working set leave no registers to carry it through the loop, and its latency is paid once per 4 x 256 x 64 outputs)

@@ -13,6 +13,7 @@ from iprgan import ops, _lib  # noqa: E402
 
 B = int(os.environ.get("CONV_BENCH_B", "256"))
 LAYERS = [  # name, cin, cout, k, s, p, transposed, H
+    ('D.conv0 3->64 k3', 3, 64, 3, 1, 1, False, 128),
     ('D.conv1 64->64 k4s2', 64, 64, 4, 2, 1, False, 128),
     ('D.conv2 64->128 k3', 64, 128, 3, 1, 1, False, 64),
     ('D.conv3 128->128 k4s2', 128, 128, 4, 2, 1, False, 64),
@@ -48,8 +49,10 @@ def main():
         spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr)
         d = spec.desc(B, H, H)
         OH, OW = spec.out_hw(H, H)
-        x = torch.randn(B, H, H, ops.c4(cin), device=dev).bfloat16()
-        dy = torch.randn(B, OH, OW, ops.c4(cout), device=dev).bfloat16()
+        x = torch.randn(B, H, H, ops.c4(cin), device=dev)
+        dy = torch.randn(B, OH, OW, ops.c4(cout), device=dev)
+        x = x.bfloat16() if d.x_bf16 else x          # RGB tensors stay fp32 (NHWC4)
+        dy = dy.bfloat16() if d.y_bf16 else dy
         wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
         w = torch.randn(*wshape, device=dev) * 0.05
         wf, wb = ops.conv_prep(spec, d, w, None, True, True)
@@ -57,9 +60,10 @@ def main():
         row = dict(layer=name, gflop=round(flops / 1e9, 1))
         for t in tiles:
             _lib.call('iprgan_debug_force_tiles', t, -1)
-            t_f = timeit(lambda: ops.conv_fwd(spec, d, x, wf, None, stats=True))
+            t_f = timeit(lambda: ops.conv_fwd(spec, d, x, wf, None, stats=cin > 4))
             # as inside a training step: fused activation derivative of the producer (reads the layer input) + column sums
-            t_d = timeit(lambda: ops.conv_bwd_data(spec, d, dy, wb, x, 2, 0.1, colsums=True))
+            t_d = timeit(lambda: ops.conv_bwd_data(spec, d, dy, wb, x, 2, 0.1, colsums=True)) if cin > 4 else \
+                timeit(lambda: ops.conv_bwd_data(spec, d, dy, wb))
             row[f'fwd[{t}]'] = f'{t_f * 1e3:.0f}us {flops / t_f / 1e9:.0f}TF'
             row[f'dgrad[{t}]'] = f'{t_d * 1e3:.0f}us {flops / t_d / 1e9:.0f}TF'
         _lib.call('iprgan_debug_force_tiles', -1, -1)

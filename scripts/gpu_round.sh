@@ -1,11 +1,11 @@
 #!/bin/bash
 # One GPU-box pass that produces everything profiles/ holds for a round.  Run through gpurun from the repo root:
-#   gpurun --timeout 2700 -- 'bash scripts/gpu_round.sh r02'
+#   gpurun --timeout 2700 -- 'bash scripts/gpu_round.sh r03'
 # then, back in the build container:
 #   for w in "" srgan_ cyclegan_; do python scripts/summarize_profiles.py gpurun_out/prof <tag>_${w%_} profiles/<tag>_${w%_}; done
 # (scripts/collect_round.sh does that).  rocprofv3 rules of this pool: the program goes directly after "--", counters
 # are collected in their own passes (never together with a trace domain other than --kernel-trace).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O/prof
@@ -50,6 +50,8 @@ timeout 900 python bench.py --math bf16 --no-cpu-baseline > $O/${TAG}_bench_dcga
 timeout 900 python bench.py --workload dcgan128 --math bf16act --no-cpu-baseline > $O/${TAG}_bench_dcgan128_bf16act.json 2>> $O/bench_dcgan128.err
 timeout 900 python bench.py --math bf16act --no-cpu-baseline > $O/${TAG}_bench_dcgan64_bf16act.json 2>> $O/bench.err
 timeout 600 python scripts/conv_bench.py > $O/${TAG}_conv_bench.jsonl 2> $O/conv_bench.err
+# per-layer, per-tile table of the bf16 kernels at BASELINE config 5 sizes (forced tiles 8-16, halo / RGB backward-weight)
+CONV_BENCH_TILES=-1,8,10,11,12,16 CONV_BENCH_WGRAD=-1,0,61,67 timeout 900 python scripts/conv_bench_bf16.py > $O/${TAG}_conv_bench_bf16.jsonl 2> $O/conv_bench_bf16.err
 # per-layer tables (conv-family launches by pass + geometry) of the four workloads
 for w in dcgan64 srgan cyclegan; do
   IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload $w --no-cpu-baseline 2>&1 >/dev/null | grep -A200 "conv-family layers" | cut -c18- > $O/${TAG}_layers_$w.txt
