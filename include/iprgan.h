@@ -318,8 +318,16 @@ enum { IPRGAN_MATH_FP32 = 0, IPRGAN_MATH_BF16 = 1 };
 int iprgan_set_math_mode(int mode);
 int iprgan_get_math_mode(void);
 
-/* test hook: force one tile configuration (gconv 0..5, wgrad candidate 0..19 = 4 * block target + tile shape; -1 = autotune / heuristic) so that
- * the parity tests can exercise every variant, not only the one the autotuner picks. */
+/* test hook: force one tile configuration so that the parity tests can exercise every variant, not only the one the
+ * autotuner picks; -1 = autotune / heuristic.  A candidate that does not apply to a geometry falls back to the default.
+ *   gconv_tile 0..7   register-staged tiles of conv_igemm.hip (6, 7: bf16 modes only)
+ *              8..13  LDS-DMA ring tiles of conv_pipe.hip: 256x128, 256x64, 256x256, 128x128, 256x64 (two blocks per
+ *                     CU), 128x64; bf16 operands in HBM, or fp32 operands with the exact fp32 MFMA
+ *              14, 15 the persistent 256x128 / 256x64 form (bf16 operands)
+ *              16     four sub-pixel phases per block (k4 s2 p1 backward-data forms, bf16 operands)
+ *   wgrad_cand 0..59  = 20 * variant + 4 * block target + tile shape (split-M GEMM of conv_igemm.hip)
+ *              60..68 halo form for bf16 tensors (wgrad_halo.hip): 3 * variant + block target {128, 256, 512}
+ *              69, 70 RGB-layer streaming form (block targets 256 / 512) */
 int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand);
 /* test hook: force the split count (1..4) of the split-K path that convolutions with few output tiles take when their
  * workspace is passed (iprgan_conv_fwd_ws_floats / iprgan_conv_bwd_data_ws_floats); -1 = autotuned. */

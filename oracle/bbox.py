@@ -3,7 +3,9 @@ transforms of reference tools/{transform_dist,random_bitmask,transform_var,rando
 and the loss factories of tools/loss.py, on plain torch CPU ops.
 
 Pinned: TransformDist, RandomBitMask, TransformVar (torch-only files, imported from the real reference by
-gen_golden.py -> tests/golden/bbox_transforms.npz).  PARITY UNPINNED: RandomNoisePatch and PasteWatermark import
+gen_golden.py -> tests/golden/bbox_transforms.npz); ``l1`` / ``mse`` / ``Loss`` (tools/loss.py:10-20,72-76: the REAL file is
+loaded by ref_loader.load_loss() behind empty stand-ins for its torchvision / pytorch_msssim imports ->
+tests/golden/loss_factories.npz, bit-exact).  PARITY UNPINNED: RandomNoisePatch and PasteWatermark import
 torchvision (absent; only ``TF.normalize`` = (x - 0.5) / 0.5 and the PIL wrappers ``TF.resize`` /
 ``TF.to_tensor`` are used) and ``ssim`` is pytorch-msssim (see oracle/ssim.py); the reference's watermark PNGs
 (``data/watermarks``) are git-ignored and absent."""
