@@ -327,7 +327,8 @@ int iprgan_get_math_mode(void);
  *              16     four sub-pixel phases per block (k4 s2 p1 backward-data forms, bf16 operands)
  *   wgrad_cand 0..59  = 20 * variant + 4 * block target + tile shape (split-M GEMM of conv_igemm.hip)
  *              60..68 halo form for bf16 tensors (wgrad_halo.hip): 3 * variant + block target {128, 256, 512}
- *              69, 70 RGB-layer streaming form (block targets 256 / 512) */
+ *              69, 70 RGB-layer streaming form (block targets 256 / 512)
+ *              71..73 halo form on the exact fp32 MFMA for fp32 tensors (block targets 256 / 512 / 1024) */
 int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand);
 /* test hook: force the split count (1..4) of the split-K path that convolutions with few output tiles take when their
  * workspace is passed (iprgan_conv_fwd_ws_floats / iprgan_conv_bwd_data_ws_floats); -1 = autotuned. */

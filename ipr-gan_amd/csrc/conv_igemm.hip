@@ -39,6 +39,7 @@ static ProfSlot g_slots[] = {
     {"gconv_pipe_kernel", 0, 0, 0},     {"gconv_pipe_kernel<256x64>", 0, 0, 0},
     {"wgrad_halo_kernel", 0, 0, 0},     {"wgrad_rgb_kernel", 0, 0, 0},
     {"gconv_pipe_f32_kernel", 0, 0, 0}, {"gconv_phase4_kernel", 0, 0, 0},
+    {"wgrad_halo_f32_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; int tag; };
@@ -2170,12 +2171,19 @@ bool wgrad_rgb_eligible(const iprgan_conv_desc* d);
 int wgrad_rgb_nsplit(const iprgan_conv_desc* d, int target_blocks);
 int launch_wgrad_rgb(const iprgan_conv_desc* d, const void* x, const void* dy, float* ws, int target_blocks, hipStream_t st,
                      int* nsplit_out, int* Nrows_out, int* Kw_out);
+bool wgrad_halo_f32_eligible(const iprgan_conv_desc* d);
+int wgrad_halo_f32_nsplit(const iprgan_conv_desc* d, int target_blocks);
+int launch_wgrad_halo_f32(const iprgan_conv_desc* d, const float* x, const float* dy, float* ws, int target_blocks,
+                          hipStream_t st, int* nsplit_out, int* Nrows_out, int* Kw_out);
+#define WGRAD_NH32 3                        // candidates WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB + {0, 1, 2}: fp32 halo form
+static const int g_h32_targets[WGRAD_NH32] = {256, 512, 1024};
 #define WGRAD_NRGB 2                        // candidates WGRAD_NCAND + WGRAD_NHALO + {0, 1}: 256 / 512 blocks
 static const int g_rgb_targets[WGRAD_NRGB] = {256, 512};
 #define WGRAD_NHALO 9                       // candidate WGRAD_NCAND + 3 * variant + target index
 static const int g_halo_targets[3] = {128, 256, 512};
 static bool wgrad_halo_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_BF16 && wgrad_halo_eligible(d); }
 static bool wgrad_rgb_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_BF16 && wgrad_rgb_eligible(d); }
+static bool wgrad_h32_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_FP32 && wgrad_halo_f32_eligible(d); }
 
 static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that fits every candidate
   size_t m = 0;
@@ -2184,6 +2192,13 @@ static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that
     for (int i = 0; i < WGRAD_NHALO; ++i) {
       const size_t n = (size_t)wgrad_halo_nsplit(d, i / 3, g_halo_targets[i % 3]) * c4(g.N) * d->KH * d->KW * c4(g.Cq);
       if (n > m) m = n;
+    }
+  }
+  if (wgrad_h32_ok(d)) {
+    const WGeom g = wgrad_geom(d);
+    for (int i = 0; i < WGRAD_NH32; ++i) {
+      const size_t n = (size_t)wgrad_halo_f32_nsplit(d, g_h32_targets[i]) * c4(g.N) * d->KH * d->KW * c4(g.Cq);
+      if (n > m && n <= WGRAD_MAX_SLAB_FLOATS) m = n;
     }
   }
   if (wgrad_rgb_ok(d)) {
@@ -2550,8 +2565,13 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   auto run_to = [&](int cand, float* dw_out, float beta_out) -> int {
     if (cand >= WGRAD_NCAND) {           // halo / RGB forms: same slabs, same fixed-order reduce
       int nsplit = 0, Nrows = 0, Kw = 0, rc;
-      if (cand >= WGRAD_NCAND + WGRAD_NHALO) {
-        if (cand >= WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB || !wgrad_rgb_ok(d)) return -1;
+      if (cand >= WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB) {
+        const int i = cand - WGRAD_NCAND - WGRAD_NHALO - WGRAD_NRGB;
+        if (i >= WGRAD_NH32 || !wgrad_h32_ok(d) || g.swap || g.padded) return -1;
+        if ((size_t)wgrad_halo_f32_nsplit(d, g_h32_targets[i]) * c4(g.N) * d->KH * d->KW * c4(g.Cq) > WGRAD_MAX_SLAB_FLOATS) return -1;
+        rc = launch_wgrad_halo_f32(d, x, dy, ws, g_h32_targets[i], st, &nsplit, &Nrows, &Kw);
+      } else if (cand >= WGRAD_NCAND + WGRAD_NHALO) {
+        if (!wgrad_rgb_ok(d)) return -1;
         rc = launch_wgrad_rgb(d, x, dy, ws, g_rgb_targets[cand - WGRAD_NCAND - WGRAD_NHALO], st, &nsplit, &Nrows, &Kw);
       } else {
         if (!wgrad_halo_ok(d)) return -1;
@@ -2635,7 +2655,8 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   }
   if (g_force_wgrad >= 0) {
     WGradPlan pf;
-    if (g_force_wgrad >= WGRAD_NCAND + WGRAD_NHALO ? (g_force_wgrad < WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB && wgrad_rgb_ok(d))
+    if (g_force_wgrad >= WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB ? (g_force_wgrad < WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB + WGRAD_NH32 && wgrad_h32_ok(d) && !g.swap && !g.padded)
+        : g_force_wgrad >= WGRAD_NCAND + WGRAD_NHALO ? wgrad_rgb_ok(d)
         : g_force_wgrad >= WGRAD_NCAND ? wgrad_halo_ok(d) : wgrad_plan_c(d, g_force_wgrad, pf))
       cand = g_force_wgrad;
   } else if (g_autotune) {     // same scheme as the forward/backward-data tiles: time every candidate once per geometry
@@ -2649,7 +2670,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
       g_prof_on = false;
       float best_us = 0.f;
       int err = 0;
-      cand = tune_pick(WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB, run, st, cand, &best_us, &err);
+      cand = tune_pick(WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB + WGRAD_NH32, run, st, cand, &best_us, &err);
       g_prof_on = prof_was;
       if (err) return err;
       if (getenv("IPRGAN_TUNE_LOG"))

@@ -246,6 +246,203 @@ __global__ __launch_bounds__(wh_threads(KH * KW, TPW)) void wgrad_halo_kernel(co
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The halo form for fp32 tensors (every fp32 workload: the headline DCGAN-64, SRGAN, CycleGAN): same staging - one
+// 8x8 patch of the small grid + the halo of the gathered tensor per step, taps as LDS row shifts - on the exact fp32
+// MFMA (v_mfma_f32_32x32x2_f32: k = 2 pixels per instruction).  An LDS row is 32 channels x 4 bytes = 128 bytes of one
+// pixel; lane (l31, half) reads element l31 of pixel 2 ks + half with one ds_read_b32 (the 32 lanes of a half cover a
+// row: conflict-free), so both operands are read straight in MFMA layout with immediate offsets per k step and tap.
+// A block owns 64 S-channels x 32 L-channels x all taps (one tap per wave: 32 accumulator registers); the fp32 MFMA is
+// 16x slower than the bf16 one, so the DMA (~57 KB per 16 k cycles) is nowhere near a bound and the ring of two stages
+// hides it.  ReflectionPad2d (CycleGAN's residual convolutions) is folded into the DMA offsets.
+struct WHalo32Args {
+  const float* S;       // [B][PH][PW][Ss]
+  const float* L;       // [B][QH][QW][Ls]
+  float* ws;
+  int B, PH, PW, QH, QW, Ss, Ls, pad, reflect;
+  int PTY, PTX;
+  FastDiv d_ptx, d_ppi;
+  int npatch, pps, Nrows, Kw;
+  unsigned s_bytes, l_bytes;
+  double flops;
+};
+
+template <int KH, int KW, int STR, int NSTAGE>
+struct WH32Geom {
+  static constexpr int NTAP = KH * KW, NWAVE = NTAP;            // one tap per wave
+  static constexpr int HH = 7 * STR + KH, HW = 7 * STR + KW;
+  static constexpr int PHS = (HH + STR - 1) / STR, PWS = (HW + STR - 1) / STR, PP = PHS * PWS;
+  static constexpr int HROWS = STR * STR * PP;                  // halo pixel rows (128 bytes each)
+  static constexpr int HPP = (HROWS + 7) / 8 * 8;
+  static constexpr int P_ROWS = 2 * 64;                         // [nb][patch pixel]
+  static constexpr int NINST = (HPP + P_ROWS) / 8;              // 8 rows per DMA instruction
+  static constexpr int LPW = (NINST + NWAVE - 1) / NWAVE;
+  static constexpr int STAGE_BYTES = LPW * NWAVE * 1024;
+  static constexpr int Q_BYTES = HPP * 128;
+  static constexpr int SMEM = NSTAGE * STAGE_BYTES;
+  static_assert(SMEM <= 160 * 1024 && Q_BYTES + P_ROWS * 128 < 65536 && LPW * (NSTAGE - 1) <= 63, "ring geometry");
+};
+
+template <int KH, int KW, int STR, int NSTAGE>
+__global__ __launch_bounds__(KH * KW * 64) void wgrad_halo_f32_kernel(const WHalo32Args a) {
+  using G = WH32Geom<KH, KW, STR, NSTAGE>;
+  constexpr int NWAVE = G::NWAVE, LPW = G::LPW;
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                gridDim.x * gridDim.y * gridDim.z);
+  const int cx = (int)(lt % gridDim.x), ny = (int)((lt / gridDim.x) % gridDim.y), split = (int)(lt / (gridDim.x * gridDim.y));
+  const int c0 = cx * 32, n0 = ny * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int pbeg = split * a.pps, pend = pbeg + a.pps;
+  if (pend > a.npatch) pend = a.npatch;
+  const int np = pend - pbeg;
+  const wh_u32x4 rs_s = wh_make_rsrc(a.S, a.s_bytes), rs_l = wh_make_rsrc(a.L, a.l_bytes);
+
+  // DMA slots of this lane: LDS row 8 * inst + lane / 8, 16-byte piece lane % 8 (8 pieces = 32 fp32 channels)
+  int rel[LPW], ryx[LPW];
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    const int inst = i * NWAVE + wave, row = inst * 8 + (lane >> 3), piece = lane & 7;
+    rel[i] = 0; ryx[i] = 0x7fff << 16;
+    if (row < G::HPP) {
+      if (row < G::HROWS) {
+        const int plane = row / G::PP, r = row % G::PP, hyy = r / G::PWS, hxx = r % G::PWS;
+        const int hy = hyy * STR + plane / STR, hx = hxx * STR + plane % STR;
+        rel[i] = c0 * 4 + piece * 16;            // the pixel part depends on the (possibly mirrored) position: added per stage
+        ryx[i] = (hy << 16) | hx;
+      }
+    } else if (row < G::HPP + G::P_ROWS) {
+      const int pr = row - G::HPP, nb = pr >> 6, m = pr & 63, my = m >> 3, mx = m & 7;
+      rel[i] = (n0 + nb * 32) * 4 + piece * 16;
+      ryx[i] = (my << 16) | mx;
+    }
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+  auto issue = [&](int patch, int buf) {
+    const int b = fdiv(patch, a.d_ppi);
+    const int r = patch - b * (a.PTY * a.PTX);
+    const int pty = fdiv(r, a.d_ptx), ptx = r - pty * a.PTX;
+    const int py0 = pty * 8, px0 = ptx * 8;
+    const int qy0 = py0 * STR - a.pad, qx0 = px0 * STR - a.pad;
+    const unsigned sb = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)buf * G::STAGE_BYTES + (unsigned)wave * 1024u);
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+      const bool isS = (i * NWAVE + wave) * 8 >= G::HPP;               // wave-uniform: HPP % 8 == 0
+      int y = (isS ? py0 : qy0) + (ryx[i] >> 16), x = (isS ? px0 : qx0) + (ryx[i] & 0xffff);
+      const bool valid = (ryx[i] >> 16) != 0x7fff;
+      if (a.reflect && !isS) { y = reflect_idx(y, a.QH); x = reflect_idx(x, a.QW); }
+      const int H = isS ? a.PH : a.QH, W = isS ? a.PW : a.QW, Cs = isS ? a.Ss : a.Ls;
+      const bool ok = valid & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
+      const unsigned off = ok ? (unsigned)(((b * H + y) * W + x) * Cs) * 4u + (unsigned)rel[i] : OOB_OFFSET;
+      if (isS) wh_dma16(rs_s, sb + (unsigned)(i * NWAVE) * 1024u, off);
+      else wh_dma16(rs_l, sb + (unsigned)(i * NWAVE) * 1024u, off);
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tap = wave, ty = tap / KW, tx = tap % KW;
+  const int trow = ((ty % STR) * STR + tx % STR) * G::PP + (ty / STR) * G::PWS + tx / STR;
+  const unsigned a_lane = G::Q_BYTES + (unsigned)(half * 128 + l31 * 4);          // + nb * 8192 + ks * 256
+  const unsigned b_lane = (unsigned)((trow + half) * 128 + l31 * 4);              // + ((ks >> 2) * PWS + 2 * (ks & 3)) * 128
+  const char* ldsc = (const char*)lds;
+  auto compute = [&](int buf) {
+    const char* sb = ldsc + buf * G::STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {            // pixels 2 ks, 2 ks + 1 of the patch = (ks >> 2, 2 (ks & 3) + half)
+      const float a0 = *(const float*)(sb + a_lane + ks * 256);
+      const float a1 = *(const float*)(sb + a_lane + 8192 + ks * 256);
+      const float bv = *(const float*)(sb + b_lane + ((ks >> 2) * G::PWS + 2 * (ks & 3)) * 128);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < np) issue(pbeg + s, s);
+  int cur = 0, nxt = NSTAGE - 1;
+  for (int t = 0; t < np; ++t) {
+    const int rem = np - 1 - t;
+    const int inflight = rem < NSTAGE - 2 ? rem : NSTAGE - 2;
+    if (inflight >= 1) wh_wait_vmcnt<(NSTAGE > 2 ? LPW : 0)>(); else wh_wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (rem >= NSTAGE - 1) issue(pbeg + t + NSTAGE - 1, nxt);
+    compute(cur);
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+  }
+  float* slab = a.ws + (size_t)split * a.Nrows * a.Kw;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      slab[(size_t)n * a.Kw + tap * a.Ls + c0 + l31] = acc[i][r];
+    }
+}
+
+bool wgrad_halo_f32_eligible(const iprgan_conv_desc* d) {
+  if (d->x_bf16 || d->y_bf16 || d->KH != d->KW) return false;
+  const int Ss = d->transposed ? d->Cin : d->Cout, Ls = d->transposed ? d->Cout : d->Cin;
+  if ((Ss % 64) != 0 || (Ls % 32) != 0) return false;
+  if (d->pad_mode == IPRGAN_PAD_REFLECT && (d->transposed || d->pad >= d->H || d->pad >= d->W)) return false;
+  return (d->KH == 3 && (d->stride == 1 || d->stride == 2)) || (d->KH == 4 && (d->stride == 1 || d->stride == 2));
+}
+int wgrad_halo_f32_nsplit(const iprgan_conv_desc* d, int target_blocks) {
+  const int PH = d->transposed ? d->H : (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  const int PW = d->transposed ? d->W : (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  const int npatch = d->B * cdiv(PH, 8) * cdiv(PW, 8);
+  const int Ss = d->transposed ? d->Cin : d->Cout, Ls = d->transposed ? d->Cout : d->Cin;
+  const int tiles = (Ls / 32) * (Ss / 64);
+  int want = cdiv(target_blocks, tiles);
+  if (want < 1) want = 1;
+  if (want > npatch) want = npatch;
+  return cdiv(npatch, cdiv(npatch, want));
+}
+template <int KH, int KW, int STR, int NSTAGE>
+static int launch_wh32(const WHalo32Args& a, dim3 grid, hipStream_t st) {
+  using G = WH32Geom<KH, KW, STR, NSTAGE>;
+  auto kern = wgrad_halo_f32_kernel<KH, KW, STR, NSTAGE>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM); attr_set = true; }
+  prof_launch(kern, grid, dim3(G::NWAVE * 64), (size_t)G::SMEM, st, 25, a.flops, a);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int launch_wgrad_halo_f32(const iprgan_conv_desc* d, const float* x, const float* dy, float* ws, int target_blocks,
+                          hipStream_t st, int* nsplit_out, int* Nrows_out, int* Kw_out) {
+  if (!wgrad_halo_f32_eligible(d)) return -1;
+  const int OH = d->transposed ? (d->H - 1) * d->stride - 2 * d->pad + d->KH + d->outpad : (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  const int OW = d->transposed ? (d->W - 1) * d->stride - 2 * d->pad + d->KW + d->outpad : (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  WHalo32Args a;
+  memset(&a, 0, sizeof(a));
+  a.B = d->B; a.pad = d->pad; a.reflect = d->pad_mode == IPRGAN_PAD_REFLECT;
+  if (d->transposed) { a.S = x; a.L = dy; a.PH = d->H; a.PW = d->W; a.QH = OH; a.QW = OW; a.Ss = d->Cin; a.Ls = d->Cout; }
+  else { a.S = dy; a.L = x; a.PH = OH; a.PW = OW; a.QH = d->H; a.QW = d->W; a.Ss = d->Cout; a.Ls = d->Cin; }
+  a.ws = ws;
+  a.PTY = cdiv(a.PH, 8); a.PTX = cdiv(a.PW, 8);
+  a.d_ptx = make_fastdiv(a.PTX); a.d_ppi = make_fastdiv(a.PTY * a.PTX);
+  a.npatch = a.B * a.PTY * a.PTX;
+  const int nsplit = wgrad_halo_f32_nsplit(d, target_blocks);
+  a.pps = cdiv(a.npatch, nsplit);
+  a.Nrows = a.Ss; a.Kw = d->KH * d->KW * a.Ls;
+  const unsigned long long sb = (unsigned long long)a.B * a.PH * a.PW * a.Ss * 4, lb = (unsigned long long)a.B * a.QH * a.QW * a.Ls * 4;
+  IPR_CHECK(sb < 0x7fffffffull && lb < 0x7fffffffull, "conv_bwd_weight: tensor larger than 2 GiB");
+  IPR_CHECK(a.QH < 32000 && a.QW < 32000, "conv_bwd_weight: image too large for the halo form");
+  a.s_bytes = (unsigned)sb; a.l_bytes = (unsigned)lb;
+  a.flops = 2.0 * a.B * (double)a.PH * a.PW * d->Cout * d->Cin * d->KH * d->KW;
+  *nsplit_out = nsplit; *Nrows_out = a.Nrows; *Kw_out = a.Kw;
+  dim3 grid(a.Ls / 32, a.Ss / 64, nsplit);
+  if (d->KH == 4) return d->stride == 2 ? launch_wh32<4, 4, 2, 2>(a, grid, st) : launch_wh32<4, 4, 1, 2>(a, grid, st);
+  return d->stride == 2 ? launch_wh32<3, 3, 2, 2>(a, grid, st) : launch_wh32<3, 3, 1, 3>(a, grid, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Backward-weight of the RGB layers (3 -> C stems, C -> 3 heads; k3 s1 p1): dW[n][c][tap] = sum_p T64[p][n] T4[p+tap-1][c]
 // with T64 the bf16 tensor with many channels (Conv2d 3->C: dy; ConvTranspose2d C->3: x) and T4 the fp32 NHWC4 image
 // (x / dy).  19 GFLOP over 0.6 GB at DCGAN-128 batch 256: bound by READING T64 once.  The split-M GEMM spent 330 us on it

@@ -30,7 +30,7 @@ def main():
         wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
         flops = 2.0 * b * (H * H if tr else OH * OW) * cin * cout * k * k
         res = {}
-        for cand in range(60):
+        for cand in list(range(60)) + [71, 72, 73]:
             _lib.call('iprgan_debug_force_tiles', -1, cand)
             t = timeit(lambda: ops.conv_bwd_weight(spec, d, x, dy, wshape, False), n=5)
             res[cand] = t
@@ -40,6 +40,7 @@ def main():
         for v in range(3):
             vb = min(range(20 * v, 20 * v + 20), key=res.get)
             row[f'v{v}'] = f'{SHAPES[vb % 4]}/{TARGETS[(vb % 20) // 4]}: {res[vb] * 1e3:.1f}us {flops / res[vb] / 1e9:.1f}TF'
+        row['halo32'] = {c: f'{res[c] * 1e3:.1f}us {flops / res[c] / 1e9:.1f}TF' for c in (71, 72, 73)}
         row['top'] = [f'{c}:{res[c] * 1e3:.1f}' for c in best]
         print(json.dumps(row), flush=True)
 

@@ -538,6 +538,51 @@ def test_wgrad_halo(dev, shape, cand):
         _lib.set_math('fp32')
 
 
+HALO32_SHAPES = [  # cin, cout, k, s, p, outpad, transposed, pad_mode, H, W, B
+    (64, 64, 3, 1, 1, 0, False, 0, 16, 16, 3),    # k3 s1 zero padding
+    (32, 128, 3, 1, 1, 0, False, 1, 13, 11, 2),   # k3 s1 ReflectionPad2d (CycleGAN residual convolutions), ragged maps
+    (64, 64, 3, 2, 1, 0, False, 0, 17, 15, 2),    # k3 s2 (Discriminator96 / Resnet down-sampling): four stride residues
+    (64, 128, 4, 2, 1, 0, False, 0, 16, 16, 3),   # k4 s2 Conv2d
+    (128, 64, 4, 2, 1, 0, True, 0, 8, 8, 4),      # k4 s2 ConvTranspose2d
+    (64, 64, 4, 1, 1, 0, False, 0, 12, 10, 2),    # k4 s1 (PatchGAN), output 11 x 9
+    (64, 32, 3, 2, 1, 1, True, 0, 6, 5, 2),       # ConvT k3 s2 with output_padding (Resnet up-sampling)
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cand', [71, 72, 73])
+@pytest.mark.parametrize('shape', HALO32_SHAPES, ids=lambda c: '-'.join(map(str, c)))
+def test_wgrad_halo_fp32(dev, shape, cand):
+    """Backward-weight in the halo form on the exact fp32 MFMA (wgrad_halo_f32_kernel; candidates 71-73 = block targets
+    256 / 512 / 1024) against torch: every kernel size / stride it serves, zero and reflection padding, transposed layers,
+    ragged patches; the accumulate-into-bucket form (beta = 1) as well."""
+    from iprgan import _lib, ops
+    cin, cout, k, s, p, op, tr, pm, H, W, B = shape
+    x = rnd(B, cin, H, W, seed=1)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = torch.zeros(*wshape, requires_grad=True)
+    if tr:
+        y = F.conv_transpose2d(x, w, None, stride=s, padding=p, output_padding=op)
+    elif pm:
+        y = F.conv2d(F.pad(x, (p, p, p, p), mode='reflect'), w, None, stride=s)
+    else:
+        y = F.conv2d(x, w, None, stride=s, padding=p)
+    g = rnd(*y.shape, seed=4)
+    y.backward(g)
+    try:
+        _lib.call('iprgan_debug_force_tiles', -1, cand)
+        spec = ops.ConvSpec(cin, cout, k, s, p, op, tr, pad_mode=pm)
+        d = spec.desc(B, H, W)
+        xd, gd = to_nhwc(x).to(dev), to_nhwc(g).to(dev)
+        dw, _ = ops.conv_bwd_weight(spec, d, xd, gd, wshape, False)
+        close(dw, w.grad, what=f'fp32 halo wgrad cand {cand}')
+        acc = torch.full(wshape, 0.5, device=dev)
+        ops.conv_bwd_weight(spec, d, xd, gd, wshape, False, dw=acc, beta=1.0)
+        close(acc.cpu(), w.grad + 0.5, what=f'fp32 halo wgrad beta=1 cand {cand}')
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
+
+
 RGB_WGRAD_SHAPES = [  # cin, cout, transposed, H, W, B
     (3, 64, False, 16, 16, 3),        # stem 3 -> 64: tiles of 16 rows, halo rows above / below the image are zero padding
     (3, 128, False, 12, 32, 2),       # two 64-channel tiles of dy; H not a multiple of the tile's rows (ragged last tile)
