@@ -365,6 +365,8 @@ def main():
         peak_mode = PEAK_BF16_MFMA if args.math != 'fp32' else PEAK_FP32_MFMA
         # profiles/<round>_[<workload>_]pmc_traffic.json; the headline workload has no infix
         tag = '' if args.workload == 'dcgan64' else args.workload + '_'
+        if args.math != 'fp32':
+            tag = f'{args.workload}_{args.math}_'
         rnd = 'r[0-9][0-9]_'
         traffic = traffic_src = util_pmc = util_src = None
         try:          # HBM bytes per launch from the committed PMC passes (profiles/: separate rocprofv3 runs)

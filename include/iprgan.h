@@ -325,6 +325,7 @@ int iprgan_get_math_mode(void);
  *                     CU), 128x64; bf16 operands in HBM, or fp32 operands with the exact fp32 MFMA
  *              14, 15 the persistent 256x128 / 256x64 form (bf16 operands)
  *              16     four sub-pixel phases per block (k4 s2 p1 backward-data forms, bf16 operands)
+ *              17     256x256 with a half-tile ring: quadrant phases, five half-tiles of DMA in flight (bf16 operands)
  *   wgrad_cand 0..59  = 20 * variant + 4 * block target + tile shape (split-M GEMM of conv_igemm.hip)
  *              60..68 halo form for bf16 tensors (wgrad_halo.hip): 3 * variant + block target {128, 256, 512}
  *              69, 70 RGB-layer streaming form (block targets 256 / 512)

@@ -39,7 +39,7 @@ static ProfSlot g_slots[] = {
     {"gconv_pipe_kernel", 0, 0, 0},     {"gconv_pipe_kernel<256x64>", 0, 0, 0},
     {"wgrad_halo_kernel", 0, 0, 0},     {"wgrad_rgb_kernel", 0, 0, 0},
     {"gconv_pipe_f32_kernel", 0, 0, 0}, {"gconv_phase4_kernel", 0, 0, 0},
-    {"wgrad_halo_f32_kernel", 0, 0, 0},
+    {"wgrad_halo_f32_kernel", 0, 0, 0}, {"gconv_pipe8_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; int tag; };
@@ -1936,7 +1936,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
       case 5: return launch_gconv_t<4, 2, 1, 1>(a, st);      // 128x64, 8 waves of 32x32
       case 6: return launch_gconv_bf16big<2, 2, 4, 2>(a, st);   // bf16 only: 256x128, 4 waves of 128x64
       case 7: return launch_gconv_bf16big<2, 2, 4, 4>(a, st);   // bf16 only: 256x256, 4 waves of 128x128
-      case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16:   // LDS-DMA ring tiles (conv_pipe.hip)
+      case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17:   // LDS-DMA ring tiles (conv_pipe.hip)
         return launch_gconv_pipe(a, tile - 8, st, &t_last_bm);
       default: return launch_gconv_t<2, 2, 1, 1>(a, st);
     }
@@ -1967,7 +1967,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   g_prof_on = false;
   float best_us = 0.f;
   int err = 0;
-  const int best = tune_pick(17, [&](int cand) -> int {
+  const int best = tune_pick(18, [&](int cand) -> int {
     if ((cand == 0 || cand == 3 || cand == 4) && N < 128) return -1;
     if ((cand == 6 || cand == 7) && (long long)cdiv(maxM, 256) * cdiv(N, 128) * a.nphase < 256) return -1;    // not even one block per CU
     return run(cand);

@@ -24,6 +24,7 @@
 //     pixel address per 8 values, 16-byte loads of the fused-derivative operand (issued before the K loop, so they
 //     cost no latency) and 16-byte stores of whole contiguous rows.
 #include "conv_shared.h"
+#include <type_traits>
 
 namespace iprgan {
 
@@ -286,7 +287,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
     }
     return;
   }
-  const int p_tw = a.ph[pz].tw;
+  const int p_tw = a.ph[pz].tw, p_th = a.ph[pz].th;
+  const bool korder = (a.korder & 1) != 0, krot = (a.korder & 2) != 0;
+  const bool weave = (a.korder & 16) != 0;
   const int nt = F32 ? a.ph[pz].steps : a.ph[pz].steps / 2;          // steps counts 32-deep K steps (bf16: Cs % 64 == 0)
   const bool reflect = F32 && a.pad_mode == IPRGAN_PAD_REFLECT;
   const int p_dy0 = a.ph[pz].dy0, p_dx0 = a.ph[pz].dx0, p_dys = a.ph[pz].dys, p_dxs = a.ph[pz].dxs;
@@ -339,7 +342,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const unsigned lds_base = (unsigned)(uintptr_t)lds;                  // LDS byte address of the ring
-  int u_c = 0, u_ty = 0, u_tx = 0;                                     // wave-uniform tap walk (channel offset, tap)
+  // wave-uniform walk over (channel chunk, tap).  Tile rows start at different chunks (krot): at any moment the blocks of an
+  // XCD then fetch different 128-byte columns of the NHWC rows instead of all camping on the L2 channels of one column
+  const int nchunk = Cs / KSTEP;
+  int u_c = krot ? (int)(lq % (unsigned)nchunk) * KSTEP : 0, u_ty = 0, u_tx = 0, u_n = 0;
   // issue the LDS-DMA of the next K step of the walk into stage buffer `buf`
   auto issue = [&](int buf) {
     const int dy = p_dy0 + u_ty * p_dys, dx = p_dx0 + u_tx * p_dxs;
@@ -364,8 +370,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
 #pragma unroll
     for (int i = 0; i < LB; ++i)
       dma16(rs_wt, sbase + A_BYTES + (unsigned)(i * NW) * 1024u, wrow[i] + wk);
-    u_c += KSTEP;
-    if (u_c >= Cs) { u_c = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
+    if (korder) {                 // taps inside a channel chunk: consecutive K steps re-read the same pixels, shifted
+      if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; u_c += KSTEP; if (u_c >= Cs) u_c = 0; } }
+    } else {
+      u_c += KSTEP;
+      if (u_c >= Cs) u_c = 0;
+      if (++u_n == nchunk) { u_n = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
+    }
   };
 
   // fragment read offsets: row (wm*WM+i)*32 + l31 of A / (wn*WN+j)*32 + l31 of B, chunk (2 kk + half) ^ swz(l31)
@@ -413,6 +424,76 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
     }
   };
 
+  // bf16 K step with the refill of stage `nb` woven into the MFMA stream of stage `cb`.  Issued as one burst behind the
+  // barrier (issue(); compute()), the L pieces of all eight waves queue up in the CU's one address path and every wave
+  // sits in its issue slot until the burst has drained: measured on the 256x256 tile, K loop with only the DMA 57 us,
+  // with only the MFMAs 85 us, with both 134 us - the two did not overlap.  Here a piece follows every (SPREAD / L)-th
+  // MFMA, so a wave waits for one queue slot at a time while its (and its SIMD partner's) MFMAs run.  Two-stage rings
+  // keep the pieces in the first half of the step (the rest of it is landing time before the next barrier).  The
+  // fragments of sub-step kk + 1 are read while those of kk are multiplied.
+  auto step_bf16 = [&](int cb, int nb, auto ISS) {
+    constexpr bool iss = decltype(ISS)::value;
+    constexpr int NMF = WM * WN, SPREAD = NSTAGE >= 3 ? 3 * NMF : 2 * NMF;
+    const char* sb = ldsc + cb * STAGE_BYTES;
+    int dy = 0, dx = 0, tapoff = 0;
+    unsigned wk = 0, sbase = 0;
+    if constexpr (iss) {
+      dy = p_dy0 + u_ty * p_dys; dx = p_dx0 + u_tx * p_dxs;
+      tapoff = ((dy * IW + dx) * Cs + u_c) * ESZ;
+      wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c) * (unsigned)ESZ;
+      sbase = lds_base + (unsigned)nb * STAGE_BYTES + (unsigned)wave * 1024u;
+    }
+    auto piece = [&](int q) {
+      if (q < LA) {
+        const int iy = aiy[q] + dy, ix = aix[q] + dx;
+        const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+        dma16(rs_in, sbase + (unsigned)(q * NW) * 1024u, ok ? arow[q] + (unsigned)tapoff : OOB_OFFSET);
+      } else {
+        dma16(rs_wt, sbase + A_BYTES + (unsigned)((q - LA) * NW) * 1024u, wrow[q - LA] + wk);
+      }
+    };
+    bf16x8 af[2][WM], bf[2][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) af[0][i] = *(const bf16x8*)(sb + a_wave + i * 4096 + foff[0]);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bf[0][j] = *(const bf16x8*)(sb + b_wave + j * 4096 + foff[0]);
+    int q = 0, mi = 0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk < 3) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[(kk + 1) & 1][i] = *(const bf16x8*)(sb + a_wave + i * 4096 + foff[kk + 1]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[(kk + 1) & 1][j] = *(const bf16x8*)(sb + b_wave + j * 4096 + foff[kk + 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+          ++mi;
+          if constexpr (iss) {
+            if (q < L && q * SPREAD < mi * L) {
+              piece(q);
+              ++q;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+    }
+    if constexpr (iss) {
+#pragma unroll
+      for (; q < L; ++q) piece(q);
+      if (korder) {
+        if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; u_c += KSTEP; if (u_c >= Cs) u_c = 0; } }
+      } else {
+        u_c += KSTEP;
+        if (u_c >= Cs) u_c = 0;
+        if (++u_n == nchunk) { u_n = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
+      }
+    }
+  };
+
   // PREF: the fused-derivative operand of this thread's stores, loaded FIRST: vmcnt retires in order, so the wait for
   // stage 0 covers these loads (the same latency, once per tile) and every later counted wait is unaffected
   using G = EpiGeom<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES>;
@@ -424,20 +505,274 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nt) issue(s);
   int cur = 0, nxt = NSTAGE - 1;                 // stage read at step t, stage refilled at step t (= read at t-1)
-  for (int t = 0; t < nt; ++t) {
-    const int rem = nt - 1 - t;                  // K steps after this one
-    wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads of step t-1 are complete
-    __builtin_amdgcn_s_barrier();
-    if (rem >= NSTAGE - 1) issue(nxt);
-    compute(cur);
-    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
-    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+  if (F32 || !weave) {
+    for (int t = 0; t < nt; ++t) {
+      const int rem = nt - 1 - t;                  // K steps after this one
+      wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads of step t-1 are complete
+      __builtin_amdgcn_s_barrier();
+      if (rem >= NSTAGE - 1) issue(nxt);
+      compute(cur);
+      cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+      nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+    }
+  } else {
+    int t = 0;
+    for (; t < nt - (NSTAGE - 1); ++t) {           // steps that refill a stage
+      wait_stages<L>(NSTAGE - 2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      step_bf16(cur, nxt, std::true_type{});
+      cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+      nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+    }
+    for (; t < nt; ++t) {                          // the last NSTAGE - 1 steps drain the ring
+      const int rem = nt - 1 - t;
+      wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      step_bf16(cur, nxt, std::false_type{});
+      cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                  // the epilogue reuses the ring
 
   pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf);
+}
+
+// ---- 256x256 tile with a half-tile ring ---------------------------------------------------------------------------
+// gconv_pipe_kernel's 256x256 tile refills a whole 64 KB stage per K step: with two stages at most one step of DMA is in
+// flight, all of it issued in one burst, and every step ends in a wait for its slowest piece (measured, K loop only:
+// DMA alone 57 us, MFMAs alone 85 us, together 134 us).  Here the two K-tile buffers are cut into half-tiles of 128 rows
+// (A0 / A1: the first / second 64 rows of each wave row; B0 / B1: the first / second 32 columns of each wave column),
+// a K tile is multiplied quadrant by quadrant (A0 B0, A0 B1, A1 B1, A1 B0; the fragments of a half are read from LDS
+// once and stay in registers for both of its quadrants), and each of the four phases refills the half-tile slot that
+// was last read one phase earlier.  The DMA stream is therefore in half-tile order A0 B0 B1 A1 of K tile 0, 1, 2, ...;
+// phase p of K tile t issues half-tile 4t + 7 + p, waits (counted vmcnt, never 0) for half-tile 4t + 1 + p to have
+// landed and leaves FIVE younger half-tiles (80 KB) in flight across the barrier.  One barrier per phase covers both
+// hazards: every wave has waited for its own pieces of the half-tile read next, and every wave has finished the reads
+// (they precede its MFMAs) of the half-tile that is overwritten next.
+template <bool STATS, bool PREF>
+__global__ __launch_bounds__(512) void gconv_pipe8_kernel(const GConvArgs a) {
+  constexpr int WGM = 2, WGN = 4, WM = 4, WN = 2, NW = 8, BM = 256, BN = 256;
+  constexpr int HT = 16384, BUF = 4 * HT;                // half-tile, K-tile buffer (slots in stream order A0 B0 B1 A1)
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+
+  const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                gridDim.x * gridDim.y * gridDim.z);
+  const unsigned lq = lt / gridDim.y;
+  const int pz = (int)(lq % gridDim.z);
+  const int pM = a.ph[pz].M;
+  const int m0 = (int)(lq / gridDim.z) * BM, n0 = (int)(lt % gridDim.y) * BN;
+  if (m0 >= pM) {
+    if (STATS) {
+      for (int c = threadIdx.x; c < BN; c += NW * 64)
+        if (n0 + c < a.Ns) { a.stat_part[((size_t)lq * 2) * a.Ns + n0 + c] = 0.f; a.stat_part[((size_t)lq * 2 + 1) * a.Ns + n0 + c] = 0.f; }
+    }
+    return;
+  }
+  const int p_tw = a.ph[pz].tw, p_th = a.ph[pz].th;
+  const int nt = a.ph[pz].steps / 2;                   // 64-channel K tiles
+  const int total = 4 * nt;                            // half-tiles of the stream
+  const int p_dy0 = a.ph[pz].dy0, p_dx0 = a.ph[pz].dx0, p_dys = a.ph[pz].dys, p_dxs = a.ph[pz].dxs;
+  const int p_wbase = a.ph[pz].wbase, p_wsy = a.ph[pz].wsy, p_wsx = a.ph[pz].wsx;
+  const int p_owg = a.ph[pz].owg, plane = a.ph[pz].ohg * a.ph[pz].owg;
+  const FastDiv d_plane = a.ph[pz].d_plane, d_owg = a.ph[pz].d_owg;
+  const int IH = a.IH, IW = a.IW, Cs = a.Cs;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lrow = lane >> 3, lchunk = lane & 7;
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+
+  // what this lane stages: piece i of a half-tile = its rows 8 * (8 i + wave) .. + 7, this lane row rho = 8 (8 i + wave) + lrow,
+  // 16-byte position lchunk <- source chunk lchunk ^ swz(rho).  A half h row rho = tile row (rho / 64) * 128 + 64 h + rho % 64,
+  // B half h row rho = tile column (rho / 32) * 64 + 32 h + rho % 32.
+  int aiy[2][2], aix[2][2];
+  unsigned arow[2][2], wrow[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rho = (i * 8 + wave) * 8 + lrow;
+      const unsigned sc = (unsigned)(lchunk ^ ((rho >> 1) & 7)) * 16u;
+      const int m = m0 + (rho >> 6) * 128 + h * 64 + (rho & 63);
+      if (m < pM) {
+        const int b = fdiv(m, d_plane);
+        const int rem = m - b * plane;
+        const int y = fdiv(rem, d_owg);
+        const int x = rem - y * p_owg;
+        aiy[h][i] = y * a.isy;
+        aix[h][i] = x * a.isx;
+        arow[h][i] = (unsigned)(((b * IH + aiy[h][i]) * IW + aix[h][i]) * Cs) * 2u + sc;
+      } else {
+        aiy[h][i] = ROW_INVALID; aix[h][i] = 0; arow[h][i] = 0;
+      }
+      const int c = (rho >> 5) * 64 + h * 32 + (rho & 31);
+      wrow[h][i] = (unsigned)((n0 + c) * a.Kp) * 2u + sc;
+    }
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+  const bool korder = (a.korder & 1) != 0;
+  const int nchunk = Cs / 64;
+  struct Walk { int c, ty, tx, n; };
+  auto advance = [&](Walk& w) {
+    if (korder) {
+      if (++w.tx == p_tw) { w.tx = 0; if (++w.ty == p_th) { w.ty = 0; w.c += 64; } }
+    } else {
+      w.c += 64;
+      if (++w.n == nchunk) { w.n = 0; w.c = 0; if (++w.tx == p_tw) { w.tx = 0; ++w.ty; } }
+    }
+  };
+  // the two pieces of half-tile X (0: A0, 1: B0, 2: B1, 3: A1) of the K tile at walk position w, into buffer `buf`;
+  // piece i is issued by issue_piece<X>(.., i)
+  auto issue_piece = [&](auto XC, int buf, const Walk& w, int i) {
+    constexpr int X = decltype(XC)::value;
+    const unsigned dst = lds_base + (unsigned)buf * BUF + (unsigned)X * HT + (unsigned)(i * 8 + wave) * 1024u;
+    if constexpr (X == 0 || X == 3) {
+      constexpr int h = X == 3;
+      const int dy = p_dy0 + w.ty * p_dys, dx = p_dx0 + w.tx * p_dxs;
+      const int tapoff = ((dy * IW + dx) * Cs + w.c) * 2;
+      const int iy = aiy[h][i] + dy, ix = aix[h][i] + dx;
+      const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+      dma16(rs_in, dst, ok ? arow[h][i] + (unsigned)tapoff : OOB_OFFSET);
+    } else {
+      constexpr int h = X == 2;
+      const unsigned wk = (unsigned)((p_wbase + w.ty * p_wsy + w.tx * p_wsx) * Cs + w.c) * 2u;
+      dma16(rs_wt, dst, wrow[h][i] + wk);
+    }
+  };
+
+  // fragment reads: A half h row wm * 64 + i * 32 + l31, B half h row wn * 32 + l31, chunk (2 kk + half) ^ swz(l31)
+  const int half = lane >> 5, l31 = lane & 31;
+  unsigned foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) foff[kk] = (unsigned)l31 * 128u + (unsigned)((2 * kk + half) ^ ((l31 >> 1) & 7)) * 16u;
+  const char* ldsc = (const char*)lds;
+  const unsigned a_wave = (unsigned)(wm * 64) * 128u, b_wave = (unsigned)(wn * 32) * 128u;
+  bf16x8 af[2][4], b0[4], b1[4];
+  auto read_a = [&](int buf, int h) {
+    const char* sb = ldsc + buf * BUF + (h ? 3 * HT : 0) + a_wave;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) af[i][kk] = *(const bf16x8*)(sb + i * 4096 + foff[kk]);
+  };
+  auto read_b = [&](int buf, int h, bf16x8 (&bf)[4]) {
+    const char* sb = ldsc + buf * BUF + (h ? 2 * HT : HT) + b_wave;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) bf[kk] = *(const bf16x8*)(sb + foff[kk]);
+  };
+  // quadrant (hA, hB) with the two pieces of the refill woven behind the first MFMAs
+  auto quad = [&](int hA, int hB, const bf16x8 (&bf)[4], auto ISSUE) {
+    int n = 0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        acc[hA * 2 + i][hB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][kk], bf[kk], acc[hA * 2 + i][hB], 0, 0, 0);
+        if (n < 2) { ISSUE(n); __builtin_amdgcn_sched_barrier(0); }
+        ++n;
+      }
+  };
+  auto wait_dyn = [&](int halves) {        // at most `halves` younger half-tiles (2 pieces each) still in flight
+    if (halves >= 5) wait_vmcnt<10>();
+    else if (halves == 4) wait_vmcnt<8>();
+    else if (halves == 3) wait_vmcnt<6>();
+    else if (halves == 2) wait_vmcnt<4>();
+    else if (halves == 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+  };
+  auto barrier = [&]() {                   // (the fragment reads of the previous phase fed its MFMAs: long complete)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  using G = EpiGeom<WGM, WGN, WM, WN, 2 * BUF>;
+  u32x4 auxpf[G::NIT];
+  if constexpr (PREF) pipe_aux_load<G>(a, pz, m0, n0, 0, auxpf);
+
+  // ---- prologue: half-tiles 0 .. 6 (K tile 0 and A0 B0 B1 of K tile 1)
+  Walk w1{0, 0, 0, 0}, w2{0, 0, 0, 0};
+  {
+    issue_piece(std::integral_constant<int, 0>{}, 0, w1, 0); issue_piece(std::integral_constant<int, 0>{}, 0, w1, 1);
+    issue_piece(std::integral_constant<int, 1>{}, 0, w1, 0); issue_piece(std::integral_constant<int, 1>{}, 0, w1, 1);
+    issue_piece(std::integral_constant<int, 2>{}, 0, w1, 0); issue_piece(std::integral_constant<int, 2>{}, 0, w1, 1);
+    issue_piece(std::integral_constant<int, 3>{}, 0, w1, 0); issue_piece(std::integral_constant<int, 3>{}, 0, w1, 1);
+    advance(w1);                          // K tile 1
+    if (nt > 1) {
+      issue_piece(std::integral_constant<int, 0>{}, 1, w1, 0); issue_piece(std::integral_constant<int, 0>{}, 1, w1, 1);
+      issue_piece(std::integral_constant<int, 1>{}, 1, w1, 0); issue_piece(std::integral_constant<int, 1>{}, 1, w1, 1);
+      issue_piece(std::integral_constant<int, 2>{}, 1, w1, 0); issue_piece(std::integral_constant<int, 2>{}, 1, w1, 1);
+    }
+    w2 = w1;
+    advance(w2);                          // K tile 2
+  }
+  int issued = nt > 1 ? 7 : 4;
+
+  // one K tile; STEADY: all four refills exist and exactly five half-tiles are in flight behind each wait
+  auto ktile = [&](int t, auto STEADY) {
+    constexpr bool steady = decltype(STEADY)::value;
+    const int cb = t & 1, ob = cb ^ 1, base = 4 * t;
+    // phase 0: A0 B0
+    if constexpr (steady) wait_vmcnt<10>(); else wait_dyn(issued - (base + 2));
+    barrier();
+    read_a(cb, 0);
+    read_b(cb, 0, b0);
+    {
+      const bool go = steady || base + 7 < total;
+      quad(0, 0, b0, [&](int i) { if (go) issue_piece(std::integral_constant<int, 3>{}, ob, w1, i); });
+      if (!steady && go) ++issued;
+    }
+    // phase 1: A0 B1
+    if constexpr (steady) wait_vmcnt<10>(); else wait_dyn(issued - (base + 3));
+    barrier();
+    read_b(cb, 1, b1);
+    {
+      const bool go = steady || base + 8 < total;
+      quad(0, 1, b1, [&](int i) { if (go) issue_piece(std::integral_constant<int, 0>{}, cb, w2, i); });
+      if (!steady && go) ++issued;
+    }
+    // phase 2: A1 B1
+    if constexpr (steady) wait_vmcnt<10>(); else wait_dyn(issued - (base + 4));
+    barrier();
+    read_a(cb, 1);
+    {
+      const bool go = steady || base + 9 < total;
+      quad(1, 1, b1, [&](int i) { if (go) issue_piece(std::integral_constant<int, 1>{}, cb, w2, i); });
+      if (!steady && go) ++issued;
+    }
+    // phase 3: A1 B0 (registers only; the slot of B1 was last read in phase 1, two barriers ago)
+    {
+      const bool go = steady || base + 10 < total;
+      quad(1, 0, b0, [&](int i) { if (go) issue_piece(std::integral_constant<int, 2>{}, cb, w2, i); });
+      if (!steady && go) ++issued;
+    }
+    w1 = w2;
+    advance(w2);
+  };
+
+  int t = 0;
+  for (; t < nt - 2; ++t) ktile(t, std::true_type{});
+  if (nt > 2) issued = 4 * t + 7;
+  for (; t < nt; ++t) ktile(t, std::false_type{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                  // the epilogue reuses the ring
+
+  pipe_epilogue<WGM, WGN, WM, WN, 2 * BUF, STATS, PREF>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf);
 }
 
 // ---- persistent form -------------------------------------------------------------------------------------------
@@ -950,6 +1285,21 @@ static int launch_pipe_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   return 0;
 }
 
+static int launch_pipe8(const GConvArgs& a, hipStream_t st, int* bm_out) {
+  if (!a.in16 || a.Ns < 256) return -1;
+  int maxM = 0;
+  for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
+  if (maxM == 0) return 0;
+  const size_t smem = 128 * 1024;
+  dim3 grid(cdiv(maxM, 256), cdiv(a.Ns, 256), a.nphase);
+  *bm_out = 256;
+  const dim3 block(512);
+  if (a.stat_part) pipe_go<gconv_pipe8_kernel<true, false>>(a, grid, block, smem, 26, st);
+  else pipe_go<gconv_pipe8_kernel<false, false>>(a, grid, block, smem, 26, st);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int WGM, int WGN, int WM, int WN, int NSTAGE>
 static int launch_pipe2_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
@@ -1026,8 +1376,14 @@ static int launch_phase4(const GConvArgs& a, hipStream_t st, int* bm_out) {
 //          6 / 7 = persistent 256x128 / 256x64 (gconv_pipe2_kernel: one block per CU walks the tile list),
 //          8 = gconv_phase4_kernel (the four sub-pixel phases of a k4 s2 p1 backward-data form in one block)
 // returns -1 when the variant does not apply to the geometry
-int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_out) {
-  if (!gconv_pipe_eligible(a)) return -1;
+// A/B switch (GConvArgs::korder): bit 0 = taps inside a channel chunk, bit 1 = tile rows start at different chunks (measured
+// neutral: the L2 channels are not the limit), bit 4 = refill pieces woven into the MFMA stream (+5-10 % on the 8-wave tiles)
+static int g_pipe_korder = getenv("IPRGAN_PIPE_KORDER") ? atoi(getenv("IPRGAN_PIPE_KORDER")) : 17;
+
+int launch_gconv_pipe(const GConvArgs& a0, int variant, hipStream_t st, int* bm_out) {
+  if (!gconv_pipe_eligible(a0)) return -1;
+  GConvArgs a = a0;
+  a.korder = g_pipe_korder;
   switch (variant) {
     case 0: return a.Ns >= 128 ? launch_pipe_t<4, 2, 2, 2, 3>(a, st, bm_out) : -1;
     case 1: return launch_pipe_t<4, 2, 2, 1, 3>(a, st, bm_out);
@@ -1038,6 +1394,7 @@ int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_o
     case 6: return a.in16 && a.Ns >= 128 ? launch_pipe2_t<4, 2, 2, 2, 2>(a, st, bm_out) : -1;   // persistent 256x128, 2 stages + 64 KB
     case 7: return a.in16 ? launch_pipe2_t<4, 2, 2, 1, 2>(a, st, bm_out) : -1;                  // persistent 256x64, 2 stages + 64 KB
     case 8: return launch_phase4(a, st, bm_out);                                                // four phases per block (k4 s2 p1)
+    case 9: return launch_pipe8(a, st, bm_out);                                                 // 256x256, half-tile ring
     default: return -1;
   }
 }

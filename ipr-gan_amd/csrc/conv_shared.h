@@ -72,6 +72,7 @@ struct GConvArgs {
   float* stat_part;    // STATS kernels: per-tile column sums [tile rows][2][Ns] (see gconv_kernel)
   int stat_mode;
   int ksplit;          // > 1: blockIdx.z splits the K loop (single-phase geometries); partial tiles go to slabs of M*Ns floats
+  int korder;          // LDS-DMA ring tiles: K-loop form bits, see g_pipe_korder (conv_pipe.hip)
   int wmod, wk1;       // > 0: operand row r lives at (r % wmod) * Kp + (r / wmod) * wk1 floats (full-map conv backward-data)
   Phase ph[4];
   double flops;   // algorithmic 2*MAC of this launch (host-side bookkeeping only)

@@ -23,6 +23,9 @@ LAYERS = [  # name, cin, cout, k, s, p, transposed, H
     ('G.up0 512->256 T k4s2', 512, 256, 4, 2, 1, True, 16),
     ('G.up1 256->128 T k4s2', 256, 128, 4, 2, 1, True, 32),
     ('G.up2 128->64 T k4s2', 128, 64, 4, 2, 1, True, 64),
+    ('GEMM 1024->1024 k1 @32', 1024, 1024, 1, 1, 0, False, 32),
+    ('GEMMsmall 1024->4096 k1 @8', 1024, 4096, 1, 1, 0, False, 8),      # both operands stay in the Infinity Cache
+    ('GEMMdeep 4096->1024 k1 @8', 4096, 1024, 1, 1, 0, False, 8),     # plain GEMM: the ring's inner loop without the im2col walk
 ]
 
 

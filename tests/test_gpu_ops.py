@@ -671,12 +671,13 @@ def test_conv_bf16_math_mode(dev, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('mode', ['bf16', 'bf16act'])
-@pytest.mark.parametrize('tile', [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 17])
 def test_bf16_gconv_tiles(dev, tile, mode):
     """Every bf16 tile of the forward / backward-data kernel, including the 128x64 and 128x128 per-wave tiles that only
     the bf16 modes build (6, 7), on bf16-representable inputs (products exact: only the summation order differs), with
     fp32 and with bf16 activations in HBM; ragged M (not a multiple of 256) and N = 256 so that 256-wide tiles apply.
-    Tiles 8-15 are the LDS-DMA ring tiles (14, 15: the persistent form) of conv_pipe.hip (bf16 operands in HBM only)."""
+    Tiles 8-15 and 17 are the LDS-DMA ring tiles (14, 15: the persistent form, 17: the half-tile ring) of conv_pipe.hip
+    (bf16 operands in HBM only)."""
     from iprgan import _lib, ops
     if tile >= 8 and mode != 'bf16act':
         pytest.skip('the LDS-DMA ring tiles read bf16 operands from HBM')
@@ -762,6 +763,8 @@ PIPE_SHAPES = [  # cin, cout, k, s, p, outpad, transposed, H, W, B
     (128, 64, 4, 2, 1, 0, True, 8, 8, 6),         # ConvT k4s2 (generator): forward = four sub-pixel phases
     (64, 64, 3, 2, 1, 1, True, 6, 5, 2),          # ConvT k3s2 with output_padding: phases of 1, 2, 2, 4 taps (one-step rings)
     (256, 256, 4, 2, 1, 0, False, 8, 8, 4),       # two channel steps per tap, N = 256 (the 256x256 tile applies)
+    (64, 256, 3, 2, 1, 1, True, 6, 5, 2),         # N = 256 with phases of 1, 2, 2, 4 K tiles (prologue / tail of the half-tile ring)
+    (128, 256, 3, 1, 1, 0, False, 9, 7, 6),       # N = 256, 18 K tiles, ragged M (two tile rows)
     # the four-phases-per-block tile (16): whole grid rows x 256 positions; halo rows above / below the image are padding
     (64, 64, 4, 2, 1, 0, False, 128, 128, 1),     # backward-data: 64 x 64 grid, one channel chunk (single halo buffer)
     (128, 64, 4, 2, 1, 0, True, 32, 32, 2),       # ConvT forward: 32 x 32 grid, two chunks (double-buffered halo), Cout 64
@@ -770,7 +773,7 @@ PIPE_SHAPES = [  # cin, cout, k, s, p, outpad, transposed, H, W, B
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tile', [8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize('tile', [8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize('shape', PIPE_SHAPES, ids=lambda c: '-'.join(map(str, c)))
 def test_pipe_tiles(dev, shape, tile):
     """The LDS-DMA ring tiles (conv_pipe.hip) on bf16-representable operands (products exact, fp32 accumulation: only the
