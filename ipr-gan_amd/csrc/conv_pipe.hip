@@ -289,7 +289,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   }
   const int p_tw = a.ph[pz].tw, p_th = a.ph[pz].th;
   const bool korder = (a.korder & 1) != 0, krot = (a.korder & 2) != 0;
-  const bool weave = (a.korder & 16) != 0;
+  const bool weave = (a.korder & 16) != 0, weave32 = (a.korder & 32) != 0;
   const int nt = F32 ? a.ph[pz].steps : a.ph[pz].steps / 2;          // steps counts 32-deep K steps (bf16: Cs % 64 == 0)
   const bool reflect = F32 && a.pad_mode == IPRGAN_PAD_REFLECT;
   const int p_dy0 = a.ph[pz].dy0, p_dx0 = a.ph[pz].dx0, p_dys = a.ph[pz].dys, p_dxs = a.ph[pz].dxs;
@@ -431,9 +431,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   // MFMA, so a wave waits for one queue slot at a time while its (and its SIMD partner's) MFMAs run.  Two-stage rings
   // keep the pieces in the first half of the step (the rest of it is landing time before the next barrier).  The
   // fragments of sub-step kk + 1 are read while those of kk are multiplied.
-  auto step_bf16 = [&](int cb, int nb, auto ISS) {
+  auto step_woven = [&](int cb, int nb, auto ISS) {
     constexpr bool iss = decltype(ISS)::value;
-    constexpr int NMF = WM * WN, SPREAD = NSTAGE >= 3 ? 3 * NMF : 2 * NMF;
+    constexpr int NMF = (F32 ? 4 : 1) * WM * WN, SPREAD = NSTAGE >= 3 ? 3 * NMF : 2 * NMF;     // MFMAs per sub-step
     const char* sb = ldsc + cb * STAGE_BYTES;
     int dy = 0, dx = 0, tapoff = 0;
     unsigned wk = 0, sbase = 0;
@@ -446,38 +446,63 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
     auto piece = [&](int q) {
       if (q < LA) {
         const int iy = aiy[q] + dy, ix = aix[q] + dx;
-        const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
-        dma16(rs_in, sbase + (unsigned)(q * NW) * 1024u, ok ? arow[q] + (unsigned)tapoff : OOB_OFFSET);
+        bool ok;
+        unsigned off;
+        if (reflect) {
+          ok = aiy[q] != ROW_INVALID;
+          const int ry = reflect_idx(iy, IH), rx = reflect_idx(ix, IW);
+          off = arow[q] + (unsigned)((((ry - aiy[q]) * IW + (rx - aix[q])) * Cs + u_c) * ESZ);
+        } else {
+          ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+          off = arow[q] + (unsigned)tapoff;
+        }
+        dma16(rs_in, sbase + (unsigned)(q * NW) * 1024u, ok ? off : OOB_OFFSET);
       } else {
         dma16(rs_wt, sbase + A_BYTES + (unsigned)((q - LA) * NW) * 1024u, wrow[q - LA] + wk);
       }
     };
-    bf16x8 af[2][WM], bf[2][WN];
+    using frag_t = typename std::conditional<F32, f32x4, bf16x8>::type;       // 16 bytes of a tile row either way
+    frag_t af[2][WM], bf[2][WN];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) af[0][i] = *(const bf16x8*)(sb + a_wave + i * 4096 + foff[0]);
+    for (int i = 0; i < WM; ++i) af[0][i] = *(const frag_t*)(sb + a_wave + i * 4096 + foff[0]);
 #pragma unroll
-    for (int j = 0; j < WN; ++j) bf[0][j] = *(const bf16x8*)(sb + b_wave + j * 4096 + foff[0]);
+    for (int j = 0; j < WN; ++j) bf[0][j] = *(const frag_t*)(sb + b_wave + j * 4096 + foff[0]);
     int q = 0, mi = 0;
+    auto after_mfma = [&]() {
+      ++mi;
+      if constexpr (iss) {
+        if (q < L && q * SPREAD < mi * L) {
+          piece(q);
+          ++q;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 3) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) af[(kk + 1) & 1][i] = *(const bf16x8*)(sb + a_wave + i * 4096 + foff[kk + 1]);
+        for (int i = 0; i < WM; ++i) af[(kk + 1) & 1][i] = *(const frag_t*)(sb + a_wave + i * 4096 + foff[kk + 1]);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) bf[(kk + 1) & 1][j] = *(const bf16x8*)(sb + b_wave + j * 4096 + foff[kk + 1]);
+        for (int j = 0; j < WN; ++j) bf[(kk + 1) & 1][j] = *(const frag_t*)(sb + b_wave + j * 4096 + foff[kk + 1]);
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-          ++mi;
-          if constexpr (iss) {
-            if (q < L && q * SPREAD < mi * L) {
-              piece(q);
-              ++q;
-              __builtin_amdgcn_sched_barrier(0);
-            }
+          if constexpr (F32) {
+            const f32x4 x = (const f32x4&)af[kk & 1][i], y = (const f32x4&)bf[kk & 1][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc[i][j], 0, 0, 0);
+            after_mfma();
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc[i][j], 0, 0, 0);
+            after_mfma();
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.z, acc[i][j], 0, 0, 0);
+            after_mfma();
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.w, acc[i][j], 0, 0, 0);
+            after_mfma();
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((const bf16x8&)af[kk & 1][i], (const bf16x8&)bf[kk & 1][j], acc[i][j], 0, 0, 0);
+            after_mfma();
           }
         }
     }
@@ -505,7 +530,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nt) issue(s);
   int cur = 0, nxt = NSTAGE - 1;                 // stage read at step t, stage refilled at step t (= read at t-1)
-  if (F32 || !weave) {
+  if ((F32 && !weave32) || !weave) {
     for (int t = 0; t < nt; ++t) {
       const int rem = nt - 1 - t;                  // K steps after this one
       wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
@@ -522,7 +547,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
       wait_stages<L>(NSTAGE - 2);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      step_bf16(cur, nxt, std::true_type{});
+      step_woven(cur, nxt, std::true_type{});
       cur = cur + 1 == NSTAGE ? 0 : cur + 1;
       nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
@@ -531,7 +556,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
       wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      step_bf16(cur, nxt, std::false_type{});
+      step_woven(cur, nxt, std::false_type{});
       cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
   }
@@ -1377,8 +1402,9 @@ static int launch_phase4(const GConvArgs& a, hipStream_t st, int* bm_out) {
 //          8 = gconv_phase4_kernel (the four sub-pixel phases of a k4 s2 p1 backward-data form in one block)
 // returns -1 when the variant does not apply to the geometry
 // A/B switch (GConvArgs::korder): bit 0 = taps inside a channel chunk, bit 1 = tile rows start at different chunks (measured
-// neutral: the L2 channels are not the limit), bit 4 = refill pieces woven into the MFMA stream (+5-10 % on the 8-wave tiles)
-static int g_pipe_korder = getenv("IPRGAN_PIPE_KORDER") ? atoi(getenv("IPRGAN_PIPE_KORDER")) : 17;
+// neutral: the L2 channels are not the limit), bit 4 = refill pieces woven into the MFMA stream (+5-10 % on the 8-wave bf16
+// tiles), bit 5 = the same for the fp32 tiles (+1-3 %)
+static int g_pipe_korder = getenv("IPRGAN_PIPE_KORDER") ? atoi(getenv("IPRGAN_PIPE_KORDER")) : 49;
 
 int launch_gconv_pipe(const GConvArgs& a0, int variant, hipStream_t st, int* bm_out) {
   if (!gconv_pipe_eligible(a0)) return -1;

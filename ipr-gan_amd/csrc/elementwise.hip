@@ -160,42 +160,59 @@ __global__ __launch_bounds__(256) void gemv_bwd_dx_kernel(const float* __restric
     st4e(dx, i, v, x16);
   }
 }
-// dw[k] = sum_b dy[b] x[b, k] (sample order: deterministic), two columns per thread, eight samples' loads in flight
-__global__ __launch_bounds__(256) void gemv_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                   float* __restrict__ dw, float* __restrict__ db, int B, int K, int x16) {
-  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+// dw[k] = sum_b dy[b] x[b, k] (sample order: deterministic).  One 16-byte load per thread and sample (8 bf16 / 4 fp32
+// columns), eight samples in flight, one wave per block so that a 131072-column head still fills the chip.
+template <bool X16>
+__global__ __launch_bounds__(64) void gemv_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ dw, float* __restrict__ db, int B, int K) {
+  constexpr int CPT = X16 ? 8 : 4;
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * CPT;
   if (k < K && dw) {
-    float s0 = 0.f, s1 = 0.f;
-    auto ld2 = [&](int b, float& v0, float& v1) {
-      const size_t i = (size_t)b * K + k;
-      if (x16) {
-        const unsigned r = *(const unsigned*)((const __bf16*)x + i);
-        v0 = __builtin_bit_cast(float, r << 16); v1 = __builtin_bit_cast(float, r & 0xffff0000u);
-      } else {
-        const float2 t = *(const float2*)(x + i);
-        v0 = t.x; v1 = t.y;
+    if (k + CPT <= K && (K % CPT) == 0) {
+      float s[CPT];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) s[c] = 0.f;
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      auto ld = [&](int b) { return *(const u4*)((const char*)x + ((size_t)b * K + k) * (X16 ? 2 : 4)); };
+      auto fma_row = [&](const u4 rv, float g) {
+        const unsigned r[4] = {rv.x, rv.y, rv.z, rv.w};
+        if constexpr (X16) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            s[2 * c] += g * __builtin_bit_cast(float, r[c] << 16);
+            s[2 * c + 1] += g * __builtin_bit_cast(float, r[c] & 0xffff0000u);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) s[c] += g * __builtin_bit_cast(float, r[c]);
+        }
+      };
+      int b = 0;
+      for (; b + 7 < B; b += 8) {
+        u4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = ld(b + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fma_row(r[u], dy[b + u]);
       }
-    };
-    int b = 0;
-    for (; b + 7 < B; b += 8) {
-      float v0[8], v1[8];
+      for (; b < B; ++b) fma_row(ld(b), dy[b]);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) ld2(b + u, v0[u], v1[u]);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const float g = dy[b + u]; s0 += g * v0[u]; s1 += g * v1[u]; }
+      for (int c = 0; c < CPT; ++c) dw[k + c] = s[c];
+    } else {                                  // ragged K: scalar columns
+      for (int c = 0; c < CPT && k + c < K; ++c) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) {
+          const size_t i = (size_t)b * K + k + c;
+          a += dy[b] * (X16 ? (float)((const __bf16*)x)[i] : x[i]);
+        }
+        dw[k + c] = a;
+      }
     }
-    for (; b < B; ++b) {
-      float v0, v1;
-      ld2(b, v0, v1);
-      const float g = dy[b];
-      s0 += g * v0; s1 += g * v1;
-    }
-    dw[k] = s0; dw[k + 1] = s1;
   }
   if (db && blockIdx.x == 0 && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dy[b];
-    db[0] = s;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dy[b];
+    db[0] = a;
   }
 }
 
@@ -646,7 +663,8 @@ int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float
     IPR_LAUNCH_CHECK();
   }
   if (dw || db) {
-    hipLaunchKernelGGL(gemv_bwd_dw_kernel, dim3(cdiv(K, 512)), dim3(256), 0, st, x, dy, dw, db, B, K, x_bf16);
+    if (x_bf16) hipLaunchKernelGGL(gemv_bwd_dw_kernel<true>, dim3(cdiv(K, 512)), dim3(64), 0, st, x, dy, dw, db, B, K);
+    else hipLaunchKernelGGL(gemv_bwd_dw_kernel<false>, dim3(cdiv(K, 256)), dim3(64), 0, st, x, dy, dw, db, B, K);
     IPR_LAUNCH_CHECK();
   }
   return 0;

@@ -199,6 +199,61 @@ __global__ __launch_bounds__(1024) void snm_v_kernel(const SNTable t, float* __r
     if (vo) vo[j] = a;
   }
 }
+// Wide layers (the 131072-column Linear head of the 128x128 discriminator): one block per layer walks the columns for
+// 80 us.  Split form: blocks of SNV_COLS columns write the raw column sums and one partial of the squared norm each;
+// the scale pass adds the partials in block order (deterministic) and normalises its columns in place.
+constexpr int SNV_COLS = 4096, SNV_MAX_BLOCKS = 64;
+__device__ __forceinline__ float* snv_part(const SNTable& t, float* ws, int l) {
+  return ws + t.ws_off[l] + (size_t)SN_MAX_RSPLIT * t.cols[l] + t.rows[l] + 16;
+}
+__global__ __launch_bounds__(1024) void snm_vsum_kernel(const SNTable t, float* __restrict__ ws) {
+  __shared__ float sh[16];
+  const int l = blockIdx.y;
+  const int cols = t.cols[l], nsplit = t.nsplit[l];
+  const int j0 = blockIdx.x * SNV_COLS;
+  if (j0 >= cols) return;
+  const float* tpart = ws + t.ws_off[l];
+  float* v = t.v[l];
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < SNV_COLS / 1024; ++q) {
+    const int j = j0 + threadIdx.x + q * 1024;
+    if (j < cols) {
+      float p[SN_MAX_RSPLIT];
+#pragma unroll
+      for (int s = 0; s < SN_MAX_RSPLIT; ++s) p[s] = s < nsplit ? tpart[(size_t)s * cols + j] : 0.f;
+      float a = 0.f;
+#pragma unroll
+      for (int s = 0; s < SN_MAX_RSPLIT; ++s) a += p[s];
+      v[j] = a;
+      ss += a * a;
+    }
+  }
+  ss = block_sum(ss, sh);
+  if (threadIdx.x == 0) snv_part(t, ws, l)[blockIdx.x] = ss;
+}
+__global__ __launch_bounds__(1024) void snm_vscale_kernel(const SNTable t, float* __restrict__ ws, float eps) {
+  const int l = blockIdx.y;
+  const int cols = t.cols[l];
+  const int j0 = blockIdx.x * SNV_COLS;
+  if (j0 >= cols) return;
+  const float* part = snv_part(t, ws, l);
+  const int nblk = (cols + SNV_COLS - 1) / SNV_COLS;
+  float ss = 0.f;
+  for (int b = 0; b < nblk; ++b) ss += part[b];
+  const float inv = 1.f / fmaxf(sqrtf(ss), eps);
+  float* v = t.v[l];
+  float* vo = t.v_out[l];
+#pragma unroll
+  for (int q = 0; q < SNV_COLS / 1024; ++q) {
+    const int j = j0 + threadIdx.x + q * 1024;
+    if (j < cols) {
+      const float a = v[j] * inv;
+      v[j] = a;
+      if (vo) vo[j] = a;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void snm_wv_kernel(const SNTable t, float* __restrict__ ws) {
   __shared__ float sh[16];
   const int l = blockIdx.y, row = blockIdx.x;
@@ -346,7 +401,7 @@ int iprgan_sn_power_iter(const float* w, float* u, float* v, float* sigma, float
 
 size_t iprgan_sn_multi_ws_floats(const int* rows, const int* cols, int n) {
   size_t t = 0;
-  for (int i = 0; i < n; ++i) t += (size_t)SN_MAX_RSPLIT * cols[i] + rows[i] + 16;
+  for (int i = 0; i < n; ++i) t += (size_t)SN_MAX_RSPLIT * cols[i] + rows[i] + 16 + SNV_MAX_BLOCKS;
   return t;
 }
 
@@ -370,7 +425,7 @@ int iprgan_sn_power_iter_multi(const float* const* w, float* const* u, float* co
     t.rps[i] = cdiv(rows[i], ns);
     t.nsplit[i] = cdiv(rows[i], t.rps[i]);
     t.ws_off[i] = off;
-    off += (long long)SN_MAX_RSPLIT * cols[i] + rows[i] + 16;
+    off += (long long)SN_MAX_RSPLIT * cols[i] + rows[i] + 16 + SNV_MAX_BLOCKS;
     if (cols[i] > max_cols) max_cols = cols[i];
     if (rows[i] > max_rows) max_rows = rows[i];
     if (t.nsplit[i] > max_split) max_split = t.nsplit[i];
@@ -378,7 +433,14 @@ int iprgan_sn_power_iter_multi(const float* const* w, float* const* u, float* co
   if (training) {
     hipLaunchKernelGGL(snm_wtu_kernel, dim3(cdiv(max_cols, 256), max_split, n), dim3(256), 0, st, t, ws);
     IPR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(snm_v_kernel, dim3(n), dim3(1024), 0, st, t, ws, eps);
+    if (max_cols > 32768 && max_cols <= SNV_COLS * SNV_MAX_BLOCKS) {
+      const dim3 g(cdiv(max_cols, SNV_COLS), n);
+      hipLaunchKernelGGL(snm_vsum_kernel, g, dim3(1024), 0, st, t, ws);
+      IPR_LAUNCH_CHECK();
+      hipLaunchKernelGGL(snm_vscale_kernel, g, dim3(1024), 0, st, t, ws, eps);
+    } else {
+      hipLaunchKernelGGL(snm_v_kernel, dim3(n), dim3(1024), 0, st, t, ws, eps);
+    }
     IPR_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(snm_wv_kernel, dim3(max_rows, n), dim3(256), 0, st, t, ws);

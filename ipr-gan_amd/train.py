@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from iprgan import Config, models  # noqa: E402
+from iprgan import Config, configs, models  # noqa: E402
 
 
 class SyntheticLoader:
@@ -58,6 +58,7 @@ class Experiment:
             with open(os.path.join(config.log.path, 'config.yaml'), 'w') as f:
                 f.write(config.to_yaml())                      # dumped BEFORE the mutations below (base.py:15-19)
         self.init_step = 1
+        self.engine = configs.apply_engine(config)               # optional `engine:` block (math mode, buckets, switches)
         self.configure_device()
         self.configure_dataset()
         self.configure_model()
@@ -199,7 +200,8 @@ class Experiment:
             target = getattr(self.model, 'GB' if self.kind == 'translation' else 'G')
             ber = float(self.model.loss_model.compute_ber(target))
             with open(os.path.join(self.config.log.path, 'metrics.json'), 'w') as f:
-                json.dump({'BER': ber}, f)
+                from iprgan import _lib
+                json.dump({'BER': ber, 'engine': {**self.engine, 'math': _lib.get_math()}}, f)
         return last
 
 

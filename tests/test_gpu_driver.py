@@ -61,6 +61,23 @@ def test_train_driver_complete_protection(tmp_path):
     assert json.load(open(os.path.join(log, 'metrics.json')))['BER'] == 0.0
 
 
+def test_train_driver_engine_block(tmp_path):
+    """The optional `engine:` block of the YAML (iprgan/configs.py): bf16 MFMA tiles with bf16 activations selected from
+    the config file; the run records the mode it trained in and still embeds the watermark."""
+    base = open(os.path.join(ROOT, 'tests', 'configs', 'dcgan-wbox-tiny.yaml')).read()
+    cfg = tmp_path / 'bf16.yaml'
+    cfg.write_text(base + "engine:\n  math: 'bf16act'\n  bucket_mb: 4\n")
+    log = str(tmp_path / 'log')
+    subprocess.run([sys.executable, os.path.join(PKG, 'train.py'), '-c', str(cfg), '--log-path', log], check=True, timeout=600)
+    m = json.load(open(os.path.join(log, 'metrics.json')))
+    assert m['engine'] == {'math': 'bf16act', 'bucket_mb': 4} and m['BER'] == 0.0
+    bad = tmp_path / 'bad.yaml'
+    bad.write_text(base + "engine:\n  maths: 'bf16'\n")
+    r = subprocess.run([sys.executable, os.path.join(PKG, 'train.py'), '-c', str(bad), '--log-path', log + '2'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and 'unknown key' in r.stderr
+
+
 def test_two_ranks_draw_different_data_and_hold_equal_parameters(tmp_path):
     """train.py seeded every rank identically.  Two ranks (sharing the test box's one GPU, gloo) now build
     the model with the common seed - identical parameters, sign buffers and trigger modules - and draw their data /

@@ -210,6 +210,27 @@ def test_spectral_norm(dev, rows, cols):
     close(s2, torch.dot(u1, torch.mv(w, v1)).view(1), 1e-5, 'sigma eval')
 
 
+@pytest.mark.parametrize('shapes', [[(64, 27), (128, 1024), (1, 8192)], [(64, 576), (1, 131072), (8, 40000), (512, 2304)]],
+                         ids=['narrow', 'wide'])
+def test_spectral_norm_multi(dev, shapes):
+    """All layers of a discriminator in one call (iprgan_sn_power_iter_multi); the 'wide' table takes the split form of
+    the v normalisation (columns > 32768: the 131072-column Linear head of sn_discriminator.py:27-32 at 128x128)."""
+    from iprgan import ops
+    ws = [rnd(r, c, seed=10 + i, scale=c ** -0.5) for i, (r, c) in enumerate(shapes)]
+    us = [F.normalize(rnd(r, seed=20 + i), dim=0) for i, (r, c) in enumerate(shapes)]
+    vs = [F.normalize(rnd(c, seed=30 + i), dim=0) for i, (r, c) in enumerate(shapes)]
+    wd, ud, vd = [w.to(dev) for w in ws], [u.to(dev) for u in us], [v.to(dev) for v in vs]
+    sig, u_out, v_out = ops.sn_power_iter_multi(wd, ud, vd, True)
+    for i, (w, u, v) in enumerate(zip(ws, us, vs)):
+        v1 = F.normalize(torch.mv(w.t(), u), dim=0, eps=1e-12)
+        u1 = F.normalize(torch.mv(w, v1), dim=0, eps=1e-12)
+        close(vd[i], v1, 1e-5, f'v[{i}]'); close(ud[i], u1, 1e-5, f'u[{i}]')
+        assert torch.equal(v_out[i], vd[i]) and torch.equal(u_out[i], ud[i])
+        close(sig[i:i + 1], torch.dot(u1, torch.mv(w, v1)).view(1), 1e-5, f'sigma[{i}]')
+    sig2, _, _ = ops.sn_power_iter_multi(wd, [u.to(dev) for u in us], [v.to(dev) for v in vs], True)
+    assert torch.equal(sig, sig2)              # fixed-order partial sums: bit-identical on repeat
+
+
 def test_gemv_head(dev):
     from iprgan import ops
     B, K = 5, 2048
@@ -221,6 +242,17 @@ def test_gemv_head(dev):
     close(dx, g[:, None] * (w / sigma)[None], 1e-5, 'gemv dx')
     close(dw, g @ x, 1e-5, 'gemv dw')
     close(db, g.sum().view(1), 1e-5, 'gemv db')
+    # backward-weight: 16-byte loads (4 fp32 / 8 bf16 columns per thread), more samples than one unrolled round,
+    # ragged K (scalar tail columns), bf16 activations
+    for B2, K2, b16 in ((19, 2048, False), (19, 2050, False), (21, 4096, True), (9, 1028, True)):
+        x2 = rnd(B2, K2, seed=7)
+        g2 = rnd(B2, seed=8)
+        xd = x2.to(dev).bfloat16() if b16 else x2.to(dev)
+        xr = x2.bfloat16().float() if b16 else x2
+        w2 = rnd(K2, seed=9, scale=0.02).to(dev)
+        _, dw2, db2 = ops.gemv_bwd(xd, w2, g2.to(dev), sigma.to(dev), False, True)
+        close(dw2.float(), g2 @ xr, 1e-5, f'gemv dw B{B2} K{K2} bf16={b16}')
+        close(db2.float(), g2.sum().view(1), 1e-5, 'gemv db')
 
 
 LOSSES = {

@@ -50,6 +50,33 @@ def test_config_semantics(tmp_path):
     assert Config.parse(str(p)).to_dict() == c.to_dict()
 
 
+def test_engine_block_of_the_config(tmp_path, monkeypatch):
+    """The optional ``engine:`` block (configs.apply_engine): applied to the environment and the import-time switches;
+    typos and bad values are errors; a config without the block changes nothing."""
+    import os
+    from iprgan import Config, configs, engine, models
+    for k in ('IPRGAN_BUCKET_MB', 'IPRGAN_COMM', 'IPRGAN_TUNE_CACHE', 'IPRGAN_FUSE_STATS', 'IPRGAN_PAIR_D'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(engine, '_FUSE_STATS', True)
+    monkeypatch.setattr(models, '_PAIR_D', True)
+    f = tmp_path / 'c.yaml'
+    f.write_text('experiment: ImageGeneration\nengine:\n  math: bf16act\n  bucket_mb: 16\n  comm: torch\n'
+                 '  tune_cache: /tmp/t.json\n  fuse_stats: false\n  pair_d: false\n')
+    cfg = Config.parse(str(f))
+    applied = configs.apply_engine(cfg, set_math=False)          # (the math mode itself is a library call: GPU tests)
+    assert applied['math'] == 'bf16act' and applied['bucket_mb'] == 16
+    assert os.environ['IPRGAN_BUCKET_MB'] == '16' and os.environ['IPRGAN_COMM'] == 'torch'
+    assert os.environ['IPRGAN_TUNE_CACHE'] == '/tmp/t.json' and os.environ['IPRGAN_FUSE_STATS'] == '0'
+    assert engine._FUSE_STATS is False and models._PAIR_D is False
+    assert configs.apply_engine(Config({'experiment': 'x'})) == {}
+    with pytest.raises(ValueError):
+        configs.apply_engine(Config({'engine': {'mathh': 'fp32'}}))
+    with pytest.raises(ValueError):
+        configs.apply_engine(Config({'engine': {'math': 'fp8'}}), set_math=False)
+    with pytest.raises(ValueError):
+        configs.apply_engine(Config({'engine': {'comm': 'mpi'}}))
+
+
 def test_models_build_on_cpu_but_refuse_to_compute():
     from iprgan import Config, models
     m = models.DCGAN(Config(cases.DCGAN_CFG))
