@@ -811,13 +811,15 @@ __global__ __launch_bounds__(512) void gconv_pipe8_kernel(const GConvArgs a) {
 //   block); the tile goes to LDS as bf16 and leaves as a plain copy: 16-byte LDS read -> 16-byte store of whole rows.
 //   !FWD: pipe_epilogue on a 64 KB fp32 region (256x128 tiles in two column halves), operand of the fused derivative
 //   prefetched for the next tile while the current one is stored.
-template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool FWD>
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool FWD, bool F32 = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConvArgs a, int ntn, int nphz, int total) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NW = WGM * WGN, NT = NW * 64;
+  constexpr int ESZ = F32 ? 4 : 2, KSTEP = F32 ? 32 : 64;         // F32: fp32 operands, exact fp32 MFMA (as gconv_pipe_kernel)
+  static_assert(!(F32 && FWD), "the accumulator-layout epilogue stores bf16");
   constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW, L = LA + LB;
   constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128, RING = NSTAGE * STAGE_BYTES;
   constexpr int T_BYTES = 64 * 1024;
-  static_assert(RING + T_BYTES <= 160 * 1024 && BM * BN * 2 <= T_BYTES, "LDS budget");
+  static_assert(RING + T_BYTES <= 160 * 1024 && (!FWD || BM * BN * 2 <= T_BYTES), "LDS budget");
   using G = EpiGeom<WGM, WGN, WM, WN, T_BYTES>;
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
   char* ldsc = (char*)lds;
@@ -828,6 +830,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
   const int wm = wave / WGN, wn = wave % WGN;
   const int lrow = lane >> 3, lchunk = lane & 7, half = lane >> 5, l31 = lane & 31;
   const int IH = a.IH, IW = a.IW, Cs = a.Cs;
+  const bool reflect = F32 && a.pad_mode == IPRGAN_PAD_REFLECT;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
@@ -855,7 +858,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
             if (n0 + c < a.Ns) { a.stat_part[((size_t)lq * 2) * a.Ns + n0 + c] = 0.f; a.stat_part[((size_t)lq * 2 + 1) * a.Ns + n0 + c] = 0.f; }
         continue;
       }
-      l_pz = pz; l_m0 = m0; l_n0 = n0; l_lq = lq; l_nt = a.ph[pz].steps / 2;
+      l_pz = pz; l_m0 = m0; l_n0 = n0; l_lq = lq; l_nt = F32 ? a.ph[pz].steps : a.ph[pz].steps / 2;
       return true;
     }
   };
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
         const int x = rem - y * ph.owg;
         aiy[i] = y * a.isy;
         aix[i] = x * a.isx;
-        arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * 2u + sc;
+        arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * (unsigned)ESZ + sc;
       } else {
         aiy[i] = ROW_INVALID; aix[i] = 0; arow[i] = 0;
       }
@@ -884,25 +887,34 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       const int r = (i * NW + wave) * 8 + lrow;
-      wrow[i] = (unsigned)((l_n0 + r) * a.Kp) * 2u + (unsigned)(lchunk ^ ((r >> 1) & 7)) * 16u;
+      wrow[i] = (unsigned)((l_n0 + r) * a.Kp) * (unsigned)ESZ + (unsigned)(lchunk ^ ((r >> 1) & 7)) * 16u;
     }
     u_c = 0; u_ty = 0; u_tx = 0;
   };
   auto issue = [&](int buf) {
     const int dy = p_dy0 + u_ty * p_dys, dx = p_dx0 + u_tx * p_dxs;
-    const int tapoff = ((dy * IW + dx) * Cs + u_c) * 2;
-    const unsigned wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c) * 2u;
+    const int tapoff = ((dy * IW + dx) * Cs + u_c) * ESZ;
+    const unsigned wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c) * (unsigned)ESZ;
     const unsigned sbase = lds_base + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int iy = aiy[i] + dy, ix = aix[i] + dx;
-      const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
-      dma16(rs_in, sbase + (unsigned)(i * NW) * 1024u, ok ? arow[i] + (unsigned)tapoff : OOB_OFFSET);
+      bool ok;
+      unsigned off;
+      if (reflect) {              // wave-uniform branch: the mirrored pixel instead of a zero
+        ok = aiy[i] != ROW_INVALID;
+        const int ry = reflect_idx(iy, IH), rx = reflect_idx(ix, IW);
+        off = arow[i] + (unsigned)((((ry - aiy[i]) * IW + (rx - aix[i])) * Cs + u_c) * ESZ);
+      } else {
+        ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+        off = arow[i] + (unsigned)tapoff;
+      }
+      dma16(rs_in, sbase + (unsigned)(i * NW) * 1024u, ok ? off : OOB_OFFSET);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i)
       dma16(rs_wt, sbase + A_BYTES + (unsigned)(i * NW) * 1024u, wrow[i] + wk);
-    u_c += 64;
+    u_c += KSTEP;
     if (u_c >= Cs) { u_c = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
   };
   auto prologue = [&]() {            // first NSTAGE - 1 stages of the loading tile into ring slots 0 ..
@@ -918,6 +930,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe2_kernel(const GConv
   f32x16 acc[WM][WN];
   auto compute = [&](int buf) {
     const char* sb = ldsc + buf * STAGE_BYTES;
+    if constexpr (F32) {
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        f32x4 af[WM], bf[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = *(const f32x4*)(sb + a_wave + i * 4096 + foff[kq]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[j] = *(const f32x4*)(sb + b_wave + j * 4096 + foff[kq]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 af[WM], bf[WN];
@@ -1340,9 +1372,13 @@ static int launch_pipe2_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   dim3 grid(total < ncu ? total : ncu), block(WGM * WGN * 64);
   *bm_out = BM;
   const bool fwd = !a.aux && !a.res && a.out16;
-  const int slot = BN >= 128 ? 19 : 20;
+  const int slot = !a.in16 ? 23 : BN >= 128 ? 19 : 20;
   auto go = [&](auto kern) { prof_launch(kern, grid, block, smem, st, slot, a.flops, a, ntn, a.nphase, total); };
 #define PIPE2_ATTR(K) { static bool s = false; if (!s) { (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); s = true; } }
+  if (!a.in16) {            // fp32 operands, exact fp32 MFMA
+    if (a.stat_part) { auto k = gconv_pipe2_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, true>; PIPE2_ATTR(k) go(k); }
+    else { auto k = gconv_pipe2_kernel<WGM, WGN, WM, WN, NSTAGE, false, false, true>; PIPE2_ATTR(k) go(k); }
+  } else
   if (a.stat_part) {
     if (fwd) { auto k = gconv_pipe2_kernel<WGM, WGN, WM, WN, NSTAGE, true, true>; PIPE2_ATTR(k) go(k); }
     else { auto k = gconv_pipe2_kernel<WGM, WGN, WM, WN, NSTAGE, true, false>; PIPE2_ATTR(k) go(k); }
@@ -1417,8 +1453,8 @@ int launch_gconv_pipe(const GConvArgs& a0, int variant, hipStream_t st, int* bm_
     case 3: return a.Ns >= 128 ? launch_pipe_t<2, 2, 2, 2, 2>(a, st, bm_out) : -1;
     case 4: return launch_pipe_t<4, 2, 2, 1, 2>(a, st, bm_out);
     case 5: return launch_pipe_t<2, 2, 2, 1, 3>(a, st, bm_out);
-    case 6: return a.in16 && a.Ns >= 128 ? launch_pipe2_t<4, 2, 2, 2, 2>(a, st, bm_out) : -1;   // persistent 256x128, 2 stages + 64 KB
-    case 7: return a.in16 ? launch_pipe2_t<4, 2, 2, 1, 2>(a, st, bm_out) : -1;                  // persistent 256x64, 2 stages + 64 KB
+    case 6: return a.Ns >= 128 ? launch_pipe2_t<4, 2, 2, 2, 2>(a, st, bm_out) : -1;             // persistent 256x128, 2 stages + 64 KB
+    case 7: return launch_pipe2_t<4, 2, 2, 1, 2>(a, st, bm_out);                                // persistent 256x64, 2 stages + 64 KB
     case 8: return launch_phase4(a, st, bm_out);                                                // four phases per block (k4 s2 p1)
     case 9: return launch_pipe8(a, st, bm_out);                                                 // 256x256, half-tile ring
     default: return -1;

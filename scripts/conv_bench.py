@@ -48,6 +48,8 @@ def main():
     dev = torch.device('cuda:0')
     from iprgan import _lib
     _lib.set_math(os.environ.get('CONV_BENCH_MATH', 'fp32'))
+    if os.environ.get('CONV_BENCH_TILE'):            # force one forward / backward-data tile (include/iprgan.h: iprgan_debug_force_tiles)
+        _lib.call('iprgan_debug_force_tiles', int(os.environ['CONV_BENCH_TILE']), -1)
     only = sys.argv[1] if len(sys.argv) > 1 else None
     rows = []
     for name, cin, cout, k, s, p, tr, H in LAYERS:

@@ -51,7 +51,7 @@ timeout 900 python bench.py --workload dcgan128 --math bf16act --no-cpu-baseline
 timeout 900 python bench.py --math bf16act --no-cpu-baseline > $O/${TAG}_bench_dcgan64_bf16act.json 2>> $O/bench.err
 timeout 600 python scripts/conv_bench.py > $O/${TAG}_conv_bench.jsonl 2> $O/conv_bench.err
 # per-layer, per-tile table of the bf16 kernels at BASELINE config 5 sizes (forced tiles 8-16, halo / RGB backward-weight)
-CONV_BENCH_TILES=-1,8,10,11,12,16 CONV_BENCH_WGRAD=-1,0,61,67 timeout 900 python scripts/conv_bench_bf16.py > $O/${TAG}_conv_bench_bf16.jsonl 2> $O/conv_bench_bf16.err
+CONV_BENCH_TILES=-1,8,10,11,12,16,17 CONV_BENCH_WGRAD=-1,0,61,67 timeout 900 python scripts/conv_bench_bf16.py > $O/${TAG}_conv_bench_bf16.jsonl 2> $O/conv_bench_bf16.err
 # per-layer tables (conv-family launches by pass + geometry) of the four workloads
 for w in dcgan64 srgan cyclegan; do
   IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload $w --no-cpu-baseline 2>&1 >/dev/null | grep -A200 "conv-family layers" | cut -c18- > $O/${TAG}_layers_$w.txt

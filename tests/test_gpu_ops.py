@@ -739,7 +739,7 @@ def test_bf16_gconv_tiles(dev, tile, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tile', [8, 9, 11, 13])
+@pytest.mark.parametrize('tile', [8, 9, 11, 13, 14, 15])
 def test_pipe_tiles_fp32_reflect_and_epilogue(dev, tile):
     """fp32 form of the LDS-DMA ring tiles: ReflectionPad2d folded into the DMA offsets (CycleGAN's residual convolutions,
     networks/resnet_generator.py:26-29), bias + LeakyReLU, epilogue column sums, the fused activation derivative with a
