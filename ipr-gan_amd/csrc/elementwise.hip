@@ -332,7 +332,10 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ part, size_t n) {
   __shared__ float sh[16];
   const float a = *alpha;
-  float s = 0.f;
+  // the slope gradient is ONE number summed over the whole tensor, with terms of both signs: this thread's running sum
+  // and the final sum over the block partials are kept in double (against the float64 evaluation the fp32 chain was
+  // 2e-5 off where torch's pairwise reduction is 2e-7; tests/test_gpu_models.py::test_net_accuracy_against_float64)
+  double s = 0.0;
   typedef float f4 __attribute__((ext_vector_type(4)));
   const size_t n4 = ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(dx)) & 15) == 0
                         ? n / 4 : 0;
@@ -340,26 +343,28 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
   for (size_t i = i0; i < n4; i += stride) {              // 16-byte accesses (scalar ones ran at 0.8 TB/s)
     const f4 v = ((const f4*)x)[i], g = ((const f4*)dy)[i];
     f4 o;
+    float q = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       o[k] = v[k] > 0.f ? g[k] : a * g[k];
-      s += v[k] > 0.f ? 0.f : g[k] * v[k];
+      q += v[k] > 0.f ? 0.f : g[k] * v[k];
     }
+    s += (double)q;
     ((f4*)dx)[i] = o;
   }
   for (size_t i = n4 * 4 + i0; i < n; i += stride) {
     const float v = x[i], g = dy[i];
     dx[i] = v > 0.f ? g : a * g;
-    s += v > 0.f ? 0.f : g * v;
+    s += v > 0.f ? 0.0 : (double)(g * v);
   }
-  s = block_sum(s, sh);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
+  const float sb = block_sum((float)s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = sb;
 }
 __global__ void sum_partials_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < nb; ++i) s += part[i];
-    *out = s;
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += (double)part[i];
+    *out = (float)s;
   }
 }
 
