@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 200
+#define IPRGAN_VERSION 210
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -112,6 +112,19 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
                          const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
                          const float* pair_sigma1, float* stat_part, int* stat_rows, const float* residual,
                          void* stream);
+/* Backward-data INTO a BatchNorm (networks/conv_generator.py:8-10, discriminator_96.py:27-31: conv -> BatchNorm -> ReLU /
+ * LeakyReLU -> THIS conv): the result is the gradient w.r.t. the norm layer's OUTPUT, and the norm backward's two
+ * reductions over (x, dy) can be taken in this epilogue.  bn_x = the norm layer's INPUT (same shape and storage type as
+ * the result), bn_mean / bn_invstd = its saved statistics, bn_gamma / bn_beta its affine parameters (both or neither),
+ * bn_act / bn_slope the activation behind it (none, ReLU, LeakyReLU).  Stored: dz = backward-data(dy, w) * act'(v),
+ * v = (x - mean) * invstd * gamma + beta (the forward's own expression); stat_part[row][2][C4(Cin)] receives per tile
+ * s1 = sum dz and s2 = sum dz * (x - mean) * invstd.  iprgan_bn_bwd_pre finishes the norm backward from dz and these
+ * rows: three tensor passes instead of five, one launch less.  iprgan_conv_bwd_data_bn_ok: 1 if the layer qualifies
+ * (zero-padded, not a full-map convolution, more than 32 input channels). */
+int iprgan_conv_bwd_data_bn_ok(const iprgan_conv_desc* d);
+int iprgan_conv_bwd_data_bn(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dz, const float* bn_x,
+                            const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                            int bn_act, float bn_slope, float* stat_part, int* stat_rows, void* stream);
 /* residual (optional, same shape as dx): dx = backward-data(...) * act'(prev_out) + residual - the gradient that arrives
  * over a skip connection at the input of a residual block (networks/sr_resnet.py:37-38, resnet_generator.py:52-53) is
  * added in the epilogue instead of by a separate pass. */
@@ -167,6 +180,12 @@ int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* 
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                   float* dbeta, float* ws, int M, int C, int act, float slope, float* dbias_prev, int dbias_n,
                   float dbias_beta, int act_bf16, void* stream);
+/* the norm backward behind iprgan_conv_bwd_data_bn: dz and its per-tile sums part[rows][2][C] come from that pass
+ * (the buffer holds iprgan_conv_stat_floats(d, 1) floats: the rows are compacted in place when there are many) */
+int iprgan_bn_bwd_pre(const float* x, const float* dz, const float* gamma, const float* save_mean,
+                      const float* save_invstd, const float* part, int rows, float* dx, float* dgamma, float* dbeta,
+                      float* ws, int M, int C, float* dbias_prev, int dbias_n, float dbias_beta, int act_bf16,
+                      void* stream);
 
 /* ---- InstanceNorm2d (networks/resnet_generator.py:8-49 affine, conv_discriminator.py:10-18 plain):
  * per-(sample, channel) statistics over HW rows of x[B,HW,C]; gamma/beta may be NULL; never tracks

@@ -1958,7 +1958,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   // order, results stay within fp32 rounding of each other.
   TuneKey key = {{a.B, a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.isy, a.osy, a.nphase, a.ph[0].th, a.ph[0].tw,
                   a.ph[0].ohg, a.ph[0].owg, a.pad_mode + 16 * g_math + 64 * a.ksplit + 8192 * (a.wmod > 0) + 16384 * (a.rs0 != nullptr) +
-                      32768 * (a.stat_part != nullptr) + 65536 * a.in16 + 131072 * a.out16, a.Kp}};
+                      32768 * (a.stat_part != nullptr) + 65536 * a.in16 + 131072 * a.out16 + 262144 * (a.bn_mean != nullptr), a.Kp}};
   {
     int cached;
     if (tune_lookup(key, &cached)) return run(cached);
@@ -2473,10 +2473,43 @@ size_t iprgan_conv_bwd_data_ws_floats(const iprgan_conv_desc* d) {
   return reflect_padded_floats(d) + smalln_ws_for(d, false);
 }
 
+struct BnAux { const float *mean, *invstd, *gamma, *beta; int act; float slope; };
+static int conv_bwd_data_impl(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
+                              const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
+                              const float* pair_sigma1, float* stat_part, int* stat_rows, const float* residual,
+                              void* stream, const BnAux* bn);
+
 int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
                          const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
                          const float* pair_sigma1, float* stat_part, int* stat_rows, const float* residual,
                          void* stream) {
+  return conv_bwd_data_impl(d, dy, wbwd, dx, ws, prev_out, prev_act, prev_slope, pair_sigma0, pair_sigma1, stat_part,
+                            stat_rows, residual, stream, nullptr);
+}
+
+// 1 when iprgan_conv_bwd_data_bn applies to the layer: a zero-padded regular (not full-map) convolution whose input has
+// more than 4 channels - the tile kernels' epilogue then takes the norm backward's two reductions
+int iprgan_conv_bwd_data_bn_ok(const iprgan_conv_desc* d) {
+  return !fullmap_conv(d) && d->pad_mode != IPRGAN_PAD_REFLECT && c4(d->Cin) > 32 && d->stride >= 1 && d->stride <= 2;
+}
+
+int iprgan_conv_bwd_data_bn(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dz, const float* bn_x,
+                            const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                            int bn_act, float bn_slope, float* stat_part, int* stat_rows, void* stream) {
+  IPR_CHECK(iprgan_conv_bwd_data_bn_ok(d), "conv_bwd_data_bn: layer not eligible (iprgan_conv_bwd_data_bn_ok)");
+  IPR_CHECK(bn_x && bn_mean && bn_invstd && stat_part && stat_rows && !bn_gamma == !bn_beta,
+            "conv_bwd_data_bn: x, mean, invstd and the partial-sum buffer are required; gamma and beta come together");
+  IPR_CHECK(bn_act == IPRGAN_ACT_NONE || bn_act == IPRGAN_ACT_RELU || bn_act == IPRGAN_ACT_LRELU,
+            "conv_bwd_data_bn: activation %d has no mask form", bn_act);
+  const BnAux bn = {bn_mean, bn_invstd, bn_gamma, bn_beta, bn_act, bn_slope};
+  return conv_bwd_data_impl(d, dy, wbwd, dz, nullptr, bn_x, IPRGAN_ACT_NONE, 0.f, nullptr, nullptr, stat_part, stat_rows,
+                            nullptr, stream, &bn);
+}
+
+static int conv_bwd_data_impl(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
+                              const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
+                              const float* pair_sigma1, float* stat_part, int* stat_rows, const float* residual,
+                              void* stream, const BnAux* bn) {
   IPR_CHECK(!stat_part || (stat_rows && !fullmap_conv(d) && d->pad_mode != IPRGAN_PAD_REFLECT && c4(d->Cin) > 4),
             "conv_bwd_data: column sums need the row-count output and a zero-padded regular convolution with more than 4 input channels");
   IPR_CHECK(!pair_sigma0 == !pair_sigma1 &&
@@ -2518,6 +2551,10 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
   if (!reflect) { a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.ws = ws; a.ws_floats = ws ? smalln_ws_for(d, false) : 0; }
   else { a.ws = ws + reflect_padded_floats(d); a.ws_floats = smalln_ws_for(d, false); }    // RGB stems: few-channel path
   a.stat_part = stat_part; a.stat_mode = 2;
+  if (bn) {
+    a.bn_mean = bn->mean; a.bn_invstd = bn->invstd; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
+    a.bn_act = bn->act; a.bn_slope = bn->slope; a.stat_mode = 3;
+  }
   if (!reflect) a.res = residual;
   IPR_CHECK(!residual || reflect || !(smalln_eligible(a) && ws), "conv_bwd_data: no residual input on the few-channel path");
   if (!reflect && splitk_eligible(a, ws)) return gconv_splitk(a, ws, (hipStream_t)stream);

@@ -119,7 +119,7 @@ __device__ __forceinline__ void pipe_aux_load(const GConvArgs& a, int pz, int m0
 // Same order of operations as gconv_epilogue (conv_shared.h): pair scale, [column sums of the accumulator], bias,
 // activation, fused derivative, residual, [column sums of the stored value], store.  Activations: none / ReLU /
 // LeakyReLU only (the launcher refuses the others).  T: the ring, free by now (all DMA landed, all fragment reads done).
-template <int WGM, int WGN, int WM, int WN, int RING_BYTES, bool STATS, bool PF>
+template <int WGM, int WGN, int WM, int WN, int RING_BYTES, bool STATS, bool PF, bool BNM = false>
 __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[WM][WN], float* T, int pz, unsigned lq,
                                               int m0, int n0, const u32x4* auxpf) {      // PF: [NH][NIT] prefetched
   using G = EpiGeom<WGM, WGN, WM, WN, RING_BYTES>;
@@ -161,6 +161,21 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
     float cs1[8], cs2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) cs1[k] = cs2[k] = 0.f;
+    // norm-backward mode (GConvArgs::bn_mean; BNM instantiations only: the 32 registers of per-channel constants of this
+    // thread's 8 channels spill in the 256x256 and four-phase tiles, which keep accumulators live across column halves)
+    constexpr bool bn = STATS && BNM;
+    const float bn_neg = a.bn_act == IPRGAN_ACT_NONE ? 1.f : a.bn_act == IPRGAN_ACT_RELU ? 0.f : a.bn_slope;
+    float bnI[8], bnM[8], bnG[8], bnT[8];
+    if (bn) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool nk = n + k < a.N;
+        bnI[k] = nk ? a.bn_invstd[n + k] : 0.f;
+        bnM[k] = nk ? a.bn_mean[n + k] : 0.f;
+        bnG[k] = nk ? (a.bn_gamma ? a.bn_gamma[n + k] : 1.f) : 0.f;
+        bnT[k] = nk ? (a.bn_beta ? a.bn_beta[n + k] : 0.f) : 0.f;
+      }
+    }
     // Rows of one thread are RPI apart.  When a pass covers whole grid rows (RPI % width == 0) inside one image and the
     // tile is full, the pixel offset advances by a constant per pass: one division chain per tile instead of one per row.
     const Phase& ph = a.ph[pz];
@@ -197,8 +212,19 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
           o0 = buf_load4(rs_aux, ok ? e * 4u : OOB_OFFSET);
           o1 = buf_load4(rs_aux, ok ? e * 4u + 16u : OOB_OFFSET);
         }
+        if (bn) {               // (the forward's own expression for the mask: bit-identical to the stored activation's sign)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v0[k] *= o0[k] > 0.f ? 1.f : neg_aux; v1[k] *= o1[k] > 0.f ? 1.f : neg_aux; }
+          for (int k = 0; k < 4; ++k) {
+            const float xh0 = (o0[k] - bnM[k]) * bnI[k], xh1 = (o1[k] - bnM[4 + k]) * bnI[4 + k];
+            v0[k] *= (xh0 * bnG[k] + bnT[k]) > 0.f ? 1.f : bn_neg;
+            v1[k] *= (xh1 * bnG[4 + k] + bnT[4 + k]) > 0.f ? 1.f : bn_neg;
+            const float t0 = ok ? v0[k] : 0.f, t1 = ok ? v1[k] : 0.f;
+            cs1[k] += t0; cs2[k] += t0 * xh0; cs1[4 + k] += t1; cs2[4 + k] += t1 * xh1;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v0[k] *= o0[k] > 0.f ? 1.f : neg_aux; v1[k] *= o1[k] > 0.f ? 1.f : neg_aux; }
+        }
       }
       if (a.res) {
         if (a.out16) {
@@ -235,7 +261,7 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
       for (int k = 0; k < 8; ++k)
 #pragma unroll
         for (int o = OCT; o < 64; o <<= 1) cs1[k] += __shfl_xor(cs1[k], o, 64);
-      if (a.stat_mode == 1) {                        // sums of squares: forward statistics only
+      if (a.stat_mode != 2) {                        // second sums: forward statistics (1) and the norm backward (3)
 #pragma unroll
         for (int k = 0; k < 8; ++k)
 #pragma unroll
@@ -263,7 +289,7 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
 // fragment, so a K step is 4096 cycles of matrix work per wave against the same 48 KB of DMA: the ring hides it entirely
 // and the kernel's job is to keep the matrix pipe issuing (no staging registers, no ds_write pass, one barrier per step).
 // ReflectionPad2d (fp32 workloads: CycleGAN) is folded into the DMA source offsets.
-template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF, bool F32 = false>
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF, bool F32 = false, bool BNM = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvArgs a) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NW = WGM * WGN;
   constexpr int ESZ = F32 ? 4 : 2, KSTEP = F32 ? 32 : 64;             // bytes per operand element, channels per K step
@@ -563,7 +589,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                  // the epilogue reuses the ring
 
-  pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf);
+  pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, BNM>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf);
 }
 
 // ---- 256x256 tile with a half-tile ring ---------------------------------------------------------------------------
@@ -1324,6 +1350,18 @@ static int launch_pipe_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * (BM + BN) * 128>::PF_FIRST;
   const bool pref = a.aux && a.aux16 && can_pf;
   const dim3 block(WGM * WGN * 64);
+  if (a.bn_mean) {          // norm-backward mode of a backward-data pass (iprgan_conv_bwd_data_bn): its own instantiations
+    constexpr bool bn_tile = !(BM == 256 && BN == 256);       // (the 256x256 tile keeps accumulators live across its column halves)
+    if constexpr (bn_tile) {
+      if (!a.stat_part) return -1;
+      if (!a.in16) pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, true, true>>(a, grid, block, smem, 23, st);
+      else if (pref && can_pf) pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true, can_pf, false, true>>(a, grid, block, smem, BN >= 128 ? 19 : 20, st);
+      else pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, false, true>>(a, grid, block, smem, BN >= 128 ? 19 : 20, st);
+      IPR_LAUNCH_CHECK();
+      return 0;
+    }
+    return -1;
+  }
   if (!a.in16) {            // fp32 operands, exact fp32 MFMA
     if (a.stat_part) pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, true>>(a, grid, block, smem, 23, st);
     else pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, false, false, true>>(a, grid, block, smem, 23, st);
@@ -1343,7 +1381,7 @@ static int launch_pipe_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
 }
 
 static int launch_pipe8(const GConvArgs& a, hipStream_t st, int* bm_out) {
-  if (!a.in16 || a.Ns < 256) return -1;
+  if (!a.in16 || a.Ns < 256 || a.bn_mean) return -1;
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   if (maxM == 0) return 0;
@@ -1360,6 +1398,7 @@ static int launch_pipe8(const GConvArgs& a, hipStream_t st, int* bm_out) {
 template <int WGM, int WGN, int WM, int WN, int NSTAGE>
 static int launch_pipe2_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+  if (a.bn_mean) return -1;          // norm-backward mode: one-tile kernels only (launch_pipe_t)
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   if (maxM == 0) return 0;
@@ -1409,7 +1448,7 @@ static bool phase4_eligible(const GConvArgs& a) {
 }
 
 static int launch_phase4(const GConvArgs& a, hipStream_t st, int* bm_out) {
-  if (!phase4_eligible(a)) return -1;
+  if (!phase4_eligible(a) || a.bn_mean) return -1;
   const int W = a.ph[0].owg, mtiles = a.ph[0].M / 256;
   dim3 grid(mtiles, a.Ns / 64), block(512);
   *bm_out = 256;

@@ -73,6 +73,16 @@ struct GConvArgs {
   int stat_mode;
   int ksplit;          // > 1: blockIdx.z splits the K loop (single-phase geometries); partial tiles go to slabs of M*Ns floats
   int korder;          // LDS-DMA ring tiles: K-loop form bits, see g_pipe_korder (conv_pipe.hip)
+  // Norm-backward mode of a backward-data pass (stat_mode 3; iprgan_conv_bwd_data_bn): the result is the gradient w.r.t.
+  // the OUTPUT of a BatchNorm (+ReLU / LeakyReLU) whose INPUT x is `aux`.  Per element: xh = (x - mean) * invstd,
+  // v = xh * gamma + beta, dz = acc * act'(v) is what is stored, and the STATS rows hold sum dz and sum dz * xh: the
+  // two reductions of the norm backward, taken here instead of in a pass over (x, dy).
+  const float* bn_mean;
+  const float* bn_invstd;
+  const float* bn_gamma;
+  const float* bn_beta;
+  int bn_act;
+  float bn_slope;
   int wmod, wk1;       // > 0: operand row r lives at (r % wmod) * Kp + (r / wmod) * wk1 floats (full-map conv backward-data)
   Phase ph[4];
   double flops;   // algorithmic 2*MAC of this launch (host-side bookkeeping only)
@@ -190,6 +200,26 @@ __device__ __forceinline__ void gconv_epilogue(const GConvArgs& a, f32x16 (&acc)
       for (int k = 0; k < 4; ++k) if (n + k < a.N) bias4[j][k] = a.bias[n + k];
     }
   }
+  // norm-backward mode: xh = (o - bnB) * bnA, v = xh * bnG + bnT per channel of this lane's quads - the forward's own
+  // expression ((x - mean) * invstd * gamma + beta, bn_apply_kernel), so that the mask agrees with the stored output bit for bit
+  const bool bn = STATS && a.bn_mean != nullptr;
+  const float bn_neg = a.bn_act == IPRGAN_ACT_NONE ? 1.f : a.bn_act == IPRGAN_ACT_RELU ? 0.f : a.bn_slope;
+  f32x4 bnA[WN], bnB[WN], bnG[WN], bnT[WN];
+  if (bn) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + (wn * WN + j) * 32 + qcol;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool nk = n + k < a.N;
+        const float is = nk ? a.bn_invstd[n + k] : 0.f;
+        bnA[j][k] = is;
+        bnB[j][k] = nk ? a.bn_mean[n + k] : 0.f;
+        bnG[j][k] = nk ? (a.bn_gamma ? a.bn_gamma[n + k] : 1.f) : 0.f;
+        bnT[j][k] = nk ? (a.bn_beta ? a.bn_beta[n + k] : 0.f) : 0.f;
+      }
+    }
+  }
   constexpr int GC = WN >= 2 ? 2 : 4;     // row groups per pass (4 stores in flight per lane: registers stay at the K loop's level)
 #pragma unroll
   for (int ig = 0; ig < WM * (4 / GC); ++ig) {
@@ -253,7 +283,17 @@ __device__ __forceinline__ void gconv_epilogue(const GConvArgs& a, f32x16 (&acc)
       for (int g = 0; g < GC; ++g)
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          if (aux_simple) {
+          if (bn) {
+            const bool ok = eoff[g][j] != OOB_OFFSET;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float xh = (o[g][j][k] - bnB[j][k]) * bnA[j][k];
+              const float dz = val[g][j][k] * ((xh * bnG[j][k] + bnT[j][k]) > 0.f ? 1.f : bn_neg);
+              val[g][j][k] = dz;
+              const float t = ok ? dz : 0.f;
+              cs1[j][k] += t; cs2[j][k] += t * xh;
+            }
+          } else if (aux_simple) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) val[g][j][k] *= o[g][j][k] > 0.f ? 1.f : neg_aux;
           } else {

@@ -488,19 +488,32 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
 static int norm_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                     const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
                     float* ws, int G, int M, int C, int act, float slope, hipStream_t st,
-                    float* dbias_prev = nullptr, int dbias_n = 0, float dbias_beta = 0.f, int b16 = 0) {
+                    float* dbias_prev = nullptr, int dbias_n = 0, float dbias_beta = 0.f, int b16 = 0,
+                    const float* pre_part = nullptr, int pre_rows = 0) {
+  // pre_part: the two reductions (sum dz, sum dz * xhat; dz = dy * act') were taken by the epilogue of the backward-data
+  // pass that produced dy (iprgan_conv_bwd_data_bn), which stored dz in dy's place: no reduction pass, no mask here
   IPR_CHECK(C % 4 == 0, "norm_bwd: C=%d must be a multiple of 4", C);
+  if (pre_part) act = IPRGAN_ACT_NONE;
   IPR_CHECK(act == IPRGAN_ACT_NONE || act_from_x(act) || y, "norm_bwd: this activation needs the saved output y");
   IPR_CHECK(!act_from_x(act) || !gamma == !beta, "norm_bwd: the ReLU mask is recomputed from x: gamma and beta are both needed (or both absent)");
   const ColGeom g = col_geom(M, C);
   float* sums = ws + (size_t)G * g.NB * 2 * C;
-  auto kr2 = b16 ? colreduce_kernel<2, true> : colreduce_kernel<2, false>;
-  hipLaunchKernelGGL(kr2, dim3(g.NB, g.gy, G), dim3(256), 0, st,
-                     x, y, dy, save_mean, save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope, gamma, beta);
-  IPR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, g.NB, C, sums,
-                     G == 1 ? dgamma : nullptr, G == 1 ? dbeta : nullptr);
-  IPR_LAUNCH_CHECK();
+  if (pre_part) {
+    IPR_CHECK(G == 1 && pre_rows > 0, "norm_bwd: epilogue partials are per batch (G = 1)");
+    const float* pp = pre_part;
+    int rows = pre_rows;
+    if (compact_partials(pp, rows, 1, C, st)) return 2;
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64), 1), dim3(64 * FL), 0, st, pp, rows, C, sums, dgamma, dbeta);
+    IPR_LAUNCH_CHECK();
+  } else {
+    auto kr2 = b16 ? colreduce_kernel<2, true> : colreduce_kernel<2, false>;
+    hipLaunchKernelGGL(kr2, dim3(g.NB, g.gy, G), dim3(256), 0, st,
+                       x, y, dy, save_mean, save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope, gamma, beta);
+    IPR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, g.NB, C, sums,
+                       G == 1 ? dgamma : nullptr, G == 1 ? dbeta : nullptr);
+    IPR_LAUNCH_CHECK();
+  }
   if (G > 1 && (dgamma || dbeta)) {
     hipLaunchKernelGGL(group_sum_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, G, C, dgamma, dbeta);
     IPR_LAUNCH_CHECK();
@@ -583,6 +596,17 @@ int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* 
                   float dbias_beta, int act_bf16, void* stream) {
   return norm_bwd(x, y, dy, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, ws, 1, M, C, act, slope,
                   (hipStream_t)stream, dbias_prev, dbias_n, dbias_beta, act_bf16);
+}
+// BatchNorm backward behind iprgan_conv_bwd_data_bn: dz = dy * act'(y) is already in `dz`, part[rows][2][C] holds the
+// per-tile sums (sum dz, sum dz * xhat) of that pass's epilogue (room for the compacted rows behind them as for
+// iprgan_conv_stat_floats).  Two launches (final + apply) and three tensor passes (x, dz -> dx) instead of five.
+int iprgan_bn_bwd_pre(const float* x, const float* dz, const float* gamma, const float* save_mean,
+                      const float* save_invstd, const float* part, int rows, float* dx, float* dgamma, float* dbeta,
+                      float* ws, int M, int C, float* dbias_prev, int dbias_n, float dbias_beta, int act_bf16,
+                      void* stream) {
+  IPR_CHECK(part && rows > 0, "bn_bwd_pre: the epilogue partials are required");
+  return norm_bwd(x, nullptr, dz, gamma, nullptr, save_mean, save_invstd, dx, dgamma, dbeta, ws, 1, M, C, IPRGAN_ACT_NONE,
+                  0.f, (hipStream_t)stream, dbias_prev, dbias_n, dbias_beta, act_bf16, part, rows);
 }
 int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                         float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,

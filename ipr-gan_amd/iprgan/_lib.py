@@ -47,6 +47,8 @@ SIGNATURES = {
     'iprgan_colsum_partials': (_I, [_P, _I, _I, _I, _P, _F, _P]),
     'iprgan_conv_bwd_data_ws_floats': (_Z, [_D]),
     'iprgan_conv_bwd_data': (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, C.POINTER(C.c_int), _P, _P]),
+    'iprgan_conv_bwd_data_bn_ok': (_I, [_D]),
+    'iprgan_conv_bwd_data_bn': (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, C.POINTER(C.c_int), _P]),
     'iprgan_colsum_ws_floats': (_Z, [_I, _I]),
     'iprgan_colsum': (_I, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
     'iprgan_conv_bwd_weight': (_I, [_D, _P, _P, _P, _P, _P, _F, _P]),
@@ -58,6 +60,7 @@ SIGNATURES = {
     'iprgan_bn_ws_floats': (_Z, [_I, _I]),
     'iprgan_bn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _P, _P, _P, _I, _P]),
     'iprgan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _F, _I, _P]),
+    'iprgan_bn_bwd_pre': (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _F, _I, _P]),
     'iprgan_instnorm_ws_floats': (_Z, [_I, _I, _I]),
     'iprgan_instnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _I, _P, _P, _I, _P]),
     'iprgan_instnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _F, _I, _P]),

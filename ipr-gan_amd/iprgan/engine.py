@@ -18,6 +18,12 @@ from . import ops, parallel
 
 _BATCH_PREP = os.environ.get('IPRGAN_BATCH_PREP', '1') != '0'
 _FUSE_STATS = os.environ.get('IPRGAN_FUSE_STATS', '1') != '0'       # A/B switch: column sums from conv epilogues
+# BatchNorm-backward sums from the consumer's dgrad epilogue (iprgan_conv_bwd_data_bn / iprgan_bn_bwd_pre): built, parity-
+# tested, and OFF by default - it removes the reduction pass over (x, dy) (norm-backward traffic 1.67x -> 1.0x of the
+# algorithmic bytes) but puts an operand read and the mask arithmetic into epilogues that are already the slow part of the
+# short-K layers, and keeps the 256x256 / four-phase / persistent tiles out of those passes: DCGAN-128 bf16act 17.15 ->
+# 17.68 ms, SRGAN 33.30 -> 33.53 ms, DCGAN-64 11.52 -> 11.53 ms (round 3, same box, back to back).
+_FUSE_BN_BWD = os.environ.get('IPRGAN_FUSE_BN_BWD', '0') != '0'
 
 
 class Op:
@@ -215,6 +221,12 @@ class Conv(Op):
             if st.get('open_skip'):         # this conv opens a residual branch: the skip gradient is added in its epilogue
                 res = st['ctx']['skip_grads'][-1]
                 st['ctx']['skip_grad_fused'] = True
+            bnf = st.pop('bn_fuse', None)
+            if bnf is not None and res is None and pair is None and prev_act is None:
+                # the layer below is a BatchNorm (+ReLU / LeakyReLU): its activation derivative and both reductions of its
+                # backward are taken in this epilogue (include/iprgan.h: iprgan_conv_bwd_data_bn)
+                dx, st['bn_partials'] = ops.conv_bwd_data_bn(sp, d, dy, wb, *bnf)
+                return dx, grads
             dx = ops.conv_bwd_data(sp, d, dy, wb, pa[0], pa[1], pa[2], pair=pair, colsums=want_cs, residual=res)
             if want_cs:
                 dx, st['dx_colsums'] = dx
@@ -326,11 +338,16 @@ class BatchNorm(Op):
                                      m.eps, mom if mom is not None else 0.0, use_batch, self.act, self.slope,
                                      conv_stats=cs[0] if cs else None, conv_bias=cs[1] if cs else None,
                                      counter=counter, residual=res)
-        st.update(x=x, y=y, mean=mean, invstd=invstd)
+        st.update(x=x, y=y, mean=mean, invstd=invstd, use_batch=use_batch)
         return y
 
     def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         tgt = st.get('dbias_prev')          # (tensor, beta): bias gradient of the convolution below, see ChainFn.backward
+        pre = st.pop('dz_partials', None)
+        if pre is not None:                 # dy is dz: the consumer's dgrad epilogue applied act' and took both reductions
+            dx, dg, db = ops.bn_bwd_pre(st['x'], dy, self.m.weight, st['mean'], st['invstd'], pre,
+                                        dbias=tgt[0] if tgt else None, dbias_beta=tgt[1] if tgt else 0.0)
+            return dx, [dg, db]
         dx, dg, db = ops.bn_bwd(st['x'], st['y'], dy, self.m.weight, st['mean'], st['invstd'],
                                 self.act, self.slope, beta=self.m.bias, dbias=tgt[0] if tgt else None,
                                 dbias_beta=tgt[1] if tgt else 0.0)
@@ -718,7 +735,15 @@ class ChainFn(torch.autograd.Function):
             if (_FUSE_STATS and need_dx and isinstance(op, Conv) and isinstance(prev, SkipStart)
                     and not (ops.c4(op.spec.cin) <= 4 and op.spec.stride == 1)):
                 st['open_skip'] = True
+            if (_FUSE_BN_BWD and _FUSE_STATS and need_dx and isinstance(op, Conv) and isinstance(prev, BatchNorm)
+                    and stash[i - 1].get('use_batch') and prev.act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU)
+                    and 'pair' not in st and not st.get('open_skip') and ops.conv_bwd_data_bn_ok(st['d'])
+                    and i - 1 >= first_needed):
+                pst = stash[i - 1]
+                st['bn_fuse'] = (pst['x'], pst['mean'], pst['invstd'], prev.m.weight, prev.m.bias, prev.act, prev.slope)
             g, pg = op.backward(g, st, need_dx, op_need_w[i], fuse, sink)
+            if 'bn_partials' in st:
+                stash[i - 1]['dz_partials'] = st.pop('bn_partials')
             if 'dx_colsums' in st:
                 stash[i - 1]['db_part'] = st.pop('dx_colsums')
             grads_per_op[i] = pg

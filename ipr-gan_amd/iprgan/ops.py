@@ -175,6 +175,25 @@ def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_sl
     return (dx, (part, rows.value)) if colsums else dx
 
 
+def conv_bwd_data_bn_ok(d):
+    return bool(query('iprgan_conv_bwd_data_bn_ok', C.byref(d)))
+
+
+def conv_bwd_data_bn(spec, d, dy, wbwd, bn_x, mean, invstd, gamma, beta, act, slope=0.0):
+    """Backward-data into a BatchNorm (+ReLU / LeakyReLU): returns (dz, (partials, rows)) - the gradient w.r.t. the norm
+    layer's output with the activation derivative applied, and the per-tile sums (sum dz, sum dz * xhat) that
+    ``bn_bwd_pre`` finishes the norm backward from (include/iprgan.h: iprgan_conv_bwd_data_bn)."""
+    if is16(dy) != d.y_bf16:
+        dy = cast(dy, torch.bfloat16 if d.y_bf16 else torch.float32)
+    if is16(bn_x) != d.x_bf16:
+        raise RuntimeError('conv_bwd_data_bn: the norm input must have the storage type of the layer input')
+    dz = empty((d.B, d.H, d.W, c4(spec.cin)), dy, torch.bfloat16 if d.x_bf16 else torch.float32)
+    part, rows = empty((query('iprgan_conv_stat_floats', C.byref(d), 1),), dy), C.c_int(0)
+    call('iprgan_conv_bwd_data_bn', C.byref(d), ptr(dy), ptr(wbwd), ptr(dz), ptr(bn_x), ptr(mean), ptr(invstd), ptr(gamma),
+         ptr(beta), act, float(slope), ptr(part), C.byref(rows), stream())
+    return dz, (part, rows.value)
+
+
 def colsum_partials(part, rows, Cs, channels, out=None, beta=0.0):
     res = empty((channels,), part) if out is None else out
     call('iprgan_colsum_partials', ptr(part), int(rows), int(Cs), int(channels), ptr(res), float(beta), stream())
@@ -257,6 +276,20 @@ def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None,
     ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
     call('iprgan_bn_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
          ptr(dgamma), ptr(dbeta), ptr(ws), M, C_, act, float(slope), ptr(dbias), dbias.numel() if dbias is not None else 0,
+         float(dbias_beta), is16(x), stream())
+    return dx, dgamma, dbeta
+
+
+def bn_bwd_pre(x, dz, gamma, mean, invstd, partials, dbias=None, dbias_beta=0.0):
+    """The norm backward from ``conv_bwd_data_bn``'s outputs: dz (activation derivative applied) and its per-tile sums."""
+    C_ = x.shape[-1]
+    M = x.numel() // C_
+    part, rows = partials
+    dx = torch.empty_like(x)
+    dgamma, dbeta = empty((C_,), x), empty((C_,), x)
+    ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    call('iprgan_bn_bwd_pre', ptr(x), ptr(dz), ptr(gamma), ptr(mean), ptr(invstd), ptr(part), int(rows), ptr(dx),
+         ptr(dgamma), ptr(dbeta), ptr(ws), M, C_, ptr(dbias), dbias.numel() if dbias is not None else 0,
          float(dbias_beta), is16(x), stream())
     return dx, dgamma, dbeta
 

@@ -111,6 +111,30 @@ def test_net_accuracy_against_float64(name, dev):
         assert ee <= 4.0 * eo + floor, f'{name} {k}: engine {ee:.3e} vs fp32 oracle {eo:.3e} (rms / scale, against float64)'
 
 
+def test_bn_backward_fusion_matches_the_separate_passes(dev, monkeypatch):
+    """engine._FUSE_BN_BWD (default off: measured slower, see engine.py): with it on, every BatchNorm of the DCGAN-64
+    generator whose gradient arrives from a convolution takes its two backward reductions and its activation derivative
+    from that convolution's backward-data epilogue.  One G+D step at batch 16 must agree with the default path to fp32
+    summation-order level (same mask rule, same kernels otherwise) and keep the watermark."""
+    from iprgan import Config, engine, models
+    base = cases.run_dcgan_steps(Config, models, [dev], n_steps=1, batch=16, seed=77)
+    monkeypatch.setattr(engine, '_FUSE_BN_BWD', True)
+    from iprgan import ops
+    calls, real = [], ops.conv_bwd_data_bn
+    monkeypatch.setattr(ops, 'conv_bwd_data_bn', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    fused = cases.run_dcgan_steps(Config, models, [dev], n_steps=1, batch=16, seed=77)
+    assert len(calls) == 3          # ConvGenerator64: the norms behind fc, up0 and up1 (G is differentiated once per step)
+    assert fused['final/ber'] == base['final/ber'] == 0.0
+    n = 0
+    for k, v in base.items():
+        if np.asarray(v).dtype.kind in 'iuU':
+            continue
+        is_w = k.startswith(('final/G/', 'final/D/')) and k.rsplit('.', 1)[-1] not in cases.BUFFER_LEAVES
+        np.testing.assert_allclose(np.asarray(fused[k]), np.asarray(v), rtol=2e-3, atol=8e-4 if is_w else 2e-4, err_msg=k)
+        n += 1
+    assert n > 50
+
+
 def step_policy(steps, lr=2e-4):
     """Tolerances for multi-step training parity.
     step 0 (metrics, generated images, Adam first moments = (1-beta1)*grad of EVERY parameter, BN/SN

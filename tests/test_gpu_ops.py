@@ -185,6 +185,71 @@ def test_batchnorm(dev, M, C, act):
     close(y2.view(M, C), ye.view(M, C), 1e-4, 'bn eval')
 
 
+BN_DGRAD_CASES = [  # cin (norm channels), cout, k, s, p, transposed, H, W, B, act
+    (64, 128, 3, 1, 1, False, 13, 11, 5, 'relu'),        # ragged M, two 64-row tile rows of the small tiles
+    (128, 64, 4, 2, 1, False, 16, 16, 4, 'lrelu'),       # strided consumer: four sub-pixel phases write dz
+    (64, 32, 4, 2, 1, True, 8, 8, 6, 'relu'),            # ConvTranspose consumer (the generator's case)
+    (256, 256, 3, 1, 1, False, 8, 8, 8, 'none'),         # no activation behind the norm; 256-wide tiles apply
+]
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16act'])
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 4, 5, 8, 9, 10, 11, 13, 14, 16, 17])
+@pytest.mark.parametrize('case', BN_DGRAD_CASES, ids=lambda c: '-'.join(map(str, c)))
+def test_conv_bwd_data_into_batchnorm(dev, case, tile, mode):
+    """iprgan_conv_bwd_data_bn + iprgan_bn_bwd_pre (x -> BatchNorm -> act -> conv): the consumer's backward-data epilogue
+    applies the activation derivative (mask recomputed from x with the forward's expression) and takes the two reductions
+    of the norm backward; the norm backward then needs no reduction pass.  Against torch autograd for dx, dgamma, dbeta
+    and the bias-gradient column sums, through every tile family (a tile that does not apply falls back)."""
+    from iprgan import _lib, ops
+    cin, cout, k, s_, p, tr, H, W, B, actname = case
+    act = {'relu': 1, 'lrelu': 2, 'none': 0}[actname]
+    slope = 0.2 if actname == 'lrelu' else 0.0
+    x = rnd(B, cin, H, W, seed=1)
+    gamma, beta = rnd(cin, seed=2, scale=0.5) + 1.0, rnd(cin, seed=3, scale=0.3)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = rnd(*wshape, seed=4, scale=(cin * k * k) ** -0.5)
+    if mode == 'bf16act':
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    bn = F.batch_norm(xr, None, None, gr, br, training=True, eps=1e-5)
+    a = {'relu': F.relu, 'lrelu': lambda t: F.leaky_relu(t, 0.2), 'none': lambda t: t}[actname](bn)
+    y = F.conv_transpose2d(a, w, None, stride=s_, padding=p) if tr else F.conv2d(a, w, None, stride=s_, padding=p)
+    gy = rnd(*y.shape, seed=5)
+    if mode == 'bf16act':
+        gy = gy.bfloat16().float()
+    y.backward(gy)
+    try:
+        _lib.set_math(mode)
+        _lib.call('iprgan_debug_force_tiles', tile, -1)
+        xd = to_nhwc(x).to(dev)
+        adt = ops.act_dtype(cin)
+        xd = xd.to(adt)
+        yb, mean, invstd = ops.bn_fwd(xd, gamma.to(dev), beta.to(dev), None, None, 1e-5, 0.0, True, act, slope)
+        spec = ops.ConvSpec(cin, cout, k, s_, p, 0, tr)
+        d = spec.desc(B, H, W)
+        assert ops.conv_bwd_data_bn_ok(d)
+        _, wb = ops.conv_prep(spec, d, w.to(dev), None, False, True)
+        gd = to_nhwc(gy).to(dev).to(ops.act_dtype(cout))
+        dz, partials = ops.conv_bwd_data_bn(spec, d, gd, wb, xd, mean, invstd, gamma.to(dev), beta.to(dev), act, slope)
+        dbias = torch.zeros(cin, device=dev)
+        dx, dg, db = ops.bn_bwd_pre(xd, dz, gamma.to(dev), mean, invstd, partials, dbias=dbias)
+        tol = 2e-4 if mode == 'fp32' else 2e-2
+        close(from_nhwc(dx.float().cpu(), cin), xr.grad, tol, f'dx tile {tile}')
+        close(dg.cpu(), gr.grad, tol, f'dgamma tile {tile}')
+        close(db.cpu(), br.grad, tol, f'dbeta tile {tile}')
+        # column sums of dx (the bias gradient of a convolution below): sum over positions of a batch-norm gradient is 0
+        assert float(dbias.abs().max()) <= (1e-3 if mode == 'fp32' else 5e-2) * float(xr.grad.abs().max()) * (B * H * W) ** 0.5
+        # and the unfused pair of calls gives the same result (same mask rule)
+        dy_plain = ops.conv_bwd_data(spec, d, gd, wb)
+        dx2, dg2, db2 = ops.bn_bwd(xd, yb, dy_plain, gamma.to(dev), mean, invstd, act, slope, beta=beta.to(dev))
+        close(dx.float(), dx2.float(), tol, 'fused vs unfused dx')
+        close(dg, dg2, tol, 'fused vs unfused dgamma')
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
+        _lib.set_math('fp32')
+
+
 @pytest.mark.parametrize('rows,cols', [(64, 27), (512, 2304), (1, 32768), (128, 2048)])
 def test_spectral_norm(dev, rows, cols):
     from iprgan import ops
