@@ -104,6 +104,11 @@ def make_workload(name, device, impl):
         def step(i):
             model.update_d({'real_sample': xs[i % pool], 'latent': zs[i % pool]})
             model.update_g({'fake_sample': model.fake_sample})
+
+        def graph_body(s):          # the same step on static inputs (iprgan/graphs.py)
+            model.update_d({'real_sample': s['x'], 'latent': s['z']})
+            model.update_g({'fake_sample': model.fake_sample})
+        step.graph_spec = (graph_body, lambda i: {'x': xs[i % pool], 'z': zs[i % pool]})
     elif name == 'srgan':
         model = models.WhiteBoxWrapper(models.SRGAN(make_cfg(SRGAN_CFG), device=device), make_cfg(dict(WBOX_CFG, target='G')))
         pool = 4
@@ -113,6 +118,11 @@ def make_workload(name, device, impl):
         def step(i):
             model.update_g({'low_res': lrs[i % pool], 'high_res': hrs[i % pool], 'pretrain': False})
             model.update_d({'high_res': model.high_res, 'super_res': model.super_res})
+
+        def graph_body(s):
+            model.update_g({'low_res': s['lr'], 'high_res': s['hr'], 'pretrain': False})
+            model.update_d({'high_res': model.high_res, 'super_res': model.super_res})
+        step.graph_spec = (graph_body, lambda i: {'lr': lrs[i % pool], 'hr': hrs[i % pool]})
     else:
         model = models.WhiteBoxWrapper(models.CycleGAN(make_cfg(CYCLEGAN_CFG), device=device), make_cfg(dict(WBOX_CFG, target='GB')))
         pool = 2
@@ -246,6 +256,9 @@ def main():
                     help="conv math mode; the headline metric is fp32 (the reference's precision). 'bf16' = bf16 MFMA "
                          "tiles with fp32 accumulation / master weights, reported with dtype bf16; 'bf16act' additionally "
                          "keeps activations with a multiple of 64 channels as bf16 in HBM")
+    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
+                    help="capture the whole step in one HIP graph (iprgan/graphs.py): 'auto' = where the step is "
+                         "capturable (DCGAN, SRGAN; one GPU); steps sampled by the per-kernel timer run eagerly")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     heavy = args.workload in ('cyclegan', 'dcgan128')
@@ -287,12 +300,26 @@ def main():
     _lib.set_math(args.math)
     torch.manual_seed(1234 + rank)              # every rank its own data shard / latents
     model, step_fn = make_workload(args.workload, [device], (Config, models))
+    graphed = None
+    if args.graph != 'off' and world == 1 and hasattr(step_fn, 'graph_spec'):
+        from iprgan import graphs
+        body, inputs_of = step_fn.graph_spec
+        graphed = graphs.GraphedStep(model, body, inputs_of(0), warmup=max(2, args.warmup - 2))
+        eager_step = step_fn
+
+        def step_fn(i, eager=False):              # noqa: F811  (sampled steps carry HIP events: they cannot be replayed)
+            graphed(inputs_of(i), eager=eager)
+    elif args.graph == 'on':
+        raise SystemExit(f'bench.py: --graph on is not available for {args.workload} on {world} rank(s)')
 
     log(f'{args.workload}: model built on {device}; warm-up {args.warmup} steps')
     for i in range(args.warmup):
         # the last warm-up step also warms the instrumentation (HIP event pool of the per-kernel timer)
         _lib.prof_enable(i == args.warmup - 1)
-        step_fn(i)
+        if graphed is not None:
+            step_fn(i, eager=(i == args.warmup - 1))
+        else:
+            step_fn(i)
     _lib.prof_enable(False)
     _lib.prof_results()
     torch.cuda.synchronize()
@@ -313,13 +340,19 @@ def main():
     # handling, and the headline value should not pay for its own instrumentation.
     every = PROF_EVERY if (args.steps >= 2 * PROF_EVERY or PROF_EVERY <= 0) else 1
     fence()
+    replays_before = graphed.replays if graphed is not None else 0
     t0 = time.perf_counter()
     stamps = []
     for i in range(args.steps):
-        _lib.prof_enable(every > 0 and i % every == 0)
-        step_fn(i)
+        sampled = every > 0 and i % every == 0
+        _lib.prof_enable(sampled)
+        if graphed is not None:
+            step_fn(i, eager=sampled)
+        else:
+            step_fn(i)
         stamps.append(time.perf_counter())
     host_elapsed = time.perf_counter() - t0          # the host has ENQUEUED all steps (no sync inside the loop)
+    replays_timed = (graphed.replays - replays_before) if graphed is not None else 0
     fence()
     elapsed = time.perf_counter() - t0
     _lib.prof_enable(False)
@@ -413,6 +446,9 @@ def main():
                                             'tflops': round(k['flops'] / max(k['ms'], 1e-9) / 1e9, 2)}
                                            for k in kernels]},
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
+            'graph': ({'captured': graphed.graph is not None, 'replays_in_timed_region': replays_timed,
+                       'eager_steps_in_timed_region': args.steps - replays_timed, 'failed': graphed.failed}
+                      if graphed is not None else None),
             'transport': comm['transport'], 'comm_nranks': comm['nranks'],
             'allreduce_exposed_ms_per_step': comm['exposed_ms'],
             'step_algorithmic_tflops': round(wl['gflop'] * B * world / ms, 2),

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 210
+#define IPRGAN_VERSION 211
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -316,6 +316,13 @@ int iprgan_sign_ber(const float* const* gammas, const float* const* signs, const
 int iprgan_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const long long* sizes, int n, double lr, double beta1,
                      double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
+/* the same step with the step COUNT on the device: *step_dev (int, device) is incremented by the call and the bias
+ * corrections are computed from it on the device into coef (two floats, device) - the form a captured HIP graph needs,
+ * whose kernel arguments are frozen at capture time (iprgan/graphs.py) */
+int iprgan_adam_step_dev(float* const* params, const float* const* grads, float* const* exp_avg,
+                         float* const* exp_avg_sq, const long long* sizes, int n, double lr, double beta1,
+                         double beta2, double eps, double weight_decay, int* step_dev, float* coef, double grad_scale,
+                         void* stream);
 
 /* ---- measurement (bench.py roofline): when enabled, every conv-family launch is bracketed by HIP
  * events on its own stream; collect() waits for them and accumulates per-kernel launch count, device

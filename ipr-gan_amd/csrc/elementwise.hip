@@ -545,9 +545,21 @@ struct AdamTable {
   float* v[ADAM_MAX_TENSORS];
   long long n[ADAM_MAX_TENSORS];
 };
+// step count on the device (iprgan_adam_step_dev: a captured HIP graph replays the same kernel arguments every step, so
+// the bias corrections cannot be host-computed arguments): one thread advances the counter and writes
+// coef[0] = lr / (1 - beta1^t), coef[1] = sqrt(1 - beta2^t), computed in double like the host path
+__global__ void adam_prep_kernel(int* __restrict__ step, double lr, double beta1, double beta2, float* __restrict__ coef) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int t = *step + 1;
+    *step = t;
+    coef[0] = (float)(lr / (1.0 - pow(beta1, (double)t)));
+    coef[1] = (float)sqrt(1.0 - pow(beta2, (double)t));
+  }
+}
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float omb1, float beta2, float omb2,
                                                    float eps, float weight_decay, float step_size,
-                                                   float bc2_sqrt, float grad_scale) {
+                                                   float bc2_sqrt, float grad_scale, const float* __restrict__ coef) {
+  if (coef) { step_size = coef[0]; bc2_sqrt = coef[1]; }
   const int ti = blockIdx.y;
   const long long n = t.n[ti];
   float* __restrict__ p = t.p[ti];
@@ -841,14 +853,36 @@ int iprgan_sign_ber(const float* const* gammas, const float* const* signs, const
   return 0;
 }
 
+static int adam_launch(float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const long long* sizes, int n, double beta1, double beta2, double eps,
+                       double weight_decay, float step_size, float bc2_sqrt, const float* coef, double grad_scale,
+                       void* stream);
+
 int iprgan_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const long long* sizes, int n, double lr, double beta1,
                      double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
   IPR_CHECK(step >= 1, "adam_step: step must be >= 1");
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
-  const float step_size = (float)(lr / bc1);
-  const float bc2_sqrt = (float)sqrt(bc2);
+  return adam_launch(params, grads, exp_avg, exp_avg_sq, sizes, n, beta1, beta2, eps, weight_decay, (float)(lr / bc1),
+                     (float)sqrt(bc2), nullptr, grad_scale, stream);
+}
+
+int iprgan_adam_step_dev(float* const* params, const float* const* grads, float* const* exp_avg,
+                         float* const* exp_avg_sq, const long long* sizes, int n, double lr, double beta1,
+                         double beta2, double eps, double weight_decay, int* step_dev, float* coef, double grad_scale,
+                         void* stream) {
+  IPR_CHECK(step_dev && coef, "adam_step_dev: the device step counter and the two-float coefficient buffer are required");
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr, beta1, beta2, coef);
+  IPR_LAUNCH_CHECK();
+  return adam_launch(params, grads, exp_avg, exp_avg_sq, sizes, n, beta1, beta2, eps, weight_decay, 0.f, 0.f, coef,
+                     grad_scale, stream);
+}
+
+static int adam_launch(float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const long long* sizes, int n, double beta1, double beta2, double eps,
+                       double weight_decay, float step_size, float bc2_sqrt, const float* coef, double grad_scale,
+                       void* stream) {
   for (int b = 0; b < n; b += ADAM_MAX_TENSORS) {
     AdamTable t;
     memset(&t, 0, sizeof(t));
@@ -863,7 +897,7 @@ int iprgan_adam_step(float* const* params, const float* const* grads, float* con
     const int gx = grid_for((size_t)maxn, 256);
     hipLaunchKernelGGL(adam_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, t,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)weight_decay, step_size, bc2_sqrt, (float)grad_scale);
+                       (float)weight_decay, step_size, bc2_sqrt, (float)grad_scale, coef);
     IPR_LAUNCH_CHECK();
   }
   return 0;

@@ -96,6 +96,8 @@ SIGNATURES = {
     'iprgan_sign_ber': (_I, [_P, _P, _P, _I, _P, _P]),
     'iprgan_adam_step': (_I, [_P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _I,
                          C.c_double, _P]),
+    'iprgan_adam_step_dev': (_I, [_P, _P, _P, _P, _P, _I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P,
+                             _P, C.c_double, _P]),
     'iprgan_debug_force_tiles': (_I, [_I, _I]),
     'iprgan_debug_force_splitk': (_I, [_I]),
     'iprgan_set_math_mode': (_I, [_I]),

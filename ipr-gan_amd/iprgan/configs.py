@@ -48,7 +48,8 @@ class Config(object):
 #     fuse_stats: true       # norm statistics / bias gradients from conv epilogues (IPRGAN_FUSE_STATS)
 #     pair_d: true           # D(real) and D(fake) as one paired pass              (IPRGAN_PAIR_D)
 #     batch_passes: true     # same-network passes of CycleGAN batched             (IPRGAN_BATCH_PASSES)
-ENGINE_KEYS = ('math', 'bucket_mb', 'comm', 'comm_timeout', 'tune_cache', 'fuse_stats', 'pair_d', 'batch_passes')
+#     graph: true            # ImageGeneration on one GPU: the whole step as one captured HIP graph (graphs.py)
+ENGINE_KEYS = ('math', 'bucket_mb', 'comm', 'comm_timeout', 'tune_cache', 'fuse_stats', 'pair_d', 'batch_passes', 'graph')
 
 
 def apply_engine(config, set_math=True):

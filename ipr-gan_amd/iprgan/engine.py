@@ -547,6 +547,24 @@ class Squeeze(Op):
         return ops.nchw_to_nhwc(dy.contiguous().view(B, 1, 1, 1)), []
 
 
+def drop_operand_caches(root):
+    """Forget every version-keyed operand copy (prepared conv operands of layers without spectral norm, the row-permuted
+    weights of LinearNHWC / GemvHead) of every engine network under ``root`` (an nn.Module).  graphs.GraphedStep calls it
+    right before a capture: a cache HIT during the capture would bake the address of a tensor computed by an earlier,
+    eager pass into the graph, and later replays would read that stale copy (observed: the discriminator head's permuted
+    weight is computed in update_g's pass and reused by the next step's update_d pass - same weights, same version)."""
+    n = 0
+    for mod in root.modules():
+        ch = mod.__dict__.get('_chain')
+        if ch is None:
+            continue
+        for op in ch.ops:
+            for k in ('_op_wf', '_op_wb', '_perm_key', '_perm'):
+                if op.__dict__.pop(k, None) is not None:
+                    n += 1
+    return n
+
+
 class Chain:
     """A sequential network plan.  ``ops`` run in order; parameters are collected in op order."""
 

@@ -1,0 +1,108 @@
+"""Capture of a whole training step (update_d + update_g) in ONE HIP graph.
+
+The reference's loop (experiments/image_generation.py:86-101) issues two optimizer steps per iteration; here those are
+~170 kernel launches (DCGAN-64) driven from Python through ctypes.  On the fp32 workloads the GPU is the bottleneck, but
+with bf16 activations a DCGAN-64 step is 3.0 ms of device work behind 3.9 ms of host work.  ``GraphedStep`` runs the step
+eagerly for a few warm-up calls (autotuning, operand caches, lazily built tables), then captures one call with
+``torch.cuda.graph`` - every launch of the library goes to torch's current stream, which is the capture stream, and the
+autograd engine's backward thread inherits it - and from then on replays the graph: one launch per training step.
+
+What makes the step capturable (all of it already true for the DCGAN / VAE models, none of it for CycleGAN, whose
+ImagePool and LR schedule decide on the host):
+  * inputs live in static device tensors (``copy_`` before each replay);
+  * no host decision inside the step depends on device data; metrics are read after the step, from tensors the graph
+    wrote (their Python bindings are restored after each replay, because an eager step in between rebinds them);
+  * Adam's step number lives on the device (``optim.Adam.device_step``, ``iprgan_adam_step_dev``): a replay carries the
+    kernel arguments of the captured call, so a host-computed bias correction would be frozen;
+  * host bookkeeping that the skipped Python would have done is redone per replay: optimizer step counts for
+    ``state_dict()``, parameter version counters (operand caches and the stale-graph check key on them).
+
+Capturing does not execute: the captured call's device work happens at the first replay, its host side effects happened
+during the capture - together they are exactly one step.  If the capture fails (an op that may not be captured), the
+step stays eager and ``failed`` holds the reason: correctness never depends on the graph.
+"""
+import torch
+
+from . import engine, optim
+
+
+def _chain(model):
+    """model, model.model, ... (the protection wrappers nest the GAN model)."""
+    seen = []
+    while model is not None and all(model is not s for s in seen):
+        seen.append(model)
+        nxt = model.__dict__.get('model', None)        # (an nn.Module attribute lives in _modules, not in __dict__)
+        model = nxt if nxt is not None else getattr(model, '_modules', {}).get('model', None)
+    return seen
+
+
+def _optimizers(model):
+    out = []
+    for m in _chain(model):
+        for v in list(m.__dict__.values()) + list(getattr(m, '_modules', {}).values()):
+            if isinstance(v, optim.Adam) and all(v is not o for o in out):
+                out.append(v)
+    return out
+
+
+class GraphedStep:
+    """``step = GraphedStep(model, body, inputs)``; ``step(inputs)`` runs ``body(static_inputs)`` - eagerly ``warmup`` times,
+    then as a captured graph.  ``body`` takes the dict of STATIC input tensors and performs one whole training step on
+    ``model`` (e.g. ``update_d`` then ``update_g``).  ``step(inputs, eager=True)`` forces an eager step (profiling runs)."""
+
+    def __init__(self, model, body, inputs, warmup=3):
+        self.model, self.body = model, body
+        self.static = {k: v.detach().clone() for k, v in inputs.items()}
+        self.warm = int(warmup)
+        self.graph, self.failed, self.replays = None, None, 0
+        self.opts = _optimizers(model)
+        if not self.opts:
+            raise ValueError('GraphedStep: no iprgan.optim.Adam found on the model (its step count must move to the device)')
+        for o in self.opts:
+            o.device_step = True
+        self._bound = []
+
+    def _snapshot(self):
+        self._bound = [(m, k, v) for m in _chain(self.model) for k, v in m.__dict__.items() if isinstance(v, torch.Tensor)]
+
+    def _capture(self):
+        torch.cuda.synchronize()
+        # version-keyed operand caches must not be HIT inside the capture (engine.drop_operand_caches)
+        for m in _chain(self.model):
+            for sub in (m.__dict__.get('_modules') or {}).values():
+                if isinstance(sub, torch.nn.Module):
+                    engine.drop_operand_caches(sub)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                self.body(self.static)
+        except Exception as e:                    # not capturable here: stay eager (the half-captured call did no device work)
+            self.failed = f'{type(e).__name__}: {e}'
+            torch.cuda.synchronize()
+            return False
+        self.graph = g
+        self._snapshot()
+        return True
+
+    def __call__(self, inputs=None, eager=False):
+        if inputs is not None:
+            for k, v in inputs.items():
+                if v is not self.static[k]:
+                    self.static[k].copy_(v, non_blocking=True)
+        if eager or self.failed is not None or self.warm > 0:
+            if self.warm > 0 and not eager:
+                self.warm -= 1
+            return self.body(self.static)
+        if self.graph is None:
+            if not self._capture():
+                return self.body(self.static)
+            self.graph.replay()                   # the captured call's device work (its host side ran during the capture)
+            self.replays += 1
+            return None
+        self.graph.replay()
+        self.replays += 1
+        for o in self.opts:
+            o.replayed()
+        for m, k, v in self._bound:               # an eager step in between rebinds these to its own tensors
+            m.__dict__[k] = v
+        return None

@@ -3,6 +3,7 @@ allocator (plumbing) and enqueue the HIP kernels on the current stream.  No auto
 no ATen arithmetic; activations are fp32 NHWC tensors [B,H,W,C4] (C4 = channels padded to 4).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -18,8 +19,17 @@ def _int_table(sizes):
     return (C.c_int * len(sizes))(*sizes)
 
 
+_POISON = os.environ.get('IPRGAN_DEBUG_POISON') == '1'     # debugging aid: every workspace / output starts as NaN
+
+
 def empty(shape, like, dtype=torch.float32):
+    if _POISON:
+        return torch.full(shape, float('nan'), dtype=dtype, device=like.device)
     return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _empty_like(t):
+    return torch.full_like(t, float('nan')) if (_POISON and t.is_floating_point()) else torch.empty_like(t)
 
 
 def act_dtype(channels):
@@ -75,7 +85,7 @@ def permute_021(src, A, Bd, K, out=None, beta=0.0):
 def act_bwd(dy, out, act, slope=0.0):
     if dy.dtype != out.dtype:
         dy = cast(dy, out.dtype)
-    dz = torch.empty_like(dy)
+    dz = _empty_like(dy)
     call('iprgan_act_bwd', ptr(dy), ptr(out), ptr(dz), dy.numel(), act, float(slope), is16(dy), stream())
     return dz
 
@@ -238,7 +248,7 @@ def gemv_fwd(x2d, w, bias, sigma, out=None):
 
 def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0, dx_out=None):
     B, K = x2d.shape
-    dx = (torch.empty_like(x2d) if dx_out is None else dx_out) if need_dx else None
+    dx = (_empty_like(x2d) if dx_out is None else dx_out) if need_dx else None
     dw = empty((K,), x2d) if need_dw else None
     db = empty((1,), x2d) if need_dw else None
     call('iprgan_gemv_bwd', ptr(x2d), ptr(w), ptr(dy), ptr(sigma), ptr(dx), ptr(dw), ptr(db),
@@ -253,7 +263,7 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, a
     over x.  counter: the module's int64 num_batches_tracked, incremented on the device."""
     C_ = x.shape[-1]
     M = x.numel() // C_
-    y = torch.empty_like(x)
+    y = _empty_like(x)
     mean, invstd = empty((C_,), x), empty((C_,), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
@@ -271,7 +281,7 @@ def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None,
     M = x.numel() // C_
     if dy.dtype != x.dtype:
         dy = cast(dy, x.dtype)
-    dx = torch.empty_like(x)
+    dx = _empty_like(x)
     dgamma, dbeta = empty((C_,), x), empty((C_,), x)
     ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
     call('iprgan_bn_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
@@ -285,7 +295,7 @@ def bn_bwd_pre(x, dz, gamma, mean, invstd, partials, dbias=None, dbias_beta=0.0)
     C_ = x.shape[-1]
     M = x.numel() // C_
     part, rows = partials
-    dx = torch.empty_like(x)
+    dx = _empty_like(x)
     dgamma, dbeta = empty((C_,), x), empty((C_,), x)
     ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
     call('iprgan_bn_bwd_pre', ptr(x), ptr(dz), ptr(gamma), ptr(mean), ptr(invstd), ptr(part), int(rows), ptr(dx),
@@ -312,8 +322,8 @@ def sn_power_iter_multi(weights, us, vs, training, eps=1e-12):
     rows = [w.shape[0] for w in weights]
     cols = [w.numel() // w.shape[0] for w in weights]
     sig = empty((n,), weights[0])
-    u_out = [torch.empty_like(u) for u in us]
-    v_out = [torch.empty_like(v) for v in vs]
+    u_out = [_empty_like(u) for u in us]
+    v_out = [_empty_like(v) for v in vs]
     r, c = _int_table(rows), _int_table(cols)
     ws = empty((query('iprgan_sn_multi_ws_floats', r, c, n),), weights[0])
     call('iprgan_sn_power_iter_multi', L.ptr_table(weights), L.ptr_table(us), L.ptr_table(vs),
@@ -325,7 +335,7 @@ def sn_power_iter_multi(weights, us, vs, training, eps=1e-12):
 def sn_bwd(dwsn, w_orig, u, v, sigma):
     rows = w_orig.shape[0]
     cols = w_orig.numel() // rows
-    dw = torch.empty_like(w_orig)
+    dw = _empty_like(w_orig)
     ws = empty((query('iprgan_sn_ws_floats', rows, cols),), w_orig)
     call('iprgan_sn_bwd', ptr(dwsn), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(dw), ptr(ws), rows,
          cols, stream())
@@ -338,7 +348,7 @@ def sn_bwd_multi(dwsns, weights, us, vs, sigmas, outs=None, beta=0.0):
     n = len(weights)
     rows = [w.shape[0] for w in weights]
     cols = [w.numel() // w.shape[0] for w in weights]
-    dws = [torch.empty_like(w) for w in weights] if outs is None else outs
+    dws = [_empty_like(w) for w in weights] if outs is None else outs
     ws = empty((64 * 16,), weights[0])
     call('iprgan_sn_bwd_multi', L.ptr_table(dwsns), L.ptr_table(weights), L.ptr_table(us), L.ptr_table(vs),
          L.ptr_table(sigmas), L.ptr_table(dws), ptr(ws), _int_table(rows), _int_table(cols), n, float(beta), stream())
@@ -354,7 +364,7 @@ def loss_fwd(kind, x, y=None):
 
 
 def loss_bwd(kind, x, y, gscale):
-    dx = torch.empty_like(x)
+    dx = _empty_like(x)
     call('iprgan_loss_bwd', kind, ptr(x), ptr(y), ptr(gscale), ptr(dx), x.numel(), stream())
     return dx
 
@@ -368,7 +378,7 @@ def loss_sum_fwd(kind, x, y, scale):
 
 
 def loss_sum_bwd(kind, x, y, gscale, scale):
-    dx = torch.empty_like(x)
+    dx = _empty_like(x)
     call('iprgan_loss_sum_bwd', kind, ptr(x), ptr(y), ptr(gscale), ptr(dx), x.numel(), float(scale), stream())
     return dx
 
@@ -387,7 +397,7 @@ def ssim_fwd(x, y, denorm, want_grad):
 
 def ssim_bwd(x, y, gmaps, gscale, denorm):
     B, Cc, H, W = x.shape
-    dx = torch.empty_like(x)
+    dx = _empty_like(x)
     call('iprgan_ssim_bwd', ptr(x), ptr(y), ptr(gmaps), ptr(gscale), ptr(dx), B * Cc, H, W, int(bool(denorm)),
          stream())
     return dx
@@ -410,7 +420,7 @@ def msssim_fwd(x, y, denorm, want_grad):
 def msssim_bwd(x, y, state, gscale, denorm):
     B, Cc, H, W = x.shape
     pyr, gm, small = state
-    dx = torch.empty_like(x)
+    dx = _empty_like(x)
     ws = empty((2 * B * Cc * ((H + 1) // 2) * ((W + 1) // 2),), x)
     call('iprgan_msssim_bwd', ptr(x), ptr(y), ptr(pyr), ptr(gm), ptr(small), ptr(gscale), ptr(dx), ptr(ws), B * Cc, H, W,
          int(bool(denorm)), stream())
@@ -419,13 +429,13 @@ def msssim_bwd(x, y, state, gscale, denorm):
 
 # ---- VAE reparameterisation -----------------------------------------------------------------------
 def reparam_fwd(mean, logvar, eps):
-    z = torch.empty_like(mean)
+    z = _empty_like(mean)
     call('iprgan_reparam_fwd', ptr(mean), ptr(logvar), ptr(eps), ptr(z), mean.numel(), stream())
     return z
 
 
 def reparam_bwd(dz, logvar, eps):
-    dmean, dlogvar = torch.empty_like(dz), torch.empty_like(dz)
+    dmean, dlogvar = _empty_like(dz), _empty_like(dz)
     call('iprgan_reparam_bwd', ptr(dz), ptr(logvar), ptr(eps), ptr(dmean), ptr(dlogvar), dz.numel(), stream())
     return dmean, dlogvar
 
@@ -441,7 +451,7 @@ def sign_loss_fwd(gammas, signs, gamma0):
 
 
 def sign_loss_bwd(gammas, signs, gamma0, gscale, outs=None, beta=0.0):
-    grads = [torch.empty_like(g) for g in gammas] if outs is None else outs
+    grads = [_empty_like(g) for g in gammas] if outs is None else outs
     call('iprgan_sign_loss_bwd', L.ptr_table(gammas), L.ptr_table(signs), L.ptr_table(grads),
          _int_table([g.numel() for g in gammas]), len(gammas), float(gamma0), ptr(gscale), float(beta), stream())
     return grads
@@ -469,6 +479,15 @@ def adam_step_tables(ptab, grads, mtab, vtab, sizes, n, lr, beta1, beta2, eps, w
          float(eps), float(weight_decay), int(step), float(grad_scale), stream())
 
 
+def adam_step_tables_dev(ptab, grads, mtab, vtab, sizes, n, lr, beta1, beta2, eps, weight_decay, step_dev, coef,
+                         grad_scale=1.0):
+    """adam_step_tables with the step count on the device (``step_dev`` int32[1] is incremented by the call; ``coef``
+    float32[2] receives the bias corrections): nothing in the launch depends on the host's step number, so a captured
+    HIP graph can replay it (graphs.py)."""
+    call('iprgan_adam_step_dev', ptab, L.ptr_table(grads), mtab, vtab, sizes, n, float(lr), float(beta1), float(beta2),
+         float(eps), float(weight_decay), C.c_void_p(step_dev.data_ptr()), ptr(coef), float(grad_scale), stream())
+
+
 def axpy_multi(dsts, srcs, alpha=1.0):
     """dsts[i] += alpha * srcs[i] for a list of tensors in one launch."""
     n = len(dsts)
@@ -485,7 +504,7 @@ def fill(t, value=0.0):
 # ---- instance norm / PReLU / pixel shuffle / max pool / residual add ---------------------------------
 def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias=None, residual=None):
     B, H, W, C_ = x.shape
-    y = torch.empty_like(x)
+    y = _empty_like(x)
     mean, invstd = empty((B, C_), x), empty((B, C_), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
@@ -497,7 +516,7 @@ def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias
 
 def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None, dbias_beta=0.0):
     B, H, W, C_ = x.shape
-    dx = torch.empty_like(x)
+    dx = _empty_like(x)
     dgamma = empty((C_,), x) if gamma is not None else None
     dbeta = empty((C_,), x) if gamma is not None else None
     ws = empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
@@ -509,14 +528,14 @@ def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias
 
 def prelu_fwd(x, alpha):
     _f32(x)
-    y = torch.empty_like(x)
+    y = _empty_like(x)
     call('iprgan_prelu_fwd', ptr(x), ptr(alpha), ptr(y), x.numel(), stream())
     return y
 
 
 def prelu_bwd(x, dy, alpha):
     _f32(x, dy)
-    dx = torch.empty_like(x)
+    dx = _empty_like(x)
     dalpha = empty((1,), x)
     ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
     call('iprgan_prelu_bwd', ptr(x), ptr(dy), ptr(alpha), ptr(dx), ptr(dalpha), ptr(ws), x.numel(), stream())
@@ -549,13 +568,13 @@ def maxpool2_fwd(x):
 def maxpool2_bwd(x, dy):
     _f32(x, dy)
     B, H, W, C_ = x.shape
-    dx = torch.empty_like(x)
+    dx = _empty_like(x)
     call('iprgan_maxpool2_bwd', ptr(x), ptr(dy), ptr(dx), B, H, W, C_, stream())
     return dx
 
 
 def add(a, b):
     _f32(a, b)
-    out = torch.empty_like(a)
+    out = _empty_like(a)
     call('iprgan_add', ptr(a), ptr(b), ptr(out), a.numel(), stream())
     return out

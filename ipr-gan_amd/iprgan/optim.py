@@ -66,6 +66,16 @@ class Adam(Optimizer):
         self._fast[id(group)] = sh
         return sh
 
+    def replayed(self):
+        """Host bookkeeping for one optimizer step that a captured graph executed on the device: the step count the
+        state_dict reports, and the parameters' version counters (version-keyed caches, stale-graph check)."""
+        for group in self.param_groups:
+            sh = getattr(self, '_fast', {}).get(id(group))
+            if sh is not None:
+                sh['step'] += 1
+                sh['step_t'].fill_(sh['step'])
+            torch.autograd.graph.increment_version(group['params'])
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -80,11 +90,24 @@ class Adam(Optimizer):
             if params and all(g is not None and g.is_contiguous() for g in grads):
                 sh = self._shared(group)
                 if sh is not None and sh['ptrs'][0] == params[0].data_ptr() and sh['ptrs'][-1] == params[-1].data_ptr():
-                    sh['step'] += 1
-                    sh['step_t'].fill_(sh['step'])
                     beta1, beta2 = group['betas']
-                    ops.adam_step_tables(sh['ptab'], grads, sh['mtab'], sh['vtab'], sh['sizes'], sh['n'], group['lr'],
-                                         beta1, beta2, group['eps'], group['weight_decay'], sh['step'], self.grad_scale)
+                    if getattr(self, 'device_step', False):
+                        # step count on the device (graphs.py): the launch carries no host step number.  The counter is
+                        # created from the host count the first time (outside any capture: warm-up steps run eagerly)
+                        if 'step_dev' not in sh:
+                            sh['step_dev'] = torch.tensor([sh['step']], dtype=torch.int32, device=params[0].device)
+                            sh['coef'] = torch.zeros(2, dtype=torch.float32, device=params[0].device)
+                        sh['step'] += 1
+                        sh['step_t'].fill_(sh['step'])
+                        ops.adam_step_tables_dev(sh['ptab'], grads, sh['mtab'], sh['vtab'], sh['sizes'], sh['n'],
+                                                 group['lr'], beta1, beta2, group['eps'], group['weight_decay'],
+                                                 sh['step_dev'], sh['coef'], self.grad_scale)
+                    else:
+                        sh.pop('step_dev', None)
+                        sh['step'] += 1
+                        sh['step_t'].fill_(sh['step'])
+                        ops.adam_step_tables(sh['ptab'], grads, sh['mtab'], sh['vtab'], sh['sizes'], sh['n'], group['lr'],
+                                             beta1, beta2, group['eps'], group['weight_decay'], sh['step'], self.grad_scale)
                     torch.autograd.graph.increment_version(params)
                     continue
                 self._fast.pop(id(group), None)          # parameters were replaced (.to(), load): rebuild next time

@@ -125,7 +125,22 @@ class Experiment:
     def train(self):
         hp, m = self.config.hparam, self.model
         d_iter, g_iter = hp.get('d_iter', 1), hp.get('g_iter', 1)
-        if self.kind == 'generation':
+        if self.kind == 'generation' and self.engine.get('graph') and self.world == 1 and d_iter == 1 and g_iter == 1 \
+                and not self.config.get('protection', Config({})).get('bbox', None):
+            # `engine: {graph: true}`: update_d + update_g as ONE captured HIP graph (iprgan/graphs.py).  The data and the
+            # latent draw stay on the host, as in the reference loop; they are copied into the graph's static inputs.
+            x, _ = next(self.data_loader)
+            z = torch.randn(x.size(0), 128)
+            if getattr(self, '_graphed', None) is None:
+                from iprgan import graphs
+                dev = self.device[0]
+
+                def body(s):
+                    m.update_d({'real_sample': s['x'], 'latent': s['z']})
+                    m.update_g({'fake_sample': m.fake_sample})
+                self._graphed = graphs.GraphedStep(m, body, {'x': x.to(dev), 'z': z.to(dev)}, warmup=3)
+            self._graphed({'x': x, 'z': z})
+        elif self.kind == 'generation':
             for _ in range(d_iter):
                 x, _ = next(self.data_loader)
                 m.update_d({'real_sample': x, 'latent': torch.randn(x.size(0), 128)})

@@ -66,11 +66,13 @@ def test_train_driver_engine_block(tmp_path):
     the config file; the run records the mode it trained in and still embeds the watermark."""
     base = open(os.path.join(ROOT, 'tests', 'configs', 'dcgan-wbox-tiny.yaml')).read()
     cfg = tmp_path / 'bf16.yaml'
-    cfg.write_text(base + "engine:\n  math: 'bf16act'\n  bucket_mb: 4\n")
+    cfg.write_text(base.replace('iteration: 4', 'iteration: 6') + "engine:\n  math: 'bf16act'\n  bucket_mb: 4\n  graph: true\n")
     log = str(tmp_path / 'log')
     subprocess.run([sys.executable, os.path.join(PKG, 'train.py'), '-c', str(cfg), '--log-path', log], check=True, timeout=600)
     m = json.load(open(os.path.join(log, 'metrics.json')))
-    assert m['engine'] == {'math': 'bf16act', 'bucket_mb': 4} and m['BER'] == 0.0
+    assert m['engine'] == {'math': 'bf16act', 'bucket_mb': 4, 'graph': True} and m['BER'] == 0.0
+    steps = [json.loads(l)['step'] for l in open(os.path.join(log, 'metrics.jsonl'))]
+    assert steps == [1, 2, 3, 4, 5, 6]           # (three eager warm-up calls, the capture + its replay, two more replays)
     bad = tmp_path / 'bad.yaml'
     bad.write_text(base + "engine:\n  maths: 'bf16'\n")
     r = subprocess.run([sys.executable, os.path.join(PKG, 'train.py'), '-c', str(bad), '--log-path', log + '2'],

@@ -135,6 +135,81 @@ def test_bn_backward_fusion_matches_the_separate_passes(dev, monkeypatch):
     assert n > 50
 
 
+def _state_fingerprint(model):
+    out = {}
+    sd = model.state_dict()
+    for net in ('G', 'D'):
+        for k, v in sd[net].items():
+            out[f'{net}/{k}'] = v.detach().cpu().clone()
+    for opt in ('optG', 'optD'):
+        for idx, st in sd[opt]['state'].items():
+            for leaf in ('exp_avg', 'exp_avg_sq'):
+                out[f'{opt}/{idx}/{leaf}'] = st[leaf].detach().cpu().clone()
+            out[f'{opt}/{idx}/step'] = torch.as_tensor(float(st['step']))
+    return out
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16act'])
+def test_graphed_step_is_bit_identical_to_eager(dev, mode):
+    _graphed_vs_eager(dev, mode, 7, 4, 4)
+
+
+@pytest.mark.parametrize('n_steps,eager_at,replays', [(3, -1, 1), (4, 3, 1), (4, -1, 2), (5, -1, 3), (5, 3, 2)])
+def test_graphed_step_variants(dev, n_steps, eager_at, replays):
+    """Shorter schedules around the capture: only the capturing call; an eager step right behind it; two and three
+    replays; an eager step between replays.  (The second replay is the one that caught a cache hit baked into the graph:
+    the discriminator head's permuted weight, computed by update_g's pass of the previous EAGER step and reused by
+    update_d's pass - engine.drop_operand_caches.)"""
+    _graphed_vs_eager(dev, 'fp32', n_steps, eager_at, replays)
+
+
+def _graphed_vs_eager(dev, mode, n_steps, eager_at, replays):
+    """iprgan.graphs.GraphedStep: update_d + update_g of DCGAN-64 + sign loss captured in ONE HIP graph (warm-up eager,
+    capture, replays, an eager step in between, more replays) leaves networks, spectral-norm / BatchNorm buffers, both
+    Adam moments and the step counts BIT-IDENTICAL to the same seven steps run eagerly (with the device-side step count
+    both use), the metrics of the last step included.  The capture must actually have happened."""
+    from iprgan import Config, _lib, graphs, models
+    import bench
+    B = 16
+    xs = [torch.tanh(recipe.tensor(5, 100 + s, (B, 3, 64, 64))).to(dev) for s in range(n_steps)]
+    zs = [recipe.tensor(5, 200 + s, (B, 128)).to(dev) for s in range(n_steps)]
+
+    def build():
+        m = models.DCGAN(Config(bench.DCGAN_CFG), device=[dev])
+        recipe.fill(m.G.module, 41); recipe.fill(m.D.module, 42)
+        m.G.to(dev); m.D.to(dev)
+        return models.WhiteBoxWrapper(m, Config(dict(bench.WBOX_CFG, target='G')))
+
+    def body_of(m):
+        def body(s):
+            m.update_d({'real_sample': s['x'], 'latent': s['z']})
+            m.update_g({'fake_sample': m.fake_sample})
+        return body
+    try:
+        _lib.set_math(mode)
+        a = build()
+        for o in graphs._optimizers(a):
+            o.device_step = True
+        body_a = body_of(a)
+        for s in range(n_steps):
+            body_a({'x': xs[s], 'z': zs[s]})
+        fa, ma = _state_fingerprint(a), a.get_metrics()
+        b = build()
+        step = graphs.GraphedStep(b, body_of(b), {'x': xs[0], 'z': zs[0]}, warmup=2)
+        for s in range(n_steps):
+            step({'x': xs[s], 'z': zs[s]}, eager=(s == eager_at))
+        assert step.failed is None, step.failed
+        assert step.graph is not None and step.replays == replays      # (7 steps: 2 = capture + replay, 3, 5, 6)
+        fb, mb = _state_fingerprint(b), b.get_metrics()
+    finally:
+        _lib.set_math('fp32')
+    assert fa.keys() == fb.keys()
+    bad = [(k, float((fa[k].double() - fb[k].double()).abs().max())) for k in fa if not torch.equal(fa[k], fb[k])]
+    assert not bad, f'{len(bad)} of {len(fa)} tensors differ: {bad[:12]}'
+    assert ma == mb, (ma, mb)
+    assert float(b.loss_model.compute_ber(b.G)) == 0.0
+
+
 def step_policy(steps, lr=2e-4):
     """Tolerances for multi-step training parity.
     step 0 (metrics, generated images, Adam first moments = (1-beta1)*grad of EVERY parameter, BN/SN
