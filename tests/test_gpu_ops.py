@@ -1027,6 +1027,39 @@ def test_conv_epilogue_column_sums(dev, shape, tile):
         _lib.call('iprgan_debug_force_splitk', -1)
 
 
+@pytest.mark.parametrize('ratio', [3.0, 20.0, 60.0])
+def test_fused_norm_statistics_with_large_mean_channels(dev, ratio):
+    """the statistics a BatchNorm takes from the producing conv's epilogue are sums about ZERO of the pre-bias
+    accumulator (s2 / M - (s1 / M)^2), not shifted sums: fp32 cancellation grows with (mean / std)^2 of a channel.  A
+    convolution whose output channels sit ``ratio`` standard deviations away from zero (positive weights on a positive
+    input), normalised by the fused path, against torch.batch_norm in float64: the normalised output must stay within
+    1e-6 * (1 + ratio^2) of the unit scale (measured: 2e-6 / 6e-5 / 5e-4 for ratio 3 / 20 / 60; DCGAN's and SRGAN's
+    layers sit below ratio 3) and mean / invstd within the same relative bound."""
+    from iprgan import ops
+    cin, cout, k, H, W, B = 64, 64, 3, 32, 32, 8
+    x = rnd(B, cin, H, W, seed=1, scale=0.1) + 1.0
+    w = rnd(cout, cin, k, k, seed=2, scale=0.01).abs()
+    acc = F.conv2d(x.double(), w.double(), None, padding=1)
+    std, mean = acc.std((0, 2, 3)), acc.mean((0, 2, 3))
+    shift = (ratio * std - mean) / (w.double().sum((1, 2, 3)))       # move every channel's mean to ratio * std via the input offset
+    # (one common offset cannot hit every channel exactly; use the median channel's and report the achieved ratios)
+    x = x + float(shift.median())
+    acc = F.conv2d(x.double(), w.double(), None, padding=1)
+    got_ratio = (acc.mean((0, 2, 3)).abs() / acc.std((0, 2, 3)))
+    gamma, beta = rnd(cout, seed=3, scale=0.3) + 1.0, rnd(cout, seed=4, scale=0.2)
+    want = F.batch_norm(acc, None, None, gamma.double(), beta.double(), training=True, eps=1e-5)
+    spec = ops.ConvSpec(cin, cout, k, 1, 1)
+    d = spec.desc(B, H, W)
+    wf, _ = ops.conv_prep(spec, d, w.to(dev), None, True, False)
+    y, stats = ops.conv_fwd(spec, d, to_nhwc(x).to(dev), wf, None, stats=True)
+    out, mean_d, invstd_d = ops.bn_fwd(y, gamma.to(dev), beta.to(dev), None, None, 1e-5, 0.0, True, 0, 0.0, conv_stats=stats)
+    bound = 1e-6 * (1.0 + float(got_ratio.max()) ** 2)
+    err = float((from_nhwc(out.cpu(), cout).double() - want).abs().max())
+    assert err <= bound * float(want.abs().max()), (err, bound, float(got_ratio.min()), float(got_ratio.max()))
+    var = acc.var((0, 2, 3), unbiased=False)
+    assert float(((invstd_d.cpu().double() - (var + 1e-5).rsqrt()) / (var + 1e-5).rsqrt()).abs().max()) <= bound
+
+
 SPLITK_SHAPES = [   # cin, cout, k, stride, pad, transposed, H, W, B, pad_mode: few output tiles, long reductions
     (512, 512, 3, 1, 1, False, 6, 6, 16, 0),      # VGG block 5 of the SRGAN content loss (networks/vgg.py) at a small batch
     (256, 128, 3, 2, 1, False, 12, 10, 8, 0),     # strided: still one phase in the forward pass; backward is 4 phases
