@@ -1033,28 +1033,32 @@ def test_fused_norm_statistics_with_large_mean_channels(dev, ratio):
     accumulator (s2 / M - (s1 / M)^2), not shifted sums: fp32 cancellation grows with (mean / std)^2 of a channel.  A
     convolution whose output channels sit ``ratio`` standard deviations away from zero (positive weights on a positive
     input), normalised by the fused path, against torch.batch_norm in float64: the normalised output must stay within
-    1e-6 * (1 + ratio^2) of the unit scale (measured: 2e-6 / 6e-5 / 5e-4 for ratio 3 / 20 / 60; DCGAN's and SRGAN's
-    layers sit below ratio 3) and mean / invstd within the same relative bound."""
+    1e-6 * (1 + ratio^2) of the output scale (measured: 2.5e-6 / 9.0e-5 / 7.6e-4 for ratio 3 / 20 / 60, i.e. a quarter of
+    the bound; the generator / discriminator layers of the three GANs sit below ratio 3) and invstd within the same
+    relative bound."""
     from iprgan import ops
-    cin, cout, k, H, W, B = 64, 64, 3, 32, 32, 8
-    x = rnd(B, cin, H, W, seed=1, scale=0.1) + 1.0
-    w = rnd(cout, cin, k, k, seed=2, scale=0.01).abs()
-    acc = F.conv2d(x.double(), w.double(), None, padding=1)
-    std, mean = acc.std((0, 2, 3)), acc.mean((0, 2, 3))
-    shift = (ratio * std - mean) / (w.double().sum((1, 2, 3)))       # move every channel's mean to ratio * std via the input offset
-    # (one common offset cannot hit every channel exactly; use the median channel's and report the achieved ratios)
-    x = x + float(shift.median())
-    acc = F.conv2d(x.double(), w.double(), None, padding=1)
+    cin, cout, k, H, W, B = 64, 64, 3, 34, 34, 4          # unpadded: a zero border would put a floor under the channel's std
+    x0 = rnd(B, cin, H, W, seed=1, scale=0.1)
+    w = 0.01 + rnd(cout, cin, k, k, seed=2, scale=0.0005)        # nearly equal row sums: one input offset moves every channel alike
+    sw = float(w.double().sum((1, 2, 3)).median())
+    c = 0.0
+    for _ in range(4):                                            # input offset that puts the median channel at `ratio` sigma
+        acc = F.conv2d((x0 + c).double(), w.double(), None)
+        m, sd = acc.mean((0, 2, 3)), acc.std((0, 2, 3))
+        c += float(((ratio * sd - m) / sw).median())
+    x = x0 + c
+    acc = F.conv2d(x.double(), w.double(), None)
     got_ratio = (acc.mean((0, 2, 3)).abs() / acc.std((0, 2, 3)))
     gamma, beta = rnd(cout, seed=3, scale=0.3) + 1.0, rnd(cout, seed=4, scale=0.2)
     want = F.batch_norm(acc, None, None, gamma.double(), beta.double(), training=True, eps=1e-5)
-    spec = ops.ConvSpec(cin, cout, k, 1, 1)
+    spec = ops.ConvSpec(cin, cout, k, 1, 0)
     d = spec.desc(B, H, W)
     wf, _ = ops.conv_prep(spec, d, w.to(dev), None, True, False)
     y, stats = ops.conv_fwd(spec, d, to_nhwc(x).to(dev), wf, None, stats=True)
     out, mean_d, invstd_d = ops.bn_fwd(y, gamma.to(dev), beta.to(dev), None, None, 1e-5, 0.0, True, 0, 0.0, conv_stats=stats)
     bound = 1e-6 * (1.0 + float(got_ratio.max()) ** 2)
     err = float((from_nhwc(out.cpu(), cout).double() - want).abs().max())
+    print(f'large-mean statistics: mean/std {float(got_ratio.min()):.1f}..{float(got_ratio.max()):.1f}: output error {err / float(want.abs().max()):.2e} of the output scale (bound {bound:.2e})')
     assert err <= bound * float(want.abs().max()), (err, bound, float(got_ratio.min()), float(got_ratio.max()))
     var = acc.var((0, 2, 3), unbiased=False)
     assert float(((invstd_d.cpu().double() - (var + 1e-5).rsqrt()) / (var + 1e-5).rsqrt()).abs().max()) <= bound
