@@ -306,7 +306,8 @@ def main():
     torch.manual_seed(1234 + rank)              # every rank its own data shard / latents
     model, step_fn = make_workload(args.workload, [device], (Config, models))
     graphed = None
-    if args.graph != 'off' and world == 1 and hasattr(step_fn, 'graph_spec'):
+    # (auto: only when the capture - two eager calls, then the capturing one - fits inside the warm-up)
+    if args.graph != 'off' and world == 1 and hasattr(step_fn, 'graph_spec') and (args.graph == 'on' or args.warmup >= 4):
         from iprgan import graphs
         body, inputs_of = step_fn.graph_spec
         graphed = graphs.GraphedStep(model, body, inputs_of(0), warmup=max(2, args.warmup - 2))
