@@ -360,12 +360,15 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
   const float sb = block_sum((float)s, sh);
   if (threadIdx.x == 0) part[blockIdx.x] = sb;
 }
+// one wave: lane l adds partials l, l + 64, ... in double, then a fixed butterfly over the 64 lanes (deterministic; the
+// single-thread walk over up to LOSS_BLOCKS partials took 12 us per PReLU layer)
 __global__ void sum_partials_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < nb; ++i) s += (double)part[i];
-    *out = (float)s;
-  }
+  if (blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 64) s += (double)part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) *out = (float)s;
 }
 
 // ---- PixelShuffle(2) on NHWC: out[b,2h+i,2w+j,c] = in[b,h,w,c*4+i*2+j] (networks/sr_resnet.py:42) ----
