@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 211
+#define IPRGAN_VERSION 212
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -180,6 +180,19 @@ int iprgan_bn_bwd(const float* x, const float* y, const float* dy, const float* 
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                   float* dbeta, float* ws, int M, int C, int act, float slope, float* dbias_prev, int dbias_n,
                   float dbias_beta, int act_bf16, void* stream);
+/* BatchNorm2d + PReLU with one learnable slope (networks/sr_resnet.py:7,13: conv -> BatchNorm -> PReLU) in the norm layer's
+ * own passes: `slope` is the PReLU parameter ON THE DEVICE (one float); forward = iprgan_bn_fwd with the activation
+ * v > 0 ? v : slope * v; backward also returns dslope = sum dy * min(v, 0) (v = the normalised, affine value) - no
+ * separate PReLU forward / backward passes over the tensor. */
+int iprgan_bn_prelu_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float* save_mean, float* save_invstd, float* ws, int M, int C, float eps,
+                        float momentum, int use_running, const float* slope, const float* conv_part, int conv_part_rows,
+                        const float* conv_bias, long long* num_batches_tracked, const float* residual, int act_bf16,
+                        void* stream);
+int iprgan_bn_prelu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* save_mean,
+                        const float* save_invstd, const float* slope, float* dx, float* dgamma, float* dbeta,
+                        float* dslope, float* ws, int M, int C, float* dbias_prev, int dbias_n, float dbias_beta,
+                        int act_bf16, void* stream);
 /* the norm backward behind iprgan_conv_bwd_data_bn: dz and its per-tile sums part[rows][2][C] come from that pass
  * (the buffer holds iprgan_conv_stat_floats(d, 1) floats: the rows are compacted in place when there are many) */
 int iprgan_bn_bwd_pre(const float* x, const float* dz, const float* gamma, const float* save_mean,

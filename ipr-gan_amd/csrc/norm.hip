@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
                                                         float* __restrict__ part, int M, int C, int TC,
                                                         int rows_per_block, int act, float slope,
                                                         const float* __restrict__ gamma = nullptr,
-                                                        const float* __restrict__ beta = nullptr) {
+                                                        const float* __restrict__ beta = nullptr,
+                                                        const float* __restrict__ slope_ptr = nullptr) {
+  if (slope_ptr) slope = *slope_ptr;          // PReLU fused into the norm layer: LeakyReLU with a learnable, device-resident slope
   // blockIdx.z = group (InstanceNorm: one group per sample; BatchNorm: a single group)
   const int grp = blockIdx.z;
   const size_t gofs = (size_t)grp * M * C;       // element offset of the group (pointer arithmetic below is per element)
@@ -299,7 +301,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        unsigned n4, int C4n, FastDiv d_c4n, FastDiv d_group4, int act,
-                                                       float slope, const float* __restrict__ residual) {
+                                                       float slope, const float* __restrict__ residual,
+                                                       const float* __restrict__ slope_ptr) {
+  if (slope_ptr) slope = *slope_ptr;          // PReLU as the norm layer's activation (networks/sr_resnet.py:7,13)
   // residual: y = act(norm(x)) + residual - the skip connection that closes a residual block right after its last norm
   // layer (networks/sr_resnet.py:37-38, resnet_generator.py:52-53), folded into this pass
   const unsigned stride = gridDim.x * blockDim.x;
@@ -358,7 +362,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ sums,
                                                            unsigned n4, int C4n, int C, FastDiv d_c4n, FastDiv d_group4,
-                                                           float invM, int act, float slope, float* __restrict__ colpart) {
+                                                           float invM, int act, float slope, float* __restrict__ colpart,
+                                                           const float* __restrict__ slope_ptr, float* __restrict__ apart) {
+  // slope_ptr / apart: PReLU fused into the norm layer - the slope is read from the device and every block emits its share
+  // of the slope gradient sum dy * min(v, 0), v = the normalised, affine value (one more partial array, summed in double)
+  if (slope_ptr) slope = *slope_ptr;
+  float asum = 0.f;
   // colpart (needs 256 % C4n == 0: a thread keeps its channel chunk): per-block column sums of dx, [block][2][C] like
   // every other partial buffer - the bias gradient of the convolution that feeds this norm layer, without another
   // pass over dx (colreduce_kernel<0>)
@@ -375,7 +384,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float t = (xv[k] - m[k]) * is[k];
-      const float dz = no_act ? gv[k] : gv[k] * act_grad_from_out(from_x ? t * g[k] + b[k] : yv[k], act, slope);
+      const float v = t * g[k] + b[k];
+      if (apart) asum += v > 0.f ? 0.f : gv[k] * v;
+      const float dz = no_act ? gv[k] : gv[k] * act_grad_from_out(from_x ? v : yv[k], act, slope);
       o[k] = g[k] * is[k] * (dz - s1[k] * invM - t * s2[k] * invM);
     }
     stv<B16>(dx, idx * 4, o);
@@ -398,6 +409,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       const f32x4 s1 = ld4(sums + grp * 2 * C, c, 0.f), s2 = ld4(sums + grp * 2 * C + C, c, 0.f);
       body(i, g, b, m, is, s1, s2);
     }
+  }
+  if (apart) {
+    __shared__ float sha[16];
+    const float sb = block_sum(asum, sha);
+    if (threadIdx.x == 0) apart[blockIdx.y * gridDim.x + blockIdx.x] = sb;
   }
   if (colpart) {
     __shared__ f32x4 sh[256];
@@ -431,7 +447,7 @@ int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, h
   const ColGeom g = col_geom(M, Cs);
   auto kr0 = b16 ? colreduce_kernel<0, true> : colreduce_kernel<0, false>;
   hipLaunchKernelGGL(kr0, dim3(g.NB, g.gy), dim3(256), 0, st, x,
-                     nullptr, nullptr, nullptr, nullptr, ws, M, Cs, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr);
+                     nullptr, nullptr, nullptr, nullptr, ws, M, Cs, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr, nullptr);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, st, ws, g.NB, Cs, C, out, beta);
   IPR_LAUNCH_CHECK();
@@ -442,11 +458,23 @@ int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, h
 
 using namespace iprgan;
 
+namespace iprgan {
+// sum of up to a few thousand block partials on one wave, in double, fixed order
+__global__ void wave_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += (double)part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) *out = (float)s;
+}
+}  // namespace iprgan
+
 static int norm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_invstd, float* ws, int G, int M, int C,
                     float eps, float momentum, int use_running, int act, float slope, hipStream_t st,
                     const float* part = nullptr, int part_rows = 0, const float* shift = nullptr,
-                    long long* counter = nullptr, const float* residual = nullptr, int b16 = 0) {
+                    long long* counter = nullptr, const float* residual = nullptr, int b16 = 0,
+                    const float* slope_ptr = nullptr) {
   IPR_CHECK(C % 4 == 0, "norm_fwd: C=%d must be a multiple of 4", C);
   IPR_CHECK(M > 0 && G > 0, "norm_fwd: empty input");
   if (use_running) {
@@ -464,7 +492,7 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
     const ColGeom g = col_geom(M, C);
     auto kr1 = b16 ? colreduce_kernel<1, true> : colreduce_kernel<1, false>;
   hipLaunchKernelGGL(kr1, dim3(g.NB, g.gy, G), dim3(256), 0, st,
-                       x, nullptr, nullptr, nullptr, nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr);
+                       x, nullptr, nullptr, nullptr, nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr, nullptr);
     IPR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, x, g.NB, M, C,
                        eps, momentum, running_mean, running_var, save_mean, save_invstd, 0, counter, b16);
@@ -480,7 +508,7 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
   if (fixed) blocks = (int)(cdivz(n4g, 256) < (size_t)cdiv(4096, G) ? cdivz(n4g, 256) : (size_t)cdiv(4096, G));
   hipLaunchKernelGGL(kern, dim3(blocks, fixed ? G : 1), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_invstd,
                      (unsigned)(fixed ? n4g : n4), C / 4,
-                     make_fastdiv(C / 4), make_fastdiv((uint32_t)n4g), act, slope, residual);
+                     make_fastdiv(C / 4), make_fastdiv((uint32_t)n4g), act, slope, residual, slope_ptr);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -489,7 +517,8 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
                     const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
                     float* ws, int G, int M, int C, int act, float slope, hipStream_t st,
                     float* dbias_prev = nullptr, int dbias_n = 0, float dbias_beta = 0.f, int b16 = 0,
-                    const float* pre_part = nullptr, int pre_rows = 0) {
+                    const float* pre_part = nullptr, int pre_rows = 0, const float* slope_ptr = nullptr,
+                    float* dslope = nullptr) {
   // pre_part: the two reductions (sum dz, sum dz * xhat; dz = dy * act') were taken by the epilogue of the backward-data
   // pass that produced dy (iprgan_conv_bwd_data_bn), which stored dz in dy's place: no reduction pass, no mask here
   IPR_CHECK(C % 4 == 0, "norm_bwd: C=%d must be a multiple of 4", C);
@@ -508,7 +537,7 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
   } else {
     auto kr2 = b16 ? colreduce_kernel<2, true> : colreduce_kernel<2, false>;
     hipLaunchKernelGGL(kr2, dim3(g.NB, g.gy, G), dim3(256), 0, st,
-                       x, y, dy, save_mean, save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope, gamma, beta);
+                       x, y, dy, save_mean, save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope, gamma, beta, slope_ptr);
     IPR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, g.NB, C, sums,
                        G == 1 ? dgamma : nullptr, G == 1 ? dbeta : nullptr);
@@ -527,6 +556,7 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
   if (fixed) { gy = G; blocks = (int)(cdivz(n4g, 256) < (size_t)cdiv(4096, G) ? cdivz(n4g, 256) : (size_t)cdiv(4096, G)); }
   // column sums of dx (bias gradient of the producing convolution) ride on the apply pass when a thread keeps its
   // channel chunk; the per-block partials (at most 1024 rows) live behind the reduction workspace
+  float* apart = sums + (size_t)G * 2 * C + (size_t)(1024 + NBC) * 2 * C;     // per-block slope-gradient partials (<= 4096)
   float* colpart = nullptr;
   if (dbias_prev && 256 % (C / 4) == 0) {
     const int cap = fixed ? (1024 / G > 0 ? 1024 / G : 1) : 1024;
@@ -538,8 +568,12 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
   hipLaunchKernelGGL(kern, dim3(blocks, gy), dim3(256), 0, st, x, y, dy, dx, gamma, beta, save_mean, save_invstd, sums,
                      (unsigned)(fixed ? n4g : n4), C / 4, C,
                      make_fastdiv(C / 4), make_fastdiv((uint32_t)n4g), 1.0f / (float)M, act, slope,
-                     colpart);
+                     colpart, slope_ptr, dslope ? apart : nullptr);
   IPR_LAUNCH_CHECK();
+  if (dslope) {
+    hipLaunchKernelGGL(wave_sum_kernel, dim3(1), dim3(64), 0, st, apart, blocks * gy, dslope);
+    IPR_LAUNCH_CHECK();
+  }
   if (dbias_prev) {
     if (colpart) {
       const float* pp = colpart;
@@ -561,7 +595,7 @@ extern "C" {
 // [reduction partials | sums] + [per-block column sums of dx (1024 blocks) | their compacted rows] for the bias gradient
 size_t iprgan_bn_ws_floats(int M, int C) {
   const ColGeom g = col_geom(M, C);
-  return (size_t)g.NB * 2 * C + 2 * (size_t)C + (size_t)(1024 + NBC) * 2 * C;
+  return (size_t)g.NB * 2 * C + 2 * (size_t)C + (size_t)(1024 + NBC) * 2 * C + 4096;
 }
 size_t iprgan_instnorm_ws_floats(int B, int HW, int C) {
   const ColGeom g = col_geom(HW, C);
@@ -607,6 +641,27 @@ int iprgan_bn_bwd_pre(const float* x, const float* dz, const float* gamma, const
   IPR_CHECK(part && rows > 0, "bn_bwd_pre: the epilogue partials are required");
   return norm_bwd(x, nullptr, dz, gamma, nullptr, save_mean, save_invstd, dx, dgamma, dbeta, ws, 1, M, C, IPRGAN_ACT_NONE,
                   0.f, (hipStream_t)stream, dbias_prev, dbias_n, dbias_beta, act_bf16, part, rows);
+}
+// BatchNorm2d + PReLU (one learnable slope, networks/sr_resnet.py:7,13: conv -> BatchNorm -> PReLU): the slope is read from
+// the device (`slope`, one float), so the norm's apply pass IS the PReLU forward and its backward apply pass produces dx
+// through both, with the slope gradient d_slope = sum dy * min(v, 0) summed on the same pass.
+int iprgan_bn_prelu_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float* save_mean, float* save_invstd, float* ws, int M, int C, float eps,
+                        float momentum, int use_running, const float* slope, const float* conv_part, int conv_part_rows,
+                        const float* conv_bias, long long* num_batches_tracked, const float* residual, int act_bf16,
+                        void* stream) {
+  IPR_CHECK(slope, "bn_prelu_fwd: the slope pointer is required");
+  return norm_fwd(x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, ws, 1, M, C, eps, momentum,
+                  use_running, IPRGAN_ACT_LRELU, 0.f, (hipStream_t)stream, conv_part, conv_part_rows, conv_bias,
+                  use_running ? nullptr : num_batches_tracked, residual, act_bf16, slope);
+}
+int iprgan_bn_prelu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* save_mean,
+                        const float* save_invstd, const float* slope, float* dx, float* dgamma, float* dbeta,
+                        float* dslope, float* ws, int M, int C, float* dbias_prev, int dbias_n, float dbias_beta,
+                        int act_bf16, void* stream) {
+  IPR_CHECK(slope && dslope && gamma && beta, "bn_prelu_bwd: slope, its gradient output, gamma and beta are required");
+  return norm_bwd(x, nullptr, dy, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, ws, 1, M, C, IPRGAN_ACT_LRELU, 0.f,
+                  (hipStream_t)stream, dbias_prev, dbias_n, dbias_beta, act_bf16, nullptr, 0, slope, dslope);
 }
 int iprgan_instnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* save_mean,
                         float* save_invstd, float* ws, int B, int HW, int C, float eps, int act, float slope,

@@ -60,6 +60,8 @@ SIGNATURES = {
     'iprgan_bn_ws_floats': (_Z, [_I, _I]),
     'iprgan_bn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _P, _P, _P, _I, _P]),
     'iprgan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _F, _I, _P]),
+    'iprgan_bn_prelu_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P, _P, _I, _P, _P, _P, _I, _P]),
+    'iprgan_bn_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _F, _I, _P]),
     'iprgan_bn_bwd_pre': (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _F, _I, _P]),
     'iprgan_instnorm_ws_floats': (_Z, [_I, _I, _I]),
     'iprgan_instnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _I, _P, _P, _I, _P]),

@@ -306,14 +306,17 @@ class LinearNHWC(Op):
 class BatchNorm(Op):
     """BatchNorm2d (+activation) over NHWC; owns nothing, mutates the module's running stats."""
 
-    def __init__(self, bn_module, act=L.ACT_NONE, slope=0.0):
+    def __init__(self, bn_module, act=L.ACT_NONE, slope=0.0, prelu=None):
         self.m = bn_module
         self.act, self.slope = act, slope
+        # prelu: the nn.PReLU() (one slope) that follows the norm layer (networks/sr_resnet.py:7,13), folded into the norm's
+        # apply passes (iprgan_bn_prelu_fwd / _bwd): no separate pass over the tensor for its forward or backward
+        self.prelu = prelu
         self.out_act = (L.ACT_NONE, 0.0)     # handles its own activation derivative
 
     @property
     def params(self):
-        return (self.m.weight, self.m.bias)
+        return (self.m.weight, self.m.bias) + ((self.prelu.weight,) if self.prelu is not None else ())
 
     def forward(self, x, st, train):
         m = self.m
@@ -332,12 +335,17 @@ class BatchNorm(Op):
         if st.get('close_skip'):            # the residual block ends right behind this layer: its add rides on the apply
             res = st['ctx']['skips'][-1]
             st['ctx']['skip_fused'] = True
-        y, mean, invstd = ops.bn_fwd(x, m.weight, m.bias,
-                                     m.running_mean if (track or not use_batch) else None,
-                                     m.running_var if (track or not use_batch) else None,
-                                     m.eps, mom if mom is not None else 0.0, use_batch, self.act, self.slope,
-                                     conv_stats=cs[0] if cs else None, conv_bias=cs[1] if cs else None,
-                                     counter=counter, residual=res)
+        rm = m.running_mean if (track or not use_batch) else None
+        rv = m.running_var if (track or not use_batch) else None
+        if self.prelu is not None:
+            y, mean, invstd = ops.bn_prelu_fwd(x, m.weight, m.bias, rm, rv, m.eps, mom if mom is not None else 0.0,
+                                               use_batch, self.prelu.weight, conv_stats=cs[0] if cs else None,
+                                               conv_bias=cs[1] if cs else None, counter=counter, residual=res)
+        else:
+            y, mean, invstd = ops.bn_fwd(x, m.weight, m.bias, rm, rv,
+                                         m.eps, mom if mom is not None else 0.0, use_batch, self.act, self.slope,
+                                         conv_stats=cs[0] if cs else None, conv_bias=cs[1] if cs else None,
+                                         counter=counter, residual=res)
         st.update(x=x, y=y, mean=mean, invstd=invstd, use_batch=use_batch)
         return y
 
@@ -348,6 +356,11 @@ class BatchNorm(Op):
             dx, dg, db = ops.bn_bwd_pre(st['x'], dy, self.m.weight, st['mean'], st['invstd'], pre,
                                         dbias=tgt[0] if tgt else None, dbias_beta=tgt[1] if tgt else 0.0)
             return dx, [dg, db]
+        if self.prelu is not None:
+            dx, dg, db, da = ops.bn_prelu_bwd(st['x'], dy, self.m.weight, self.m.bias, st['mean'], st['invstd'],
+                                              self.prelu.weight, dbias=tgt[0] if tgt else None,
+                                              dbias_beta=tgt[1] if tgt else 0.0)
+            return dx, [dg, db, da]
         dx, dg, db = ops.bn_bwd(st['x'], st['y'], dy, self.m.weight, st['mean'], st['invstd'],
                                 self.act, self.slope, beta=self.m.bias, dbias=tgt[0] if tgt else None,
                                 dbias_beta=tgt[1] if tgt else 0.0)
@@ -754,7 +767,7 @@ class ChainFn(torch.autograd.Function):
                     and not (ops.c4(op.spec.cin) <= 4 and op.spec.stride == 1)):
                 st['open_skip'] = True
             if (_FUSE_BN_BWD and _FUSE_STATS and need_dx and isinstance(op, Conv) and isinstance(prev, BatchNorm)
-                    and stash[i - 1].get('use_batch') and prev.act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU)
+                    and prev.prelu is None and stash[i - 1].get('use_batch') and prev.act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU)
                     and 'pair' not in st and not st.get('open_skip') and ops.conv_bwd_data_bn_ok(st['d'])
                     and i - 1 >= first_needed):
                 pst = stash[i - 1]

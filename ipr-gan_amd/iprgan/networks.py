@@ -12,9 +12,13 @@ import torch
 import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
+import os
+
 from . import _lib as L
 from . import engine as E
 from .ops import ConvSpec, reparam_bwd as ops_reparam_bwd, reparam_fwd as ops_reparam_fwd
+
+_FUSE_PRELU = os.environ.get('IPRGAN_FUSE_PRELU', '1') != '0'      # A/B switch: PReLU folded into the BatchNorm in front of it
 
 __all__ = ['ConvGenerator', 'ConvGenerator32', 'ConvGenerator64', 'ConvGenerator128',
            'SNDiscriminator', 'SNDiscriminator32', 'SNDiscriminator64', 'SNDiscriminator128', 'Flatten',
@@ -205,7 +209,10 @@ class SRResNet(nn.Sequential, _HipNet):
 
     def _unit_ops(self, unit, cin, cout, k, pad):
         ops_ = [E.Conv(ConvSpec(cin, cout, k, 1, pad), unit[0])]
-        for m in list(unit)[1:]:
+        rest = list(unit)[1:]
+        if _FUSE_PRELU and len(rest) == 2 and isinstance(rest[0], nn.BatchNorm2d) and isinstance(rest[1], nn.PReLU):
+            return ops_ + [E.BatchNorm(rest[0], prelu=rest[1])]       # conv -> BatchNorm -> PReLU: PReLU rides on the norm's passes
+        for m in rest:
             ops_.append(E.BatchNorm(m) if isinstance(m, nn.BatchNorm2d) else E.PReLU(m))
         return ops_
 

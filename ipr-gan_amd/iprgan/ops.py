@@ -290,6 +290,36 @@ def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None,
     return dx, dgamma, dbeta
 
 
+def bn_prelu_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, slope_t, conv_stats=None,
+                 conv_bias=None, counter=None, residual=None):
+    """BatchNorm + PReLU (``slope_t``: the PReLU parameter, one float on the device) in the norm's own passes."""
+    C_ = x.shape[-1]
+    M = x.numel() // C_
+    y = _empty_like(x)
+    mean, invstd = empty((C_,), x), empty((C_,), x)
+    part, rows = conv_stats if conv_stats is not None else (None, 0)
+    ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    call('iprgan_bn_prelu_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(mean),
+         ptr(invstd), ptr(ws), M, C_, float(eps), float(momentum), 0 if training else 1, ptr(slope_t), ptr(part), int(rows),
+         ptr(conv_bias) if part is not None else None, counter.data_ptr() if counter is not None else None, ptr(residual),
+         is16(x), stream())
+    return y, mean, invstd
+
+
+def bn_prelu_bwd(x, dy, gamma, beta, mean, invstd, slope_t, dbias=None, dbias_beta=0.0):
+    C_ = x.shape[-1]
+    M = x.numel() // C_
+    if dy.dtype != x.dtype:
+        dy = cast(dy, x.dtype)
+    dx = _empty_like(x)
+    dgamma, dbeta, dslope = empty((C_,), x), empty((C_,), x), empty((1,), x)
+    ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    call('iprgan_bn_prelu_bwd', ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(slope_t), ptr(dx),
+         ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(ws), M, C_, ptr(dbias), dbias.numel() if dbias is not None else 0,
+         float(dbias_beta), is16(x), stream())
+    return dx, dgamma, dbeta, dslope
+
+
 def bn_bwd_pre(x, dz, gamma, mean, invstd, partials, dbias=None, dbias_beta=0.0):
     """The norm backward from ``conv_bwd_data_bn``'s outputs: dz (activation derivative applied) and its per-tile sums."""
     C_ = x.shape[-1]

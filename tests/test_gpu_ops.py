@@ -250,6 +250,30 @@ def test_conv_bwd_data_into_batchnorm(dev, case, tile, mode):
         _lib.set_math('fp32')
 
 
+@pytest.mark.parametrize('M,C', [(2 * 24 * 24, 64), (777, 64), (5 * 12 * 12, 256)])
+def test_batchnorm_with_fused_prelu(dev, M, C):
+    """iprgan_bn_prelu_fwd / _bwd (networks/sr_resnet.py:7,13: conv -> BatchNorm -> PReLU with one learnable slope read
+    from the device): output, dx, dgamma, dbeta, the slope gradient and the bias-gradient column sums against torch."""
+    from iprgan import ops
+    x = rnd(M, C, seed=1) * 1.5 + 0.3
+    gamma, beta = rnd(C, seed=2, scale=0.5) + 1.0, rnd(C, seed=3, scale=0.3)
+    alpha = torch.tensor([0.25])
+    xr, gr, br, ar = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_(), alpha.clone().requires_grad_()
+    y_ref = F.prelu(F.batch_norm(xr.view(M, C, 1, 1), None, None, gr, br, training=True, eps=1e-5), ar).view(M, C)
+    g = rnd(M, C, seed=4)
+    y_ref.backward(g)
+    xd, ad = x.to(dev), alpha.to(dev)
+    y, mean, invstd = ops.bn_prelu_fwd(xd, gamma.to(dev), beta.to(dev), None, None, 1e-5, 0.0, True, ad)
+    close(y, y_ref, 1e-5, 'bn+prelu fwd')
+    dbias = torch.zeros(C, device=dev)
+    dx, dg, db, da = ops.bn_prelu_bwd(xd, g.to(dev), gamma.to(dev), beta.to(dev), mean, invstd, ad, dbias=dbias)
+    close(dx, xr.grad, 2e-4, 'bn+prelu dx')
+    close(dg, gr.grad, 2e-4, 'dgamma')
+    close(db, br.grad, 2e-4, 'dbeta')
+    close(da, ar.grad, 2e-4, 'dslope')
+    assert float(dbias.abs().max()) <= 1e-3 * float(xr.grad.abs().max()) * M ** 0.5
+
+
 @pytest.mark.parametrize('rows,cols', [(64, 27), (512, 2304), (1, 32768), (128, 2048)])
 def test_spectral_norm(dev, rows, cols):
     from iprgan import ops
