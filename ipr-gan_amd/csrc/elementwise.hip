@@ -569,7 +569,27 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float omb1
   const float* __restrict__ g = t.g[ti];
   float* __restrict__ m = t.m[ti];
   float* __restrict__ v = t.v[ti];
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+  // 16-byte accesses where the four arrays allow it (the scalar loop moved 2.7 TB/s on the 19 M-element tensors of D96
+  // and of the DCGAN-128 generator; the arithmetic per element is unchanged)
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  long long n4 = 0;
+  if (((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) | reinterpret_cast<size_t>(v)) & 15) == 0)
+    n4 = n / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f4 g4 = ((const f4*)g)[i], p4 = ((const f4*)p)[i], m4 = ((const f4*)m)[i], v4 = ((const f4*)v)[i];
+    f4 po, mo, vo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gi = g4[k] * grad_scale;
+      if (weight_decay != 0.f) gi += weight_decay * p4[k];
+      const float mi = m4[k] + (gi - m4[k]) * omb1;
+      const float vi = v4[k] * beta2 + omb2 * gi * gi;
+      mo[k] = mi; vo[k] = vi;
+      po[k] = p4[k] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+    ((f4*)m)[i] = mo; ((f4*)v)[i] = vo; ((f4*)p)[i] = po;
+  }
+  for (long long i = n4 * 4 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     float gi = g[i] * grad_scale;       // 1/world of the summed data-parallel gradient (1 on a single GPU)
     const float pi = p[i];
@@ -897,7 +917,7 @@ static int adam_launch(float* const* params, const float* const* grads, float* c
       t.n[i] = sizes[b + i];
       if (t.n[i] > maxn) maxn = t.n[i];
     }
-    const int gx = grid_for((size_t)maxn, 256);
+    const int gx = grid_for((size_t)maxn / 4 + 1, 1024);          // (16-byte accesses: four elements per thread and round)
     hipLaunchKernelGGL(adam_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, t,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
                        (float)weight_decay, step_size, bc2_sqrt, (float)grad_scale, coef);
