@@ -746,6 +746,7 @@ def test_dcgan128_bf16_steps_vs_reference_golden(golden, dev, mode):
         res = cases.run_dcgan_steps(Config, models, [dev], n_steps=2, batch=8, seed=91, cfg=cases.DCGAN128_CFG, size=128)
     finally:
         _lib.set_math('fp32')
+    worst = 0.0
     for k in ref.files:
         if '/metric/' in k:
             assert abs(float(res[k]) - float(ref[k])) < 3e-2, (k, float(res[k]), float(ref[k]))
@@ -754,6 +755,13 @@ def test_dcgan128_bf16_steps_vs_reference_golden(golden, dev, mode):
             n_est = abs(b) / max(1e-30, float(np.abs(ref[k.replace('::asum', '::samp')]).mean()))     # ~ element count
             vector = n_est <= 1024          # BatchNorm weight / bias (64..512 channels); the smallest weight tensor has 1728
             assert abs(a - b) <= (8e-2 if vector else 5e-2) * abs(b) + 1e-6, (k, a, b)
+            # ... and element-wise on the fixture's strided samples: every sampled entry within 10 % of
+            # the tensor's largest sampled entry (measured over both modes: weights <= 4.2 %, vectors <= 6.5 %)
+            ks = k.replace('::asum', '::samp')
+            rs, fs = np.asarray(res[ks], np.float64), np.asarray(ref[ks], np.float64)
+            worst = max(worst, float(np.abs(rs - fs).max()) / max(float(np.abs(fs).max()), 1e-30))
+            assert float(np.abs(rs - fs).max()) <= 0.10 * float(np.abs(fs).max()) + 1e-7, (ks, float(np.abs(rs - fs).max()), float(np.abs(fs).max()))
+    print(f'bf16 step-0 moments ({mode}): largest sampled deviation {worst:.3f} of the tensor scale')
     a, b = res['step0/fake_sample'].astype(np.float64), ref['step0/fake_sample'].astype(np.float64)
     assert np.linalg.norm(a - b) / np.linalg.norm(b) < 3e-2
     assert float(res['final/ber']) == 0.0
