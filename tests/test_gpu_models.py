@@ -277,6 +277,13 @@ def step_policy(steps, lr=2e-4):
         if k.startswith(('final/optG', 'final/optD')):
             return (0.1, 1e-3, 'scale')
         net = k.split('/')[1] if k.count('/') >= 2 else ''
+        if k.startswith('final/') and leaf in ('running_mean', 'running_var'):
+            # BatchNorm statistics of the LAST step: the activations they average were produced by weights that the first
+            # Adam step moved by +-lr wherever the gradient is rounding noise (see the weights' slack below), which shifts
+            # a channel mean of the 128x128 generator by up to ~1e-2 and the running value (momentum 0.1) by ~1e-3: one
+            # entry of 256 at 1.46e-3 observed in one of eight full-suite runs (the tile the autotuner picks decides which
+            # gradients round which way) against the 1e-3 this policy used to allow
+            return (2e-2, 3e-3)
         if k.startswith('final/') and net in ('G', 'D', 'GA', 'GB', 'DA', 'DB') and leaf not in cases.BUFFER_LEAVES:
             # (CycleGAN's four networks included: the bias of a convolution that feeds an InstanceNorm has a zero true
             # gradient, Adam turns its rounding noise into +-lr moves - up to 1.05 lr on the second step - and the two
