@@ -727,13 +727,15 @@ def test_cyclegan_step0_moments_split_rounding_from_error(golden, dev):
     layers and, through fake_A = GB(real_B), every gradient of GB - moves by 0.5 %, nothing else moves at all (the per-network
     test_net_accuracy_against_float64 shows the engine in the same accuracy class as the fp32 oracle on the same PatchGAN
     at batch 1: 1.7e-7 vs 8e-8).  Bounds: every tensor within 4x of the reference's deviation + 1 % (one flip), per
-    optimizer within 8x + 5e-3, and at least 45 % of each optimizer's tensors as close to the float64 gradients as the
-    reference itself (2x + 5e-6) - a systematic loss of accuracy would fail the last bound, a flip cannot."""
+    optimizer within 8x + 5e-3, and at least a quarter of each optimizer's tensors as close to the float64 gradients as the
+    reference itself (2x + 5e-6; observed: 51 of 105 and 10 of 14) - a systematic loss of accuracy would fail the last
+    bound; one flip (which takes out at most the tensors upstream of it in ONE generator / discriminator pair) cannot, and
+    a second one in the other pair still leaves the quarter."""
     from iprgan import Config, models
     ref = golden('cyclegan_steps_wbox')
     o64 = _cyclegan_step0_moments_fp64()
     res = cases.run_cyclegan_steps(Config, models, [dev], n_steps=1)
-    _split_rounding_from_error(o64, res, ref, ('optG', 'optD'), 8.0, 5e-3, 4.0, 1e-2, tight_share=0.45)
+    _split_rounding_from_error(o64, res, ref, ('optG', 'optD'), 8.0, 5e-3, 4.0, 1e-2, tight_share=0.25)
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'bf16act'])
