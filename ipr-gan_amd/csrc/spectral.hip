@@ -125,6 +125,7 @@ struct SNTable {
   float* u_out[SN_MAX_LAYERS];      // this pass's copies (later passes overwrite u, v)
   float* v_out[SN_MAX_LAYERS];
   int rows[SN_MAX_LAYERS], cols[SN_MAX_LAYERS], nsplit[SN_MAX_LAYERS], rps[SN_MAX_LAYERS];
+  int csplit[SN_MAX_LAYERS];        // > 1: W v of this (few-row, wide) layer is summed over column chunks by blockIdx.z
   long long ws_off[SN_MAX_LAYERS];  // per layer: tpart [SN_MAX_RSPLIT*cols] then s [rows]
   int n;
 };
@@ -254,31 +255,52 @@ __global__ __launch_bounds__(1024) void snm_vscale_kernel(const SNTable t, float
     }
   }
 }
+// column chunks of a few-row, wide layer (the 1 x 131072 Linear head at 128x128: one block walked the row for 38 us):
+// partial dot products per (row, chunk), summed in chunk order by snm_u_kernel
+constexpr int SNW_MAX_CSPLIT = 16, SNW_SPLIT_ROWS = 8;
+__device__ __forceinline__ float* snw_part(const SNTable& t, float* ws, int l) {
+  return ws + t.ws_off[l] + (size_t)SN_MAX_RSPLIT * t.cols[l] + t.rows[l] + 16 + SNV_MAX_BLOCKS;
+}
 __global__ __launch_bounds__(256) void snm_wv_kernel(const SNTable t, float* __restrict__ ws) {
   __shared__ float sh[16];
   const int l = blockIdx.y, row = blockIdx.x;
-  const int cols = t.cols[l];
-  if (row >= t.rows[l]) return;
+  const int cols = t.cols[l], cs = t.csplit[l];
+  if (row >= t.rows[l] || (int)blockIdx.z >= cs) return;
   const float* wr = t.w[l] + (size_t)row * cols;
   const float* v = t.v[l];
+  // chunk of this block: multiples of 1024 columns so that the 16-byte path keeps its alignment
+  const int per = cs > 1 ? ((cols + cs - 1) / cs + 1023) / 1024 * 1024 : cols;
+  const int j0 = (int)blockIdx.z * per, j1 = j0 + per < cols ? j0 + per : cols;
   float acc = 0.f;
   if ((cols & 3) == 0) {
-    for (int j = threadIdx.x * 4; j < cols; j += 1024) {
+    for (int j = j0 + threadIdx.x * 4; j < j1; j += 1024) {
       const float4 a = *(const float4*)(wr + j), b = *(const float4*)(v + j);
       acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
     }
   } else {
-    for (int j = threadIdx.x; j < cols; j += 256) acc += wr[j] * v[j];
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) acc += wr[j] * v[j];
   }
   acc = block_sum(acc, sh);
-  if (threadIdx.x == 0) ws[t.ws_off[l] + (size_t)SN_MAX_RSPLIT * cols + row] = acc;
+  if (threadIdx.x == 0) {
+    if (cs > 1) snw_part(t, ws, l)[row * SNW_MAX_CSPLIT + blockIdx.z] = acc;
+    else ws[t.ws_off[l] + (size_t)SN_MAX_RSPLIT * cols + row] = acc;
+  }
 }
 __global__ __launch_bounds__(1024) void snm_u_kernel(const SNTable t, const float* __restrict__ ws, float eps,
                                                       float* __restrict__ sigma, int training) {
   __shared__ float sh[16];
   const int l = blockIdx.x;
   const int rows = t.rows[l], cols = t.cols[l];
-  const float* s = ws + t.ws_off[l] + (size_t)SN_MAX_RSPLIT * cols;
+  float* s = const_cast<float*>(ws) + t.ws_off[l] + (size_t)SN_MAX_RSPLIT * cols;
+  if (t.csplit[l] > 1) {               // column-chunk partials of W v -> s[row], in chunk order
+    if ((int)threadIdx.x < rows) {
+      const float* part = snw_part(t, const_cast<float*>(ws), l) + threadIdx.x * SNW_MAX_CSPLIT;
+      float a = 0.f;
+      for (int z = 0; z < t.csplit[l]; ++z) a += part[z];
+      s[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
   float* u = t.u[l];
   float* uo = t.u_out[l];
   float d = 0.f;
@@ -401,7 +423,7 @@ int iprgan_sn_power_iter(const float* w, float* u, float* v, float* sigma, float
 
 size_t iprgan_sn_multi_ws_floats(const int* rows, const int* cols, int n) {
   size_t t = 0;
-  for (int i = 0; i < n; ++i) t += (size_t)SN_MAX_RSPLIT * cols[i] + rows[i] + 16 + SNV_MAX_BLOCKS;
+  for (int i = 0; i < n; ++i) t += (size_t)SN_MAX_RSPLIT * cols[i] + rows[i] + 16 + SNV_MAX_BLOCKS + SNW_SPLIT_ROWS * SNW_MAX_CSPLIT;
   return t;
 }
 
@@ -414,7 +436,7 @@ int iprgan_sn_power_iter_multi(const float* const* w, float* const* u, float* co
   memset(&t, 0, sizeof(t));
   t.n = n;
   long long off = 0;
-  int max_cols = 0, max_rows = 0, max_split = 1;
+  int max_cols = 0, max_rows = 0, max_split = 1, max_csplit = 1;
   for (int i = 0; i < n; ++i) {
     t.w[i] = w[i]; t.u[i] = u[i]; t.v[i] = v[i];
     t.u_out[i] = u_out ? u_out[i] : nullptr; t.v_out[i] = v_out ? v_out[i] : nullptr;
@@ -425,10 +447,16 @@ int iprgan_sn_power_iter_multi(const float* const* w, float* const* u, float* co
     t.rps[i] = cdiv(rows[i], ns);
     t.nsplit[i] = cdiv(rows[i], t.rps[i]);
     t.ws_off[i] = off;
-    off += (long long)SN_MAX_RSPLIT * cols[i] + rows[i] + 16 + SNV_MAX_BLOCKS;
+    off += (long long)SN_MAX_RSPLIT * cols[i] + rows[i] + 16 + SNV_MAX_BLOCKS + SNW_SPLIT_ROWS * SNW_MAX_CSPLIT;
     if (cols[i] > max_cols) max_cols = cols[i];
     if (rows[i] > max_rows) max_rows = rows[i];
     if (t.nsplit[i] > max_split) max_split = t.nsplit[i];
+    t.csplit[i] = 1;
+    if (rows[i] <= SNW_SPLIT_ROWS && cols[i] >= 16384) {
+      int cs = cols[i] / 8192;
+      t.csplit[i] = cs > SNW_MAX_CSPLIT ? SNW_MAX_CSPLIT : cs;
+    }
+    if (t.csplit[i] > max_csplit) max_csplit = t.csplit[i];
   }
   if (training) {
     hipLaunchKernelGGL(snm_wtu_kernel, dim3(cdiv(max_cols, 256), max_split, n), dim3(256), 0, st, t, ws);
@@ -443,7 +471,7 @@ int iprgan_sn_power_iter_multi(const float* const* w, float* const* u, float* co
     }
     IPR_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(snm_wv_kernel, dim3(max_rows, n), dim3(256), 0, st, t, ws);
+  hipLaunchKernelGGL(snm_wv_kernel, dim3(max_rows, n, max_csplit), dim3(256), 0, st, t, ws);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(snm_u_kernel, dim3(n), dim3(1024), 0, st, t, ws, eps, sigma, training);
   IPR_LAUNCH_CHECK();
