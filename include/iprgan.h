@@ -353,7 +353,7 @@ int iprgan_prof_get_layer(int i, char* name, int name_len, long long* launches, 
  * rounded to bf16 (nearest-even) when staged into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32
  * accumulation; layers with fewer than 32 (padded) input channels keep the fp32 kernel.  Norms, losses, spectral
  * norm and Adam are fp32 in both modes. */
-enum { IPRGAN_MATH_FP32 = 0, IPRGAN_MATH_BF16 = 1 };
+enum { IPRGAN_MATH_FP32 = 0, IPRGAN_MATH_BF16 = 1, IPRGAN_MATH_FP32X3 = 2 };
 int iprgan_set_math_mode(int mode);
 int iprgan_get_math_mode(void);
 

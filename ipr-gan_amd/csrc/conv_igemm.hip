@@ -40,6 +40,7 @@ static ProfSlot g_slots[] = {
     {"wgrad_halo_kernel", 0, 0, 0},     {"wgrad_rgb_kernel", 0, 0, 0},
     {"gconv_pipe_f32_kernel", 0, 0, 0}, {"gconv_phase4_kernel", 0, 0, 0},
     {"wgrad_halo_f32_kernel", 0, 0, 0}, {"gconv_pipe8_kernel", 0, 0, 0},
+    {"gconv_x3_kernel", 0, 0, 0},       {"wgrad_x3_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; int tag; };
@@ -101,10 +102,18 @@ bool prof_events(int slot, double flops, hipEvent_t* start, hipEvent_t* stop) {
 // IN16 (math mode 2, "bf16 activations"): both operands ARE bf16 in HBM (activations with C4 % 32 == 0 are stored as
 // bf16 by every producer, prepared weights are emitted as bf16): a 16-byte load is 8 K-elements and goes to the LDS
 // image as it is - half the loader bytes of the fp32-in-HBM form, no conversion in the staging path.
-template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false, bool STATS = false, bool IN16 = false>
+// SPLIT (math mode 2, "fp32 as three bf16 terms"): fp32 operands, fp32-grade products, on the bf16 matrix pipe.  Every
+// element is split on its way into LDS into x = h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 3 x 8
+// mantissa bits, the subtractions are exact), three bf16 images per operand, and a product a * b is accumulated as the
+// six terms l*h' + h*l' + m*m' + m*h' + h*m' + h*h' (small first; m*l', l*m', l*l' are below 2^-26 of the product and
+// dropped).  Six v_mfma_f32_32x32x16_bf16 (8 passes for 16 k) replace eight v_mfma_f32_32x32x2_f32 (16 passes for 2 k
+// each): 6 x 8 = 48 matrix-pipe passes per 16 k instead of 128, with the accumulation in fp32 as before.
+template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false, bool STATS = false, bool IN16 = false, bool SPLIT = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a) {
   static_assert(!BF16 || BK == 32 || BK == 64 || BK == 128, "bf16 tiles: K steps of 32, 64 or 128");
   static_assert(!IN16 || (BF16 && FAST), "bf16 operands in HBM: bf16 tiles on the one-tap-per-step path");
+  static_assert(!SPLIT || (BF16 && FAST && !IN16), "split tiles: fp32 operands in HBM on the bf16 image");
+  constexpr int NPL = SPLIT ? 3 : 1;            // bf16 images per operand
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;            // threads: one wave per (32*WM)x(32*WN) sub-tile
   constexpr int CH = IN16 ? BK / 8 : BK / 4;    // 16-byte chunks per tile row the LOADER handles (K step = BK elements)
@@ -113,7 +122,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   constexpr int RP = NT / CH;                   // tile rows loaded per pass of the block
   constexpr int RA = BM / RP, RB = BN / RP;
   constexpr int CHB = BK / 8;                   // bf16 mode: 16-byte chunks per tile row
-  constexpr int TILE4 = (BM + BN) * (BF16 ? CHB : CH);         // 16-byte chunks per stage buffer
+  constexpr int PLANE4 = (BM + BN) * (BF16 ? CHB : CH);        // 16-byte chunks of one image pair (A rows, then B rows)
+  constexpr int TILE4 = NPL * PLANE4;                          // 16-byte chunks per stage buffer
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
 
   // logical tile order (see xcd_remap): n tiles fastest, then the sub-pixel phases, then m tiles, so the
@@ -267,6 +277,27 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
       }
       return;
     }
+    if (SPLIT) {                 // three images (h, m, l) of the bf16 layout below
+      bf16x4* A8 = (bf16x4*)(lds + buf * TILE4);
+      bf16x4* B8 = A8 + BM * CHB * 2;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int r = lrow + RP * i;
+        bf16x4 t3[3];
+        split3_bf16(ra[i], t3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) A8[p * PLANE4 * 2 + (r * CHB + ((chunk >> 1) ^ swzb(r))) * 2 + (chunk & 1)] = t3[p];
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int r = lrow + RP * i;
+        bf16x4 t3[3];
+        split3_bf16(rb[i], t3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) B8[p * PLANE4 * 2 + (r * CHB + ((chunk >> 1) ^ swzb(r))) * 2 + (chunk & 1)] = t3[p];
+      }
+      return;
+    }
     if (BF16) {                  // this thread's 4 floats are half of 16-byte chunk (chunk >> 1)
       bf16x4* A8 = (bf16x4*)(lds + buf * TILE4);
       bf16x4* B8 = A8 + BM * CHB * 2;
@@ -297,6 +328,40 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
   };
   auto compute = [&](int buf) {
     const int half = lane >> 5, l31 = lane & 31;
+    if (SPLIT) {
+      const bf16x8* A16 = (const bf16x8*)(lds + buf * TILE4);
+      const bf16x8* B16 = A16 + BM * CHB;
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 af[3][WM], bf[3][WN];
+        const int c = 2 * kk + half;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < WM; ++i) {
+            const int r = (wm * WM + i) * 32 + l31;
+            af[p][i] = A16[p * PLANE4 + r * CHB + (c ^ swzb(r))];
+          }
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const int r = (wn * WN + j) * 32 + l31;
+            bf[p][j] = B16[p * PLANE4 + r * CHB + (c ^ swzb(r))];
+          }
+        }
+        // (A term, B term): l h', h l', m m', m h', h m', h h' - consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          const int pa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+          const int pb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+        }
+      }
+      return;
+    }
     if (BF16) {
       const bf16x8* A16 = (const bf16x8*)(lds + buf * TILE4);
       const bf16x8* B16 = A16 + BM * CHB;
@@ -895,10 +960,12 @@ __device__ __forceinline__ bf16x8 wg_tr_read8(const char* base, unsigned off0, u
   return u.v;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = false, bool IN16 = false>
+// SPLIT (math mode 2): three bf16 images (h, m, l) per operand and six MFMAs per product block, as in gconv_kernel.
+template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = false, bool IN16 = false, bool SPLIT = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a) {
   static_assert(!BF16 || (WGM * WM == 4 && WGN * WN == 4), "the bf16 wgrad image is written for 128x128 tiles");
   static_assert(!IN16 || BF16, "bf16 operands in HBM need the bf16 image");
+  static_assert(!SPLIT || (BF16 && !IN16), "split tiles: fp32 operands in HBM on the bf16 image");
   constexpr int BN = WGM * WM * 32;   // tile over n (P channels)  -> MFMA rows
   constexpr int BK = WGN * WN * 32;   // tile over k (tap,c)       -> MFMA cols
   constexpr int EPC = IN16 ? 8 : 4;                // elements per loader chunk (IN16: P and Q are bf16 tensors, 16-byte chunks of 8)
@@ -1014,6 +1081,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
       for (int i = 0; i < NQ; ++i) *(f32x4*)(Qb + wg_bf16_off(rq + RPQ * i, cq)) = rQ[i];
       return;
     }
+    if (SPLIT) {              // stage = 3 P images, then 3 Q images, of 8 KB each
+      char* Pb = (char*)lds + buf * 49152;
+      char* Qb = Pb + 24576;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        bf16x4 t3[3];
+        split3_bf16(rP[i], t3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *(bf16x4*)(Pb + p * 8192 + wg_bf16_off(rp + RPP * i, cp >> 1) + 8 * (cp & 1)) = t3[p];
+      }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        bf16x4 t3[3];
+        split3_bf16(rQ[i], t3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *(bf16x4*)(Qb + p * 8192 + wg_bf16_off(rq + RPQ * i, cq >> 1) + 8 * (cq & 1)) = t3[p];
+      }
+      return;
+    }
     if (BF16) {               // stage = two [32][128] bf16 images of 8 KB
       char* Pb = (char*)lds + buf * 16384;
       char* Qb = Pb + 8192;
@@ -1034,6 +1120,40 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
   };
   auto compute = [&](int buf) {
     const int half = lane >> 5, l31 = lane & 31;
+    if (SPLIT) {
+      const char* Pb = (const char*)lds + buf * 49152;
+      const char* Qb = Pb + 24576;
+      const int gq = (lane & 15) >> 2, gp = lane & 3, gcol = (lane >> 4) & 1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int r0 = 16 * kk + 8 * half + gq;
+        bf16x8 af[3][WM], bf[3][WN];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < WM; ++i) {
+            const int ch = (wm * WM + i) * 4 + 2 * gcol + (gp >> 1);
+            af[p][i] = wg_tr_read8(Pb + p * 8192, wg_bf16_off(r0, ch) + 8 * (gp & 1), wg_bf16_off(r0 + 4, ch) + 8 * (gp & 1));
+          }
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const int ch = (wn * WN + j) * 4 + 2 * gcol + (gp >> 1);
+            bf[p][j] = wg_tr_read8(Qb + p * 8192, wg_bf16_off(r0, ch) + 8 * (gp & 1), wg_bf16_off(r0 + 4, ch) + 8 * (gp & 1));
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {           // l h', h l', m m', m h', h m', h h'
+          const int pa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+          const int pb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+        }
+      }
+      return;
+    }
     if (BF16) {
       const char* Pb = (const char*)lds + buf * 16384;
       const char* Qb = Pb + 8192;
@@ -1709,14 +1829,14 @@ static int g_nbuf = getenv("IPRGAN_LDS_BUFS") ? atoi(getenv("IPRGAN_LDS_BUFS")) 
 
 static thread_local int t_last_bm = 0;      // M tile of the last gconv launch of this thread (partial-row count of STATS launches)
 
-template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false, bool STATS = false, bool IN16 = false>
+template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF16 = false, bool STATS = false, bool IN16 = false, bool SPLIT = false>
 static int launch_gconv_tfnk(const GConvArgs& a, hipStream_t st) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   if (maxM == 0) return 0;
-  const size_t smem = NBUF * (size_t)(BM + BN) * (BF16 ? BK / 8 : BK / 4) * sizeof(f32x4);
-  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST, NBUF, BK, BF16, STATS, IN16>;
+  const size_t smem = NBUF * (size_t)(BM + BN) * (BF16 ? BK / 8 : BK / 4) * sizeof(f32x4) * (SPLIT ? 3 : 1);
+  auto kern = gconv_kernel<WGM, WGN, WM, WN, FAST, NBUF, BK, BF16, STATS, IN16, SPLIT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1725,7 +1845,7 @@ static int launch_gconv_tfnk(const GConvArgs& a, hipStream_t st) {
   dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.ksplit > 1 ? a.ksplit : a.nphase);
   t_last_bm = BM;
   prof_launch(kern, grid, dim3(WGM * WGN * 64), smem, st,
-              BF16 ? 12 : WGM * WGN == 8 ? (BN == 128 ? 9 : 10) : BM == 128 ? (BN == 128 ? 0 : (BN == 64 ? 1 : 3)) : (BN == 128 ? 8 : 2),
+              SPLIT ? 27 : BF16 ? 12 : WGM * WGN == 8 ? (BN == 128 ? 9 : 10) : BM == 128 ? (BN == 128 ? 0 : (BN == 64 ? 1 : 3)) : (BN == 128 ? 8 : 2),
               a.flops, a);
   IPR_LAUNCH_CHECK();
   return 0;
@@ -1740,6 +1860,9 @@ static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
   if (a.in16)        // bf16 operands in HBM: 64-deep K steps (8 loader chunks per row)
     return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, true, true>(a, st)
                        : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, false, true>(a, st);
+  if (g_math == IPRGAN_MATH_FP32X3 && fast)       // fp32 operands as three bf16 terms each, six bf16 MFMAs per product block
+    return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, true, false, true>(a, st)
+                       : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, false, false, true>(a, st);
   if (g_math == IPRGAN_MATH_BF16 && fast) {
     // the bf16 MFMA retires a 32-deep K step in a quarter of the fp32 time, so the two barriers per step dominate:
     // deeper steps (more MFMAs per barrier pair) when the channel count allows a step to stay inside one tap
@@ -1764,6 +1887,11 @@ static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
 // 16 (50 %).  (The fp32 MFMA is 4x slower per fragment, so the fp32 tiles are nowhere near this limit.)
 template <int WGM, int WGN, int WM, int WN>
 static int launch_gconv_bf16big(const GConvArgs& a, hipStream_t st) {
+  if constexpr (WM * WN <= 8) {
+    if (g_math == IPRGAN_MATH_FP32X3 && (a.Cs % 32) == 0 && a.Ns >= WGN * WN * 32)
+      return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, true, false, true>(a, st)
+                         : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, false, false, true>(a, st);
+  }
   if (g_math != IPRGAN_MATH_BF16 || (a.Cs % 64) != 0 || a.Ns < WGN * WN * 32) return -1;
   if (a.in16)
     return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, true, true>(a, st)
@@ -2183,7 +2311,7 @@ static const int g_rgb_targets[WGRAD_NRGB] = {256, 512};
 static const int g_halo_targets[3] = {128, 256, 512};
 static bool wgrad_halo_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_BF16 && wgrad_halo_eligible(d); }
 static bool wgrad_rgb_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_BF16 && wgrad_rgb_eligible(d); }
-static bool wgrad_h32_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_FP32 && wgrad_halo_f32_eligible(d); }
+static bool wgrad_h32_ok(const iprgan_conv_desc* d) { return g_math != IPRGAN_MATH_BF16 && wgrad_halo_f32_eligible(d); }
 
 static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that fits every candidate
   size_t m = 0;
@@ -2217,11 +2345,11 @@ static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that
   return m;
 }
 
-template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = false, bool IN16 = false>
+template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = false, bool IN16 = false, bool SPLIT = false>
 static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
   constexpr int BN = WGM * WM * 32, BK = WGN * WN * 32;
-  const size_t smem = NBUF * (size_t)32 * (BN + BK) * (BF16 ? 2 : sizeof(float));
-  auto kern = wgrad_kernel<WGM, WGN, WM, WN, NBUF, REFLECT, BF16, IN16>;
+  const size_t smem = NBUF * (size_t)32 * (BN + BK) * (SPLIT ? 6 : BF16 ? 2 : sizeof(float));
+  auto kern = wgrad_kernel<WGM, WGN, WM, WN, NBUF, REFLECT, BF16, IN16, SPLIT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -2229,7 +2357,7 @@ static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t s
   }
   dim3 grid(p.Kw / BK, p.Nrows / BN, p.nsplit);
   prof_launch(kern, grid, dim3(WGM * WGN * 64), smem, st,
-              BF16 ? 13 : WGM * WGN == 8 ? 11 : BN == 128 ? (BK == 128 ? 4 : 5) : (BN == 64 ? 6 : 7), a.flops, a);
+              SPLIT ? 28 : BF16 ? 13 : WGM * WGN == 8 ? 11 : BN == 128 ? (BK == 128 ? 4 : 5) : (BN == 64 ? 6 : 7), a.flops, a);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -2241,6 +2369,9 @@ static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st
     if (g_math == IPRGAN_MATH_BF16)
       return a.pad_mode == IPRGAN_PAD_REFLECT ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true, true>(a, p, st)
                                               : launch_wgrad_tn<WGM, WGN, WM, WN, 1, false, true>(a, p, st);
+    if (g_math == IPRGAN_MATH_FP32X3 && !a.p16 && !a.q16)
+      return a.pad_mode == IPRGAN_PAD_REFLECT ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true, true, false, true>(a, p, st)
+                                              : launch_wgrad_tn<WGM, WGN, WM, WN, 1, false, true, false, true>(a, p, st);
   }
   if (a.pad_mode == IPRGAN_PAD_REFLECT)
     return g_nbuf == 1 ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true>(a, p, st)
@@ -2730,7 +2861,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
 }
 
 int iprgan_set_math_mode(int mode) {
-  IPR_CHECK(mode == IPRGAN_MATH_FP32 || mode == IPRGAN_MATH_BF16, "set_math_mode: unknown mode %d", mode);
+  IPR_CHECK(mode == IPRGAN_MATH_FP32 || mode == IPRGAN_MATH_BF16 || mode == IPRGAN_MATH_FP32X3, "set_math_mode: unknown mode %d", mode);
   g_math = mode;
   return 0;
 }

@@ -27,6 +27,15 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 f) {      // round-to-nearest-
   const bf16x4 v = {(__bf16)f.x, (__bf16)f.y, (__bf16)f.z, (__bf16)f.w};
   return v;
 }
+// x = h + m + l, three bf16 terms (nearest-even each; the two subtractions are exact in fp32): t[0] = h, t[1] = m, t[2] = l
+__device__ __forceinline__ void split3_bf16(f32x4 f, bf16x4 (&t)[3]) {
+  t[0] = to_bf16x4(f);
+  const f32x4 h = {(float)t[0].x, (float)t[0].y, (float)t[0].z, (float)t[0].w};
+  const f32x4 r1 = f - h;
+  t[1] = to_bf16x4(r1);
+  const f32x4 m = {(float)t[1].x, (float)t[1].y, (float)t[1].z, (float)t[1].w};
+  t[2] = to_bf16x4(r1 - m);
+}
 // 4 consecutive bf16 elements (element index idx of a tensor whose storage type is bf16) -> 4 floats
 __device__ __forceinline__ f32x4 ld_bf16x4(const float* base, size_t idx) {
   const bf16x4 h = *(const bf16x4*)((const __bf16*)base + idx);

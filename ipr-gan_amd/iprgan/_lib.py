@@ -137,6 +137,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
         _lib = lib
+        if _FP32_VIA_X3:
+            lib.iprgan_set_math_mode(MATH_MODES['fp32x3'])
     return _lib
 
 
@@ -219,7 +221,10 @@ def prof_layers():
     return out
 
 
-MATH_MODES = {'fp32': 0, 'bf16': 1, 'bf16act': 1}
+MATH_MODES = {'fp32': 0, 'bf16': 1, 'bf16act': 1, 'fp32x3': 2}
+# validation switch: every 'fp32' request (and the library default) runs as 'fp32x3', so that the whole GPU suite, with its
+# fp32 tolerances, can be pointed at the split-operand tiles: IPRGAN_FP32_VIA_X3=1 python -m pytest tests -m gpu
+_FP32_VIA_X3 = os.environ.get('IPRGAN_FP32_VIA_X3', '0') == '1'
 _act_bf16 = False
 
 
@@ -227,8 +232,13 @@ def set_math(mode):
     """Process-wide math mode of the conv family (include/iprgan.h: iprgan_set_math_mode): 'fp32' (default), 'bf16'
     (bf16 MFMA tiles, fp32 accumulation, fp32 tensors and master weights in HBM) or 'bf16act' (the same tiles, and
     activations whose padded channel count is a multiple of 64 LIVE as bf16 in HBM: half the activation traffic, operands
-    reach LDS without a conversion; DCGAN-family layers only this round)."""
+    reach LDS without a conversion; DCGAN-family layers only this round).  'fp32x3': fp32 tensors and fp32-grade
+    products on the bf16 matrix pipe - every operand element is split into three bf16 terms while it is staged into LDS and
+    a product block is six bf16 MFMAs (conv_igemm.hip: SPLIT); layers whose channel count is not a multiple of 32 keep the
+    fp32 MFMA."""
     global _math_cached, _act_bf16
+    if _FP32_VIA_X3 and mode in ('fp32', 0):
+        mode = 'fp32x3'
     _act_bf16 = mode == 'bf16act'
     _math_cached = MATH_MODES[mode] if isinstance(mode, str) else int(mode)
     call('iprgan_set_math_mode', _math_cached)
@@ -239,7 +249,7 @@ def act_bf16():
     return _act_bf16
 
 
-_math_cached = 0
+_math_cached = 2 if _FP32_VIA_X3 else 0
 
 
 def get_math_cached():
@@ -248,4 +258,4 @@ def get_math_cached():
 
 
 def get_math():
-    return 'bf16act' if _act_bf16 else {0: 'fp32', 1: 'bf16'}[load().iprgan_get_math_mode()]
+    return 'bf16act' if _act_bf16 else {0: 'fp32', 1: 'bf16', 2: 'fp32x3'}[load().iprgan_get_math_mode()]

@@ -64,8 +64,8 @@ def apply_engine(config, set_math=True):
     if unknown:
         raise ValueError(f'engine: unknown key(s) {unknown}; known: {list(ENGINE_KEYS)}')
     if 'math' in blk:
-        if blk['math'] not in ('fp32', 'bf16', 'bf16act'):
-            raise ValueError(f"engine.math: {blk['math']!r} (fp32 | bf16 | bf16act)")
+        if blk['math'] not in ('fp32', 'bf16', 'bf16act', 'fp32x3'):
+            raise ValueError(f"engine.math: {blk['math']!r} (fp32 | bf16 | bf16act | fp32x3)")
         if set_math:
             from . import _lib
             _lib.set_math(blk['math'])
