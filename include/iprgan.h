@@ -352,7 +352,12 @@ int iprgan_prof_get_layer(int i, char* name, int name_len, long long* launches, 
  * BF16 (BASELINE config "DCGAN 128x128 bs256 bf16"): tensors and master weights stay fp32 in HBM, tiles are
  * rounded to bf16 (nearest-even) when staged into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32
  * accumulation; layers with fewer than 32 (padded) input channels keep the fp32 kernel.  Norms, losses, spectral
- * norm and Adam are fp32 in both modes. */
+ * norm and Adam are fp32 in both modes.
+ * FP32X3: fp32 tensors, fp32-grade products on the bf16 matrix pipe: layers with (padded) input channels % 32 == 0 split
+ * every operand element into three bf16 terms while staging it into LDS (x = h + m + l, exact) and accumulate a product
+ * block from six bf16 MFMAs (l h' + h l' + m m' + m h' + h m' + h h', fp32 accumulator); the dropped terms are below
+ * 2^-26 of a product, the distance to a float64 convolution is that of the fp32 MFMA or smaller (tests/test_gpu_x3.py).
+ * All other layers and kernels run as in FP32. */
 enum { IPRGAN_MATH_FP32 = 0, IPRGAN_MATH_BF16 = 1, IPRGAN_MATH_FP32X3 = 2 };
 int iprgan_set_math_mode(int mode);
 int iprgan_get_math_mode(void);

@@ -40,7 +40,7 @@ class Config(object):
 # before it builds the model (every key is optional, the defaults are the environment-variable defaults):
 #
 #   engine:
-#     math: bf16act          # fp32 | bf16 | bf16act           (iprgan_set_math_mode, include/iprgan.h)
+#     math: bf16act          # fp32 | fp32x3 | bf16 | bf16act           (iprgan_set_math_mode, include/iprgan.h)
 #     bucket_mb: 8           # gradient bucket size of the N > 1 reducer           (IPRGAN_BUCKET_MB)
 #     comm: rccl             # rccl (C-ABI communicator) | torch (torch.distributed) (IPRGAN_COMM)
 #     comm_timeout: 90       # seconds allowed for the RCCL bring-up               (IPRGAN_COMM_TIMEOUT)
