@@ -35,11 +35,13 @@ prof_workload dcgan64 ${TAG} fp32 --steps 20 --warmup 8
 prof_workload srgan ${TAG}_srgan fp32 --steps 8 --warmup 4
 prof_workload cyclegan ${TAG}_cyclegan fp32 --steps 4 --warmup 2
 prof_workload dcgan128 ${TAG}_dcgan128_bf16act bf16act --steps 8 --warmup 4
+prof_workload dcgan64 ${TAG}_dcgan64_fp32x3 fp32x3 --steps 20 --warmup 8
 # the counters of THIS build first, so that the bench line's roofline.traffic (read from profiles/) matches it
 python scripts/summarize_profiles.py $O/prof $TAG $R/profiles/$TAG > /dev/null
 python scripts/summarize_profiles.py $O/prof ${TAG}_srgan $R/profiles/${TAG}_srgan > /dev/null
 python scripts/summarize_profiles.py $O/prof ${TAG}_cyclegan $R/profiles/${TAG}_cyclegan > /dev/null
 python scripts/summarize_profiles.py $O/prof ${TAG}_dcgan128_bf16act $R/profiles/${TAG}_dcgan128_bf16act > /dev/null
+python scripts/summarize_profiles.py $O/prof ${TAG}_dcgan64_fp32x3 $R/profiles/${TAG}_dcgan64_fp32x3 > /dev/null
 cp $R/profiles/${TAG}*_pmc_traffic.json $R/profiles/${TAG}*_mfma_util.json $R/profiles/${TAG}*_bench_kernel_stats.csv $O/ 2>/dev/null
 timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err; cut -c1-400 $O/${TAG}_bench.json
 for w in srgan cyclegan dcgan128; do
@@ -50,6 +52,8 @@ timeout 900 python bench.py --math bf16 --no-cpu-baseline > $O/${TAG}_bench_dcga
 timeout 900 python bench.py --workload dcgan128 --math bf16act --no-cpu-baseline > $O/${TAG}_bench_dcgan128_bf16act.json 2>> $O/bench_dcgan128.err
 timeout 900 python bench.py --math bf16act --no-cpu-baseline > $O/${TAG}_bench_dcgan64_bf16act.json 2>> $O/bench.err
 timeout 600 python scripts/conv_bench.py > $O/${TAG}_conv_bench.jsonl 2> $O/conv_bench.err
+timeout 900 python bench.py --math fp32x3 --no-cpu-baseline > $O/${TAG}_bench_dcgan64_fp32x3.json 2>> $O/bench.err
+CONV_BENCH_MATH=fp32x3 timeout 600 python scripts/conv_bench.py > $O/${TAG}_conv_bench_fp32x3.jsonl 2>> $O/conv_bench.err
 # per-layer, per-tile table of the bf16 kernels at BASELINE config 5 sizes (forced tiles 8-16, halo / RGB backward-weight)
 CONV_BENCH_TILES=-1,8,10,11,12,16,17 CONV_BENCH_WGRAD=-1,0,61,67 timeout 900 python scripts/conv_bench_bf16.py > $O/${TAG}_conv_bench_bf16.jsonl 2> $O/conv_bench_bf16.err
 # per-layer tables (conv-family launches by pass + geometry) of the four workloads
@@ -70,7 +74,7 @@ unset IPRGAN_TUNE_CACHE
 python scripts/summarize_ns_pmc.py $O/prof $O/${TAG} > /dev/null 2> $O/ns_pmc.err
 # Everything judged is summarised HERE (gpurun merges at most 64 MiB back): per-workload kernel stats, HBM traffic and
 # MFMA-busy summaries into $O, then the raw per-dispatch traces and counter dumps are dropped.
-for t in $TAG ${TAG}_srgan ${TAG}_cyclegan ${TAG}_dcgan128_bf16act; do
+for t in $TAG ${TAG}_srgan ${TAG}_cyclegan ${TAG}_dcgan128_bf16act ${TAG}_dcgan64_fp32x3; do
   python scripts/summarize_profiles.py $O/prof $t $O/$t > /dev/null 2>> $O/summarize.err
 done
 find $O/prof -name '*kernel_trace.csv' -delete

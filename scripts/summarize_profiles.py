@@ -15,8 +15,10 @@ import sys
 
 def short(k):
     """rocprof kernel name -> the name bench.py reports (iprgan_prof_get slots)."""
-    m = re.match(r'void iprgan::gconv_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)(?:, (true|false))?(?:, (true|false))?(?:, (true|false))?>', k)
+    m = re.match(r'void iprgan::gconv_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)(?:, (true|false))?(?:, (true|false))?(?:, (true|false))?(?:, (true|false))?>', k)
     if m:
+        if m.group(11) == 'true':         # SPLIT: math mode fp32x3
+            return 'gconv_x3_kernel'
         if m.group(8) == 'true':
             return 'gconv_bf16_kernel'
         wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
@@ -29,8 +31,10 @@ def short(k):
     m = re.match(r'void iprgan::(wgrad_halo_f32_kernel|wgrad_halo_kernel|gconv_phase4_kernel|gconv_pipe8_kernel)<', k)
     if m:
         return m.group(1)
-    m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?(?:, (true|false))?>', k)
+    m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?(?:, (true|false))?(?:, (true|false))?>', k)
     if m:
+        if m.group(9) == 'true':
+            return 'wgrad_x3_kernel'
         if m.group(7) == 'true':
             return 'wgrad_bf16_kernel'
         wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
