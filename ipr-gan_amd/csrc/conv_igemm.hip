@@ -1825,7 +1825,6 @@ static int g_smalln = getenv("IPRGAN_SMALLN") ? atoi(getenv("IPRGAN_SMALLN")) : 
 static int g_fewin = getenv("IPRGAN_FEWIN") ? atoi(getenv("IPRGAN_FEWIN")) : 1;      // A/B switch: direct few-input-channel kernel
 static int g_math = IPRGAN_MATH_FP32;                 // iprgan_set_math_mode
 static int g_bf16_bk = getenv("IPRGAN_BF16_BK") ? atoi(getenv("IPRGAN_BF16_BK")) : 64;   // K step of the bf16 gconv tiles
-static int g_x3_ring = getenv("IPRGAN_X3_RING") ? atoi(getenv("IPRGAN_X3_RING")) : 1;    // A/B switch: fp32x3 on the LDS-DMA ring tiles (0: those stay exact fp32)
 static int g_nbuf = getenv("IPRGAN_LDS_BUFS") ? atoi(getenv("IPRGAN_LDS_BUFS")) : 1;  // wgrad_kernel only: 1 = single LDS buffer (measured faster: 3-4 blocks/CU)
 
 static thread_local int t_last_bm = 0;      // M tile of the last gconv launch of this thread (partial-row count of STATS launches)
@@ -2065,11 +2064,8 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
       case 5: return launch_gconv_t<4, 2, 1, 1>(a, st);      // 128x64, 8 waves of 32x32
       case 6: return launch_gconv_bf16big<2, 2, 4, 2>(a, st);   // bf16 only: 256x128, 4 waves of 128x64
       case 7: return launch_gconv_bf16big<2, 2, 4, 4>(a, st);   // bf16 only: 256x256, 4 waves of 128x128
-      case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17: {   // LDS-DMA ring tiles (conv_pipe.hip)
-        GConvArgs ap = a;
-        ap.korder = (g_math == IPRGAN_MATH_FP32X3 && g_x3_ring) ? 64 : 0;       // fp32x3: the ring tiles form split products too
-        return launch_gconv_pipe(ap, tile - 8, st, &t_last_bm);
-      }
+      case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17:   // LDS-DMA ring tiles (conv_pipe.hip)
+        return launch_gconv_pipe(a, tile - 8, st, &t_last_bm);
       default: return launch_gconv_t<2, 2, 1, 1>(a, st);
     }
   };

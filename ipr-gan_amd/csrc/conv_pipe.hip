@@ -289,14 +289,8 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
 // fragment, so a K step is 4096 cycles of matrix work per wave against the same 48 KB of DMA: the ring hides it entirely
 // and the kernel's job is to keep the matrix pipe issuing (no staging registers, no ds_write pass, one barrier per step).
 // ReflectionPad2d (fp32 workloads: CycleGAN) is folded into the DMA source offsets.
-// X3 (math mode fp32x3, with F32): the same fp32 ring, but the products come from the bf16 matrix pipe - a lane reads the
-// 8 fp32 of two fragment chunks (16 k of its row), splits them in registers into three bf16 terms (split3_bf16) and a
-// 32x32 block takes six v_mfma_f32_32x32x16_bf16 (l h', h l', m m', m h', h m', h h').  A and B use the same k -> element
-// mapping, so which 16 k a lane holds does not matter.  No staging registers, no ds_write pass: the split is the only
-// vector-ALU work of the K loop (44 instructions per fragment against 6 x WN or 6 x WM MFMAs).
-template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF, bool F32 = false, bool BNM = false, bool X3 = false>
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF, bool F32 = false, bool BNM = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvArgs a) {
-  static_assert(!X3 || (F32 && !BNM), "split products: the fp32 ring");
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NW = WGM * WGN;
   constexpr int ESZ = F32 ? 4 : 2, KSTEP = F32 ? 32 : 64;             // bytes per operand element, channels per K step
   constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW, L = LA + LB;          // LDS-DMA instructions per wave and stage
@@ -465,7 +459,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   // fragments of sub-step kk + 1 are read while those of kk are multiplied.
   auto step_woven = [&](int cb, int nb, auto ISS) {
     constexpr bool iss = decltype(ISS)::value;
-    constexpr int NMF = (X3 ? 3 : F32 ? 4 : 1) * WM * WN, SPREAD = NSTAGE >= 3 ? 3 * NMF : 2 * NMF;     // MFMAs per sub-step (X3: 12 WM WN per step)
+    constexpr int NMF = (F32 ? 4 : 1) * WM * WN, SPREAD = NSTAGE >= 3 ? 3 * NMF : 2 * NMF;     // MFMAs per sub-step
     const char* sb = ldsc + cb * STAGE_BYTES;
     int dy = 0, dx = 0, tapoff = 0;
     unsigned wk = 0, sbase = 0;
@@ -494,6 +488,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
       }
     };
     using frag_t = typename std::conditional<F32, f32x4, bf16x8>::type;       // 16 bytes of a tile row either way
+    frag_t af[2][WM], bf[2][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) af[0][i] = *(const frag_t*)(sb + a_wave + i * 4096 + foff[0]);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bf[0][j] = *(const frag_t*)(sb + b_wave + j * 4096 + foff[0]);
     int q = 0, mi = 0;
     auto after_mfma = [&]() {
       ++mi;
@@ -505,60 +504,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
         }
       }
     };
-    if constexpr (X3) {
-      f32x4 a32[2][WM][2], b32[2][WN][2];          // [sub-step parity][tile][chunk pair]: 8 fp32 = 16 k of this lane's row
-      auto rd = [&](int s2, int pb) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-          a32[pb][i][0] = *(const f32x4*)(sb + a_wave + i * 4096 + foff[2 * s2]);
-          a32[pb][i][1] = *(const f32x4*)(sb + a_wave + i * 4096 + foff[2 * s2 + 1]);
-        }
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          b32[pb][j][0] = *(const f32x4*)(sb + b_wave + j * 4096 + foff[2 * s2]);
-          b32[pb][j][1] = *(const f32x4*)(sb + b_wave + j * 4096 + foff[2 * s2 + 1]);
-        }
-      };
-      rd(0, 0);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        if (s2 == 0) rd(1, 1);
-        bf16x8 a3[3][WM], b3[3][WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-          bf16x4 lo[3], hi[3];
-          split3_bf16(a32[s2][i][0], lo);
-          split3_bf16(a32[s2][i][1], hi);
-#pragma unroll
-          for (int p = 0; p < 3; ++p) a3[p][i] = __builtin_shufflevector(lo[p], hi[p], 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          bf16x4 lo[3], hi[3];
-          split3_bf16(b32[s2][j][0], lo);
-          split3_bf16(b32[s2][j][1], hi);
-#pragma unroll
-          for (int p = 0; p < 3; ++p) b3[p][j] = __builtin_shufflevector(lo[p], hi[p], 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-          const int pa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
-          const int pb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
-#pragma unroll
-          for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[pa][i], b3[pb][j], acc[i][j], 0, 0, 0);
-              after_mfma();
-            }
-        }
-      }
-    } else {
-    frag_t af[2][WM], bf[2][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i) af[0][i] = *(const frag_t*)(sb + a_wave + i * 4096 + foff[0]);
-#pragma unroll
-    for (int j = 0; j < WN; ++j) bf[0][j] = *(const frag_t*)(sb + b_wave + j * 4096 + foff[0]);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 3) {
@@ -587,7 +532,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
           }
         }
     }
-    }
     if constexpr (iss) {
 #pragma unroll
       for (; q < L; ++q) piece(q);
@@ -612,7 +556,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nt) issue(s);
   int cur = 0, nxt = NSTAGE - 1;                 // stage read at step t, stage refilled at step t (= read at t-1)
-  if (!X3 && ((F32 && !weave32) || !weave)) {
+  if ((F32 && !weave32) || !weave) {
     for (int t = 0; t < nt; ++t) {
       const int rem = nt - 1 - t;                  // K steps after this one
       wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
@@ -1418,15 +1362,6 @@ static int launch_pipe_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
     }
     return -1;
   }
-  if (!a.in16 && (a.korder & 64)) {       // math mode fp32x3: fp32 ring, split products (64x64 / 64x32 wave tiles)
-    if constexpr (WM * WN <= 4) {
-      if (a.stat_part) pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, true, false, true>>(a, grid, block, smem, 27, st);
-      else pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, false, false, true, false, true>>(a, grid, block, smem, 27, st);
-      IPR_LAUNCH_CHECK();
-      return 0;
-    }
-    return -1;
-  }
   if (!a.in16) {            // fp32 operands, exact fp32 MFMA
     if (a.stat_part) pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, true>>(a, grid, block, smem, 23, st);
     else pipe_go<gconv_pipe_kernel<WGM, WGN, WM, WN, NSTAGE, false, false, true>>(a, grid, block, smem, 23, st);
@@ -1549,7 +1484,7 @@ static int g_pipe_korder = getenv("IPRGAN_PIPE_KORDER") ? atoi(getenv("IPRGAN_PI
 int launch_gconv_pipe(const GConvArgs& a0, int variant, hipStream_t st, int* bm_out) {
   if (!gconv_pipe_eligible(a0)) return -1;
   GConvArgs a = a0;
-  a.korder = g_pipe_korder | (a0.korder & 64);        // bit 6 (set by launch_gconv in math mode fp32x3): split products
+  a.korder = g_pipe_korder;
   switch (variant) {
     case 0: return a.Ns >= 128 ? launch_pipe_t<4, 2, 2, 2, 3>(a, st, bm_out) : -1;
     case 1: return launch_pipe_t<4, 2, 2, 1, 3>(a, st, bm_out);

@@ -23,10 +23,8 @@ def short(k):
             return 'gconv_bf16_kernel'
         wgm, wgn, wm, wn = [int(x) for x in m.groups()[:4]]
         return f'gconv_kernel<{wgm * wm * 32}x{wgn * wn * 32}' + (',8w>' if wgm * wgn == 8 else '>')
-    m = re.match(r'void iprgan::gconv_pipe2?_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(?:, (true|false))?(?:, (true|false))?(?:, (true|false))?>', k)
+    m = re.match(r'void iprgan::gconv_pipe2?_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(?:, (true|false))?(?:, (true|false))?>', k)
     if m:           # LDS-DMA ring tiles (conv_pipe.hip): profiling slots 19 / 20 by tile width, 23 for the fp32 form
-        if 'gconv_pipe_kernel' in k and m.group(10) == 'true':
-            return 'gconv_x3_kernel'            # fp32 ring with split products (math mode fp32x3)
         if 'gconv_pipe_kernel' in k and m.group(8) == 'true':
             return 'gconv_pipe_f32_kernel'
         return 'gconv_pipe_kernel' if int(m.group(2)) * int(m.group(4)) * 32 >= 128 else 'gconv_pipe_kernel<256x64>'

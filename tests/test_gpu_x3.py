@@ -3,7 +3,7 @@ into three bf16 terms on its way into LDS, a product block accumulated from six 
 
 The claim under test is "the same accuracy class as the fp32 MFMA path", so every check here uses the fp32 tolerances:
   * per layer, the distance to a float64 convolution next to the fp32 mode's distance (forward, backward-data,
-    backward-weight, every register-staged tile and every ring tile that has a split form);
+    backward-weight, every register-staged tile);
   * the network / training-step parity tests of test_gpu_models.py, re-run with every 'fp32' request routed to the split
     tiles (the switch IPRGAN_FP32_VIA_X3 of iprgan/_lib.py does the same for a whole pytest run).
 Discriminator96 at batch 2 is left out of the network list on purpose: with this fixture's input one LeakyReLU mask
@@ -49,13 +49,13 @@ LAYERS = [  # B, cin, cout, k, stride, pad, H, transposed
 
 
 @pytest.mark.parametrize('layer', LAYERS, ids=lambda l: f'B{l[0]}_{l[1]}to{l[2]}_k{l[3]}s{l[4]}_{l[6]}' + ('T' if l[7] else ''))
-@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3, 4, 5, 6, 8, 9, 11, 12, 13])
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3, 4, 5, 6, 8, 11])
 def test_split_tiles_are_as_close_to_float64_as_the_fp32_tiles(layer, tile, dev):
     """rms error against the float64 convolution, relative to the result's rms: fp32x3 within 1.25x of the fp32 mode's
     own error + 1e-7, and below 1.5e-6 in absolute terms, for y, dx and dw.  (Measured: 0.6x .. 1.0x - the split products
-    are exact where the fp32 MFMA rounds every fused multiply-add.)  Tiles 0-6: register-staged (split while staging
-    into LDS); 8, 9, 11, 12, 13: the LDS-DMA ring tiles (fp32 tiles by DMA, split at fragment-read time).  96 -> 160
-    channels: a multiple of 32 but not of 64 or 128, so tiles have ragged columns."""
+    are exact where the fp32 MFMA rounds every fused multiply-add.)  Tiles 0-6: the split tiles; 8, 11: LDS-DMA ring
+    tiles, which stay on the exact fp32 MFMA in this mode and remain autotune candidates (mixing them in must not cost
+    accuracy).  96 -> 160 channels: a multiple of 32 but not of 64 or 128, so tiles have ragged columns."""
     from iprgan import ops, _lib
     B, cin, cout, k, s, p, H, tr = layer
     g = torch.Generator().manual_seed(1234 + cin + cout)
@@ -89,7 +89,7 @@ def test_split_tiles_are_as_close_to_float64_as_the_fp32_tiles(layer, tile, dev)
         assert ex3 <= 1.25 * e32 + 1e-7 and ex3 < 1.5e-6, f'{name}: fp32x3 {ex3:.3e} vs fp32 {e32:.3e} (rms, against float64)'
 
 
-@pytest.mark.parametrize('tile', [0, 2, 4, 6, 8, 9, 11, 12, 13])
+@pytest.mark.parametrize('tile', [0, 2, 4, 6, 8])
 def test_split_tiles_epilogue_statistics(tile, dev):
     """Column statistics from the epilogue of the split tiles (the BatchNorm that follows takes them instead of a pass
     over y): mean and 1/std against the float64 statistics of the stored y, ragged last tile included (M = 1152)."""
