@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O/prof
 cd $R
-if [ "$2" != "noprof-tests" ]; then
+if [ "$2" != "noprof-tests" ] && [ "$2" != "reprof" ]; then
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -3 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
@@ -22,15 +22,27 @@ prof_workload () {   # $1 = workload, $2 = file tag, $3 = math mode, $4.. = step
   export IPRGAN_TUNE_CACHE=$O/tune_cache_$T.txt
   rm -f $IPRGAN_TUNE_CACHE
   cd $R
-  timeout 600 python bench.py --workload $W --math $MATH --no-cpu-baseline "$@" > /dev/null 2> $O/tune_pass_$T.err
+  timeout 600 python bench.py --workload $W --math $MATH --alt-math none --no-cpu-baseline "$@" > /dev/null 2> $O/tune_pass_$T.err
   cd /tmp && export TMPDIR=/tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o $T --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --no-cpu-baseline "$@" > $O/${T}_bench_under_rocprof.json 2> $O/prof_$T.err
-  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof -o ${T}_fetch --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_fetch.err
-  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof -o ${T}_write --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_write.err
-  timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/prof -o ${T}_mfma --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_mfma.err
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o $T --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --alt-math none --no-cpu-baseline "$@" > $O/${T}_bench_under_rocprof.json 2> $O/prof_$T.err
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof -o ${T}_fetch --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --alt-math none --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_fetch.err
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof -o ${T}_write --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --alt-math none --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_write.err
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/prof -o ${T}_mfma --output-format csv -- python3 $R/bench.py --workload $W --math $MATH --alt-math none --no-cpu-baseline --steps 4 --warmup 4 > /dev/null 2> $O/prof_${T}_mfma.err
   cd $R
   unset IPRGAN_TUNE_CACHE
 }
+if [ "$2" = "reprof" ]; then      # only the profiler passes of the listed file tags ("" = headline): $3 = "headline srgan ..."
+  for w in $3; do
+    case $w in
+      headline) prof_workload dcgan64 ${TAG} fp32 --steps 20 --warmup 8; t=$TAG;;
+      srgan) prof_workload srgan ${TAG}_srgan fp32 --steps 8 --warmup 4; t=${TAG}_srgan;;
+      cyclegan) prof_workload cyclegan ${TAG}_cyclegan fp32 --steps 4 --warmup 2; t=${TAG}_cyclegan;;
+    esac
+    python scripts/summarize_profiles.py $O/prof $t $O/$t > /dev/null 2>> $O/summarize.err
+  done
+  find $O/prof -name '*kernel_trace.csv' -delete; find $O/prof -name '*counter_collection.csv' -delete; find $O/prof -name '*agent_info.csv' -delete
+  ls $O | grep -c .; exit 0
+fi
 prof_workload dcgan64 ${TAG} fp32 --steps 20 --warmup 8
 prof_workload srgan ${TAG}_srgan fp32 --steps 8 --warmup 4
 prof_workload cyclegan ${TAG}_cyclegan fp32 --steps 4 --warmup 2
