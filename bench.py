@@ -389,25 +389,29 @@ def main():
     alt = None
     if (args.alt_math != 'none' and args.math == 'fp32' and world == 1 and graphed is not None and graphed.graph is not None
             and graphed.failed is None):
-        from iprgan import graphs
-        _lib.set_math(args.alt_math)
-        g2 = graphs.GraphedStep(model, body, inputs_of(0), warmup=3)
-        for i in range(6):                            # three eager steps (autotune of the new tiles), capture, replays
-            g2(inputs_of(i))
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        for i in range(args.steps):
-            g2(inputs_of(i))
-        torch.cuda.synchronize()
-        ea = time.perf_counter() - ta
-        m2 = model.get_metrics()
-        assert all(v == v for v in m2.values()), f'non-finite metrics {m2}'
-        alt = {'mode': args.alt_math, 'value': round(wl['batch'] * args.steps / ea, 2), 'unit': wl['unit'],
-               'ms_per_step': round(ea / args.steps * 1e3, 3), 'steps': args.steps, 'graph_failed': g2.failed,
-               'note': 'same workload and tensors (fp32 in HBM); conv operands split into three bf16 terms in LDS, six bf16 '
-                       'MFMAs per product block, fp32 accumulation; not part of `value`'}
-        _lib.set_math(args.math)
-        log(f"alt math {args.alt_math}: {alt['ms_per_step']} ms/step")
+        try:                                          # (a failure here must never cost the headline line)
+            from iprgan import graphs
+            _lib.set_math(args.alt_math)
+            g2 = graphs.GraphedStep(model, body, inputs_of(0), warmup=3)
+            for i in range(6):                            # three eager steps (autotune of the new tiles), capture, replays
+                g2(inputs_of(i))
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for i in range(args.steps):
+                g2(inputs_of(i))
+            torch.cuda.synchronize()
+            ea = time.perf_counter() - ta
+            m2 = model.get_metrics()
+            assert all(v == v for v in m2.values()), f'non-finite metrics {m2}'
+            alt = {'mode': args.alt_math, 'value': round(wl['batch'] * args.steps / ea, 2), 'unit': wl['unit'],
+                   'ms_per_step': round(ea / args.steps * 1e3, 3), 'steps': args.steps, 'graph_failed': g2.failed,
+                   'note': 'same workload and tensors (fp32 in HBM); conv operands split into three bf16 terms in LDS, six bf16 '
+                           'MFMAs per product block, fp32 accumulation; not part of `value`'}
+        except Exception as e:                        # noqa: BLE001
+            alt = {'mode': args.alt_math, 'error': f'{type(e).__name__}: {e}'}
+        finally:
+            _lib.set_math(args.math)
+        log(f'alt math {args.alt_math}: {alt}')
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
