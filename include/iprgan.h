@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 213
+#define IPRGAN_VERSION 214
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -223,6 +223,12 @@ int iprgan_prelu_fwd(const float* x, const float* alpha, float* y, size_t n, voi
 int iprgan_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, float* ws,
                      size_t n, void* stream);
 int iprgan_pixel_shuffle2(const float* src, float* dst, int B, int H, int W, int C, int inverse, void* stream);
+/* conv -> PixelShuffle(2) -> PReLU (the upsampling blocks, sr_resnet.py:39-45) in one pass each way: x [B,H,W,4C] is the
+ * convolution's output, y / dy [B,2H,2W,C]; y = prelu(shuffle(x)), dx = unshuffle(dy) * prelu'(x), dalpha as above
+ * (ws >= iprgan_loss_ws_floats(B*H*W*C) floats).  C % 4 == 0. */
+int iprgan_pixel_shuffle2_prelu_fwd(const float* x, const float* alpha, float* y, int B, int H, int W, int C, void* stream);
+int iprgan_pixel_shuffle2_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, float* ws,
+                                    int B, int H, int W, int C, void* stream);
 int iprgan_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 int iprgan_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream);
 int iprgan_add(const float* a, const float* b, float* out, size_t n, void* stream);

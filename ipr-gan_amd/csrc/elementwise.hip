@@ -390,6 +390,77 @@ __global__ void pixel_shuffle2_kernel(const float* __restrict__ src, float* __re
   }
 }
 
+// ---- PixelShuffle(2) + PReLU in one pass (the upsampling blocks of SRResNet, networks/sr_resnet.py:39-45: conv ->
+// PixelShuffle -> PReLU; the PReLU has ONE slope, so it commutes with the permutation).  A thread owns pixel (b, h, w)
+// and FOUR consecutive output channels c0..c0+3: the 16 source values x[b,h,w,4 c0 .. 4 c0 + 15] are four contiguous
+// 16-byte loads, and each of the four sub-pixels (i, j) receives one 16-byte store {x[4 (c0+k) + 2 i + j]}, k = 0..3.
+// Backward: the same walk reads dy at the four sub-pixels, writes dx contiguously and accumulates the slope gradient
+// (double per thread, as prelu_bwd_kernel).  C % 4 == 0.
+typedef float ps_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void ps2_prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                            float* __restrict__ y, int B, int H, int W, int C) {
+  const float a = *alpha;
+  const int cg = C / 4;
+  const size_t total = (size_t)B * H * W * cg;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % cg);
+    size_t p = t / cg;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const size_t b = p / H;
+    const ps_f4* src = (const ps_f4*)(x + (((b * H + h) * W + w) * (size_t)(4 * C) + (size_t)g * 16));
+    ps_f4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = src[k];
+#pragma unroll
+    for (int ij = 0; ij < 4; ++ij) {
+      ps_f4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float e = v[k][ij]; o[k] = e > 0.f ? e : a * e; }
+      *(ps_f4*)(y + (((b * 2 * H + 2 * h + (ij >> 1)) * (size_t)(2 * W) + 2 * w + (ij & 1)) * (size_t)C + (size_t)g * 4)) = o;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void ps2_prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ alpha, float* __restrict__ dx,
+                                                            float* __restrict__ part, int B, int H, int W, int C) {
+  __shared__ float sh[16];
+  const float a = *alpha;
+  const int cg = C / 4;
+  const size_t total = (size_t)B * H * W * cg;
+  double s = 0.0;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % cg);
+    size_t p = t / cg;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const size_t b = p / H;
+    const size_t xo = ((b * H + h) * W + w) * (size_t)(4 * C) + (size_t)g * 16;
+    ps_f4 v[4], d[4], o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ((const ps_f4*)(x + xo))[k];
+#pragma unroll
+    for (int ij = 0; ij < 4; ++ij)
+      d[ij] = *(const ps_f4*)(dy + (((b * 2 * H + 2 * h + (ij >> 1)) * (size_t)(2 * W) + 2 * w + (ij & 1)) * (size_t)C + (size_t)g * 4));
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int ij = 0; ij < 4; ++ij) {
+        const float e = v[k][ij], gr = d[ij][k];
+        o[k][ij] = e > 0.f ? gr : a * gr;
+        q += e > 0.f ? 0.f : gr * e;
+      }
+    s += (double)q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ((ps_f4*)(dx + xo))[k] = o[k];
+  }
+  const float sb = block_sum((float)s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = sb;
+}
+
 // ---- MaxPool2d(2,2) on NHWC (VGG19 features, networks/vgg.py) ---------------------------------------------
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W,
                                     int C) {
@@ -732,6 +803,26 @@ int iprgan_pixel_shuffle2(const float* src, float* dst, int B, int H, int W, int
   if (!n) return 0;
   hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst,
                      B, H, W, C, inverse);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_pixel_shuffle2_prelu_fwd(const float* x, const float* alpha, float* y, int B, int H, int W, int C, void* stream) {
+  IPR_CHECK(C > 0 && (C % 4) == 0, "pixel_shuffle2_prelu: %d output channels (a multiple of 4 is required)", C);
+  const size_t n = (size_t)B * H * W * (C / 4);
+  if (!n) return 0;
+  hipLaunchKernelGGL(ps2_prelu_fwd_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, B, H, W, C);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_pixel_shuffle2_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, float* ws,
+                                    int B, int H, int W, int C, void* stream) {
+  IPR_CHECK(C > 0 && (C % 4) == 0, "pixel_shuffle2_prelu: %d output channels (a multiple of 4 is required)", C);
+  const size_t n = (size_t)B * H * W * (C / 4);
+  if (!n) return 0;
+  const int nb = grid_for(n, LOSS_BLOCKS);
+  hipLaunchKernelGGL(ps2_prelu_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, dy, alpha, dx, ws, B, H, W, C);
+  IPR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, dalpha);
   IPR_LAUNCH_CHECK();
   return 0;
 }

@@ -69,6 +69,8 @@ SIGNATURES = {
     'iprgan_prelu_fwd': (_I, [_P, _P, _P, _Z, _P]),
     'iprgan_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _P]),
     'iprgan_pixel_shuffle2': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'iprgan_pixel_shuffle2_prelu_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'iprgan_pixel_shuffle2_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'iprgan_maxpool2_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'iprgan_maxpool2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'iprgan_add': (_I, [_P, _P, _P, _Z, _P]),

@@ -511,6 +511,25 @@ class PixelShuffle2(Op):
         return ops.pixel_shuffle2(dy.contiguous(), inverse=True), []
 
 
+class PixelShufflePReLU(Op):
+    """nn.PixelShuffle(2) followed by nn.PReLU() (one slope) in one pass each way (sr_resnet.py:39-45)."""
+
+    def __init__(self, module):
+        self.m = module
+
+    @property
+    def params(self):
+        return (self.m.weight,)
+
+    def forward(self, x, st, train):
+        st['x'] = x
+        return ops.pixel_shuffle2_prelu_fwd(x, self.m.weight)
+
+    def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
+        dx, dalpha = ops.pixel_shuffle2_prelu_bwd(st['x'], dy.contiguous(), self.m.weight)
+        return dx, [dalpha]
+
+
 class MaxPool2(Op):
     def forward(self, x, st, train):
         st['x'] = x

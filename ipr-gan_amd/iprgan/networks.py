@@ -229,7 +229,8 @@ class SRResNet(nn.Sequential, _HipNet):
         plan.append(E.SkipEnd())
         for up in (self[2], self[3]):
             plan += self._unit_ops(up[0], 64, 256, 3, 1)
-            plan += [E.PixelShuffle2(), E.PReLU(up[2])]
+            # PixelShuffle -> PReLU (one slope: it commutes with the permutation) in one pass each way
+            plan += [E.PixelShufflePReLU(up[2])] if _FUSE_PRELU else [E.PixelShuffle2(), E.PReLU(up[2])]
         plan += self._unit_ops(self[4], 64, 3, 9, 4)
         plan.append(E.ToNCHW(3))
         return E.Chain(plan)

@@ -587,6 +587,27 @@ def pixel_shuffle2(x, inverse=False):
     return y
 
 
+def pixel_shuffle2_prelu_fwd(x, alpha):
+    """prelu(pixel_shuffle(x, 2)) in one pass: [B,H,W,4C] -> [B,2H,2W,C] (C % 4 == 0)."""
+    _f32(x)
+    B, H, W, C4_ = x.shape
+    Cc = C4_ // 4
+    y = empty((B, 2 * H, 2 * W, Cc), x)
+    call('iprgan_pixel_shuffle2_prelu_fwd', ptr(x), ptr(alpha), ptr(y), B, H, W, Cc, stream())
+    return y
+
+
+def pixel_shuffle2_prelu_bwd(x, dy, alpha):
+    _f32(x, dy)
+    B, H, W, C4_ = x.shape
+    Cc = C4_ // 4
+    dx = _empty_like(x)
+    dalpha = empty((1,), x)
+    ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
+    call('iprgan_pixel_shuffle2_prelu_bwd', ptr(x), ptr(dy), ptr(alpha), ptr(dx), ptr(dalpha), ptr(ws), B, H, W, Cc, stream())
+    return dx, dalpha
+
+
 def maxpool2_fwd(x):
     _f32(x)
     B, H, W, C_ = x.shape

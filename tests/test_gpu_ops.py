@@ -250,6 +250,33 @@ def test_conv_bwd_data_into_batchnorm(dev, case, tile, mode):
         _lib.set_math('fp32')
 
 
+@pytest.mark.parametrize('shape', [(2, 5, 7, 64), (3, 12, 12, 8), (1, 1, 1, 4)])
+def test_pixel_shuffle_with_fused_prelu(shape, dev):
+    """iprgan_pixel_shuffle2_prelu_fwd / _bwd against torch's pixel_shuffle + prelu (sr_resnet.py:39-45), and against the
+    two separate kernels bit for bit (the same arithmetic, one pass)."""
+    import torch.nn.functional as F
+    from iprgan import ops
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(B * 100 + C)
+    x = torch.randn(B, H, W, 4 * C, generator=g).to(dev)
+    dy = torch.randn(B, 2 * H, 2 * W, C, generator=g).to(dev)
+    alpha = torch.tensor([0.23], device=dev)
+    y = ops.pixel_shuffle2_prelu_fwd(x, alpha)
+    dx, da = ops.pixel_shuffle2_prelu_bwd(x, dy, alpha)
+    xt = x.permute(0, 3, 1, 2).detach().clone().requires_grad_(True)
+    at = alpha.detach().clone().requires_grad_(True)
+    yt = F.prelu(F.pixel_shuffle(xt, 2), at)
+    yt.backward(dy.permute(0, 3, 1, 2))
+    assert torch.equal(y, yt.detach().permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(dx, xt.grad.permute(0, 2, 3, 1).contiguous())
+    assert abs(float(da) - float(at.grad)) <= 2e-6 * max(1.0, float((dy.abs() * F.pixel_shuffle(xt, 2).permute(0, 2, 3, 1).abs()).sum()) ** 0.5)
+    s = ops.pixel_shuffle2(x)
+    y2 = ops.prelu_fwd(s, alpha)
+    d2, da2 = ops.prelu_bwd(s, dy, alpha)
+    assert torch.equal(y, y2) and torch.equal(dx, ops.pixel_shuffle2(d2, inverse=True))
+    assert abs(float(da) - float(da2)) <= 1e-5 * max(1.0, abs(float(da2)))
+
+
 @pytest.mark.parametrize('M,C', [(2 * 24 * 24, 64), (777, 64), (5 * 12 * 12, 256)])
 def test_batchnorm_with_fused_prelu(dev, M, C):
     """iprgan_bn_prelu_fwd / _bwd (networks/sr_resnet.py:7,13: conv -> BatchNorm -> PReLU with one learnable slope read
