@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 214
+#define IPRGAN_VERSION 220
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -50,9 +50,19 @@ typedef struct {
   int32_t pad_mode;       /* IPRGAN_PAD_*: reflect = ReflectionPad2d(pad) folded into the gather */
   int32_t act;            /* IPRGAN_ACT_* fused into the forward epilogue */
   float   slope;          /* LeakyReLU negative slope */
-  int32_t x_bf16;         /* storage type of the layer's INPUT activation x (and of dx, prev_out): 0 = fp32, 1 = bf16 */
-  int32_t y_bf16;         /* storage type of the layer's OUTPUT activation y (and of dy) */
+  int32_t x_bf16;         /* storage kind (IPRGAN_ST_*) of the layer's INPUT activation x (and of dx, prev_out, residual) */
+  int32_t y_bf16;         /* storage kind of the layer's OUTPUT activation y (and of dy) */
+  int64_t x_pstride;      /* IPRGAN_ST_X3 only: distance between the planes of x / y in ELEMENTS; 0 = the tensor is     */
+  int64_t y_pstride;      /*   contiguous (B*H*W*C4).  A batch slice of a larger tensor keeps the larger tensor's stride. */
 } iprgan_conv_desc;
+/* Storage kinds of an activation tensor.  F32: fp32.  BF16: see below.  X3 ("three planes", math mode IPRGAN_MATH_FP32X3,
+ * padded channel count % 32 == 0): the tensor is stored as THREE bf16 tensors of its shape, plane-major - h = bf16(x),
+ * m = bf16(x - h), l = bf16(x - h - m), all round-to-nearest-even; x = h + (m + l) EXACTLY (3 x 8 mantissa bits cover
+ * the 24 of fp32; the subtractions are exact), so this is an fp32 tensor in 6 bytes per element whose first plane alone is
+ * its bf16 rounding (same sign: activation masks read only that plane).  The pointer handed to an entry point is plane h.
+ * Producers split ONCE per element; the convolution kernels then move the planes to LDS by DMA and multiply plane pairs
+ * on the bf16 matrix pipe (csrc/conv_x3.hip) with no vector-ALU work in their K loops. */
+enum { IPRGAN_ST_F32 = 0, IPRGAN_ST_BF16 = 1, IPRGAN_ST_X3 = 2 };
 /* bf16 activations ("bf16 in HBM", BASELINE config 5): only with IPRGAN_MATH_BF16 and only for tensors whose padded
  * channel count is a multiple of 64; such a tensor is bf16 for EVERY entry point that touches it (element offsets and
  * shapes are unchanged, the `float*` in the signatures is then a bf16 buffer).  Prepared weights follow the operand
@@ -389,6 +399,10 @@ int iprgan_debug_force_splitk(int splits);
 int iprgan_fill(float* p, float v, size_t n, void* stream);
 /* dst[i] = src[i] for n elements between the fp32 and bf16 storage types (round-to-nearest-even) */
 int iprgan_cast(const float* src, float* dst, size_t n, int src_bf16, int dst_bf16, void* stream);
+/* fp32 <-> three planes (IPRGAN_ST_X3; exact both ways): to_planes != 0 splits n fp32 elements of src into planes
+ * dst + p * pstride (bf16 elements, p = 0, 1, 2); otherwise src is the h plane of a three-plane tensor with that plane
+ * stride and dst receives h + (m + l).  pstride >= n (a batch slice of a larger tensor keeps the larger stride). */
+int iprgan_cast_planes(const void* src, void* dst, size_t n, size_t pstride, int to_planes, void* stream);
 /* 1 if iprgan_conv_bwd_weight consumes bf16 x / dy of this layer directly (desc flags set), 0 if it wants fp32 copies */
 int iprgan_conv_wgrad_takes_bf16(const iprgan_conv_desc* d);
 int iprgan_axpy(float* y, const float* x, float a, size_t n, void* stream);   /* y += a*x */

@@ -12,7 +12,13 @@ namespace iprgan {
 void set_error(const char* fmt, ...);
 // norm.hip: deterministic column sums of x[M][Cs] -> out[C] (bias gradients)
 size_t colsum_ws_floats(int M, int Cs);
-int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st, float beta = 0.f, int b16 = 0);
+int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st, float beta = 0.f, int b16 = 0,
+                  size_t ps = 0);     // b16: storage kind of x; ps: plane stride (elements) of a three-plane x, 0 = M * Cs
+// conv_x3.hip: fp32 <-> three bf16 planes (plane stride ps elements)
+int cast_planes(const void* src, void* dst, size_t n, size_t ps, bool to_planes, hipStream_t st);
+// elementwise.hip: gradient of ReflectionPad2d (iprgan_reflect_fold) with a result of storage kind okind (2: plane stride ps)
+int reflect_fold_launch(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope,
+                        const float* residual, int B, int H, int W, int C, int pad, int okind, size_t ps, hipStream_t stream);
 
 #define IPR_CHECK(cond, ...)                 \
   do {                                       \

@@ -41,6 +41,7 @@ static ProfSlot g_slots[] = {
     {"gconv_pipe_f32_kernel", 0, 0, 0}, {"gconv_phase4_kernel", 0, 0, 0},
     {"wgrad_halo_f32_kernel", 0, 0, 0}, {"gconv_pipe8_kernel", 0, 0, 0},
     {"gconv_x3_kernel", 0, 0, 0},       {"wgrad_x3_kernel", 0, 0, 0},
+    {"gconv_x3p_kernel", 0, 0, 0},      {"wgrad_x3p_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; int tag; };
@@ -112,7 +113,9 @@ template <int WGM, int WGN, int WM, int WN, bool FAST, int NBUF, int BK, bool BF
 __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a) {
   static_assert(!BF16 || BK == 32 || BK == 64 || BK == 128, "bf16 tiles: K steps of 32, 64 or 128");
   static_assert(!IN16 || (BF16 && FAST), "bf16 operands in HBM: bf16 tiles on the one-tap-per-step path");
-  static_assert(!SPLIT || (BF16 && FAST && !IN16), "split tiles: fp32 operands in HBM on the bf16 image");
+  static_assert(!SPLIT || (BF16 && FAST), "split tiles: the bf16 image, one tap per K step");
+  constexpr bool IN3P = IN16 && SPLIT;         // operands ARE three bf16 planes in HBM (storage kind 2): loaded plane by plane, no split arithmetic
+  constexpr int NLD = IN3P ? 3 : 1;
   constexpr int NPL = SPLIT ? 3 : 1;            // bf16 images per operand
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   constexpr int NT = WGM * WGN * 64;            // threads: one wave per (32*WM)x(32*WN) sub-tile
@@ -200,8 +203,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // split tiles: the five small terms of a product block get their own accumulator (conv_x3.hip: every bf16 MFMA into a
+  // large accumulator costs about an ulp of it; summed among themselves they cost 2^-7 of that), merged before the epilogue
+  f32x16 accs[SPLIT ? WM : 1][SPLIT ? WN : 1];
+  if (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[SPLIT ? i : 0][SPLIT ? j : 0][r] = 0.f;
+  }
 
-  f32x4 ra[RA], rb[RB];
+  f32x4 ra[NLD][RA], rb[NLD][RB];
   // wave-uniform tap walk for the FAST path
   int u_c4 = 0, u_ty = 0, u_tx = 0;
   if (FAST && s_begin > 0) {                      // K split: start the walk at step s_begin
@@ -229,10 +243,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
           ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
           off = arow[i] + (unsigned)tapoff;
         }
-        ra[i] = buf_load4(rs_in, ok ? off : OOB_OFFSET);
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) ra[p][i] = buf_load4(rs_in, ok ? off + (unsigned)p * a.in_ps : OOB_OFFSET);
       }
 #pragma unroll
-      for (int i = 0; i < RB; ++i) rb[i] = buf_load4(rs_wt, wrow[i] + wk);
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) rb[p][i] = buf_load4(rs_wt, wrow[i] + wk + (unsigned)p * a.wt_ps);
       u_c4 += KG;
       if (u_c4 >= a.c4n) { u_c4 = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
     } else {
@@ -255,25 +272,27 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
           ok = ok && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
         }
         const int tapoff = (((iy - aiy[i]) * IW + (ix - aix[i])) * Cs + c4 * 4) * 4;
-        ra[i] = buf_load4(rs_in, ok ? arow[i] + (unsigned)tapoff : OOB_OFFSET);
+        ra[0][i] = buf_load4(rs_in, ok ? arow[i] + (unsigned)tapoff : OOB_OFFSET);
       }
 #pragma unroll
-      for (int i = 0; i < RB; ++i) rb[i] = buf_load4(rs_wt, valid ? wrow[i] + wk : OOB_OFFSET);
+      for (int i = 0; i < RB; ++i) rb[0][i] = buf_load4(rs_wt, valid ? wrow[i] + wk : OOB_OFFSET);
     }
   };
   auto lstore = [&](int buf) {
-    if (IN16) {                  // the 16 bytes loaded ARE chunk `chunk` of the bf16 row image
+    if (IN16) {                  // the 16 bytes loaded ARE chunk `chunk` of the bf16 row image (IN3P: of each plane's image)
       f32x4* A16 = lds + buf * TILE4;
       f32x4* B16 = A16 + BM * CHB;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int r = lrow + RP * i;
-        A16[r * CHB + (chunk ^ swzb(r))] = ra[i];
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) A16[p * PLANE4 + r * CHB + (chunk ^ swzb(r))] = ra[p][i];
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int r = lrow + RP * i;
-        B16[r * CHB + (chunk ^ swzb(r))] = rb[i];
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) B16[p * PLANE4 + r * CHB + (chunk ^ swzb(r))] = rb[p][i];
       }
       return;
     }
@@ -284,7 +303,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
       for (int i = 0; i < RA; ++i) {
         const int r = lrow + RP * i;
         bf16x4 t3[3];
-        split3_bf16(ra[i], t3);
+        split3_bf16(ra[0][i], t3);
 #pragma unroll
         for (int p = 0; p < 3; ++p) A8[p * PLANE4 * 2 + (r * CHB + ((chunk >> 1) ^ swzb(r))) * 2 + (chunk & 1)] = t3[p];
       }
@@ -292,7 +311,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
       for (int i = 0; i < RB; ++i) {
         const int r = lrow + RP * i;
         bf16x4 t3[3];
-        split3_bf16(rb[i], t3);
+        split3_bf16(rb[0][i], t3);
 #pragma unroll
         for (int p = 0; p < 3; ++p) B8[p * PLANE4 * 2 + (r * CHB + ((chunk >> 1) ^ swzb(r))) * 2 + (chunk & 1)] = t3[p];
       }
@@ -304,12 +323,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int r = lrow + RP * i;
-        A8[(r * CHB + ((chunk >> 1) ^ swzb(r))) * 2 + (chunk & 1)] = to_bf16x4(ra[i]);
+        A8[(r * CHB + ((chunk >> 1) ^ swzb(r))) * 2 + (chunk & 1)] = to_bf16x4(ra[0][i]);
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int r = lrow + RP * i;
-        B8[(r * CHB + ((chunk >> 1) ^ swzb(r))) * 2 + (chunk & 1)] = to_bf16x4(rb[i]);
+        B8[(r * CHB + ((chunk >> 1) ^ swzb(r))) * 2 + (chunk & 1)] = to_bf16x4(rb[0][i]);
       }
       return;
     }
@@ -318,12 +337,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int r = lrow + RP * i;
-      A4[r * CH + (chunk ^ swz(r))] = ra[i];
+      A4[r * CH + (chunk ^ swz(r))] = ra[0][i];
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int r = lrow + RP * i;
-      B4[r * CH + (chunk ^ swz(r))] = rb[i];
+      B4[r * CH + (chunk ^ swz(r))] = rb[0][i];
     }
   };
   auto compute = [&](int buf) {
@@ -356,8 +375,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
 #pragma unroll
           for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < WN; ++j) {
+              if (t < 5) accs[SPLIT ? i : 0][SPLIT ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], accs[SPLIT ? i : 0][SPLIT ? j : 0], 0, 0, 0);
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+            }
         }
       }
       return;
@@ -435,6 +456,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_kernel(const GConvArgs a
     }
   }
 
+  if (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] += accs[SPLIT ? i : 0][SPLIT ? j : 0];
+  }
   gconv_epilogue<WGM, WGN, WM, WN, STATS>(a, acc, lds, pz, zi, lq, m0, n0);
 }
 
@@ -473,6 +500,15 @@ __device__ __forceinline__ void fewin_store(const GConvArgs& a, f32x4 v, const f
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] *= act_grad_from_out(o[k], a.aux_act, a.aux_slope);
     }
+  }
+  if (a.out16 == 2) {              // three-plane output (and residual): plane stride out_ps bytes
+    const size_t ps = a.out_ps / 2;
+    if (a.res) v += ld_bf16x4(a.res, idx) + (ld_bf16x4(a.res, idx + ps) + ld_bf16x4(a.res, idx + 2 * ps));
+    bf16x4 t3[3];
+    split3_bf16(v, t3);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *(bf16x4*)((__bf16*)a.out + idx + p * ps) = t3[p];
+    return;
   }
   if (a.res) v += a.out16 ? ld_bf16x4(a.res, idx) : *(const f32x4*)(a.res + idx);
   if (a.out16) *(bf16x4*)((__bf16*)a.out + idx) = to_bf16x4(v);
@@ -866,9 +902,18 @@ __global__ void smalln_weight_kernel(const float* __restrict__ wt, float* __rest
     if (t < ntap) {
       const int ty = t / tw, tx = t - ty * tw;
       const size_t src = (size_t)n * Kp + (size_t)(wbase + ty * wsy + tx * wsx) * Cs + c;
+      if (bf16 == 2) {           // three planes: copied plane by plane (source plane stride 128 rows, destination rows_alloc)
+        const size_t sps = (size_t)128 * Kp;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ((__bf16*)w2)[(size_t)p * total + i] = ((const __bf16*)wt)[p * sps + src];
+        continue;
+      }
       v = bf16 ? (float)((const __bf16*)wt)[src] : wt[src];
     }
-    if (bf16) ((__bf16*)w2)[i] = (__bf16)v;       // (exact: v already is a bf16 value)
+    if (bf16 == 2) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ((__bf16*)w2)[(size_t)p * total + i] = (__bf16)0.f;
+    } else if (bf16) ((__bf16*)w2)[i] = (__bf16)v;       // (exact: v already is a bf16 value)
     else w2[i] = v;
   }
 }
@@ -935,8 +980,10 @@ struct WGradArgs {
   unsigned p_bytes, q_bytes;
   int dx32, dy32;            // 32 rows of m = db32 images + dy32 rows + dx32 pixels (mixed radix of PH x PW)
   int xcd;                   // wgrad_t_kernel: XCD-contiguous tile order
-  int in16;                  // P and Q are bf16 tensors and the bf16 image applies (host-side: picks the IN16 kernel)
+  int in16;                  // 1: P and Q are bf16 tensors and the bf16 image applies (host-side: picks the IN16 kernel)
+                             // 2: P and Q are three-plane tensors (plane strides p_ps / q_ps bytes): the IN3P split kernel
   int p16, q16;              // storage type of P / Q (kernels without IN16 widen bf16 chunks on arrival)
+  unsigned p_ps, q_ps;
   unsigned bstep0, bstep1;   // byte step of the image base for db32 / db32+1 images
   double flops;
 };
@@ -965,7 +1012,9 @@ template <int WGM, int WGN, int WM, int WN, int NBUF, bool REFLECT, bool BF16 = 
 __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a) {
   static_assert(!BF16 || (WGM * WM == 4 && WGN * WN == 4), "the bf16 wgrad image is written for 128x128 tiles");
   static_assert(!IN16 || BF16, "bf16 operands in HBM need the bf16 image");
-  static_assert(!SPLIT || (BF16 && !IN16), "split tiles: fp32 operands in HBM on the bf16 image");
+  static_assert(!SPLIT || BF16, "split tiles: the bf16 image");
+  constexpr bool IN3P = IN16 && SPLIT;       // P and Q ARE three bf16 planes in HBM (storage kind 2): loaded plane by plane
+  constexpr int NLD = IN3P ? 3 : 1;
   constexpr int BN = WGM * WM * 32;   // tile over n (P channels)  -> MFMA rows
   constexpr int BK = WGN * WN * 32;   // tile over k (tap,c)       -> MFMA cols
   constexpr int EPC = IN16 ? 8 : 4;                // elements per loader chunk (IN16: P and Q are bf16 tensors, 16-byte chunks of 8)
@@ -1008,8 +1057,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // split tiles: the five small terms of a product block get their own accumulator (conv_x3.hip: every bf16 MFMA into a
+  // large accumulator costs about an ulp of it; summed among themselves they cost 2^-7 of that), merged before the epilogue
+  f32x16 accs[SPLIT ? WM : 1][SPLIT ? WN : 1];
+  if (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[SPLIT ? i : 0][SPLIT ? j : 0][r] = 0.f;
+  }
 
-  f32x4 rP[NP], rQ[NQ];
+  f32x4 rP[NLD][NP], rQ[NLD][NQ];
 
   const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.P, 0, a.p_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)a.Q, 0, a.q_bytes, 0x00020000);
@@ -1028,10 +1088,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
   // fall outside the buffer by themselves: p_bytes = M * Ps * 4).
   unsigned po[NP], qb[NQ];
   int qm[NQ], qy[NQ], qx[NQ];
+  int pm[IN3P ? NP : 1];            // three planes: rows past M of plane h are plane m's memory, not the end of the buffer
 #pragma unroll
-  for (int i = 0; i < NP; ++i)
+  for (int i = 0; i < NP; ++i) {
     po[i] = pvalid ? (unsigned)((chunk_begin * 32 + rp + RPP * i) * a.Ps) * pes + (unsigned)(n0 + cp * EPC) * pes
                    : OOB_OFFSET;
+    if (IN3P) pm[IN3P ? i : 0] = chunk_begin * 32 + rp + RPP * i;
+  }
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int m = chunk_begin * 32 + rq + RPQ * i;
@@ -1046,7 +1109,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
   auto gload = [&]() {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      rP[i] = (!IN16 && a.p16) ? buf_load4_bf16(rs_p, po[i]) : buf_load4(rs_p, po[i]);
+      if (IN3P) {
+        const bool okp = po[i] != OOB_OFFSET && pm[IN3P ? i : 0] < M;
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) rP[p][i] = buf_load4(rs_p, okp ? po[i] + (unsigned)p * a.p_ps : OOB_OFFSET);
+        pm[IN3P ? i : 0] += 32;
+        if (po[i] != OOB_OFFSET) po[i] += pstep;
+        continue;
+      }
+      rP[0][i] = (!IN16 && a.p16) ? buf_load4_bf16(rs_p, po[i]) : buf_load4(rs_p, po[i]);
       po[i] += pstep;
     }
 #pragma unroll
@@ -1060,7 +1131,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
         ok = ok && (unsigned)iy < (unsigned)QH && (unsigned)ix < (unsigned)QW;
       }
       const unsigned off = qb[i] + (unsigned)__mul24(__mul24(iy, QW) + ix, Qs4);
-      rQ[i] = (!IN16 && a.q16) ? buf_load4_bf16(rs_q, ok ? off : OOB_OFFSET) : buf_load4(rs_q, ok ? off : OOB_OFFSET);
+      if (IN3P) {
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) rQ[p][i] = buf_load4(rs_q, ok && qb[i] < OOB_OFFSET ? off + (unsigned)p * a.q_ps : OOB_OFFSET);
+      } else
+      rQ[0][i] = (!IN16 && a.q16) ? buf_load4_bf16(rs_q, ok ? off : OOB_OFFSET) : buf_load4(rs_q, ok ? off : OOB_OFFSET);
       int x = qx[i] + dx32, y = qy[i] + dy32;
       const bool cx = x >= PW;
       x -= cx ? PW : 0;
@@ -1072,13 +1147,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
     }
   };
   auto lstore = [&](int buf) {
-    if (IN16) {               // the 16 bytes loaded are chunk cp of row r of the [32][128] bf16 image
-      char* Pb = (char*)lds + buf * 16384;
-      char* Qb = Pb + 8192;
+    if (IN16) {               // the 16 bytes loaded are chunk cp of row r of the [32][128] bf16 image (IN3P: of each plane's image)
+      char* Pb = (char*)lds + buf * (IN3P ? 49152 : 16384);
+      char* Qb = Pb + (IN3P ? 24576 : 8192);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) *(f32x4*)(Pb + wg_bf16_off(rp + RPP * i, cp)) = rP[i];
+      for (int i = 0; i < NP; ++i)
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) *(f32x4*)(Qb + wg_bf16_off(rq + RPQ * i, cq)) = rQ[i];
+        for (int p = 0; p < NLD; ++p) *(f32x4*)(Pb + p * 8192 + wg_bf16_off(rp + RPP * i, cp)) = rP[p][i];
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) *(f32x4*)(Qb + p * 8192 + wg_bf16_off(rq + RPQ * i, cq)) = rQ[p][i];
       return;
     }
     if (SPLIT) {              // stage = 3 P images, then 3 Q images, of 8 KB each
@@ -1087,14 +1166,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         bf16x4 t3[3];
-        split3_bf16(rP[i], t3);
+        split3_bf16(rP[0][i], t3);
 #pragma unroll
         for (int p = 0; p < 3; ++p) *(bf16x4*)(Pb + p * 8192 + wg_bf16_off(rp + RPP * i, cp >> 1) + 8 * (cp & 1)) = t3[p];
       }
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         bf16x4 t3[3];
-        split3_bf16(rQ[i], t3);
+        split3_bf16(rQ[0][i], t3);
 #pragma unroll
         for (int p = 0; p < 3; ++p) *(bf16x4*)(Qb + p * 8192 + wg_bf16_off(rq + RPQ * i, cq >> 1) + 8 * (cq & 1)) = t3[p];
       }
@@ -1105,18 +1184,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
       char* Qb = Pb + 8192;
 #pragma unroll
       for (int i = 0; i < NP; ++i)
-        *(bf16x4*)(Pb + wg_bf16_off(rp + RPP * i, cp >> 1) + 8 * (cp & 1)) = to_bf16x4(rP[i]);
+        *(bf16x4*)(Pb + wg_bf16_off(rp + RPP * i, cp >> 1) + 8 * (cp & 1)) = to_bf16x4(rP[0][i]);
 #pragma unroll
       for (int i = 0; i < NQ; ++i)
-        *(bf16x4*)(Qb + wg_bf16_off(rq + RPQ * i, cq >> 1) + 8 * (cq & 1)) = to_bf16x4(rQ[i]);
+        *(bf16x4*)(Qb + wg_bf16_off(rq + RPQ * i, cq >> 1) + 8 * (cq & 1)) = to_bf16x4(rQ[0][i]);
       return;
     }
     float* Pt = ldsf + buf * STAGE;
     float* Qt = Pt + 32 * BN;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) *(f32x4*)(Pt + (rp + RPP * i) * BN + cp * 4) = rP[i];
+    for (int i = 0; i < NP; ++i) *(f32x4*)(Pt + (rp + RPP * i) * BN + cp * 4) = rP[0][i];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) *(f32x4*)(Qt + (rq + RPQ * i) * BK + cq * 4) = rQ[i];
+    for (int i = 0; i < NQ; ++i) *(f32x4*)(Qt + (rq + RPQ * i) * BK + cq * 4) = rQ[0][i];
   };
   auto compute = [&](int buf) {
     const int half = lane >> 5, l31 = lane & 31;
@@ -1148,8 +1227,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
 #pragma unroll
           for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < WN; ++j) {
+              if (t < 5) accs[SPLIT ? i : 0][SPLIT ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], accs[SPLIT ? i : 0][SPLIT ? j : 0], 0, 0, 0);
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bf[pb][j], acc[i][j], 0, 0, 0);
+            }
         }
       }
       return;
@@ -1233,6 +1314,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
     }
   }
 
+  if (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] += accs[SPLIT ? i : 0][SPLIT ? j : 0];
+  }
   // slab store: quad transpose (see gconv epilogue) so that every lane writes 16 contiguous bytes
   const int half = lane >> 5, l31 = lane & 31;
   const int qp = lane & 3, q4 = (l31 >> 2);
@@ -1510,13 +1597,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_t_kernel(const WGradArgs
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restrict__ slab, const float* __restrict__ bias,
                                                             f32x4* __restrict__ out, unsigned n4, unsigned Ns4, int N,
                                                             int ksplit, int act, float slope, const f32x4* __restrict__ aux,
-                                                            int aux_act, float aux_slope, const f32x4* __restrict__ res) {
+                                                            int aux_act, float aux_slope, const f32x4* __restrict__ res,
+                                                            int okind = 0, size_t ps = 0) {
+  // okind 2: out (and res) are three-plane tensors with plane stride ps elements, aux is the h plane of one (bf16)
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
     f32x4 v = slab[i];
     for (int z = 1; z < ksplit; ++z) v += slab[(size_t)z * n4 + i];
     const int n = (int)(i % Ns4) * 4;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    if (aux) o = aux[i];
+    if (aux) o = okind == 2 ? ld_bf16x4((const float*)aux, (size_t)i * 4) : aux[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float t = v[k];
@@ -1524,6 +1613,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restr
       t = act_apply(t, act, slope);
       if (aux) t *= act_grad_from_out(o[k], aux_act, aux_slope);
       v[k] = n + k < N ? t : 0.f;
+    }
+    if (okind == 2) {
+      const size_t e = (size_t)i * 4;
+      if (res) v += ld_bf16x4((const float*)res, e) + (ld_bf16x4((const float*)res, e + ps) + ld_bf16x4((const float*)res, e + 2 * ps));
+      bf16x4 t3[3];
+      split3_bf16(v, t3);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *(bf16x4*)((__bf16*)out + e + p * ps) = t3[p];
+      continue;
     }
     if (res) v += res[i];
     out[i] = v;
@@ -1615,7 +1713,12 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __r
       v = w[src];
       if (inv_scale) v = v / sc;
     }
-    if (out16) ((__bf16*)dst)[i] = (__bf16)v;      // operand of a bf16 activation: rounded once here (nearest-even)
+    if (out16 == 2) {                              // operand of a three-plane activation: split once here (x = h + m + l)
+      const __bf16 h = (__bf16)v;
+      const float r1 = v - (float)h;
+      const __bf16 m = (__bf16)r1;
+      ((__bf16*)dst)[i] = h; ((__bf16*)dst)[total + i] = m; ((__bf16*)dst)[2 * total + i] = (__bf16)(r1 - (float)m);
+    } else if (out16) ((__bf16*)dst)[i] = (__bf16)v;      // operand of a bf16 activation: rounded once here (nearest-even)
     else dst[i] = v;
   }
 }
@@ -1667,15 +1770,26 @@ __global__ __launch_bounds__(256) void weight_prep_multi_kernel(const PrepTable 
     for (int i = threadIdx.x; i < n_el; i += blockDim.x) {
       const int tap = i / PREP_CCH, cl = i % PREP_CCH;
       if (c0 + cl < e.Cs) {
-        if (e.out16) out16[tap * e.Cs + c0 + cl] = (__bf16)psh[cl * pitch + tap];
-        else out[tap * e.Cs + c0 + cl] = psh[cl * pitch + tap];
+        const float v = psh[cl * pitch + tap];
+        if (e.out16 == 2) {
+          const size_t ps = (size_t)e.rows_alloc * e.Kp;
+          const __bf16 h = (__bf16)v;
+          const float r1 = v - (float)h;
+          const __bf16 m = (__bf16)r1;
+          __bf16* o = out16 + tap * e.Cs + c0 + cl;
+          o[0] = h; o[ps] = m; o[2 * ps] = (__bf16)(r1 - (float)m);
+        } else if (e.out16) out16[tap * e.Cs + c0 + cl] = (__bf16)v;
+        else out[tap * e.Cs + c0 + cl] = v;
       }
     }
   }
   // K padding behind the last tap (Kp is a multiple of 32): the first channel slice clears it
   if (blockIdx.y == 0)
     for (int k = e.ntap * e.Cs + threadIdx.x; k < e.Kp; k += blockDim.x) {
-      if (e.out16) out16[k] = (__bf16)0.f;
+      if (e.out16 == 2) {
+        const size_t ps = (size_t)e.rows_alloc * e.Kp;
+        out16[k] = (__bf16)0.f; out16[ps + k] = (__bf16)0.f; out16[2 * ps + k] = (__bf16)0.f;
+      } else if (e.out16) out16[k] = (__bf16)0.f;
       else out[k] = 0.f;
     }
 }
@@ -1857,6 +1971,12 @@ static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
   // (two barriers per step but 3-4 blocks per CU: measured faster than double buffering, which is no longer built)
   const bool fast = (a.Cs % 32) == 0;
   // bf16 math: layers whose K step lies in one tap (C4 % 32 == 0); RGB stems / heads keep the fp32 kernel
+  if (a.in16 == 2) { // three bf16 planes per operand in HBM: plane-by-plane loader, the split tiles' LDS image and MFMA terms
+    if constexpr (WGM * WM * 32 >= WGM * WGN * 16 && WGN * WN * 32 >= WGM * WGN * 16)      // (a loader pass covers threads / 4 rows)
+      return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, true, true, true>(a, st)
+                         : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, false, true, true>(a, st);
+    return -1;
+  }
   if (a.in16)        // bf16 operands in HBM: 64-deep K steps (8 loader chunks per row)
     return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, true, true>(a, st)
                        : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, false, true>(a, st);
@@ -1888,11 +2008,15 @@ static int launch_gconv_t(const GConvArgs& a, hipStream_t st) {
 template <int WGM, int WGN, int WM, int WN>
 static int launch_gconv_bf16big(const GConvArgs& a, hipStream_t st) {
   if constexpr (WM * WN <= 8) {
+    if (a.in16 == 2 && a.Ns >= WGN * WN * 32)
+      return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, true, true, true>(a, st)
+                         : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, false, true, true>(a, st);
+    if (a.in16 == 2) return -1;
     if (g_math == IPRGAN_MATH_FP32X3 && (a.Cs % 32) == 0 && a.Ns >= WGN * WN * 32)
       return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, true, false, true>(a, st)
                          : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 32, true, false, false, true>(a, st);
   }
-  if (g_math != IPRGAN_MATH_BF16 || (a.Cs % 64) != 0 || a.Ns < WGN * WN * 32) return -1;
+  if (a.in16 == 2 || g_math != IPRGAN_MATH_BF16 || (a.Cs % 64) != 0 || a.Ns < WGN * WN * 32) return -1;
   if (a.in16)
     return a.stat_part ? launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, true, true>(a, st)
                        : launch_gconv_tfnk<WGM, WGN, WM, WN, true, 1, 64, true, false, true>(a, st);
@@ -1902,26 +2026,27 @@ static int launch_gconv_bf16big(const GConvArgs& a, hipStream_t st) {
 
 static int launch_gconv(const GConvArgs& ain, hipStream_t st);
 int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_out);     // conv_pipe.hip
+int launch_gconv_x3p(const GConvArgs& a, int variant, hipStream_t st, int* bm_out);      // conv_x3.hip
 
 static bool smalln_eligible(const GConvArgs& a) {
   return g_smalln && !a.rs0 && !a.stat_part && a.Ns == 4 && a.nphase == 1 && a.isy == 1 && a.isx == 1 && a.osy == 1 && a.osx == 1 &&
          (a.Cs % 32) == 0 && a.ph[0].ntap >= 2 && !a.planar_M;
 }
 static size_t smalln_ws_floats(const GConvArgs& a) {
-  return (size_t)rup(a.ph[0].ntap * 4, 128) * a.Cs + (size_t)a.ph[0].ntap * a.B * a.IH * a.IW * 4;
+  return (size_t)2 * rup(a.ph[0].ntap * 4, 128) * a.Cs + (size_t)a.ph[0].ntap * a.B * a.IH * a.IW * 4;     // (operand: up to three bf16 planes)
 }
 static int launch_smalln(const GConvArgs& a, hipStream_t st) {
   const Phase& p = a.ph[0];
   const int ntap = p.ntap, rows = rup(ntap * 4, 128);
   float* w2 = a.ws;
-  float* T = a.ws + (size_t)rows * a.Cs;
+  float* T = a.ws + (size_t)2 * rows * a.Cs;
   hipLaunchKernelGGL(smalln_weight_kernel, dim3(cdiv(rows * a.Cs, 256)), dim3(256), 0, st, a.wt, w2, a.Kp, a.Cs,
                      ntap, p.tw, p.wbase, p.wsy, p.wsx, rows, a.in16);
   IPR_LAUNCH_CHECK();
   GConvArgs g;
   memset(&g, 0, sizeof(g));
   geom_forward_form(g, a.B, a.IH, a.IW, a.Cs, a.IH, a.IW, ntap * 4, 1, 1, 1, 0);
-  g.in = a.in; g.wt = w2; g.out = T; g.in16 = a.in16;
+  g.in = a.in; g.wt = w2; g.out = T; g.in16 = a.in16; g.in_ps = a.in_ps;
   g.planar_M = a.B * a.IH * a.IW;
   g.flops = a.flops;                       // the algorithmic FLOPs of the convolution are accounted here
   int rc = launch_gconv(g, st);
@@ -1987,17 +2112,32 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   GConvArgs a = ain;
   {
     const unsigned long long esz = a.in16 ? 2ull : 4ull;
-    const unsigned long long inb = (unsigned long long)a.B * a.IH * a.IW * a.Cs * esz;
-    const unsigned long long wtb = (unsigned long long)rup(a.wmod > 0 ? a.wmod : a.N, 128) * a.Kp * esz;
-    IPR_CHECK(!a.in16 || (g_math == IPRGAN_MATH_BF16 && (a.Cs % 64) == 0 && !a.wmod && a.ksplit <= 1),
+    unsigned long long inb = (unsigned long long)a.B * a.IH * a.IW * a.Cs * esz;
+    unsigned long long wtb = (unsigned long long)rup(a.wmod > 0 ? a.wmod : a.N, 128) * a.Kp * esz;
+    IPR_CHECK(a.in16 != 1 || (g_math == IPRGAN_MATH_BF16 && (a.Cs % 64) == 0 && !a.wmod && a.ksplit <= 1),
               "conv: bf16 activations need IPRGAN_MATH_BF16, a channel count that is a multiple of 64 and a regular convolution");
+    IPR_CHECK(a.in16 != 2 || (g_math == IPRGAN_MATH_FP32X3 && (a.Cs % 32) == 0),
+              "conv: three-plane activations need IPRGAN_MATH_FP32X3 and a channel count that is a multiple of 32");
+    if (a.in16 == 2) {           // plane strides: the caller's (a batch slice of a larger tensor) or the contiguous ones
+      IPR_CHECK(inb < 0x2fffffffull && wtb < 0x2fffffffull, "conv: three-plane tensor larger than 2 GiB (%llu / %llu bytes per plane)", inb, wtb);
+      if (!a.in_ps) a.in_ps = (unsigned)inb;
+      a.wt_ps = (unsigned)wtb;
+      inb += 2ull * a.in_ps; wtb *= 3ull;
+    }
     IPR_CHECK(inb < 0x7fffffffull && wtb < 0x7fffffffull, "conv: tensor larger than 2 GiB (%llu / %llu bytes)", inb, wtb);
     a.in_bytes = (unsigned)inb; a.wt_bytes = (unsigned)wtb;
     // output (and the same-shaped fused-derivative / residual operands): addressed through buffer descriptors too
     const unsigned long long oel = a.planar_M ? (unsigned long long)a.Ns * a.planar_M
                                    : a.ksplit > 1 ? (unsigned long long)a.ksplit * a.ph[0].M * a.Ns
                                                   : (unsigned long long)a.B * a.OH * a.OW * a.Ns;
-    const unsigned long long outb = oel * (a.out16 ? 2ull : 4ull), auxb = oel * (a.aux16 ? 2ull : 4ull);
+    unsigned long long outb = oel * (a.out16 ? 2ull : 4ull);
+    const unsigned long long auxb = oel * (a.aux16 ? 2ull : 4ull);
+    if (a.out16 == 2) {
+      IPR_CHECK(!a.planar_M && a.ksplit <= 1, "conv: three-plane output on a workspace pass");
+      if (!a.out_ps) a.out_ps = (unsigned)outb;
+      outb += 2ull * a.out_ps;
+    }
+    IPR_CHECK(a.aux16 != 2, "conv: the fused-derivative operand of a three-plane tensor is passed as its h plane (aux16 = 1)");
     IPR_CHECK(outb < 0x7fffffffull && auxb < 0x7fffffffull, "conv: output tensor larger than 2 GiB (%llu bytes)", outb);
     a.out_bytes = (unsigned)outb; a.aux_bytes = (unsigned)auxb;
     a.linear_out = (a.nphase == 1 && a.osy == 1 && a.osx == 1 && a.ph[0].ooy == 0 && a.ph[0].oox == 0) ? 1 : 0;
@@ -2054,7 +2194,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   int maxM = 0;
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   const int N = a.Ns;
-  if (N <= 32) return launch_gconv_t<4, 1, 1, 1>(a, st);
+  if (N <= 32 && a.in16 != 2) return launch_gconv_t<4, 1, 1, 1>(a, st);
   auto run = [&](int tile) {
     switch (tile) {
       case 0: return launch_gconv_t<2, 2, 2, 2>(a, st);
@@ -2066,6 +2206,8 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
       case 7: return launch_gconv_bf16big<2, 2, 4, 4>(a, st);   // bf16 only: 256x256, 4 waves of 128x128
       case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17:   // LDS-DMA ring tiles (conv_pipe.hip)
         return launch_gconv_pipe(a, tile - 8, st, &t_last_bm);
+      case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25:                   // three-plane ring tiles (conv_x3.hip)
+        return launch_gconv_x3p(a, tile - 18, st, &t_last_bm);
       default: return launch_gconv_t<2, 2, 1, 1>(a, st);
     }
   };
@@ -2086,7 +2228,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   // order, results stay within fp32 rounding of each other.
   TuneKey key = {{a.B, a.IH, a.IW, a.Cs, a.OH, a.OW, a.Ns, a.isy, a.osy, a.nphase, a.ph[0].th, a.ph[0].tw,
                   a.ph[0].ohg, a.ph[0].owg, a.pad_mode + 16 * g_math + 64 * a.ksplit + 8192 * (a.wmod > 0) + 16384 * (a.rs0 != nullptr) +
-                      32768 * (a.stat_part != nullptr) + 65536 * a.in16 + 131072 * a.out16 + 262144 * (a.bn_mean != nullptr), a.Kp}};
+                      32768 * (a.stat_part != nullptr) + 65536 * a.in16 + 262144 * a.out16 + 1048576 * (a.bn_mean != nullptr), a.Kp}};
   {
     int cached;
     if (tune_lookup(key, &cached)) return run(cached);
@@ -2095,7 +2237,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   g_prof_on = false;
   float best_us = 0.f;
   int err = 0;
-  const int best = tune_pick(18, [&](int cand) -> int {
+  const int best = tune_pick(26, [&](int cand) -> int {
     if ((cand == 0 || cand == 3 || cand == 4) && N < 128) return -1;
     if ((cand == 6 || cand == 7) && (long long)cdiv(maxM, 256) * cdiv(N, 128) * a.nphase < 256) return -1;    // not even one block per CU
     return run(cand);
@@ -2240,8 +2382,13 @@ static size_t wgrad_padded_floats(const iprgan_conv_desc* d) {
 
 // both operands bf16 in HBM and the bf16 [32][128] image applicable: the IN16 kernel runs on the 128x128 tiles
 static bool wgrad_in16(const iprgan_conv_desc* d) {
-  return d->x_bf16 && d->y_bf16 && g_math == IPRGAN_MATH_BF16 && d->pad_mode == IPRGAN_PAD_ZERO;
+  return d->x_bf16 == 1 && d->y_bf16 == 1 && g_math == IPRGAN_MATH_BF16 && d->pad_mode == IPRGAN_PAD_ZERO;
 }
+// both operands three-plane tensors: the split kernel on the 128x128 tiles reads them plane by plane (any padding mode)
+static bool wgrad_in3p(const iprgan_conv_desc* d) {
+  return d->x_bf16 == 2 && d->y_bf16 == 2 && g_math == IPRGAN_MATH_FP32X3;
+}
+static bool wgrad_has_planes(const iprgan_conv_desc* d) { return d->x_bf16 == 2 || d->y_bf16 == 2; }
 static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   const WGeom g = wgrad_geom(d);
   if (cand < 0 || cand >= WGRAD_NCAND) return false;
@@ -2249,6 +2396,7 @@ static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   cand %= WGRAD_NBASE;
   if (p.variant && (g.N <= 32 || g_math == IPRGAN_MATH_BF16)) return false;   // the 32-row tile and the bf16 image exist in the first form only
   if (p.variant && (d->x_bf16 || d->y_bf16)) return false;      // the transposed-image kernel reads fp32 tensors only
+  if (wgrad_has_planes(d) && (!wgrad_in3p(d) || g.swap || (cand % WGRAD_NSHAPE != 0 && cand % WGRAD_NSHAPE != 3))) return false;
   p.N = g.N;
   p.Cq = g.Cq;
   p.Ps = c4(p.N); p.Qs = c4(p.Cq);
@@ -2259,13 +2407,14 @@ static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   const int shape = (cand % WGRAD_NSHAPE) == 3 ? 0 : cand % WGRAD_NSHAPE;
   const int target = targets[cand / WGRAD_NSHAPE];
   p.w8 = (cand % WGRAD_NSHAPE) == 3 ? 1 : 0;
-  if (p.w8 && ((p.N < 128 && !(wgrad_in16(d) && p.N >= 64)) || K < 128)) return false;
+  const bool half_ok = (wgrad_in16(d) || wgrad_in3p(d)) && p.N >= 64;     // 64 rows of P on the 128-row image: the upper half reads zeros
+  if (p.w8 && ((p.N < 128 && !half_ok) || K < 128)) return false;
   if (p.N <= 32) {
     if (shape != 0) return false;
     p.bn = 32; p.bk = 128;
   } else if (shape == 0) {
     // (a 64-row P of bf16 tensors still takes the 128x128 bf16 tile: the upper half of the rows reads zeros)
-    if ((p.N < 128 && !(wgrad_in16(d) && p.N >= 64)) || K < 128) return false;
+    if ((p.N < 128 && !half_ok) || K < 128) return false;
     p.bn = 128; p.bk = 128;
   } else if (shape == 1) {
     p.bn = 64; p.bk = 64;
@@ -2311,7 +2460,7 @@ static const int g_rgb_targets[WGRAD_NRGB] = {256, 512};
 static const int g_halo_targets[3] = {128, 256, 512};
 static bool wgrad_halo_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_BF16 && wgrad_halo_eligible(d); }
 static bool wgrad_rgb_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_BF16 && wgrad_rgb_eligible(d); }
-static bool wgrad_h32_ok(const iprgan_conv_desc* d) { return g_math != IPRGAN_MATH_BF16 && wgrad_halo_f32_eligible(d); }
+static bool wgrad_h32_ok(const iprgan_conv_desc* d) { return g_math != IPRGAN_MATH_BF16 && !wgrad_has_planes(d) && wgrad_halo_f32_eligible(d); }
 
 static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that fits every candidate
   size_t m = 0;
@@ -2357,7 +2506,7 @@ static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t s
   }
   dim3 grid(p.Kw / BK, p.Nrows / BN, p.nsplit);
   prof_launch(kern, grid, dim3(WGM * WGN * 64), smem, st,
-              SPLIT ? 28 : BF16 ? 13 : WGM * WGN == 8 ? 11 : BN == 128 ? (BK == 128 ? 4 : 5) : (BN == 64 ? 6 : 7), a.flops, a);
+              (SPLIT && IN16) ? 30 : SPLIT ? 28 : BF16 ? 13 : WGM * WGN == 8 ? 11 : BN == 128 ? (BK == 128 ? 4 : 5) : (BN == 64 ? 6 : 7), a.flops, a);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -2365,6 +2514,9 @@ static int launch_wgrad_tn(const WGradArgs& a, const WGradPlan& p, hipStream_t s
 template <int WGM, int WGN, int WM, int WN>
 static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st) {
   if constexpr (WGM * WM == 4 && WGN * WN == 4) {       // bf16 math: the 128x128 tiles (4 and 8 waves)
+    if (a.in16 == 2)
+      return a.pad_mode == IPRGAN_PAD_REFLECT ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true, true, true, true>(a, p, st)
+                                              : launch_wgrad_tn<WGM, WGN, WM, WN, 1, false, true, true, true>(a, p, st);
     if (a.in16) return launch_wgrad_tn<WGM, WGN, WM, WN, 1, false, true, true>(a, p, st);
     if (g_math == IPRGAN_MATH_BF16)
       return a.pad_mode == IPRGAN_PAD_REFLECT ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true, true>(a, p, st)
@@ -2373,6 +2525,7 @@ static int launch_wgrad_t(const WGradArgs& a, const WGradPlan& p, hipStream_t st
       return a.pad_mode == IPRGAN_PAD_REFLECT ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true, true, false, true>(a, p, st)
                                               : launch_wgrad_tn<WGM, WGN, WM, WN, 1, false, true, false, true>(a, p, st);
   }
+  if (a.in16 == 2) return -1;            // three-plane tensors: the 128x128 split tiles only
   if (a.pad_mode == IPRGAN_PAD_REFLECT)
     return g_nbuf == 1 ? launch_wgrad_tn<WGM, WGN, WM, WN, 1, true>(a, p, st)
                        : launch_wgrad_tn<WGM, WGN, WM, WN, 2, true>(a, p, st);
@@ -2433,10 +2586,13 @@ size_t iprgan_conv_stat_floats(const iprgan_conv_desc* d, int backward) {
 
 size_t iprgan_conv_wfwd_floats(const iprgan_conv_desc* d) {
   // Conv2d fwd uses rows=Cout,k=(tap,Cin); ConvT fwd uses rows=Cout,k=(tap,Cin) as well
-  return (size_t)rup(d->Cout, 128) * rup(d->KH * d->KW * c4(d->Cin), 32);
+  // (the operand of a three-plane x is three bf16 planes: 6 bytes per element)
+  const size_t n = (size_t)rup(d->Cout, 128) * rup(d->KH * d->KW * c4(d->Cin), 32);
+  return d->x_bf16 == 2 ? n + n / 2 : n;
 }
 size_t iprgan_conv_wbwd_floats(const iprgan_conv_desc* d) {
-  return (size_t)rup(d->Cin, 128) * rup(d->KH * d->KW * c4(d->Cout), 32);
+  const size_t n = (size_t)rup(d->Cin, 128) * rup(d->KH * d->KW * c4(d->Cout), 32);
+  return d->y_bf16 == 2 ? n + n / 2 : n;
 }
 
 int iprgan_conv_weight_prep(const iprgan_conv_desc* d, const float* w, const float* inv_scale,
@@ -2456,7 +2612,7 @@ int iprgan_conv_weight_prep(const iprgan_conv_desc* d, const float* w, const flo
     const long long total = (long long)R * Kp;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(weight_prep_kernel, dim3(blocks), dim3(256), 0, st, w, inv_scale, dst, R, Kp,
-                       rows, red, Cs, ntap, row_is_d0, (which == 0 ? d->x_bf16 : d->y_bf16) != 0);
+                       rows, red, Cs, ntap, row_is_d0, which == 0 ? d->x_bf16 : d->y_bf16);
     IPR_LAUNCH_CHECK();
   }
   return 0;
@@ -2471,7 +2627,7 @@ static size_t smalln_ws_for(const iprgan_conv_desc* d, bool fwd) {
   const bool src_is_in = fwd;
   const long long pix = (long long)d->B * (src_is_in ? (long long)d->H * d->W : (long long)s.OH * s.OW);
   const int ntap = d->KH * d->KW;
-  return (size_t)rup(ntap * 4, 128) * c4(c_red) + (size_t)ntap * pix * 4;
+  return (size_t)2 * rup(ntap * 4, 128) * c4(c_red) + (size_t)ntap * pix * 4;
 }
 // geometry of the regular (not full-map) forward / backward-data pass of a layer
 static GConvArgs conv_fwd_geom(const iprgan_conv_desc* d) {
@@ -2533,7 +2689,7 @@ int iprgan_conv_weight_prep_multi(const iprgan_conv_desc* descs, const float* co
       if (e.Cs > maxcs) maxcs = e.Cs;
       if (ntap > maxtap) maxtap = ntap;
       e.row_is_d0 = ((which == 0) != (d->transposed != 0)) ? 1 : 0;
-      e.out16 = (which == 0 ? d->x_bf16 : d->y_bf16) != 0;
+      e.out16 = which == 0 ? d->x_bf16 : d->y_bf16;
       if (e.rows_alloc > maxrows) maxrows = e.rows_alloc;
       if (cnt == PREP_MAX) { const int rc = flush(); if (rc) return rc; }
     }
@@ -2557,6 +2713,8 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
     const int K = d->KH * d->KW * d->Cin, ks = fullmap_ksplit(d);
     geom_forward_form(a, d->B, 1, 1, K, 1, 1, d->Cout, 1, 1, 1, 0);
     a.in = x; a.wt = wfwd; a.flops = 2.0 * d->B * (double)d->Cout * K;
+    IPR_CHECK(d->x_bf16 != 1 && d->y_bf16 != 1, "conv_fwd: bf16 activations on a full-map convolution are not built");
+    a.in16 = d->x_bf16; a.in_ps = (unsigned)(d->x_pstride * 2);
     if (ks > 1) {
       IPR_CHECK(ws, "conv_fwd: the full-map path needs its workspace (iprgan_conv_fwd_ws_floats)");
       a.ksplit = ks; a.out = ws; a.act = IPRGAN_ACT_NONE;
@@ -2565,11 +2723,13 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
       const unsigned n4 = (unsigned)d->B * (unsigned)(c4(d->Cout) / 4);
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int)n4, 256) < 1024 ? cdiv((int)n4, 256) : 1024), dim3(256), 0,
                          (hipStream_t)stream, (const f32x4*)ws, bias, (f32x4*)y, n4, (unsigned)(c4(d->Cout) / 4), d->Cout,
-                         ks, d->act, d->slope, (const f32x4*)nullptr, 0, 0.f, (const f32x4*)nullptr);
+                         ks, d->act, d->slope, (const f32x4*)nullptr, 0, 0.f, (const f32x4*)nullptr, d->y_bf16,
+                         d->y_pstride ? (size_t)d->y_pstride : (size_t)d->B * c4(d->Cout));
       IPR_LAUNCH_CHECK();
       return 0;
     }
     a.bias = bias; a.out = y; a.act = d->act; a.slope = d->slope;
+    a.out16 = d->y_bf16; a.out_ps = (unsigned)(d->y_pstride * 2);
     return launch_gconv(a, (hipStream_t)stream);
   }
   if (!d->transposed) {
@@ -2581,7 +2741,8 @@ int iprgan_conv_fwd(const iprgan_conv_desc* d, const float* x, const float* wfwd
   }
   a.in = x; a.wt = wfwd; a.bias = bias; a.out = y; a.aux = nullptr;
   a.rs0 = pair_sigma0; a.rs1 = pair_sigma1;
-  a.in16 = d->x_bf16 != 0; a.out16 = d->y_bf16 != 0;
+  a.in16 = d->x_bf16; a.out16 = d->y_bf16;
+  a.in_ps = (unsigned)(d->x_pstride * 2); a.out_ps = (unsigned)(d->y_pstride * 2);
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = d->act; a.slope = d->slope;
   a.ws = ws; a.ws_floats = ws ? iprgan_conv_fwd_ws_floats(d) : 0;
@@ -2621,7 +2782,8 @@ int iprgan_conv_bwd_data(const iprgan_conv_desc* d, const float* dy, const float
 // 1 when iprgan_conv_bwd_data_bn applies to the layer: a zero-padded regular (not full-map) convolution whose input has
 // more than 4 channels - the tile kernels' epilogue then takes the norm backward's two reductions
 int iprgan_conv_bwd_data_bn_ok(const iprgan_conv_desc* d) {
-  return !fullmap_conv(d) && d->pad_mode != IPRGAN_PAD_REFLECT && c4(d->Cin) > 32 && d->stride >= 1 && d->stride <= 2;
+  // (three-plane tensors: the mask operand of a fused derivative is the h plane only, the norm backward needs all of x)
+  return !fullmap_conv(d) && d->pad_mode != IPRGAN_PAD_REFLECT && c4(d->Cin) > 32 && d->stride >= 1 && d->stride <= 2 && d->x_bf16 != 2;
 }
 
 int iprgan_conv_bwd_data_bn(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dz, const float* bn_x,
@@ -2660,6 +2822,9 @@ static int conv_bwd_data_impl(const iprgan_conv_desc* d, const float* dy, const 
     a.wmod = d->Cin; a.wk1 = c4(d->Cout);
     a.in = dy; a.wt = wbwd; a.out = dx; a.act = IPRGAN_ACT_NONE;
     a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.res = residual;
+    IPR_CHECK(d->x_bf16 != 1 && d->y_bf16 != 1, "conv_bwd_data: bf16 activations on a full-map convolution are not built");
+    a.in16 = d->y_bf16; a.in_ps = (unsigned)(d->y_pstride * 2);
+    a.out16 = d->x_bf16; a.out_ps = (unsigned)(d->x_pstride * 2); a.aux16 = d->x_bf16 != 0;
     a.flops = 2.0 * d->B * (double)d->Cout * d->Cin * ntap;
     return launch_gconv(a, (hipStream_t)stream);
   }
@@ -2675,8 +2840,9 @@ static int conv_bwd_data_impl(const iprgan_conv_desc* d, const float* dy, const 
   }
   a.in = dy; a.wt = wbwd; a.bias = nullptr; a.out = reflect ? ws : dx;
   a.rs0 = pair_sigma0; a.rs1 = pair_sigma1;
-  a.in16 = d->y_bf16 != 0; a.out16 = d->x_bf16 != 0; a.aux16 = d->x_bf16 != 0;
-  IPR_CHECK(!(reflect && (a.in16 || a.out16)), "conv_bwd_data: bf16 activations with reflection padding are not built");
+  a.in16 = d->y_bf16; a.out16 = reflect ? 0 : d->x_bf16; a.aux16 = d->x_bf16 != 0;     // (a three-plane prev_out: its h plane)
+  a.in_ps = (unsigned)(d->y_pstride * 2); a.out_ps = (unsigned)(d->x_pstride * 2);
+  IPR_CHECK(!(reflect && (a.in16 == 1 || d->x_bf16 == 1)), "conv_bwd_data: bf16 activations with reflection padding are not built");
   a.flops = d->transposed ? 2.0 * d->B * (double)d->H * d->W * d->Cout * d->Cin * d->KH * d->KW : 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
   a.act = IPRGAN_ACT_NONE; a.slope = 0.f;
   if (!reflect) { a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.ws = ws; a.ws_floats = ws ? smalln_ws_for(d, false) : 0; }
@@ -2692,8 +2858,8 @@ static int conv_bwd_data_impl(const iprgan_conv_desc* d, const float* dy, const 
   const int rc = launch_gconv(a, (hipStream_t)stream);
   if (stat_part && !rc) *stat_rows = stat_rows_of(a);
   if (rc || !reflect) return rc;
-  return iprgan_reflect_fold(ws, dx, prev_out, prev_act, prev_slope, residual, d->B, d->H, d->W, c4(d->Cin), d->pad,
-                             stream);
+  return reflect_fold_launch(ws, dx, prev_out, prev_act, prev_slope, residual, d->B, d->H, d->W, c4(d->Cin), d->pad,
+                             d->x_bf16, (size_t)d->x_pstride, (hipStream_t)stream);
 }
 
 static size_t wgrad_weight_floats(const iprgan_conv_desc* d) { return (size_t)d->Cout * d->Cin * d->KH * d->KW; }
@@ -2708,6 +2874,10 @@ int iprgan_conv_wgrad_takes_bf16(const iprgan_conv_desc* d) {
   // bf16 x and / or dy (desc flags) are read directly by every backward-weight kernel except the reflect-padded
   // swapped form (which copies x into a padded fp32 image first): there the caller hands an fp32 x (iprgan_cast)
   const WGeom g = wgrad_geom(d);
+  if (wgrad_has_planes(d)) {      // three planes: both tensors, a regular (not role-swapped) layer with a 128x128 split tile
+    WGradPlan p;
+    return wgrad_in3p(d) && !g.swap && (wgrad_plan_c(d, 0, p) || wgrad_plan_c(d, 3, p)) ? 1 : 0;
+  }
   return !(g.padded && d->x_bf16);
 }
 
@@ -2774,10 +2944,17 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     const bool p_is_x = d->transposed || g.swap;
     a.p16 = (p_is_x ? d->x_bf16 : d->y_bf16) != 0;
     a.q16 = (p_is_x ? d->y_bf16 : d->x_bf16) != 0;
-    a.in16 = wgrad_in16(d) && p.bn == 128 && p.bk == 128;
+    a.in16 = wgrad_in3p(d) ? 2 : (wgrad_in16(d) && p.bn == 128 && p.bk == 128) ? 1 : 0;
     const unsigned long long pesz = a.p16 ? 2ull : 4ull, esz = a.q16 ? 2ull : 4ull;
-    const unsigned long long pb = (unsigned long long)a.M * a.Ps * pesz;
-    const unsigned long long qb = (unsigned long long)d->B * a.QH * a.QW * a.Qs * esz;
+    unsigned long long pb = (unsigned long long)a.M * a.Ps * pesz;
+    unsigned long long qb = (unsigned long long)d->B * a.QH * a.QW * a.Qs * esz;
+    if (a.in16 == 2) {
+      const long long pps = p_is_x ? d->x_pstride : d->y_pstride, qps = p_is_x ? d->y_pstride : d->x_pstride;
+      IPR_CHECK(pb < 0x2fffffffull && qb < 0x2fffffffull, "conv_bwd_weight: three-plane tensor larger than 2 GiB");
+      a.p_ps = pps ? (unsigned)(pps * 2) : (unsigned)pb;
+      a.q_ps = qps ? (unsigned)(qps * 2) : (unsigned)qb;
+      pb += 2ull * a.p_ps; qb += 2ull * a.q_ps;
+    }
     IPR_CHECK(pb < 0x7fffffffull && qb < 0x7fffffffull, "conv_bwd_weight: tensor larger than 2 GiB");
     a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
     IPR_CHECK(a.QH * (long long)a.QW < (1 << 24) && a.PH * (long long)a.PW < (1 << 24),
@@ -2819,7 +2996,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   int cand = 0;
   {
     WGradPlan p0;
-    if (!wgrad_plan_c(d, 0, p0)) cand = 1;
+    if (!wgrad_plan_c(d, 0, p0)) cand = wgrad_has_planes(d) ? 3 : 1;
   }
   if (g_force_wgrad >= 0) {
     WGradPlan pf;
@@ -2854,7 +3031,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   if (db) {
     const int Cs = c4(d->Cout), M = d->B * s.OH * s.OW;
     float* part = ws + wgrad_slab_floats(d);
-    const int rc2 = colsum_launch(dy, db, part, M, Cs, d->Cout, st, beta, d->y_bf16);
+    const int rc2 = colsum_launch(dy, db, part, M, Cs, d->Cout, st, beta, d->y_bf16, (size_t)d->y_pstride);
     if (rc2) return rc2;
   }
   return 0;

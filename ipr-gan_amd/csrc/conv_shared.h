@@ -76,8 +76,12 @@ struct GConvArgs {
   const float* res;    // added to the stored value (same layout as out): the gradient arriving over a skip connection
   const float* rs0;    // paired pass (two half-batches through one launch, each with its own spectral-norm sigma):
   const float* rs1;    //   rows of the first / second half of every phase are divided by *rs0 / *rs1 before the bias
-  int in16;            // both operands (activation and prepared weight) are bf16 in HBM -> IN16 kernels
-  int out16, aux16;    // bf16 storage: out (and res) / aux are bf16 tensors (element offsets stay the same)
+  int in16;            // 1: both operands (activation and prepared weight) are bf16 in HBM -> IN16 kernels
+                       // 2: both are THREE bf16 planes (x = h + m + l exactly, plane-major: plane p of the activation at byte
+                       //    in_ps * p, of the prepared weight at wt_ps * p) -> the three-plane kernels (conv_x3.hip, gconv_kernel<.., IN3P>)
+  int out16, aux16;    // storage of out (and res) / aux: 0 fp32, 1 bf16 (element offsets stay the same), out16 == 2: three
+                       // bf16 planes out_ps bytes apart (aux16 == 1 then reads the h plane of such a tensor: same sign)
+  unsigned in_ps, wt_ps, out_ps;     // plane strides in bytes (storage kind 2)
   float* stat_part;    // STATS kernels: per-tile column sums [tile rows][2][Ns] (see gconv_kernel)
   int stat_mode;
   int ksplit;          // > 1: blockIdx.z splits the K loop (single-phase geometries); partial tiles go to slabs of M*Ns floats
@@ -317,6 +321,11 @@ __device__ __forceinline__ void gconv_epilogue(const GConvArgs& a, f32x16 (&acc)
       for (int g = 0; g < GC; ++g)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
+          if (a.out16 == 2) {          // three-plane residual: h + (m + l), exact
+            const unsigned rb = eoff[g][j] == OOB_OFFSET ? OOB_OFFSET : eoff[g][j] * 2u;
+            r[g][j] = buf_load4_bf16(rs_res, rb) + (buf_load4_bf16(rs_res, rb == OOB_OFFSET ? rb : rb + a.out_ps) +
+                                                    buf_load4_bf16(rs_res, rb == OOB_OFFSET ? rb : rb + 2u * a.out_ps));
+          } else
           r[g][j] = a.out16 ? buf_load4_bf16(rs_res, eoff[g][j] == OOB_OFFSET ? OOB_OFFSET : eoff[g][j] * 2u)
                             : buf_load4(rs_res, eoff[g][j] == OOB_OFFSET ? OOB_OFFSET : eoff[g][j] * 4u);
 #pragma unroll
@@ -334,7 +343,12 @@ __device__ __forceinline__ void gconv_epilogue(const GConvArgs& a, f32x16 (&acc)
           for (int k = 0; k < 4; ++k) { const float t = ok ? val[g][j][k] : 0.f; cs1[j][k] += t; cs2[j][k] += t * t; }
         }
         const unsigned boff = ok ? eoff[g][j] * esz_out : OOB_OFFSET;
-        if (a.out16) buf_store_bf16x4(rs_out, boff, to_bf16x4(val[g][j]));     // this tensor lives as bf16
+        if (a.out16 == 2) {                // this tensor lives as three bf16 planes: split once, here
+          bf16x4 t3[3];
+          split3_bf16(val[g][j], t3);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) buf_store_bf16x4(rs_out, ok ? boff + (unsigned)p * a.out_ps : OOB_OFFSET, t3[p]);
+        } else if (a.out16) buf_store_bf16x4(rs_out, boff, to_bf16x4(val[g][j]));     // this tensor lives as bf16
         else buf_store4(rs_out, boff, val[g][j]);
       }
   }

@@ -532,7 +532,14 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const rf_f4* __restri
                                                            const rf_f4* __restrict__ prev_out, int prev_act,
                                                            float prev_slope, const rf_f4* __restrict__ residual,
                                                            unsigned total4, int H, int W, int C4n,
-                                                           int p, FastDiv d_c4n, FastDiv d_w, FastDiv d_h) {
+                                                           int p, FastDiv d_c4n, FastDiv d_w, FastDiv d_h, int okind, size_t ps) {
+  // okind 2: dx and residual are three-plane tensors (plane stride ps elements), prev_out is the h plane of one (same sign)
+  typedef __bf16 rf_b4 __attribute__((ext_vector_type(4)));
+  auto ldb = [](const void* base, size_t e) {
+    const rf_b4 h = *(const rf_b4*)((const __bf16*)base + e);
+    const rf_f4 v = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    return v;
+  };
   const int HP = H + 2 * p, WP = W + 2 * p;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
     const unsigned pix = fdiv(i, d_c4n), c = i - pix * (unsigned)C4n;
@@ -546,9 +553,23 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const rf_f4* __restri
     for (int a = 0; a < ny; ++a)
       for (int q = 0; q < nx; ++q) s += dxp[((size_t)(b * HP + ys[a]) * WP + xs[q]) * C4n + c];
     if (prev_out) {
-      const rf_f4 o = prev_out[i];
+      const rf_f4 o = okind == 2 ? ldb(prev_out, (size_t)i * 4) : prev_out[i];
 #pragma unroll
       for (int k = 0; k < 4; ++k) s[k] *= act_grad_from_out(o[k], prev_act, prev_slope);
+    }
+    if (okind == 2) {
+      const size_t e = (size_t)i * 4;
+      if (residual) s += ldb(residual, e) + (ldb(residual, e + ps) + ldb(residual, e + 2 * ps));
+      const rf_b4 h = {(__bf16)s.x, (__bf16)s.y, (__bf16)s.z, (__bf16)s.w};
+      const rf_f4 hf = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+      const rf_f4 r1 = s - hf;
+      const rf_b4 m = {(__bf16)r1.x, (__bf16)r1.y, (__bf16)r1.z, (__bf16)r1.w};
+      const rf_f4 mf = {(float)m.x, (float)m.y, (float)m.z, (float)m.w};
+      const rf_f4 r2 = r1 - mf;
+      const rf_b4 l = {(__bf16)r2.x, (__bf16)r2.y, (__bf16)r2.z, (__bf16)r2.w};
+      __bf16* o = (__bf16*)dx + e;
+      *(rf_b4*)o = h; *(rf_b4*)(o + ps) = m; *(rf_b4*)(o + 2 * ps) = l;
+      continue;
     }
     if (residual) s += residual[i];
     dx[i] = s;
@@ -748,9 +769,18 @@ int iprgan_axpy_multi(float* const* y, const float* const* x, const long long* s
 
 int iprgan_cast(const float* src, float* dst, size_t n, int src_bf16, int dst_bf16, void* stream) {
   if (!n) return 0;
+  if (src_bf16 == 2 || dst_bf16 == 2) {        // fp32 <-> three planes (contiguous: plane stride n); conv_x3.hip
+    IPR_CHECK((src_bf16 == 2 && dst_bf16 == 0) || (src_bf16 == 0 && dst_bf16 == 2), "cast: three planes convert from / to fp32 only");
+    return cast_planes(src, dst, n, n, dst_bf16 == 2, (hipStream_t)stream);
+  }
   hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, n, src_bf16, dst_bf16);
   IPR_LAUNCH_CHECK();
   return 0;
+}
+
+int iprgan_cast_planes(const void* src, void* dst, size_t n, size_t pstride, int to_planes, void* stream) {
+  IPR_CHECK(pstride >= n, "cast_planes: plane stride %zu smaller than the tensor (%zu elements)", pstride, n);
+  return cast_planes(src, dst, n, pstride, to_planes != 0, (hipStream_t)stream);
 }
 
 int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const float* inv_scale, float* y,
@@ -850,17 +880,26 @@ int iprgan_add(const float* a, const float* b, float* out, size_t n, void* strea
 int iprgan_reflect_fold(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope,
                         const float* residual, int B,
                         int H, int W, int C, int pad, void* stream) {
+  return reflect_fold_launch(dxp, dx, prev_out, prev_act, prev_slope, residual, B, H, W, C, pad, 0, 0, (hipStream_t)stream);
+}
+}  // extern "C"
+namespace iprgan {
+int reflect_fold_launch(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope,
+                        const float* residual, int B, int H, int W, int C, int pad, int okind, size_t ps, hipStream_t stream) {
   const size_t n = (size_t)B * H * W * C;
+  if (okind == 2 && !ps) ps = n;
   IPR_CHECK(pad < H && pad < W, "reflect_fold: pad %d must be smaller than the image", pad);
   IPR_CHECK(C % 4 == 0 && n / 4 < 0x7fffffffull, "reflect_fold: C=%d must be a multiple of 4 (and < 2^33 elements)", C);
   if (!n) return 0;
   hipLaunchKernelGGL(reflect_fold_kernel, dim3(grid_for(n / 4, 8192)), dim3(256), 0, (hipStream_t)stream,
                      (const rf_f4*)dxp, (rf_f4*)dx, (const rf_f4*)prev_out, prev_act, prev_slope, (const rf_f4*)residual,
                      (unsigned)(n / 4), H, W,
-                     C / 4, pad, make_fastdiv(C / 4), make_fastdiv(W), make_fastdiv(H));
+                     C / 4, pad, make_fastdiv(C / 4), make_fastdiv(W), make_fastdiv(H), okind, ps);
   IPR_LAUNCH_CHECK();
   return 0;
 }
+}  // namespace iprgan
+extern "C" {
 
 static bool loss_needs_y(int kind) {
   return kind == IPRGAN_LOSS_MSE || kind == IPRGAN_LOSS_L1 || kind == IPRGAN_LOSS_BCE_PM1 ||

@@ -14,26 +14,44 @@ namespace iprgan {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
-// Activation storage: fp32, or bf16 (B16: "bf16 activations", include/iprgan.h iprgan_conv_desc).  `e` is the ELEMENT
-// index of 4 consecutive channels; arithmetic is fp32 either way.
-template <bool B16>
-__device__ __forceinline__ f32x4 ldv(const float* base, size_t e) {
-  if (B16) {
-    const nbf16x4 h = *(const nbf16x4*)((const __bf16*)base + e);
-    const f32x4 v = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
-    return v;
+// Activation storage (ST = IPRGAN_ST_* of include/iprgan.h): fp32, bf16 ("bf16 activations"), or three bf16 planes ps
+// elements apart (x = h + (m + l) exactly; split once per element when stored).  `e` is the ELEMENT index of 4 consecutive
+// channels; arithmetic is fp32 in every case.
+__device__ __forceinline__ f32x4 widen4(const nbf16x4 h) {
+  const f32x4 v = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+  return v;
+}
+__device__ __forceinline__ nbf16x4 narrow4(const f32x4& v) {
+  const nbf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  return h;
+}
+template <int ST>
+__device__ __forceinline__ f32x4 ldv(const float* base, size_t e, size_t ps) {
+  if (ST == 2) {
+    const __bf16* b = (const __bf16*)base + e;
+    return widen4(*(const nbf16x4*)b) + (widen4(*(const nbf16x4*)(b + ps)) + widen4(*(const nbf16x4*)(b + 2 * ps)));
   }
+  if (ST == 1) return widen4(*(const nbf16x4*)((const __bf16*)base + e));
   return *(const f32x4*)(base + e);
 }
-template <bool B16>
-__device__ __forceinline__ void stv(float* base, size_t e, const f32x4& v) {
-  if (B16) {
-    const nbf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-    *(nbf16x4*)((__bf16*)base + e) = h;
+template <int ST>
+__device__ __forceinline__ void stv(float* base, size_t e, const f32x4& v, size_t ps) {
+  if (ST == 2) {
+    __bf16* b = (__bf16*)base + e;
+    const nbf16x4 h = narrow4(v);
+    const f32x4 r1 = v - widen4(h);
+    const nbf16x4 m = narrow4(r1);
+    *(nbf16x4*)b = h;
+    *(nbf16x4*)(b + ps) = m;
+    *(nbf16x4*)(b + 2 * ps) = narrow4(r1 - widen4(m));
+  } else if (ST == 1) {
+    *(nbf16x4*)((__bf16*)base + e) = narrow4(v);
   } else {
     *(f32x4*)(base + e) = v;
   }
 }
+// launch-time choice of a kernel instantiation by storage kind
+#define ST_PICK(kind, K, ...) ((kind) == 2 ? K<__VA_ARGS__, 2> : (kind) == 1 ? K<__VA_ARGS__, 1> : K<__VA_ARGS__, 0>)
 
 struct ColGeom {
   int TC, TR, gy, NB, rows_per_block;
@@ -64,7 +82,7 @@ static ColGeom col_geom(int M, int C) {
 // less per pass; with no activation y is not read either.  Other activations (never fused into a norm here) read y.
 __host__ __device__ __forceinline__ bool act_from_x(int act) { return act == IPRGAN_ACT_RELU || act == IPRGAN_ACT_LRELU; }
 
-template <int MODE, bool B16 = false>
+template <int MODE, int ST = 0>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ y,
                                                         const float* __restrict__ dy,
@@ -74,7 +92,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
                                                         int rows_per_block, int act, float slope,
                                                         const float* __restrict__ gamma = nullptr,
                                                         const float* __restrict__ beta = nullptr,
-                                                        const float* __restrict__ slope_ptr = nullptr) {
+                                                        const float* __restrict__ slope_ptr = nullptr, size_t ps = 0) {
   if (slope_ptr) slope = *slope_ptr;          // PReLU fused into the norm layer: LeakyReLU with a learnable, device-resident slope
   // blockIdx.z = group (InstanceNorm: one group per sample; BatchNorm: a single group)
   const int grp = blockIdx.z;
@@ -92,7 +110,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   if (ok) {
     f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {1.f, 1.f, 1.f, 1.f};
-    if (MODE == 1) p0 = ldv<B16>(x, gofs + cq * 4);
+    if (MODE == 1) p0 = ldv<ST>(x, gofs + cq * 4, ps);
     f32x4 pg = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 2) {
       p0 = *(const f32x4*)(mean + cq * 4); p1 = *(const f32x4*)(invstd + cq * 4);
@@ -129,18 +147,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t off = gofs + (size_t)(r + u * TR) * C + cq * 4;
-        xv[u] = ldv<B16>(x, off);
-        if (MODE == 2) gv[u] = ldv<B16>(dy, off);
-        if (need_y) yv[u] = ldv<B16>(y, off);
+        xv[u] = ldv<ST>(x, off, ps);
+        if (MODE == 2) gv[u] = ldv<ST>(dy, off, ps);
+        if (need_y) yv[u] = ldv<ST>(y, off, ps);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) accumulate(xv[u], MODE == 2 ? gv[u] : xv[u], need_y ? yv[u] : xv[u]);   // same row order as below
     }
     for (; r < r1; r += TR) {
       const size_t off = gofs + (size_t)r * C + cq * 4;
-      const f32x4 xv = ldv<B16>(x, off);
-      const f32x4 gv = MODE == 2 ? ldv<B16>(dy, off) : xv;
-      const f32x4 yv = need_y ? ldv<B16>(y, off) : xv;
+      const f32x4 xv = ldv<ST>(x, off, ps);
+      const f32x4 gv = MODE == 2 ? ldv<ST>(dy, off, ps) : xv;
+      const f32x4 yv = need_y ? ldv<ST>(y, off, ps) : xv;
       accumulate(xv, gv, yv);
     }
   }
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
                                                              float* __restrict__ running_var,
                                                              float* __restrict__ save_mean,
                                                              float* __restrict__ save_invstd,
-                                                             int shift_vec, long long* __restrict__ counter, int x_b16) {
+                                                             int shift_vec, long long* __restrict__ counter, int x_b16, size_t ps) {
   // shift_vec 0: the sums are about s = x[0][c] of the group (colreduce_kernel<1>); 1: about the per-channel vector
   // x[c] itself, or about zero when x is null (sums emitted by the producing convolution's epilogue, taken before
   // its bias was added: s = bias)
@@ -265,7 +283,12 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
   if (lane != 0 || c >= C) return;
   const float invM = 1.0f / (float)M;
   const float d = s0 * invM;                 // E[x - s]
-  const float mean = (x ? ((x_b16 && !shift_vec) ? (float)((const __bf16*)x)[xofs + c] : x[xofs + c]) : 0.f) + d;
+  float shift = 0.f;
+  if (x) {
+    const __bf16* xb = (const __bf16*)x + xofs + c;
+    shift = shift_vec || !x_b16 ? x[xofs + c] : x_b16 == 2 ? (float)xb[0] + ((float)xb[ps] + (float)xb[2 * ps]) : (float)xb[0];
+  }
+  const float mean = shift + d;
   float var = s1 * invM - d * d;             // biased variance
   if (var < 0.f) var = 0.f;
   save_mean[c] = mean;
@@ -296,13 +319,13 @@ __device__ __forceinline__ f32x4 ld4(const float* p, int c, float dflt) {
   const f32x4 d = {dflt, dflt, dflt, dflt};
   return d;
 }
-template <bool FIXED, bool B16 = false>
+template <bool FIXED, int ST = 0>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        unsigned n4, int C4n, FastDiv d_c4n, FastDiv d_group4, int act,
                                                        float slope, const float* __restrict__ residual,
-                                                       const float* __restrict__ slope_ptr) {
+                                                       const float* __restrict__ slope_ptr, size_t ps) {
   if (slope_ptr) slope = *slope_ptr;          // PReLU as the norm layer's activation (networks/sr_resnet.py:7,13)
   // residual: y = act(norm(x)) + residual - the skip connection that closes a residual block right after its last norm
   // layer (networks/sr_resnet.py:37-38, resnet_generator.py:52-53), folded into this pass
@@ -315,12 +338,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const size_t base = (size_t)blockIdx.y * n4;        // n4 = 16-byte quads per group here
 #pragma unroll 4
     for (; i < n4; i += stride) {
-      const f32x4 v = ldv<B16>(x, (base + i) * 4);
+      const f32x4 v = ldv<ST>(x, (base + i) * 4, ps);
       f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = act_apply((v[k] - m[k]) * is[k] * g[k] + b[k], act, slope);
-      if (residual) o += ldv<B16>(residual, (base + i) * 4);
-      stv<B16>(y, (base + i) * 4, o);
+      if (residual) o += ldv<ST>(residual, (base + i) * 4, ps);
+      stv<ST>(y, (base + i) * 4, o, ps);
     }
     return;
   }
@@ -328,12 +351,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const int c = (int)(i - fdiv(i, d_c4n) * (unsigned)C4n) * 4;
     const size_t go = (size_t)fdiv(i, d_group4) * (size_t)C4n * 4;     // group offset into mean/invstd
     const f32x4 g = ld4(gamma, c, 1.f), b = ld4(beta, c, 0.f), m = ld4(mean + go, c, 0.f), is = ld4(invstd + go, c, 1.f);
-    const f32x4 v = ldv<B16>(x, (size_t)i * 4);
+    const f32x4 v = ldv<ST>(x, (size_t)i * 4, ps);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = act_apply((v[k] - m[k]) * is[k] * g[k] + b[k], act, slope);
-    if (residual) o += ldv<B16>(residual, (size_t)i * 4);
-    stv<B16>(y, (size_t)i * 4, o);
+    if (residual) o += ldv<ST>(residual, (size_t)i * 4, ps);
+    stv<ST>(y, (size_t)i * 4, o, ps);
   }
 }
 
@@ -355,7 +378,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restr
   if (dbeta) dbeta[c] = s1;
 }
 
-template <bool FIXED, bool B16 = false>
+template <bool FIXED, int ST = 0>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, float* __restrict__ dx,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -363,7 +386,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ sums,
                                                            unsigned n4, int C4n, int C, FastDiv d_c4n, FastDiv d_group4,
                                                            float invM, int act, float slope, float* __restrict__ colpart,
-                                                           const float* __restrict__ slope_ptr, float* __restrict__ apart) {
+                                                           const float* __restrict__ slope_ptr, float* __restrict__ apart, size_t ps) {
   // slope_ptr / apart: PReLU fused into the norm layer - the slope is read from the device and every block emits its share
   // of the slope gradient sum dy * min(v, 0), v = the normalised, affine value (one more partial array, summed in double)
   if (slope_ptr) slope = *slope_ptr;
@@ -377,9 +400,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   auto body = [&](size_t idx, const f32x4& g, const f32x4& b, const f32x4& m, const f32x4& is, const f32x4& s1,
                   const f32x4& s2) {
-    const f32x4 xv = ldv<B16>(x, idx * 4), gv = ldv<B16>(dy, idx * 4);
+    const f32x4 xv = ldv<ST>(x, idx * 4, ps), gv = ldv<ST>(dy, idx * 4, ps);
     f32x4 yv = {0.f, 0.f, 0.f, 0.f};
-    if (!from_x && !no_act) yv = ldv<B16>(y, idx * 4);
+    if (!from_x && !no_act) yv = ldv<ST>(y, idx * 4, ps);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -389,7 +412,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       const float dz = no_act ? gv[k] : gv[k] * act_grad_from_out(from_x ? v : yv[k], act, slope);
       o[k] = g[k] * is[k] * (dz - s1[k] * invM - t * s2[k] * invM);
     }
-    stv<B16>(dx, idx * 4, o);
+    stv<ST>(dx, idx * 4, o, ps);
     csum += o;
   };
   if (FIXED) {               // see bn_apply_kernel: blockIdx.y = group, n4 = quads per group
@@ -443,11 +466,12 @@ size_t colsum_ws_floats(int M, int Cs) {
   const ColGeom g = col_geom(M, Cs);
   return (size_t)g.NB * 2 * Cs;
 }
-int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st, float beta, int b16) {
+int colsum_launch(const float* x, float* out, float* ws, int M, int Cs, int C, hipStream_t st, float beta, int b16, size_t ps) {
   const ColGeom g = col_geom(M, Cs);
-  auto kr0 = b16 ? colreduce_kernel<0, true> : colreduce_kernel<0, false>;
+  auto kr0 = ST_PICK(b16, colreduce_kernel, 0);
   hipLaunchKernelGGL(kr0, dim3(g.NB, g.gy), dim3(256), 0, st, x,
-                     nullptr, nullptr, nullptr, nullptr, ws, M, Cs, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr, nullptr);
+                     nullptr, nullptr, nullptr, nullptr, ws, M, Cs, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr, nullptr,
+                     ps ? ps : (size_t)M * Cs);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64 * FL), 0, st, ws, g.NB, Cs, C, out, beta);
   IPR_LAUNCH_CHECK();
@@ -477,6 +501,7 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
                     const float* slope_ptr = nullptr) {
   IPR_CHECK(C % 4 == 0, "norm_fwd: C=%d must be a multiple of 4", C);
   IPR_CHECK(M > 0 && G > 0, "norm_fwd: empty input");
+  const size_t ps = (size_t)G * M * C;         // three-plane tensors: contiguous, plane stride = the tensor
   if (use_running) {
     IPR_CHECK(running_mean && running_var && G == 1, "norm_fwd: eval mode needs running stats");
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, running_mean,
@@ -487,28 +512,27 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
     int rpg = part_rows / G;
     if (compact_partials(part, rpg, G, C, st)) return 2;
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, part, shift, rpg, M,
-                       C, eps, momentum, running_mean, running_var, save_mean, save_invstd, 1, counter, 0);
+                       C, eps, momentum, running_mean, running_var, save_mean, save_invstd, 1, counter, 0, (size_t)0);
   } else {
     const ColGeom g = col_geom(M, C);
-    auto kr1 = b16 ? colreduce_kernel<1, true> : colreduce_kernel<1, false>;
-  hipLaunchKernelGGL(kr1, dim3(g.NB, g.gy, G), dim3(256), 0, st,
-                       x, nullptr, nullptr, nullptr, nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr, nullptr);
+    auto kr1 = ST_PICK(b16, colreduce_kernel, 1);
+    hipLaunchKernelGGL(kr1, dim3(g.NB, g.gy, G), dim3(256), 0, st,
+                       x, nullptr, nullptr, nullptr, nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr, nullptr, ps);
     IPR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, x, g.NB, M, C,
-                       eps, momentum, running_mean, running_var, save_mean, save_invstd, 0, counter, b16);
+                       eps, momentum, running_mean, running_var, save_mean, save_invstd, 0, counter, b16, ps);
   }
   IPR_LAUNCH_CHECK();
   const size_t n4 = (size_t)G * M * C / 4;
   IPR_CHECK(n4 < 0x7fffffffull, "norm_fwd: tensor of %zu elements is too large", n4 * 4);
   int blocks = (int)(cdivz(n4, 256) < 4096 ? cdivz(n4, 256) : 4096);
   const bool fixed = 256 % (C / 4) == 0 && G <= 65535;
-  auto kern = b16 ? (fixed ? bn_apply_kernel<true, true> : bn_apply_kernel<false, true>)
-                  : (fixed ? bn_apply_kernel<true, false> : bn_apply_kernel<false, false>);
+  auto kern = fixed ? ST_PICK(b16, bn_apply_kernel, true) : ST_PICK(b16, bn_apply_kernel, false);
   const size_t n4g = (size_t)M * C / 4;              // quads per group
   if (fixed) blocks = (int)(cdivz(n4g, 256) < (size_t)cdiv(4096, G) ? cdivz(n4g, 256) : (size_t)cdiv(4096, G));
   hipLaunchKernelGGL(kern, dim3(blocks, fixed ? G : 1), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_invstd,
                      (unsigned)(fixed ? n4g : n4), C / 4,
-                     make_fastdiv(C / 4), make_fastdiv((uint32_t)n4g), act, slope, residual, slope_ptr);
+                     make_fastdiv(C / 4), make_fastdiv((uint32_t)n4g), act, slope, residual, slope_ptr, ps);
   IPR_LAUNCH_CHECK();
   return 0;
 }
@@ -522,6 +546,7 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
   // pre_part: the two reductions (sum dz, sum dz * xhat; dz = dy * act') were taken by the epilogue of the backward-data
   // pass that produced dy (iprgan_conv_bwd_data_bn), which stored dz in dy's place: no reduction pass, no mask here
   IPR_CHECK(C % 4 == 0, "norm_bwd: C=%d must be a multiple of 4", C);
+  const size_t ps = (size_t)G * M * C;
   if (pre_part) act = IPRGAN_ACT_NONE;
   IPR_CHECK(act == IPRGAN_ACT_NONE || act_from_x(act) || y, "norm_bwd: this activation needs the saved output y");
   IPR_CHECK(!act_from_x(act) || !gamma == !beta, "norm_bwd: the ReLU mask is recomputed from x: gamma and beta are both needed (or both absent)");
@@ -535,9 +560,9 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64), 1), dim3(64 * FL), 0, st, pp, rows, C, sums, dgamma, dbeta);
     IPR_LAUNCH_CHECK();
   } else {
-    auto kr2 = b16 ? colreduce_kernel<2, true> : colreduce_kernel<2, false>;
+    auto kr2 = ST_PICK(b16, colreduce_kernel, 2);
     hipLaunchKernelGGL(kr2, dim3(g.NB, g.gy, G), dim3(256), 0, st,
-                       x, y, dy, save_mean, save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope, gamma, beta, slope_ptr);
+                       x, y, dy, save_mean, save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope, gamma, beta, slope_ptr, ps);
     IPR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, g.NB, C, sums,
                        G == 1 ? dgamma : nullptr, G == 1 ? dbeta : nullptr);
@@ -563,12 +588,11 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
     if (blocks > cap) blocks = cap;
     colpart = sums + (size_t)G * 2 * C;
   }
-  auto kern = b16 ? (fixed ? bn_bwd_apply_kernel<true, true> : bn_bwd_apply_kernel<false, true>)
-                  : (fixed ? bn_bwd_apply_kernel<true, false> : bn_bwd_apply_kernel<false, false>);
+  auto kern = fixed ? ST_PICK(b16, bn_bwd_apply_kernel, true) : ST_PICK(b16, bn_bwd_apply_kernel, false);
   hipLaunchKernelGGL(kern, dim3(blocks, gy), dim3(256), 0, st, x, y, dy, dx, gamma, beta, save_mean, save_invstd, sums,
                      (unsigned)(fixed ? n4g : n4), C / 4, C,
                      make_fastdiv(C / 4), make_fastdiv((uint32_t)n4g), 1.0f / (float)M, act, slope,
-                     colpart, slope_ptr, dslope ? apart : nullptr);
+                     colpart, slope_ptr, dslope ? apart : nullptr, ps);
   IPR_LAUNCH_CHECK();
   if (dslope) {
     hipLaunchKernelGGL(wave_sum_kernel, dim3(1), dim3(64), 0, st, apart, blocks * gy, dslope);
@@ -583,7 +607,7 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
                          dbias_prev, dbias_beta);
       IPR_LAUNCH_CHECK();
     } else {                 // channel counts that do not divide the block: the separate column-sum pass
-      const int rc = colsum_launch(dx, dbias_prev, ws, G * M, C, dbias_n, st, dbias_beta, b16);
+      const int rc = colsum_launch(dx, dbias_prev, ws, G * M, C, dbias_n, st, dbias_beta, b16, ps);
       if (rc) return rc;
     }
   }
@@ -604,7 +628,7 @@ size_t iprgan_instnorm_ws_floats(int B, int HW, int C) {
 
 int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, float beta, int x_bf16, void* stream) {
   IPR_CHECK(Cs % 4 == 0 && M > 0 && C <= Cs, "colsum: row length %d must be a multiple of 4 >= C=%d, M=%d positive", Cs, C, M);
-  return colsum_launch(x, out, ws, M, Cs, C, (hipStream_t)stream, beta, x_bf16);
+  return colsum_launch(x, out, ws, M, Cs, C, (hipStream_t)stream, beta, x_bf16, 0);
 }
 size_t iprgan_colsum_ws_floats(int M, int C) { return colsum_ws_floats(M, C); }
 int iprgan_colsum_partials(const float* part, int rows, int Cs, int C, float* out, float beta, void* stream) {

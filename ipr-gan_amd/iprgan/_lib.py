@@ -22,7 +22,8 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('B', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad', 'outpad',
-                 'transposed', 'pad_mode', 'act')] + [('slope', C.c_float), ('x_bf16', C.c_int32), ('y_bf16', C.c_int32)]
+                 'transposed', 'pad_mode', 'act')] + [('slope', C.c_float), ('x_bf16', C.c_int32), ('y_bf16', C.c_int32),
+                                                     ('x_pstride', C.c_int64), ('y_pstride', C.c_int64)]
 
 
 _P, _F, _I, _Z, _LL = C.c_void_p, C.c_float, C.c_int, C.c_size_t, C.c_longlong
@@ -54,6 +55,7 @@ SIGNATURES = {
     'iprgan_conv_bwd_weight': (_I, [_D, _P, _P, _P, _P, _P, _F, _P]),
     'iprgan_act_bwd': (_I, [_P, _P, _P, _Z, _I, _F, _I, _P]),
     'iprgan_cast': (_I, [_P, _P, _Z, _I, _I, _P]),
+    'iprgan_cast_planes': (_I, [_P, _P, _Z, _Z, _I, _P]),
     'iprgan_conv_wgrad_takes_bf16': (_I, [_D]),
     'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P]),
@@ -249,6 +251,16 @@ def set_math(mode):
 def act_bf16():
     """True in 'bf16act' mode (host-side allocation rule; the kernels are told per tensor through the descriptors)."""
     return _act_bf16
+
+
+# 'fp32x3' mode: activations whose padded channel count is a multiple of 32 live as three bf16 planes (include/iprgan.h:
+# IPRGAN_ST_X3).  IPRGAN_X3_PLANES=0: round 3's form (fp32 tensors, operands split while they are staged into LDS) for A/B.
+_X3_PLANES = os.environ.get('IPRGAN_X3_PLANES', '1') != '0'
+
+
+def act_x3():
+    """True in 'fp32x3' mode with three-plane activations (host-side allocation rule, like act_bf16)."""
+    return _math_cached == 2 and _X3_PLANES
 
 
 _math_cached = 2 if _FP32_VIA_X3 else 0

@@ -411,7 +411,7 @@ class GemvHead(Op):
         if getattr(self, '_perm_key', None) != key:
             self._perm, self._perm_key = ops.permute_021(self.weight, self.C, self.HW, 1), key
         wp = self._perm
-        x2 = x.view(B, K)
+        x2 = ops.f32(x).view(B, K)          # (a three-plane input is joined once here: the head reads it once per pass)
         if pair is not None:                # paired pass: each half-batch with its own sigma
             B2 = B // 2
             y = ops.empty((B,), x2)
@@ -681,7 +681,7 @@ class ChainFn(torch.autograd.Function):
         # remember their versions so that a step taken between this forward and its backward is an error, as it
         # is in PyTorch for tensors saved by autograd
         ctx.versions = [p._version for p in params]
-        return h
+        return ops.f32(h)                   # (autograd sees fp32 tensors only: a three-plane result is joined here)
 
     @staticmethod
     def backward(ctx, dy):
@@ -830,4 +830,4 @@ class ChainFn(torch.autograd.Function):
                 out.append(None if (gk is DIRECT or sink is not None) else gk)
             pi += n
         ctx.stash = None
-        return (None, None, g if need_x else None, *out)
+        return (None, None, ops.f32(g) if need_x else None, *out)

@@ -29,32 +29,100 @@ def empty(shape, like, dtype=torch.float32):
 
 
 def _empty_like(t):
+    if t.dtype == torch.bfloat16 and L.act_x3():
+        return empty_kind(t.shape, t, ST_X3)
     return torch.full_like(t, float('nan')) if (_POISON and t.is_floating_point()) else torch.empty_like(t)
 
 
+# Storage kinds of an activation (include/iprgan.h: IPRGAN_ST_*).  X3 = three bf16 planes (x = h + m + l exactly): the
+# tensor object IS its h plane (a contiguous bf16 tensor of the activation's shape) inside a storage that holds all three,
+# plane-major; plane stride = storage elements / 3 (a batch slice keeps the stride of the tensor it was cut from).
+ST_F32, ST_BF16, ST_X3 = 0, 1, 2
+
+
+def act_kind(channels):
+    """Storage kind of an NHWC activation with ``channels`` channels: three planes in 'fp32x3' mode when the padded channel
+    count is a multiple of 32, bf16 in 'bf16act' mode when it is a multiple of 64 (include/iprgan.h), fp32 otherwise."""
+    if L.act_x3() and c4(channels) % 32 == 0:
+        return ST_X3
+    if L.act_bf16() and c4(channels) % 64 == 0:
+        return ST_BF16
+    return ST_F32
+
+
 def act_dtype(channels):
-    """Storage type of an NHWC activation with ``channels`` channels: bf16 in 'bf16act' mode when the padded channel
-    count is a multiple of 64 (include/iprgan.h: bf16 activations), fp32 otherwise (always in the other modes)."""
-    return torch.bfloat16 if (L.act_bf16() and c4(channels) % 64 == 0) else torch.float32
+    return torch.float32 if act_kind(channels) == ST_F32 else torch.bfloat16
 
 
 def is16(t):
-    return 1 if (t is not None and t.dtype == torch.bfloat16) else 0
+    """Storage kind of a tensor: a bf16 tensor is a three-plane tensor in 'fp32x3' mode (nothing else is bf16 there)."""
+    if t is None or t.dtype != torch.bfloat16:
+        return ST_F32
+    return ST_X3 if L.act_x3() else ST_BF16
+
+
+kind = is16
+
+
+def pstride(t):
+    """Plane stride (elements) of a three-plane tensor; 0 for the other kinds (the descriptors' "contiguous" value)."""
+    return t.untyped_storage().nbytes() // 6 if is16(t) == ST_X3 else 0
+
+
+def empty_kind(shape, like, k):
+    """Uninitialised activation of storage kind ``k`` on ``like``'s device."""
+    if k != ST_X3:
+        return empty(tuple(shape), like, torch.bfloat16 if k == ST_BF16 else torch.float32)
+    n = 1
+    for s_ in shape:
+        n *= int(s_)
+    buf = torch.empty((3 * n,), dtype=torch.bfloat16, device=like.device)
+    if _POISON:
+        buf.fill_(float('nan'))
+    return buf[:n].view(tuple(shape))
+
+
+def to_kind(t, k):
+    """Copy of an activation in storage kind ``k`` (fp32 <-> bf16: round-to-nearest-even; fp32 <-> three planes: exact)."""
+    kt = is16(t)
+    if kt == k:
+        return t
+    if ST_X3 in (kt, k):
+        if ST_BF16 in (kt, k):
+            raise RuntimeError('no conversion between bf16 and three-plane activations')
+        out = empty_kind(t.shape, t, k)
+        call('iprgan_cast_planes', ptr(t), ptr(out), t.numel(), pstride(t) if kt == ST_X3 else t.numel(),
+             1 if k == ST_X3 else 0, stream())
+        return out
+    out = torch.empty(t.shape, dtype=torch.bfloat16 if k == ST_BF16 else torch.float32, device=t.device)
+    call('iprgan_cast', ptr(t), ptr(out), t.numel(), kt, k, stream())
+    return out
 
 
 def cast(t, dtype):
-    """fp32 <-> bf16 copy of an activation (round-to-nearest-even)."""
-    if t.dtype == dtype:
-        return t
-    out = torch.empty(t.shape, dtype=dtype, device=t.device)
-    call('iprgan_cast', ptr(t), ptr(out), t.numel(), is16(t), is16(out), stream())
-    return out
+    """fp32 <-> the 2-byte storage kind of the current math mode (bf16, or three planes in 'fp32x3' mode)."""
+    if dtype == torch.float32:
+        return to_kind(t, ST_F32)
+    return to_kind(t, ST_X3 if L.act_x3() else ST_BF16)
+
+
+def f32(t):
+    """fp32 view / copy of an activation of any kind (ops without a form for the 2-byte kinds go through it)."""
+    return t if (t is None or t.dtype == torch.float32) else to_kind(t, ST_F32)
 
 
 def _f32(*tensors):
     for t in tensors:
         if t is not None and t.dtype != torch.float32:
             raise RuntimeError('this op has no bf16-activation form yet (bf16act mode covers the DCGAN-family layers)')
+
+
+def _desc_with(d, **kw):
+    """Copy of a conv descriptor with some fields replaced (storage kinds / plane strides of this call's tensors)."""
+    c = ConvDesc(*[getattr(d, f) for f, _ in ConvDesc._fields_])
+    for k_, v in kw.items():
+        setattr(c, k_, v)
+    return c
 
 
 # ---- layout ---------------------------------------------------------------------------------
@@ -83,6 +151,8 @@ def permute_021(src, A, Bd, K, out=None, beta=0.0):
 
 
 def act_bwd(dy, out, act, slope=0.0):
+    if ST_X3 in (is16(dy), is16(out)):          # (no three-plane form: a stand-alone activation backward is rare)
+        dy, out = f32(dy), f32(out)
     if dy.dtype != out.dtype:
         dy = cast(dy, out.dtype)
     dz = _empty_like(dy)
@@ -109,8 +179,8 @@ class ConvSpec:
 
     def desc(self, B, H, W, x16=None, y16=None):
         """x16 / y16: storage type of the layer's input / output activation (default: the bf16act rule)."""
-        x16 = (act_dtype(self.cin) == torch.bfloat16) if x16 is None else x16
-        y16 = (act_dtype(self.cout) == torch.bfloat16) if y16 is None else y16
+        x16 = act_kind(self.cin) if x16 is None else x16
+        y16 = act_kind(self.cout) if y16 is None else y16
         return ConvDesc(B, H, W, self.cin, self.cout, self.k, self.k, self.stride, self.pad,
                         self.outpad, int(self.transposed), self.pad_mode, self.act, float(self.slope), int(x16), int(y16))
 
@@ -119,7 +189,7 @@ class ConvSpec:
         """1x1 convs whose PyTorch weight already is the forward operand (rows=Cout, k=Cin); not with a bf16 input
         (the operand is then emitted as bf16)."""
         return (self.k == 1 and not self.transposed and self.cin % 32 == 0 and self.cout % 128 == 0
-                and act_dtype(self.cin) == torch.float32)
+                and act_kind(self.cin) == ST_F32)
 
 
 def conv_prep(spec, d, w, sigma=None, fwd=True, bwd=False):
@@ -152,8 +222,10 @@ def conv_fwd(spec, d, x, wfwd, bias, pair=None, stats=False):
     follows (include/iprgan.h: column statistics from the epilogue)."""
     OH, OW = spec.out_hw(d.H, d.W)
     if is16(x) != d.x_bf16:
-        x = cast(x, torch.bfloat16 if d.x_bf16 else torch.float32)
-    y = empty((d.B, OH, OW, c4(spec.cout)), x, torch.bfloat16 if d.y_bf16 else torch.float32)
+        x = to_kind(x, d.x_bf16)
+    y = empty_kind((d.B, OH, OW, c4(spec.cout)), x, d.y_bf16)
+    if d.x_bf16 == ST_X3:
+        d = _desc_with(d, x_pstride=pstride(x), y_pstride=0)
     nws = query('iprgan_conv_fwd_ws_floats', C.byref(d))
     ws = empty((nws,), x) if nws else None
     p0, p1 = (ptr(pair[0]), ptr(pair[1])) if pair is not None else (None, None)
@@ -170,10 +242,14 @@ def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_sl
     """colsums=True: also returns (partials, rows): per-tile column sums of dx (after the fused activation derivative),
     i.e. the bias gradient of the layer that produced this layer's input, up to ``colsum_partials``."""
     if is16(dy) != d.y_bf16:
-        dy = cast(dy, torch.bfloat16 if d.y_bf16 else torch.float32)
-    dx = empty((d.B, d.H, d.W, c4(spec.cin)), dy, torch.bfloat16 if d.x_bf16 else torch.float32)
+        dy = to_kind(dy, d.y_bf16)
+    dx = empty_kind((d.B, d.H, d.W, c4(spec.cin)), dy, d.x_bf16)
     if prev_out is not None and is16(prev_out) != d.x_bf16:
         raise RuntimeError('conv_bwd_data: prev_out must have the storage type of the layer input')
+    if residual is not None and is16(residual) != d.x_bf16:
+        residual = to_kind(residual, d.x_bf16)
+    if d.y_bf16 == ST_X3:
+        d = _desc_with(d, y_pstride=pstride(dy), x_pstride=0)
     nws = query('iprgan_conv_bwd_data_ws_floats', C.byref(d))
     ws = empty((nws,), dy) if nws else None
     p0, p1 = (ptr(pair[0]), ptr(pair[1])) if pair is not None else (None, None)
@@ -212,6 +288,8 @@ def colsum_partials(part, rows, Cs, channels, out=None, beta=0.0):
 
 def colsum(x2d_like, channels, out=None, beta=0.0):
     """Column sums of an activation tensor [..., C4] over all leading dims -> [channels] (bias gradient)."""
+    if is16(x2d_like) == ST_X3 and pstride(x2d_like) != x2d_like.numel():     # a batch slice of a three-plane tensor
+        x2d_like = f32(x2d_like)
     C_ = x2d_like.shape[-1]
     M = x2d_like.numel() // C_
     res = empty((channels,), x2d_like) if out is None else out
@@ -224,10 +302,14 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
     """dw, db given (gradient-bucket views): ``dw = beta*dw + grad`` written in place, no temporary.
     bf16 x / dy are consumed directly where the 128x128 bf16 tile applies, through fp32 copies elsewhere."""
     d = ConvDesc(*[getattr(d, f) for f, _ in ConvDesc._fields_])
+    if ST_X3 in (is16(x), is16(dy)) and is16(x) != is16(dy):          # (RGB stems / heads: one side is an fp32 image)
+        x, dy = f32(x), f32(dy)
     d.x_bf16, d.y_bf16 = is16(x), is16(dy)            # the kernels read either storage type (include/iprgan.h)
+    d.x_pstride, d.y_pstride = pstride(x), pstride(dy)
     if d.x_bf16 and not query('iprgan_conv_wgrad_takes_bf16', C.byref(d)):
-        x = cast(x, torch.float32)
-        d.x_bf16 = 0
+        x, dy = (f32(x), f32(dy)) if d.x_bf16 == ST_X3 else (cast(x, torch.float32), dy)
+        d.x_bf16, d.y_bf16 = is16(x), is16(dy)
+        d.x_pstride = d.y_pstride = 0
     if dw is None:
         dw = empty(tuple(w_shape), x)
     if db is None and want_bias:
@@ -241,6 +323,7 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
 # ---- GEMV head ----------------------------------------------------------------------------------
 def gemv_fwd(x2d, w, bias, sigma, out=None):
     B, K = x2d.shape
+    x2d = f32(x2d) if is16(x2d) == ST_X3 else x2d          # (the head reads its 4 M elements once: joined on the way in)
     y = empty((B,), x2d) if out is None else out
     call('iprgan_gemv_fwd', ptr(x2d), ptr(w), ptr(bias), ptr(sigma), ptr(y), B, K, is16(x2d), stream())
     return y
@@ -248,6 +331,9 @@ def gemv_fwd(x2d, w, bias, sigma, out=None):
 
 def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0, dx_out=None):
     B, K = x2d.shape
+    if is16(x2d) == ST_X3:
+        x2d = f32(x2d)
+        prev_out = x2d if prev_out is not None else None      # (the fused derivative's operand is this layer's input)
     dx = (_empty_like(x2d) if dx_out is None else dx_out) if need_dx else None
     dw = empty((K,), x2d) if need_dw else None
     db = empty((1,), x2d) if need_dw else None
@@ -264,6 +350,8 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, a
     C_ = x.shape[-1]
     M = x.numel() // C_
     y = _empty_like(x)
+    if residual is not None and is16(residual) != is16(x):
+        residual = to_kind(residual, is16(x))
     mean, invstd = empty((C_,), x), empty((C_,), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
@@ -296,6 +384,8 @@ def bn_prelu_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, train
     C_ = x.shape[-1]
     M = x.numel() // C_
     y = _empty_like(x)
+    if residual is not None and is16(residual) != is16(x):
+        residual = to_kind(residual, is16(x))
     mean, invstd = empty((C_,), x), empty((C_,), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
@@ -535,6 +625,8 @@ def fill(t, value=0.0):
 def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias=None, residual=None):
     B, H, W, C_ = x.shape
     y = _empty_like(x)
+    if residual is not None and is16(residual) != is16(x):
+        residual = to_kind(residual, is16(x))
     mean, invstd = empty((B, C_), x), empty((B, C_), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
@@ -546,6 +638,10 @@ def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias
 
 def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None, dbias_beta=0.0):
     B, H, W, C_ = x.shape
+    if is16(dy) != is16(x):
+        dy = to_kind(dy, is16(x))
+    if y is not None and is16(y) != is16(x):
+        y = to_kind(y, is16(x))
     dx = _empty_like(x)
     dgamma = empty((C_,), x) if gamma is not None else None
     dbeta = empty((C_,), x) if gamma is not None else None
@@ -557,6 +653,7 @@ def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias
 
 
 def prelu_fwd(x, alpha):
+    x = f32(x) if L.act_x3() else x
     _f32(x)
     y = _empty_like(x)
     call('iprgan_prelu_fwd', ptr(x), ptr(alpha), ptr(y), x.numel(), stream())
@@ -564,6 +661,7 @@ def prelu_fwd(x, alpha):
 
 
 def prelu_bwd(x, dy, alpha):
+    x, dy = (f32(x), f32(dy)) if L.act_x3() else (x, dy)
     _f32(x, dy)
     dx = _empty_like(x)
     dalpha = empty((1,), x)
@@ -574,6 +672,7 @@ def prelu_bwd(x, dy, alpha):
 
 def pixel_shuffle2(x, inverse=False):
     """forward: [B,H,W,4C] -> [B,2H,2W,C]; inverse: [B,2H,2W,C] -> [B,H,W,4C]."""
+    x = f32(x) if L.act_x3() else x
     _f32(x)
     if not inverse:
         B, H, W, C4_ = x.shape
@@ -589,6 +688,7 @@ def pixel_shuffle2(x, inverse=False):
 
 def pixel_shuffle2_prelu_fwd(x, alpha):
     """prelu(pixel_shuffle(x, 2)) in one pass: [B,H,W,4C] -> [B,2H,2W,C] (C % 4 == 0)."""
+    x = f32(x) if L.act_x3() else x
     _f32(x)
     B, H, W, C4_ = x.shape
     Cc = C4_ // 4
@@ -598,6 +698,7 @@ def pixel_shuffle2_prelu_fwd(x, alpha):
 
 
 def pixel_shuffle2_prelu_bwd(x, dy, alpha):
+    x, dy = (f32(x), f32(dy)) if L.act_x3() else (x, dy)
     _f32(x, dy)
     B, H, W, C4_ = x.shape
     Cc = C4_ // 4
@@ -609,6 +710,7 @@ def pixel_shuffle2_prelu_bwd(x, dy, alpha):
 
 
 def maxpool2_fwd(x):
+    x = f32(x) if L.act_x3() else x
     _f32(x)
     B, H, W, C_ = x.shape
     y = empty((B, H // 2, W // 2, C_), x)
@@ -617,6 +719,7 @@ def maxpool2_fwd(x):
 
 
 def maxpool2_bwd(x, dy):
+    x, dy = (f32(x), f32(dy)) if L.act_x3() else (x, dy)
     _f32(x, dy)
     B, H, W, C_ = x.shape
     dx = _empty_like(x)
@@ -625,6 +728,7 @@ def maxpool2_bwd(x, dy):
 
 
 def add(a, b):
+    a, b = (f32(a), f32(b)) if L.act_x3() else (a, b)
     _f32(a, b)
     out = _empty_like(a)
     call('iprgan_add', ptr(a), ptr(b), ptr(out), a.numel(), stream())
