@@ -111,6 +111,21 @@ def f32(t):
     return t if (t is None or t.dtype == torch.float32) else to_kind(t, ST_F32)
 
 
+_IO_F32 = False
+
+
+def io_f32(on):
+    """Test switch: the convolution wrappers hand back fp32 copies of three-plane results (the kernels run on three-plane
+    operands and write three-plane results all the same), so that op-level parity tests written against fp32 tensors run
+    unchanged in 'fp32x3' mode."""
+    global _IO_F32
+    _IO_F32 = bool(on)
+
+
+def _out(t):
+    return f32(t) if (_IO_F32 and t is not None) else t
+
+
 def _f32(*tensors):
     for t in tensors:
         if t is not None and t.dtype != torch.float32:
@@ -234,6 +249,7 @@ def conv_fwd(spec, d, x, wfwd, bias, pair=None, stats=False):
         part = empty((query('iprgan_conv_stat_floats', C.byref(d), 0),), x)
     call('iprgan_conv_fwd', C.byref(d), ptr(x), ptr(wfwd), ptr(bias), ptr(y), ptr(ws), p0, p1, ptr(part),
          C.byref(rows), stream())
+    y = _out(y)
     return (y, (part, rows.value)) if stats else y
 
 
@@ -245,7 +261,9 @@ def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_sl
         dy = to_kind(dy, d.y_bf16)
     dx = empty_kind((d.B, d.H, d.W, c4(spec.cin)), dy, d.x_bf16)
     if prev_out is not None and is16(prev_out) != d.x_bf16:
-        raise RuntimeError('conv_bwd_data: prev_out must have the storage type of the layer input')
+        if ST_X3 not in (is16(prev_out), d.x_bf16):
+            raise RuntimeError('conv_bwd_data: prev_out must have the storage type of the layer input')
+        prev_out = to_kind(prev_out, d.x_bf16)
     if residual is not None and is16(residual) != d.x_bf16:
         residual = to_kind(residual, d.x_bf16)
     if d.y_bf16 == ST_X3:
@@ -258,6 +276,7 @@ def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_sl
         part = empty((query('iprgan_conv_stat_floats', C.byref(d), 1),), dy)
     call('iprgan_conv_bwd_data', C.byref(d), ptr(dy), ptr(wbwd), ptr(dx), ptr(ws), ptr(prev_out), prev_act,
          float(prev_slope), p0, p1, ptr(part), C.byref(rows), ptr(residual), stream())
+    dx = _out(dx)
     return (dx, (part, rows.value)) if colsums else dx
 
 

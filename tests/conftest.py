@@ -28,3 +28,44 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
     return load
+
+
+# ---- both math modes: the GPU parity tests of test_gpu_models.py and the convolution tests of
+# test_gpu_ops.py are collected twice - 'fp32' (exact fp32 MFMA) and 'fp32x3' (three-plane tensors, six bf16 MFMAs per
+# product block, csrc/conv_x3.hip) - with the SAME fp32 tolerances.  A module opts in by defining
+#     pytest_generate_tests = conftest.both_math_modes(names or None)
+#     math_mode = conftest.math_mode_fixture()
+MATH_MODES = ['fp32', 'fp32x3']
+
+
+def both_math_modes(names=None):
+    def hook(metafunc):
+        if 'math_mode' in metafunc.fixturenames and (names is None or metafunc.function.__name__ in names):
+            metafunc.parametrize('math_mode', MATH_MODES, indirect=True)
+    return hook
+
+
+def math_mode_fixture():
+    @pytest.fixture(autouse=True)
+    def math_mode(request):
+        """'fp32x3': every 'fp32' request of the test (and the library default) runs as 'fp32x3'; direct calls of the conv
+        ops hand back fp32 tensors (ops.io_f32: the kernels still run on three-plane operands and results)."""
+        mode = getattr(request, 'param', 'fp32')
+        from iprgan import _lib, ops
+        if mode == 'fp32x3':
+            params = getattr(getattr(request.node, 'callspec', None), 'params', {})
+            if any(str(v).startswith('bf16') for v in params.values()) or 'bf16' in request.node.name:
+                pytest.skip('a bf16-mode case: one math mode of its own')
+            _lib._FP32_VIA_X3 = True
+            _lib.set_math('fp32')
+            ops.io_f32(True)
+            assert _lib.get_math() == 'fp32x3'
+        try:
+            yield mode
+        finally:
+            if mode == 'fp32x3':
+                _lib._FP32_VIA_X3 = False
+                ops.io_f32(False)
+                _lib.call('iprgan_debug_force_tiles', -1, -1)
+                _lib.set_math('fp32')
+    return math_mode

@@ -14,7 +14,12 @@ import torch
 from oracle import cases, gan, nets, recipe, sign
 from test_oracle_golden import compare
 
+import conftest
+
 pytestmark = pytest.mark.gpu
+# every test of this file runs in both math modes ('fp32' and 'fp32x3'), same tolerances (conftest.both_math_modes)
+pytest_generate_tests = conftest.both_math_modes()
+math_mode = conftest.math_mode_fixture()
 RTOL, ATOL = 5e-4, 5e-5
 HIP_NETS = list(cases.NET_CASES)
 
@@ -111,11 +116,14 @@ def test_net_accuracy_against_float64(name, dev):
         assert ee <= 4.0 * eo + floor, f'{name} {k}: engine {ee:.3e} vs fp32 oracle {eo:.3e} (rms / scale, against float64)'
 
 
-def test_bn_backward_fusion_matches_the_separate_passes(dev, monkeypatch):
+def test_bn_backward_fusion_matches_the_separate_passes(dev, monkeypatch, math_mode):
     """engine._FUSE_BN_BWD (default off: measured slower, see engine.py): with it on, every BatchNorm of the DCGAN-64
     generator whose gradient arrives from a convolution takes its two backward reductions and its activation derivative
     from that convolution's backward-data epilogue.  One G+D step at batch 16 must agree with the default path to fp32
     summation-order level (same mask rule, same kernels otherwise) and keep the watermark."""
+    if math_mode == 'fp32x3':
+        pytest.skip('three-plane tensors: the fused-derivative operand is the h plane only, the norm backward needs all of x '
+                    '(iprgan_conv_bwd_data_bn_ok refuses; the default path is what every other test of this mode runs)')
     from iprgan import Config, engine, models
     base = cases.run_dcgan_steps(Config, models, [dev], n_steps=1, batch=16, seed=77)
     monkeypatch.setattr(engine, '_FUSE_BN_BWD', True)

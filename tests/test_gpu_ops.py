@@ -7,7 +7,16 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import conftest
+
 pytestmark = pytest.mark.gpu
+# the convolution tests run in both math modes ('fp32' and 'fp32x3'), same tolerances (conftest.both_math_modes)
+pytest_generate_tests = conftest.both_math_modes({
+    'test_conv_fwd_bwd', 'test_conv_dgrad_fused_prev_act', 'test_conv_sn_scale', 'test_reflect_pad_conv',
+    'test_every_gconv_tile_variant', 'test_every_wgrad_candidate', 'test_north_star_conv_shapes_full_size',
+    'test_conv_epilogue_column_sums', 'test_fused_norm_statistics_with_large_mean_channels', 'test_conv_splitk',
+    'test_batchnorm', 'test_instance_norm'})
+math_mode = conftest.math_mode_fixture()
 
 
 @pytest.fixture(scope='module')
