@@ -260,11 +260,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--workload', choices=list(WORKLOADS), default='dcgan64')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--alt-math', choices=['fp32x3', 'none'], default='fp32x3',
-                    help="after the timed region of an fp32 single-GPU run, time the same steps once more in this math mode "
-                         "and report them under 'alt_math' (never in 'value')")
-    ap.add_argument('--math', choices=['fp32', 'bf16', 'bf16act', 'fp32x3'], default='fp32',
-                    help="conv math mode; the headline metric is fp32 (the reference's precision). 'bf16' = bf16 MFMA "
+    ap.add_argument('--alt-math', choices=['fp32', 'fp32x3', 'auto', 'none'], default='auto',
+                    help="after the timed region of a single-GPU run in one of the two fp32 modes, time the same steps once "
+                         "more in the OTHER one and report them under 'alt_math' (never in 'value'); 'auto' = the other mode")
+    ap.add_argument('--math', choices=['fp32', 'bf16', 'bf16act', 'fp32x3'], default='fp32x3',
+                    help="conv math mode.  Both 'fp32x3' (default: fp32 tensors stored as three exact bf16 planes, products "
+                         "from six bf16 MFMAs per block with fp32 accumulation - every GPU parity test runs in this mode at "
+                         "the fp32 tolerances, per-layer error against float64 at or below the fp32 MFMA's) and 'fp32' (the "
+                         "exact fp32 MFMA, printed next to it under 'alt_math') are fp32 arithmetic.  'bf16' = bf16 MFMA "
                          "tiles with fp32 accumulation / master weights, reported with dtype bf16; 'bf16act' additionally "
                          "keeps activations with a multiple of 64 channels as bf16 in HBM")
     ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
@@ -273,10 +276,12 @@ def main():
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     heavy = args.workload in ('cyclegan', 'dcgan128')
-    if args.steps is None:
-        args.steps = 10 if heavy else 50
+    if args.steps is None:                  # >= 20 warm-up, >= 100 timed where a step is milliseconds
+        args.steps = 10 if heavy else 100
     if args.warmup is None:
-        args.warmup = 4 if heavy else 10
+        args.warmup = 4 if heavy else 20
+    if args.alt_math == 'auto':
+        args.alt_math = {'fp32': 'fp32x3', 'fp32x3': 'fp32'}.get(args.math, 'none')
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(args.gpus))     # nothing in this process has touched the GPU yet
@@ -351,10 +356,14 @@ def main():
     # (all steps when K < 2 * PROF_EVERY): timing every launch costs ~0.3 ms of a 12 ms step in completion-signal
     # handling, and the headline value should not pay for its own instrumentation.
     every = PROF_EVERY if (args.steps >= 2 * PROF_EVERY or PROF_EVERY <= 0) else 1
+    # one device timestamp per step boundary (an event on the launch stream: torch's current stream is the one the library
+    # launches on): median / p10 / p90 of the per-step device times next to the mean of the window
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     replays_before = graphed.replays if graphed is not None else 0
     t0 = time.perf_counter()
     stamps = []
+    marks[0].record()
     for i in range(args.steps):
         sampled = every > 0 and i % every == 0
         _lib.prof_enable(sampled)
@@ -362,12 +371,15 @@ def main():
             step_fn(i, eager=sampled)
         else:
             step_fn(i)
+        marks[i + 1].record()
         stamps.append(time.perf_counter())
     host_elapsed = time.perf_counter() - t0          # the host has ENQUEUED all steps (no sync inside the loop)
     replays_timed = (graphed.replays - replays_before) if graphed is not None else 0
     fence()
     elapsed = time.perf_counter() - t0
     _lib.prof_enable(False)
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]          # noqa: E731
     prof_steps = len(range(0, args.steps, every)) if every > 0 else 1
     log(f'timed {args.steps} steps in {elapsed:.3f}s')
     if os.environ.get('IPRGAN_BENCH_STAMPS'):
@@ -387,8 +399,8 @@ def main():
     # Second, separately reported measurement of the same workload in math mode 'fp32x3' (fp32 tensors, fp32-grade
     # products from six bf16 MFMAs per block).  It never enters `value`: the headline stays on the fp32 MFMA.
     alt = None
-    if (args.alt_math != 'none' and args.math == 'fp32' and world == 1 and graphed is not None and graphed.graph is not None
-            and graphed.failed is None):
+    if (args.alt_math != 'none' and args.alt_math != args.math and args.math in ('fp32', 'fp32x3') and world == 1
+            and graphed is not None and graphed.graph is not None and graphed.failed is None):
         try:                                          # (a failure here must never cost the headline line)
             from iprgan import graphs
             _lib.set_math(args.alt_math)
@@ -405,8 +417,10 @@ def main():
             assert all(v == v for v in m2.values()), f'non-finite metrics {m2}'
             alt = {'mode': args.alt_math, 'value': round(wl['batch'] * args.steps / ea, 2), 'unit': wl['unit'],
                    'ms_per_step': round(ea / args.steps * 1e3, 3), 'steps': args.steps, 'graph_failed': g2.failed,
-                   'note': 'same workload and tensors (fp32 in HBM); conv operands split into three bf16 terms in LDS, six bf16 '
-                           'MFMAs per product block, fp32 accumulation; not part of `value`'}
+                   'note': ('the same model and step on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 tensors in HBM'
+                            if args.alt_math == 'fp32' else
+                            'the same model and step with three-plane tensors and six bf16 MFMAs per product block') +
+                           '; not part of `value`'}
         except Exception as e:                        # noqa: BLE001
             alt = {'mode': args.alt_math, 'error': f'{type(e).__name__}: {e}'}
         finally:
@@ -469,11 +483,13 @@ def main():
         out = {
             'metric': wl['metric'], 'value': round(value, 2), 'unit': wl['unit'],
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'ms_per_step_median': round(pct(0.5), 3), 'ms_per_step_p10': round(pct(0.1), 3),
+            'ms_per_step_p90': round(pct(0.9), 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.math in ('fp32', 'fp32x3') else 'bf16',
             'data': 'synthetic',
             'config': {'workload': wl['text'] + ', ' +
-                                   {'fp32': 'fp32', 'fp32x3': 'fp32 tensors and fp32-grade products from six bf16 MFMAs per block (operands split into three bf16 terms in LDS)', 'bf16': 'bf16 MFMA tiles (fp32 accumulate, fp32 tensors and master weights)',
+                                   {'fp32': 'fp32 (exact fp32 MFMA)', 'fp32x3': 'fp32 tensors stored as three exact bf16 planes (x = h + m + l), fp32-grade products from six bf16 MFMAs per block with fp32 accumulation', 'bf16': 'bf16 MFMA tiles (fp32 accumulate, fp32 tensors and master weights)',
                                     'bf16act': 'bf16 MFMA tiles, bf16 activations in HBM (fp32 accumulate, statistics, master weights)'}[args.math] +
                                    ', Adam',
                        'global_batch': B * world, 'parallelism': f'dp{world}'},

@@ -383,13 +383,16 @@ int iprgan_get_math_mode(void);
  *   gconv_tile 0..7   register-staged tiles of conv_igemm.hip (6, 7: bf16 modes only)
  *              8..13  LDS-DMA ring tiles of conv_pipe.hip: 256x128, 256x64, 256x256, 128x128, 256x64 (two blocks per
  *                     CU), 128x64; bf16 operands in HBM, or fp32 operands with the exact fp32 MFMA
+ *              18..25 three-plane ring tiles of conv_x3.hip (fp32x3 mode, three-plane operands): 256x128, 128x128,
+ *                     128x64 (3 / 2 stages), 256x64, 64x64, 128x256, 128x128 (2 stages)
  *              14, 15 the persistent 256x128 / 256x64 form (bf16 operands)
  *              16     four sub-pixel phases per block (k4 s2 p1 backward-data forms, bf16 operands)
  *              17     256x256 with a half-tile ring: quadrant phases, five half-tiles of DMA in flight (bf16 operands)
  *   wgrad_cand 0..59  = 20 * variant + 4 * block target + tile shape (split-M GEMM of conv_igemm.hip)
  *              60..68 halo form for bf16 tensors (wgrad_halo.hip): 3 * variant + block target {128, 256, 512}
  *              69, 70 RGB-layer streaming form (block targets 256 / 512)
- *              71..73 halo form on the exact fp32 MFMA for fp32 tensors (block targets 256 / 512 / 1024) */
+ *              71..73 halo form on the exact fp32 MFMA for fp32 tensors (block targets 256 / 512 / 1024)
+ *              74..76 halo form for three-plane tensors, k3 s1 / k4 s2 (wgrad_x3.hip; block targets 256 / 512 / 1024) */
 int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand);
 /* test hook: force the split count (1..4) of the split-K path that convolutions with few output tiles take when their
  * workspace is passed (iprgan_conv_fwd_ws_floats / iprgan_conv_bwd_data_ws_floats); -1 = autotuned. */

@@ -2448,18 +2448,27 @@ bool wgrad_rgb_eligible(const iprgan_conv_desc* d);
 int wgrad_rgb_nsplit(const iprgan_conv_desc* d, int target_blocks);
 int launch_wgrad_rgb(const iprgan_conv_desc* d, const void* x, const void* dy, float* ws, int target_blocks, hipStream_t st,
                      int* nsplit_out, int* Nrows_out, int* Kw_out);
+bool wgrad_x3h_eligible(const iprgan_conv_desc* d);
+int wgrad_x3h_nsplit(const iprgan_conv_desc* d, int target_blocks);
+int launch_wgrad_x3h(const iprgan_conv_desc* d, const void* x, const void* dy, float* ws, int target_blocks, hipStream_t st,
+                     int* nsplit_out, int* Nrows_out, int* Kw_out);
 bool wgrad_halo_f32_eligible(const iprgan_conv_desc* d);
 int wgrad_halo_f32_nsplit(const iprgan_conv_desc* d, int target_blocks);
 int launch_wgrad_halo_f32(const iprgan_conv_desc* d, const float* x, const float* dy, float* ws, int target_blocks,
                           hipStream_t st, int* nsplit_out, int* Nrows_out, int* Kw_out);
 #define WGRAD_NH32 3                        // candidates WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB + {0, 1, 2}: fp32 halo form
 static const int g_h32_targets[WGRAD_NH32] = {256, 512, 1024};
+#define WGRAD_NX3H 3                        // the next three candidates: halo form for three-plane tensors (wgrad_x3.hip)
+static const int g_x3h_targets[WGRAD_NX3H] = {256, 512, 1024};
+#define WGRAD_X3H0 (WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB + WGRAD_NH32)
+#define WGRAD_NALL (WGRAD_X3H0 + WGRAD_NX3H)
 #define WGRAD_NRGB 2                        // candidates WGRAD_NCAND + WGRAD_NHALO + {0, 1}: 256 / 512 blocks
 static const int g_rgb_targets[WGRAD_NRGB] = {256, 512};
 #define WGRAD_NHALO 9                       // candidate WGRAD_NCAND + 3 * variant + target index
 static const int g_halo_targets[3] = {128, 256, 512};
 static bool wgrad_halo_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_BF16 && wgrad_halo_eligible(d); }
 static bool wgrad_rgb_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_BF16 && wgrad_rgb_eligible(d); }
+static bool wgrad_x3h_ok(const iprgan_conv_desc* d) { return g_math == IPRGAN_MATH_FP32X3 && wgrad_x3h_eligible(d); }
 static bool wgrad_h32_ok(const iprgan_conv_desc* d) { return g_math != IPRGAN_MATH_BF16 && !wgrad_has_planes(d) && wgrad_halo_f32_eligible(d); }
 
 static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that fits every candidate
@@ -2469,6 +2478,13 @@ static size_t wgrad_slab_floats(const iprgan_conv_desc* d) {   // workspace that
     for (int i = 0; i < WGRAD_NHALO; ++i) {
       const size_t n = (size_t)wgrad_halo_nsplit(d, i / 3, g_halo_targets[i % 3]) * c4(g.N) * d->KH * d->KW * c4(g.Cq);
       if (n > m) m = n;
+    }
+  }
+  if (wgrad_x3h_ok(d)) {
+    const WGeom g = wgrad_geom(d);
+    for (int i = 0; i < WGRAD_NX3H; ++i) {
+      const size_t n = (size_t)wgrad_x3h_nsplit(d, g_x3h_targets[i]) * c4(g.N) * d->KH * d->KW * c4(g.Cq);
+      if (n > m && n <= WGRAD_MAX_SLAB_FLOATS) m = n;
     }
   }
   if (wgrad_h32_ok(d)) {
@@ -2876,7 +2892,7 @@ int iprgan_conv_wgrad_takes_bf16(const iprgan_conv_desc* d) {
   const WGeom g = wgrad_geom(d);
   if (wgrad_has_planes(d)) {      // three planes: both tensors, a regular (not role-swapped) layer with a 128x128 split tile
     WGradPlan p;
-    return wgrad_in3p(d) && !g.swap && (wgrad_plan_c(d, 0, p) || wgrad_plan_c(d, 3, p)) ? 1 : 0;
+    return wgrad_in3p(d) && !g.swap && (wgrad_plan_c(d, 0, p) || wgrad_plan_c(d, 3, p) || wgrad_x3h_ok(d)) ? 1 : 0;
   }
   return !(g.padded && d->x_bf16);
 }
@@ -2903,6 +2919,12 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   auto run_to = [&](int cand, float* dw_out, float beta_out) -> int {
     if (cand >= WGRAD_NCAND) {           // halo / RGB forms: same slabs, same fixed-order reduce
       int nsplit = 0, Nrows = 0, Kw = 0, rc;
+      if (cand >= WGRAD_X3H0) {
+        const int i = cand - WGRAD_X3H0;
+        if (i >= WGRAD_NX3H || !wgrad_x3h_ok(d) || g.swap || g.padded) return -1;
+        if ((size_t)wgrad_x3h_nsplit(d, g_x3h_targets[i]) * c4(g.N) * d->KH * d->KW * c4(g.Cq) > WGRAD_MAX_SLAB_FLOATS) return -1;
+        rc = launch_wgrad_x3h(d, x, dy, ws, g_x3h_targets[i], st, &nsplit, &Nrows, &Kw);
+      } else
       if (cand >= WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB) {
         const int i = cand - WGRAD_NCAND - WGRAD_NHALO - WGRAD_NRGB;
         if (i >= WGRAD_NH32 || !wgrad_h32_ok(d) || g.swap || g.padded) return -1;
@@ -2996,11 +3018,12 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   int cand = 0;
   {
     WGradPlan p0;
-    if (!wgrad_plan_c(d, 0, p0)) cand = wgrad_has_planes(d) ? 3 : 1;
+    if (!wgrad_plan_c(d, 0, p0)) cand = !wgrad_has_planes(d) ? 1 : wgrad_plan_c(d, 3, p0) ? 3 : WGRAD_X3H0;
   }
   if (g_force_wgrad >= 0) {
     WGradPlan pf;
-    if (g_force_wgrad >= WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB ? (g_force_wgrad < WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB + WGRAD_NH32 && wgrad_h32_ok(d) && !g.swap && !g.padded)
+    if (g_force_wgrad >= WGRAD_X3H0 ? (g_force_wgrad < WGRAD_NALL && wgrad_x3h_ok(d) && !g.swap && !g.padded)
+        : g_force_wgrad >= WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB ? (wgrad_h32_ok(d) && !g.swap && !g.padded)
         : g_force_wgrad >= WGRAD_NCAND + WGRAD_NHALO ? wgrad_rgb_ok(d)
         : g_force_wgrad >= WGRAD_NCAND ? wgrad_halo_ok(d) : wgrad_plan_c(d, g_force_wgrad, pf))
       cand = g_force_wgrad;
@@ -3015,7 +3038,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
       g_prof_on = false;
       float best_us = 0.f;
       int err = 0;
-      cand = tune_pick(WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB + WGRAD_NH32, run, st, cand, &best_us, &err);
+      cand = tune_pick(WGRAD_NALL, run, st, cand, &best_us, &err);
       g_prof_on = prof_was;
       if (err) return err;
       if (getenv("IPRGAN_TUNE_LOG"))

@@ -156,6 +156,58 @@ def test_split_wgrad_candidates_vs_float64(dev):
         _lib.set_math('fp32')
 
 
+X3H_SHAPES = [  # B, cin, cout, k, stride, pad, H, W, transposed, reflect
+    (4, 64, 128, 3, 1, 1, 16, 16, False, False), (3, 128, 64, 3, 1, 1, 20, 12, False, False),
+    (2, 128, 128, 3, 1, 1, 16, 24, False, True), (4, 64, 64, 4, 2, 1, 32, 32, False, False),
+    (3, 128, 192, 4, 2, 1, 20, 28, False, False), (4, 128, 64, 4, 2, 1, 8, 8, True, False),
+    (2, 256, 128, 4, 2, 1, 6, 10, True, False),
+]
+
+
+@pytest.mark.parametrize('cand', [-1, 0, 74, 75, 76])
+@pytest.mark.parametrize('shape', X3H_SHAPES, ids=lambda c: '-'.join(map(str, c)))
+def test_wgrad_halo_for_three_plane_tensors(shape, cand, dev):
+    """Backward-weight of three-plane tensors: the halo form (csrc/wgrad_x3.hip, candidates 74-76; k3 s1 and k4 s2, Conv2d
+    and ConvTranspose2d, zero and reflection padding, ragged patches) and the split-M tile that reads the planes directly
+    (candidate 0), against float64 next to the fp32 mode's own distance; and on a batch slice of a larger tensor (the
+    paired discriminator pass hands such slices: plane stride of the whole tensor)."""
+    from iprgan import ops, _lib
+    B, cin, cout, k, s, p, H, W, tr, refl = shape
+    g = torch.Generator().manual_seed(99 + cin + cout + H)
+    spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr, pad_mode=1 if refl else 0)
+    OH, OW = spec.out_hw(H, W)
+    x = torch.randn(B, H, W, cin, generator=g).to(dev)
+    dy = torch.randn(B, OH, OW, cout, generator=g).to(dev)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    x64 = x.double().cpu().permute(0, 3, 1, 2)
+    if refl:
+        x64 = F.pad(x64, (p, p, p, p), mode='reflect')
+    w64 = torch.zeros(*wshape, dtype=torch.float64, requires_grad=True)
+    y64 = F.conv_transpose2d(x64, w64, None, s, p) if tr else F.conv2d(x64, w64, None, s, 0 if refl else p)
+    y64.backward(dy.double().cpu().permute(0, 3, 1, 2))
+    want = w64.grad
+    rel = lambda got, ref: float((got.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())      # noqa: E731
+    try:
+        _lib.set_math('fp32')
+        e32 = rel(ops.conv_bwd_weight(spec, spec.desc(B, H, W), x, dy, wshape, False)[0], want)
+        _lib.set_math('fp32x3')
+        _lib.call('iprgan_debug_force_tiles', -1, cand)
+        d = spec.desc(B, H, W)
+        xp, dyp = ops.to_kind(x, 2), ops.to_kind(dy, 2)
+        ex3 = rel(ops.conv_bwd_weight(spec, d, xp, dyp, wshape, False)[0], want)
+        assert ex3 <= e32 + 2e-8, f'cand {cand}: fp32x3 {ex3:.3e} vs fp32 {e32:.3e}'
+        # the first B - 1 samples as a slice of the B-sample tensors (plane stride of the whole tensor)
+        if B > 2:
+            w64.grad = None
+            y2 = F.conv_transpose2d(x64[:B - 1], w64, None, s, p) if tr else F.conv2d(x64[:B - 1], w64, None, s, 0 if refl else p)
+            y2.backward(dy[:B - 1].double().cpu().permute(0, 3, 1, 2))
+            es = rel(ops.conv_bwd_weight(spec, spec.desc(B - 1, H, W), xp[:B - 1], dyp[:B - 1], wshape, False)[0], w64.grad)
+            assert es < 4e-7, f'cand {cand}, batch slice: {es:.3e}'
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
+        _lib.set_math('fp32')
+
+
 @pytest.mark.parametrize('name', [n for n in T.HIP_NETS if n != 'Discriminator96'])
 def test_networks_vs_reference_golden_through_split_tiles(name, golden, dev, via_x3):
     T.test_net_vs_reference_golden(name, golden, dev)
