@@ -518,7 +518,9 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         parallel.RcclTransport.destroy()
-        dist.destroy_process_group()
+        if not parallel.RcclTransport.abandoned:
+            dist.destroy_process_group()
+        parallel.finish(0)
 
 
 if __name__ == '__main__':

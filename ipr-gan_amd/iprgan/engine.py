@@ -164,8 +164,9 @@ class Conv(Op):
             return True
         OH, OW = sp.out_hw(H, W)
         s_ = sp.stride if sp.transposed else 1
-        # tile rows must never straddle two samples: 128-row tiles in fp32, up to 256-row tiles in the bf16 modes
-        rows = 256 if L.get_math_cached() else 128
+        # tile rows must never straddle two samples: the autotuner may pick a 256-row tile in every math mode (the LDS-DMA
+        # ring tiles are candidates for fp32 layers too)
+        rows = 256
         return OH % s_ == 0 and OW % s_ == 0 and ((OH // s_) * (OW // s_)) % rows == 0
 
     def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):

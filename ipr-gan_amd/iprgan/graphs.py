@@ -73,16 +73,28 @@ class GraphedStep:
                 if isinstance(sub, torch.nn.Module):
                     engine.drop_operand_caches(sub)
         g = torch.cuda.CUDAGraph()
+        # host step counts as they stand: optimizers that already ran inside an aborted capture have counted a step the
+        # device never executed (a checkpoint written later would resume with bias corrections one step ahead)
+        saved = [(sh, sh['step']) for o in self.opts for sh in getattr(o, '_fast', {}).values()]
         try:
             with torch.cuda.graph(g):
                 self.body(self.static)
         except Exception as e:                    # not capturable here: stay eager (the half-captured call did no device work)
             self.failed = f'{type(e).__name__}: {e}'
+            for sh, step in saved:
+                sh['step'] = step
+                sh['step_t'].fill_(step)
             torch.cuda.synchronize()
             return False
         self.graph = g
+        self._lrs = self._hyper()
         self._snapshot()
         return True
+
+    def _hyper(self):
+        """Hyper-parameters that travel BY VALUE in the captured Adam launches: a change (SRGAN's lr *= 0.1, a scheduler)
+        must not be replayed over - the step is captured again."""
+        return [(g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']) for o in self.opts for g in o.param_groups]
 
     def __call__(self, inputs=None, eager=False):
         if inputs is not None:
@@ -99,6 +111,9 @@ class GraphedStep:
             self.graph.replay()                   # the captured call's device work (its host side ran during the capture)
             self.replays += 1
             return None
+        if self._hyper() != self._lrs:            # learning rate (...) changed since the capture: capture this call afresh
+            self.graph = None
+            return self.__call__(None, eager=False)
         self.graph.replay()
         self.replays += 1
         for o in self.opts:

@@ -50,7 +50,13 @@ class Adam(Optimizer):
         sh = self._fast.get(id(group))
         if sh is not None and sh['n'] == len(params) and self.state[params[0]].get('step') is sh['step_t'] \
                 and self.state[params[-1]].get('step') is sh['step_t']:
-            return sh
+            # the cached pointer tables must still describe THESE tensors: every parameter and both moments of every
+            # parameter (a `p.data = ...` or a hand-edited state entry in the middle of the list would otherwise keep the
+            # kernel updating a stale buffer, silently)
+            st = self.state
+            if sh['ptrs'] == [p.data_ptr() for p in params] and \
+                    sh['msum'] == sum(st[p]['exp_avg'].data_ptr() + st[p]['exp_avg_sq'].data_ptr() for p in params):
+                return sh
         states = [self._init_state(p) for p in params]
         steps = {float(st['step']) for st in states}
         if len(steps) != 1:
@@ -62,7 +68,8 @@ class Adam(Optimizer):
               'ptab': L.ptr_table(params), 'mtab': L.ptr_table([st['exp_avg'] for st in states]),
               'vtab': L.ptr_table([st['exp_avg_sq'] for st in states]),
               'sizes': (C.c_longlong * len(params))(*[p.numel() for p in params]),
-              'ptrs': [p.data_ptr() for p in params]}
+              'ptrs': [p.data_ptr() for p in params],
+              'msum': sum(st['exp_avg'].data_ptr() + st['exp_avg_sq'].data_ptr() for st in states)}
         self._fast[id(group)] = sh
         return sh
 
@@ -71,9 +78,11 @@ class Adam(Optimizer):
         state_dict reports, and the parameters' version counters (version-keyed caches, stale-graph check)."""
         for group in self.param_groups:
             sh = getattr(self, '_fast', {}).get(id(group))
-            if sh is not None:
-                sh['step'] += 1
-                sh['step_t'].fill_(sh['step'])
+            if sh is None or 'step_dev' not in sh:
+                raise RuntimeError('optim.Adam.replayed(): a parameter group has no device-side step counter - its step was '
+                                   'captured on the slow path (frozen bias corrections); the graph must not be replayed')
+            sh['step'] += 1
+            sh['step_t'].fill_(sh['step'])
             torch.autograd.graph.increment_version(group['params'])
 
     @torch.no_grad()
@@ -89,7 +98,7 @@ class Adam(Optimizer):
             grads = [p.grad for p in params]
             if params and all(g is not None and g.is_contiguous() for g in grads):
                 sh = self._shared(group)
-                if sh is not None and sh['ptrs'][0] == params[0].data_ptr() and sh['ptrs'][-1] == params[-1].data_ptr():
+                if sh is not None:
                     beta1, beta2 = group['betas']
                     if getattr(self, 'device_step', False):
                         # step count on the device (graphs.py): the launch carries no host step number.  The counter is
@@ -111,6 +120,11 @@ class Adam(Optimizer):
                     torch.autograd.graph.increment_version(params)
                     continue
                 self._fast.pop(id(group), None)          # parameters were replaced (.to(), load): rebuild next time
+            if getattr(self, 'device_step', False) and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                # (graphs.GraphedStep turns this into "stay eager": a captured slow-path step would replay with the
+                # bias corrections of the capture-time step number)
+                raise RuntimeError('optim.Adam: this step cannot be captured in a graph (a parameter without a gradient, a '
+                                   'non-contiguous gradient or differing step counts take the host-side path)')
             buckets = {}
             for p in group['params']:
                 if p.grad is None:

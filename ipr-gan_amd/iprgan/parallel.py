@@ -67,6 +67,7 @@ class RcclTransport:
     """In-place SUM through the C ABI (iprgan_comm_* in include/iprgan.h -> RCCL over xGMI).  One communicator per
     process; torch.distributed is only the out-of-band channel that ships rank 0's 128-byte unique id."""
     _ready = False
+    abandoned = False       # a bring-up thread was left blocked inside RCCL (timeout): see finish()
 
     @classmethod
     def ensure(cls, rank, nranks, probe_device=None):
@@ -111,6 +112,9 @@ class RcclTransport:
         t.start()
         t.join(float(os.environ.get('IPRGAN_COMM_TIMEOUT', '90')))
         if t.is_alive():
+            # the helper thread stays inside ncclCommInitRank: interpreter / RCCL teardown could block on it at exit, so
+            # the process must leave through finish() (os._exit once its output is flushed)
+            cls.abandoned = True
             raise TimeoutError('iprgan_comm_init did not return (a peer never entered the RCCL rendezvous?)')
         if 'error' in result:
             raise result['error']
@@ -145,6 +149,17 @@ def _all_ranks_ok(ok, device):
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(flag.item())
+
+
+def finish(code=0):
+    """End of a data-parallel program (bench.py, train.py).  Normally a no-op.  After an abandoned RCCL bring-up (timeout in
+    ``RcclTransport.ensure``) a helper thread is still blocked inside the library, and a normal interpreter shutdown can
+    hang in its teardown: flush the standard streams and leave with ``os._exit``."""
+    if RcclTransport.abandoned:
+        import sys
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(code)
 
 
 def _rccl_or_torch(rank, nranks, device):
@@ -381,6 +396,20 @@ class GradReducer:
         """Before the optimizer step: the compute stream waits for the exchanged buckets.  Afterwards ``p.grad`` holds the
         SUM over ranks (Adam multiplies by 1/world as it reads: ``opt.grad_scale``), not the mean.  Parameters nobody
         produced a gradient for get ``.grad = None`` (Adam skips them, as the reference's would)."""
+        if self.world > 1 and not self._touched_checked:
+            # Adam skips parameters without a gradient; if the ranks disagreed on WHICH parameters those are, weights and
+            # moments would diverge silently.  Every rank runs the same graph in the three GANs, so the sets are equal by
+            # construction - verified once, collectively, at the first step (one small all-reduce and a host read).  The
+            # check sits BEFORE the early-out below: a rank that produced no gradient at all contributes an all-zero mask
+            # (and is reported) instead of leaving its peers blocked in the collective.
+            self._touched_checked = True
+            mask = torch.tensor([1.0 if (self.armed and p in self.touched) else 0.0 for p in self.params], device=self.flat.device)
+            lo, hi = mask.clone(), mask.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                raise RuntimeError('data-parallel ranks disagree on which parameters received gradients: the replicas '
+                                   'would diverge (every rank must run the same passes)')
         if not self.armed:
             return
         self.armed = False
@@ -393,18 +422,6 @@ class GradReducer:
             del self.exposed_log[:-64]
         for d in dones:
             torch.cuda.current_stream().wait_event(d)
-        if self.world > 1 and not self._touched_checked:
-            # Adam skips parameters without a gradient; if the ranks disagreed on WHICH parameters those are, weights and
-            # moments would diverge silently.  Every rank runs the same graph in the three GANs, so the sets are equal by
-            # construction - verified once, collectively, at the first step (one small all-reduce and a host read).
-            self._touched_checked = True
-            mask = torch.tensor([1.0 if p in self.touched else 0.0 for p in self.params], device=self.flat.device)
-            lo, hi = mask.clone(), mask.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            if not torch.equal(lo, hi):
-                raise RuntimeError('data-parallel ranks disagree on which parameters received gradients: the replicas '
-                                   'would diverge (every rank must run the same passes)')
         for p in self.params:
             if p not in self.touched:
                 p.grad = None

@@ -251,8 +251,10 @@ def main():
         torch.save({'rank': exp.rank, 'batch_sum': float(x.double().sum()), 'param_probe': p},
                    os.environ['IPRGAN_TRAIN_PROBE'] + f'.{exp.rank}')
     exp.start(max_steps=args.max_steps)
-    if dist.is_initialized():
+    from iprgan import parallel
+    if dist.is_initialized() and not parallel.RcclTransport.abandoned:
         dist.destroy_process_group()
+    parallel.finish(0)          # (os._exit after an abandoned RCCL bring-up: a helper thread is still inside the library)
 
 
 if __name__ == '__main__':
