@@ -318,7 +318,9 @@ def main():
     model, step_fn = make_workload(args.workload, [device], (Config, models))
     graphed = None
     # (auto: only when the capture - two eager calls, then the capturing one - fits inside the warm-up)
-    if args.graph != 'off' and world == 1 and hasattr(step_fn, 'graph_spec') and (args.graph == 'on' or args.warmup >= 4):
+    # (N > 1: the gradient exchange is captured with the step when it goes through the C ABI's communicator; GraphedStep
+    # stays eager - `failed` says why - when the transport turns out to be torch.distributed)
+    if args.graph != 'off' and hasattr(step_fn, 'graph_spec') and (args.graph == 'on' or args.warmup >= 4):
         from iprgan import graphs
         body, inputs_of = step_fn.graph_spec
         graphed = graphs.GraphedStep(model, body, inputs_of(0), warmup=max(2, args.warmup - 2))
@@ -327,7 +329,7 @@ def main():
         def step_fn(i, eager=False):              # noqa: F811  (sampled steps carry HIP events: they cannot be replayed)
             graphed(inputs_of(i), eager=eager)
     elif args.graph == 'on':
-        raise SystemExit(f'bench.py: --graph on is not available for {args.workload} on {world} rank(s)')
+        raise SystemExit(f'bench.py: --graph on is not available for {args.workload}')
 
     log(f'{args.workload}: model built on {device}; warm-up {args.warmup} steps')
     for i in range(args.warmup):

@@ -7,6 +7,10 @@ eagerly for a few warm-up calls (autotuning, operand caches, lazily built tables
 ``torch.cuda.graph`` - every launch of the library goes to torch's current stream, which is the capture stream, and the
 autograd engine's backward thread inherits it - and from then on replays the graph: one launch per training step.
 
+Data-parallel runs (N > 1) capture the same way when the buckets travel through the C ABI's communicator
+(``iprgan_allreduce_bucket`` on the reducer's side stream: forked off and joined back inside the capture); with
+torch.distributed as the transport the step stays eager.
+
 What makes the step capturable (all of it already true for the DCGAN / VAE models, none of it for CycleGAN, whose
 ImagePool and LR schedule decide on the host):
   * inputs live in static device tensors (``copy_`` before each replay);
@@ -66,6 +70,13 @@ class GraphedStep:
         self._bound = [(m, k, v) for m in _chain(self.model) for k, v in m.__dict__.items() if isinstance(v, torch.Tensor)]
 
     def _capture(self):
+        from . import parallel
+        rank, nranks = parallel.world()
+        if nranks > 1 and parallel.transport_name() != 'rccl-abi':
+            # the gradient exchange is part of the step: through the C ABI's communicator it is forked / joined inside the
+            # capture (parallel.GradReducer._launch); torch.distributed's collectives (gloo test path, fallback) are not
+            self.failed = f'gradient exchange over {parallel.transport_name()} cannot be captured'
+            return False
         torch.cuda.synchronize()
         # version-keyed operand caches must not be HIT inside the capture (engine.drop_operand_caches)
         for m in _chain(self.model):

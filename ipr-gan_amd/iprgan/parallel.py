@@ -360,12 +360,16 @@ class GradReducer:
         if self.transport is None:
             return
         if self.stream is not None:
-            ready = torch.cuda.Event(enable_timing=self.trace is not None)
+            # inside a graph capture (graphs.GraphedStep) the same three steps FORK the side stream off the capturing
+            # stream and wait() joins it back: the exchange becomes part of the step's graph.  Timing events cannot be
+            # recorded into a capture, and the exposed-time log has nothing to measure there.
+            cap = torch.cuda.is_current_stream_capturing()
+            ready = torch.cuda.Event(enable_timing=self.trace is not None and not cap)
             ready.record()                                   # after the bucket's last producer on the compute stream
             self.stream.wait_event(ready)
             with torch.cuda.stream(self.stream):
                 self.transport.all_reduce(b['flat'], self.stream)
-                b['done'] = torch.cuda.Event(enable_timing=self.trace is not None or self.world > 1)
+                b['done'] = torch.cuda.Event(enable_timing=(self.trace is not None or self.world > 1) and not cap)
                 b['done'].record(self.stream)
             if self.trace is not None:
                 b['ready'] = ready
@@ -415,7 +419,7 @@ class GradReducer:
         self.armed = False
         self.pending = 0
         dones = [b['done'] for b in self.buckets if b['done'] is not None]
-        if dones and self.world > 1:                # where the compute stream stands when it starts to wait
+        if dones and self.world > 1 and not torch.cuda.is_current_stream_capturing():   # where the compute stream stands when it starts to wait
             here = torch.cuda.Event(enable_timing=True)
             here.record()
             self.exposed_log.append((here, dones))

@@ -125,7 +125,7 @@ class Experiment:
     def train(self):
         hp, m = self.config.hparam, self.model
         d_iter, g_iter = hp.get('d_iter', 1), hp.get('g_iter', 1)
-        if self.kind == 'generation' and self.engine.get('graph') and self.world == 1 and d_iter == 1 and g_iter == 1 \
+        if self.kind == 'generation' and self.engine.get('graph') and d_iter == 1 and g_iter == 1 \
                 and not self.config.get('protection', Config({})).get('bbox', None):
             # `engine: {graph: true}`: update_d + update_g as ONE captured HIP graph (iprgan/graphs.py).  The data and the
             # latent draw stay on the host, as in the reference loop; they are copied into the graph's static inputs.

@@ -322,3 +322,63 @@ def test_bench_self_launch_two_ranks_one_gpu():
     assert r['n_gpus'] == 2 and r['config']['parallelism'] == 'dp2' and r['config']['global_batch'] == 256
     assert r['transport'] == 'torch.distributed' and r['comm_nranks'] == 0 and r['allreduce_exposed_ms_per_step'] >= 0.0
     assert r['value'] > 0 and r['scaling'] == 'weak'
+
+
+# ---- the N > 1 branch of the library's own communicator on ONE GPU: tests/stub_rccl.cpp stands in for librccl.so ----------
+STUB = os.path.join(ROOT, 'tests', '_build', 'libstub_rccl.so')
+
+
+def _stub_worker(rank, port, out, scenario):
+    """Started as a fresh process before any GPU call.  Two ranks share cuda:0; torch.distributed (gloo) is the out-of-band
+    channel; IPRGAN_RCCL_LIB points comm.hip at the stub."""
+    _paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), IPRGAN_RCCL_LIB=STUB, IPRGAN_COMM_TIMEOUT='6')
+    if scenario == 'timeout':
+        os.environ['STUB_RCCL_FAIL_INIT_RANK'] = '1'         # rank 1 cannot enter the rendezvous: rank 0 would wait forever
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    import time
+    from iprgan import parallel
+    t0 = time.time()
+    t = parallel._rccl_or_torch(rank, 2, dev)
+    took = time.time() - t0
+    g = torch.Generator().manual_seed(7 + rank)
+    mine = torch.randn((5 << 20) + 3, generator=g).to(dev)   # 20 MB: two pieces of the stub's 16 MB slots + a ragged tail
+    ref = mine.clone()
+    dist.all_reduce(ref)
+    buf = mine.clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        t.all_reduce(buf, side)
+    side.synchronize()
+    torch.save({'picked': t.__name__, 'equal': bool(torch.equal(buf, ref)), 'nranks': parallel.comm_nranks(),
+                'abandoned': parallel.RcclTransport.abandoned, 'took': took}, f'{out}.{rank}')
+    if not parallel.RcclTransport.abandoned:
+        parallel.RcclTransport.destroy()
+        dist.destroy_process_group()
+    parallel.finish(0)                                       # (os._exit when a bring-up thread is still inside the library)
+
+
+@pytest.mark.parametrize('scenario', ['ok', 'timeout'])
+def test_comm_init_two_ranks_over_the_stub(tmp_path, scenario):
+    """iprgan_comm_init with nranks = 2, executed: rank 0's unique id travels over torch.distributed, both ranks join the
+    rendezvous, the verified probe all-reduce returns 2, a 20 MB bucket summed through iprgan_allreduce_bucket equals
+    torch.distributed's sum bit for bit ('ok').  'timeout': rank 1 cannot enter the rendezvous - rank 0's bring-up thread
+    is abandoned after IPRGAN_COMM_TIMEOUT, the collective AND makes BOTH ranks fall back to torch.distributed, the
+    exchange still gives the right sum, and rank 0 leaves through parallel.finish() with its thread still blocked."""
+    if not os.path.exists(STUB):
+        import __graft_entry__ as ge
+        ge.build_test_doubles()
+    out = str(tmp_path / 'stub')
+    mp.spawn(_stub_worker, args=(_free_port(), out, scenario), nprocs=2, join=True)
+    res = [torch.load(f'{out}.{r}') for r in range(2)]
+    for f in __import__('glob').glob('/tmp/iprgan_stub_rccl_*'):
+        os.remove(f)
+    assert all(r['equal'] for r in res), res
+    if scenario == 'ok':
+        assert all(r['picked'] == 'RcclTransport' and r['nranks'] == 2 and not r['abandoned'] for r in res), res
+    else:
+        assert all(r['picked'] == 'TorchDistTransport' and r['nranks'] == 0 for r in res), res
+        assert res[0]['abandoned'] and not res[1]['abandoned'] and 5.0 < res[0]['took'] < 60.0, res

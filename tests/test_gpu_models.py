@@ -171,6 +171,21 @@ def test_graphed_step_variants(dev, n_steps, eager_at, replays):
     _graphed_vs_eager(dev, 'fp32', n_steps, eager_at, replays)
 
 
+def test_graphed_step_with_a_communicator_is_bit_identical_to_eager(dev, monkeypatch):
+    """The step captured WITH the gradient exchange inside the graph (VERDICT r03, next #2a): IPRGAN_FORCE_COMM=1 gives the
+    reducers the library's own single-rank RCCL communicator, so every bucket leaves on the side stream (event after its
+    last producer, iprgan_allreduce_bucket, completion event, the compute stream's wait) - forked and joined inside the
+    capture.  Bit-identical to the eager steps of the same model, as without a communicator; at N > 1 the same graph
+    carries the real exchange (bench.py captures whenever the transport is the C ABI's)."""
+    from iprgan import parallel
+    monkeypatch.setenv('IPRGAN_FORCE_COMM', '1')
+    try:
+        _graphed_vs_eager(dev, 'fp32', 7, 4, 4)
+        assert parallel.transport_name() == 'rccl-abi' and parallel.comm_nranks() == 1
+    finally:
+        parallel.RcclTransport.destroy()
+
+
 def test_graphed_srgan_step_is_bit_identical_to_eager(dev):
     """The SRGAN GAN-phase step (update_g with the VGG content loss, then update_d; frozen VGG operands are re-prepared
     inside the graph because the caches are dropped before the capture) captured and replayed against the eager step:
