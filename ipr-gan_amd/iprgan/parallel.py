@@ -220,7 +220,9 @@ def _pick_transport(device):
 def _pick_transport_impl(device):
     rank, nranks = world()
     if nranks > 1:
-        if device.type == 'cuda' and dist.get_backend() == 'nccl':
+        # (IPRGAN_RCCL_LIB: the communicator library is given explicitly - tests/stub_rccl.cpp lets two ranks that share
+        # one GPU, whose torch.distributed backend has to be gloo, run the C ABI's N > 1 path)
+        if device.type == 'cuda' and (dist.get_backend() == 'nccl' or os.environ.get('IPRGAN_RCCL_LIB')):
             return _rccl_or_torch(rank, nranks, device)
         return TorchDistTransport
     if device.type == 'cuda' and os.environ.get('IPRGAN_FORCE_COMM') == '1':

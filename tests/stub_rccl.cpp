@@ -6,8 +6,9 @@
 // IPRGAN_RCCL_LIB=<this .so> (comm.hip: rccl_load).  Built by __graft_entry__.build() with hipcc (host code + HIP runtime).
 //
 // Semantics kept: the rendezvous of ncclCommInitRank blocks until every rank has arrived (no timeout, like the real one);
-// ncclAllReduce sums fp32 buffers in rank order (deterministic).  Not kept: asynchrony - the all-reduce synchronises the
-// stream and runs on the host (fine for a test double; it cannot be captured in a HIP graph).
+// ncclAllReduce sums fp32 buffers in rank order (deterministic) and is ENQUEUED on the caller's stream (device-to-host
+// copy, a host node that meets the peers and sums, host-to-device copy), so it can wait behind events on a side stream and
+// be captured into a HIP graph like the real one.
 // STUB_RCCL_FAIL_INIT_RANK=<r>: that rank's ncclCommInitRank fails at once without arriving - its peers stay in the
 // rendezvous, which is exactly the situation the abandonable bring-up thread of parallel.RcclTransport.ensure is for.
 #include <fcntl.h>
@@ -100,23 +101,33 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   return 0;
 }
 
+struct StubPiece { StubComm* c; size_t n; };
+// host node between the two copies of a piece: publish this rank's piece, meet the peers, sum in rank order
+static void stub_exchange(void* arg) {
+  StubPiece* p = (StubPiece*)arg;
+  StubComm* c = p->c;
+  memcpy(c->sh->slot[c->rank], c->host, p->n * sizeof(float));
+  barrier(c);                                                       // every rank's piece is in its slot
+  for (size_t i = 0; i < p->n; ++i) {
+    float s = c->sh->slot[0][i];
+    for (int r = 1; r < c->nranks; ++r) s += c->sh->slot[r][i];     // rank order: the same sum on every rank
+    c->host[i] = s;
+  }
+  barrier(c);                                                       // everybody has read the slots: they may be rewritten
+}
+
+// Enqueued like the real one (copy out, host node, copy back - all on `stream`, nothing blocks the caller), so the call
+// can sit on a side stream behind an event and can be captured into a HIP graph (the argument blocks are never freed: a
+// captured graph replays them).
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t dtype, ncclRedOp_t op, ncclComm_t c,
                            hipStream_t stream) {
   if (dtype != 7 || op != 0) return 6;                              // fp32 SUM only (what comm.hip sends for gradient buckets)
   for (size_t off = 0; off < count; off += STUB_SLOT_FLOATS) {
     const size_t n = count - off < STUB_SLOT_FLOATS ? count - off : STUB_SLOT_FLOATS;
+    StubPiece* piece = new StubPiece{c, n};
     if (hipMemcpyAsync(c->host, (const float*)send + off, n * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess) return 7;
-    if (hipStreamSynchronize(stream) != hipSuccess) return 7;
-    memcpy(c->sh->slot[c->rank], c->host, n * sizeof(float));
-    barrier(c);                                                     // every rank's piece is in its slot
-    for (size_t i = 0; i < n; ++i) {
-      float s = c->sh->slot[0][i];
-      for (int r = 1; r < c->nranks; ++r) s += c->sh->slot[r][i];   // rank order: the same sum on every rank
-      c->host[i] = s;
-    }
-    barrier(c);                                                     // everybody has read the slots: they may be rewritten
+    if (hipLaunchHostFunc(stream, stub_exchange, piece) != hipSuccess) return 7;
     if (hipMemcpyAsync((float*)recv + off, c->host, n * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess) return 7;
-    if (hipStreamSynchronize(stream) != hipSuccess) return 7;
   }
   return 0;
 }

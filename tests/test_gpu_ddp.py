@@ -382,3 +382,29 @@ def test_comm_init_two_ranks_over_the_stub(tmp_path, scenario):
     else:
         assert all(r['picked'] == 'TorchDistTransport' and r['nranks'] == 0 for r in res), res
         assert res[0]['abandoned'] and not res[1]['abandoned'] and 5.0 < res[0]['took'] < 60.0, res
+
+
+def test_bench_two_ranks_capture_the_step_with_the_exchange_inside():
+    """``bench.py --gpus 2`` with the C ABI's communicator carrying the buckets (the stub stands in for RCCL: two ranks share
+    this box's GPU): the whole step - both updates AND the bucket exchanges on the reducers' side streams - is ONE captured
+    HIP graph per rank, so the host cost of a data-parallel step is a graph launch, not ~200 kernel launches: host enqueue
+    time per step stays under half of the step time (VERDICT r03, next #2)."""
+    import json
+    import subprocess
+    if not os.path.exists(STUB):
+        import __graft_entry__ as ge
+        ge.build_test_doubles()
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(IPRGAN_SHARE_DEVICE='1', IPRGAN_DIST_BACKEND='gloo', IPRGAN_RCCL_LIB=STUB)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '12', '--warmup', '6',
+                        '--no-cpu-baseline', '--alt-math', 'none'], env=env, capture_output=True, text=True, timeout=900)
+    for f in __import__('glob').glob('/tmp/iprgan_stub_rccl_*'):
+        os.remove(f)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['transport'] == 'rccl-abi' and r['comm_nranks'] == 2, r
+    assert r['graph'] and r['graph']['captured'] and r['graph']['failed'] is None and r['graph']['replays_in_timed_region'] >= 6, r['graph']
+    assert r['host_enqueue_ms_per_step'] < 0.5 * r['ms_per_step'], (r['host_enqueue_ms_per_step'], r['ms_per_step'])
+    assert all(v == v for v in r['metrics_last_step'].values())
