@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 220
+#define IPRGAN_VERSION 221
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -160,13 +160,15 @@ int iprgan_act_bwd(const float* dy, const float* out, float* dz, size_t n, int a
 
 /* ---- GEMV head: SN-Linear 512*md*md -> 1 (networks/sn_discriminator.py:21) -------------- */
 /* y[b] = dot(x[b,:], w)/(*inv_scale) + bias[0];  x [B,K] */
+/* x_bf16: storage kind of x (and dx, prev_out); x_pstride / dx_pstride: plane strides in elements of three-plane x
+ * (= prev_out) / dx, 0 = contiguous (B*K) - a half-batch of a paired pass keeps the whole batch's stride */
 int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const float* inv_scale, float* y,
-                    int B, int K, int x_bf16, void* stream);
+                    int B, int K, int x_bf16, size_t x_pstride, void* stream);
 /* dx[b,k] = dy[b]*w[k]/(*inv_scale) [* act'(prev_out)];  dw[k] = sum_b dy[b]*x[b,k] (gradient w.r.t.
  * the NORMALISED weight w/sigma; feed it to iprgan_sn_bwd);  db[0] = sum dy.  dx/dw/db may be NULL. */
 int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float* inv_scale, float* dx,
                     float* dw, float* db, const float* prev_out, int prev_act, float prev_slope, int B,
-                    int K, int x_bf16, void* stream);
+                    int K, int x_bf16, size_t x_pstride, size_t dx_pstride, void* stream);
 
 /* ---- BatchNorm2d (networks/conv_generator.py:9, sr_resnet.py:23, discriminator_96.py:31) -- */
 size_t iprgan_bn_ws_floats(int M, int C);
@@ -229,19 +231,22 @@ int iprgan_instnorm_bwd(const float* x, const float* y, const float* dy, const f
  * dst [B,2H,2W,C] (inverse=1: the other way, i.e. its gradient).  MaxPool2d(2,2) (VGG19 features,
  * vgg.py:33): gradient to the first maximum of each window.  reflect_fold: gradient of
  * ReflectionPad2d(pad) - dxp [B,H+2p,W+2p,C] summed back onto dx [B,H,W,C] (times act'(prev_out) if given). */
-int iprgan_prelu_fwd(const float* x, const float* alpha, float* y, size_t n, void* stream);
+/* act_st (here and below): storage kind of the activation tensors of the call (IPRGAN_ST_F32, or IPRGAN_ST_X3 for
+ * contiguous three-plane tensors: plane stride = the tensor's element count) */
+int iprgan_prelu_fwd(const float* x, const float* alpha, float* y, size_t n, int act_st, void* stream);
 int iprgan_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, float* ws,
-                     size_t n, void* stream);
+                     size_t n, int act_st, void* stream);
 int iprgan_pixel_shuffle2(const float* src, float* dst, int B, int H, int W, int C, int inverse, void* stream);
 /* conv -> PixelShuffle(2) -> PReLU (the upsampling blocks, sr_resnet.py:39-45) in one pass each way: x [B,H,W,4C] is the
  * convolution's output, y / dy [B,2H,2W,C]; y = prelu(shuffle(x)), dx = unshuffle(dy) * prelu'(x), dalpha as above
  * (ws >= iprgan_loss_ws_floats(B*H*W*C) floats).  C % 4 == 0. */
-int iprgan_pixel_shuffle2_prelu_fwd(const float* x, const float* alpha, float* y, int B, int H, int W, int C, void* stream);
+int iprgan_pixel_shuffle2_prelu_fwd(const float* x, const float* alpha, float* y, int B, int H, int W, int C, int act_st,
+                                    void* stream);
 int iprgan_pixel_shuffle2_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, float* ws,
-                                    int B, int H, int W, int C, void* stream);
-int iprgan_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
-int iprgan_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream);
-int iprgan_add(const float* a, const float* b, float* out, size_t n, void* stream);
+                                    int B, int H, int W, int C, int act_st, void* stream);
+int iprgan_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, int act_st, void* stream);
+int iprgan_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int act_st, void* stream);
+int iprgan_add(const float* a, const float* b, float* out, size_t n, int act_st, void* stream);
 int iprgan_reflect_fold(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope,
                         const float* residual, int B, int H, int W, int C, int pad, void* stream);
 

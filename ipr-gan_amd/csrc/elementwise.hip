@@ -93,8 +93,15 @@ __global__ void axpy_multi_kernel(const AxpyTable t, float a) {
 }
 
 // ---- GEMV head -----------------------------------------------------------------------------
-// 4 consecutive elements of a tensor stored as fp32 or bf16
-__device__ __forceinline__ float4 ld4e(const float* p, size_t i, int b16) {
+// 4 consecutive elements of a tensor stored as fp32, bf16 or (b16 == 2) three bf16 planes ps elements apart
+__device__ __forceinline__ float4 ld4e(const float* p, size_t i, int b16, size_t ps = 0) {
+  if (b16 == 2) {
+    typedef __bf16 h4 __attribute__((ext_vector_type(4)));
+    const __bf16* b = (const __bf16*)p + i;
+    const h4 h = *(const h4*)b, m = *(const h4*)(b + ps), l = *(const h4*)(b + 2 * ps);
+    return make_float4((float)h.x + ((float)m.x + (float)l.x), (float)h.y + ((float)m.y + (float)l.y),
+                       (float)h.z + ((float)m.z + (float)l.z), (float)h.w + ((float)m.w + (float)l.w));
+  }
   if (b16) {
     typedef __bf16 h4 __attribute__((ext_vector_type(4)));
     const h4 h = *(const h4*)((const __bf16*)p + i);
@@ -102,7 +109,17 @@ __device__ __forceinline__ float4 ld4e(const float* p, size_t i, int b16) {
   }
   return *(const float4*)(p + i);
 }
-__device__ __forceinline__ void st4e(float* p, size_t i, float4 v, int b16) {
+__device__ __forceinline__ void st4e(float* p, size_t i, float4 v, int b16, size_t ps = 0) {
+  if (b16 == 2) {
+    typedef __bf16 h4 __attribute__((ext_vector_type(4)));
+    __bf16* b = (__bf16*)p + i;
+    const h4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    const float4 r1 = make_float4(v.x - (float)h.x, v.y - (float)h.y, v.z - (float)h.z, v.w - (float)h.w);
+    const h4 m = {(__bf16)r1.x, (__bf16)r1.y, (__bf16)r1.z, (__bf16)r1.w};
+    const h4 l = {(__bf16)(r1.x - (float)m.x), (__bf16)(r1.y - (float)m.y), (__bf16)(r1.z - (float)m.z), (__bf16)(r1.w - (float)m.w)};
+    *(h4*)b = h; *(h4*)(b + ps) = m; *(h4*)(b + 2 * ps) = l;
+    return;
+  }
   if (b16) {
     typedef __bf16 h4 __attribute__((ext_vector_type(4)));
     const h4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
@@ -117,7 +134,7 @@ __device__ __forceinline__ void st4e(float* p, size_t i, float4 v, int b16) {
 __global__ __launch_bounds__(1024) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ inv_scale,
-                                                        float* __restrict__ y, int K, int x16) {
+                                                        float* __restrict__ y, int K, int x16, size_t ps) {
   __shared__ float sh[16];
   const size_t row = (size_t)blockIdx.x * K;
   const int stride = blockDim.x * 4;
@@ -126,12 +143,12 @@ __global__ __launch_bounds__(1024) void gemv_fwd_kernel(const float* __restrict_
   for (; k + 3 * stride < K; k += 4 * stride) {
     float4 a[4], b[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { a[u] = ld4e(x, row + k + u * stride, x16); b[u] = *(const float4*)(w + k + u * stride); }
+    for (int u = 0; u < 4; ++u) { a[u] = ld4e(x, row + k + u * stride, x16, ps); b[u] = *(const float4*)(w + k + u * stride); }
 #pragma unroll
     for (int u = 0; u < 4; ++u) s += a[u].x * b[u].x + a[u].y * b[u].y + a[u].z * b[u].z + a[u].w * b[u].w;
   }
   for (; k < K; k += stride) {
-    const float4 a = ld4e(x, row + k, x16), b = *(const float4*)(w + k);
+    const float4 a = ld4e(x, row + k, x16, ps), b = *(const float4*)(w + k);
     s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
   }
   s = block_sum(s, sh);
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(1024) void gemv_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void gemv_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
                                    const float* __restrict__ inv_scale, float* __restrict__ dx,
                                    const float* __restrict__ prev_out, int prev_act, float prev_slope,
-                                   int B, int K, int x16) {
+                                   int B, int K, int x16, size_t ps_dx, size_t ps_prev) {
   const float sc = inv_scale ? *inv_scale : 1.f;
   const int b = blockIdx.y;
   const float g = dy[b];
@@ -153,11 +170,38 @@ __global__ __launch_bounds__(256) void gemv_bwd_dx_kernel(const float* __restric
     float4 v = make_float4(g * (wv.x / sc), g * (wv.y / sc), g * (wv.z / sc), g * (wv.w / sc));
     const size_t i = (size_t)b * K + k;
     if (prev_out) {
-      const float4 o = ld4e(prev_out, i, x16);
+      const float4 o = ld4e(prev_out, i, x16, ps_prev);
       v.x *= act_grad_from_out(o.x, prev_act, prev_slope); v.y *= act_grad_from_out(o.y, prev_act, prev_slope);
       v.z *= act_grad_from_out(o.z, prev_act, prev_slope); v.w *= act_grad_from_out(o.w, prev_act, prev_slope);
     }
-    st4e(dx, i, v, x16);
+    st4e(dx, i, v, x16, ps_dx);
+  }
+}
+// dw of a three-plane x: 4 columns per thread, four samples in flight
+__global__ __launch_bounds__(64) void gemv_bwd_dw3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dw, float* __restrict__ db, int B, int K, size_t ps) {
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (k < K && dw) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int b = 0;
+    for (; b + 3 < B; b += 4) {
+      float4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = ld4e(x, (size_t)(b + u) * K + k, 2, ps);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const float g = dy[b + u]; s.x += g * r[u].x; s.y += g * r[u].y; s.z += g * r[u].z; s.w += g * r[u].w; }
+    }
+    for (; b < B; ++b) {
+      const float4 r = ld4e(x, (size_t)b * K + k, 2, ps);
+      const float g = dy[b];
+      s.x += g * r.x; s.y += g * r.y; s.z += g * r.z; s.w += g * r.w;
+    }
+    *(float4*)(dw + k) = s;
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dy[b];
+    db[0] = a;
   }
 }
 // dw[k] = sum_b dy[b] x[b, k] (sample order: deterministic).  One 16-byte load per thread and sample (8 bf16 / 4 fp32
@@ -307,20 +351,54 @@ __global__ void reparam_bwd_kernel(const float* __restrict__ dz, const float* __
   }
 }
 
+// ---- storage kinds of the elementwise kernels below: st = 0 fp32, st = 2 three bf16 planes ps elements apart (IPRGAN_ST_X3,
+// include/iprgan.h: x = h + (m + l) exactly; split once per element when stored).  e = element index of 4 consecutive values.
+typedef float ew_f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 ew_b4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ew_f4 ew_wide(const ew_b4 h) {
+  const ew_f4 v = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+  return v;
+}
+__device__ __forceinline__ ew_b4 ew_narrow(const ew_f4& v) {
+  const ew_b4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  return h;
+}
+__device__ __forceinline__ ew_f4 ew_ld(const float* base, size_t e, int st, size_t ps) {
+  if (st == 2) {
+    const __bf16* b = (const __bf16*)base + e;
+    return ew_wide(*(const ew_b4*)b) + (ew_wide(*(const ew_b4*)(b + ps)) + ew_wide(*(const ew_b4*)(b + 2 * ps)));
+  }
+  return *(const ew_f4*)(base + e);
+}
+__device__ __forceinline__ void ew_st(float* base, size_t e, const ew_f4& v, int st, size_t ps) {
+  if (st == 2) {
+    __bf16* b = (__bf16*)base + e;
+    const ew_b4 h = ew_narrow(v);
+    const ew_f4 r1 = v - ew_wide(h);
+    const ew_b4 m = ew_narrow(r1);
+    *(ew_b4*)b = h;
+    *(ew_b4*)(b + ps) = m;
+    *(ew_b4*)(b + 2 * ps) = ew_narrow(r1 - ew_wide(m));
+  } else {
+    *(ew_f4*)(base + e) = v;
+  }
+}
+
 // ---- PReLU with ONE learnable slope (nn.PReLU(), networks/sr_resnet.py:7,14,43) ---------------------
 __global__ void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
-                                 float* __restrict__ y, size_t n) {
+                                 float* __restrict__ y, size_t n, int st) {
   const float a = *alpha;
   typedef float f4 __attribute__((ext_vector_type(4)));
-  const size_t n4 = ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(y)) & 15) == 0 ? n / 4 : 0;
+  const size_t n4 = (st == 2 || ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(y)) & 15) == 0) ? n / 4 : 0;
   const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   for (size_t i = i0; i < n4; i += stride) {              // 16-byte accesses over the aligned bulk
-    const f4 v = ((const f4*)x)[i];
+    const f4 v = ew_ld(x, i * 4, st, n);
     f4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = v[k] > 0.f ? v[k] : a * v[k];
-    ((f4*)y)[i] = o;
+    ew_st(y, i * 4, o, st, n);
   }
+  if (st == 2) return;
   for (size_t i = n4 * 4 + i0; i < n; i += stride) {
     const float v = x[i];
     y[i] = v > 0.f ? v : a * v;
@@ -329,7 +407,7 @@ __global__ void prelu_fwd_kernel(const float* __restrict__ x, const float* __res
 // dx = dy * (x>0 ? 1 : alpha); part[block] = sum dy*x*[x<=0]
 __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ alpha, float* __restrict__ dx,
-                                                        float* __restrict__ part, size_t n) {
+                                                        float* __restrict__ part, size_t n, int st) {
   __shared__ float sh[16];
   const float a = *alpha;
   // the slope gradient is ONE number summed over the whole tensor, with terms of both signs: this thread's running sum
@@ -337,11 +415,11 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
   // 2e-5 off where torch's pairwise reduction is 2e-7; tests/test_gpu_models.py::test_net_accuracy_against_float64)
   double s = 0.0;
   typedef float f4 __attribute__((ext_vector_type(4)));
-  const size_t n4 = ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(dx)) & 15) == 0
+  const size_t n4 = (st == 2 || ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(dx)) & 15) == 0)
                         ? n / 4 : 0;
   const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   for (size_t i = i0; i < n4; i += stride) {              // 16-byte accesses (scalar ones ran at 0.8 TB/s)
-    const f4 v = ((const f4*)x)[i], g = ((const f4*)dy)[i];
+    const f4 v = ew_ld(x, i * 4, st, n), g = ew_ld(dy, i * 4, st, n);
     f4 o;
     float q = 0.f;
 #pragma unroll
@@ -350,9 +428,9 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
       q += v[k] > 0.f ? 0.f : g[k] * v[k];
     }
     s += (double)q;
-    ((f4*)dx)[i] = o;
+    ew_st(dx, i * 4, o, st, n);
   }
-  for (size_t i = n4 * 4 + i0; i < n; i += stride) {
+  for (size_t i = n4 * 4 + i0; i < n && st != 2; i += stride) {
     const float v = x[i], g = dy[i];
     dx[i] = v > 0.f ? g : a * g;
     s += v > 0.f ? 0.0 : (double)(g * v);
@@ -398,10 +476,10 @@ __global__ void pixel_shuffle2_kernel(const float* __restrict__ src, float* __re
 // (double per thread, as prelu_bwd_kernel).  C % 4 == 0.
 typedef float ps_f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void ps2_prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
-                                                            float* __restrict__ y, int B, int H, int W, int C) {
+                                                            float* __restrict__ y, int B, int H, int W, int C, int st) {
   const float a = *alpha;
   const int cg = C / 4;
-  const size_t total = (size_t)B * H * W * cg;
+  const size_t total = (size_t)B * H * W * cg, ps = total * 16;
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
     const int g = (int)(t % cg);
     size_t p = t / cg;
@@ -409,26 +487,26 @@ __global__ __launch_bounds__(256) void ps2_prelu_fwd_kernel(const float* __restr
     p /= W;
     const int h = (int)(p % H);
     const size_t b = p / H;
-    const ps_f4* src = (const ps_f4*)(x + (((b * H + h) * W + w) * (size_t)(4 * C) + (size_t)g * 16));
+    const size_t so = ((b * H + h) * W + w) * (size_t)(4 * C) + (size_t)g * 16;
     ps_f4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = src[k];
+    for (int k = 0; k < 4; ++k) v[k] = ew_ld(x, so + 4 * k, st, ps);
 #pragma unroll
     for (int ij = 0; ij < 4; ++ij) {
       ps_f4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { const float e = v[k][ij]; o[k] = e > 0.f ? e : a * e; }
-      *(ps_f4*)(y + (((b * 2 * H + 2 * h + (ij >> 1)) * (size_t)(2 * W) + 2 * w + (ij & 1)) * (size_t)C + (size_t)g * 4)) = o;
+      ew_st(y, ((b * 2 * H + 2 * h + (ij >> 1)) * (size_t)(2 * W) + 2 * w + (ij & 1)) * (size_t)C + (size_t)g * 4, o, st, ps);
     }
   }
 }
 __global__ __launch_bounds__(256) void ps2_prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ alpha, float* __restrict__ dx,
-                                                            float* __restrict__ part, int B, int H, int W, int C) {
+                                                            float* __restrict__ part, int B, int H, int W, int C, int st) {
   __shared__ float sh[16];
   const float a = *alpha;
   const int cg = C / 4;
-  const size_t total = (size_t)B * H * W * cg;
+  const size_t total = (size_t)B * H * W * cg, ps = total * 16;
   double s = 0.0;
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
     const int g = (int)(t % cg);
@@ -440,10 +518,10 @@ __global__ __launch_bounds__(256) void ps2_prelu_bwd_kernel(const float* __restr
     const size_t xo = ((b * H + h) * W + w) * (size_t)(4 * C) + (size_t)g * 16;
     ps_f4 v[4], d[4], o[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = ((const ps_f4*)(x + xo))[k];
+    for (int k = 0; k < 4; ++k) v[k] = ew_ld(x, xo + 4 * k, st, ps);
 #pragma unroll
     for (int ij = 0; ij < 4; ++ij)
-      d[ij] = *(const ps_f4*)(dy + (((b * 2 * H + 2 * h + (ij >> 1)) * (size_t)(2 * W) + 2 * w + (ij & 1)) * (size_t)C + (size_t)g * 4));
+      d[ij] = ew_ld(dy, ((b * 2 * H + 2 * h + (ij >> 1)) * (size_t)(2 * W) + 2 * w + (ij & 1)) * (size_t)C + (size_t)g * 4, st, ps);
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -455,7 +533,7 @@ __global__ __launch_bounds__(256) void ps2_prelu_bwd_kernel(const float* __restr
       }
     s += (double)q;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ((ps_f4*)(dx + xo))[k] = o[k];
+    for (int k = 0; k < 4; ++k) ew_st(dx, xo + 4 * k, o[k], st, ps);
   }
   const float sb = block_sum((float)s, sh);
   if (threadIdx.x == 0) part[blockIdx.x] = sb;
@@ -507,14 +585,67 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
   }
 }
 
+// the same pool on even maps with 4 channels per thread (16-byte accesses; fp32 or three-plane tensors): forward, and a
+// backward that visits every 2x2 window once (the scalar kernels above re-read the window for each of its four pixels)
+__global__ __launch_bounds__(256) void maxpool2_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                            int W, int C, int st) {
+  const int OH = H / 2, OW = W / 2, cg = C / 4;
+  const size_t total = (size_t)B * OH * OW * cg, psx = (size_t)B * H * W * C, psy = total * 4;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % cg);
+    size_t p = t / cg;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const size_t b = p / OH;
+    const size_t i0 = ((b * H + 2 * oy) * W + 2 * ox) * (size_t)C + (size_t)g * 4;
+    const ew_f4 v0 = ew_ld(x, i0, st, psx), v1 = ew_ld(x, i0 + C, st, psx), v2 = ew_ld(x, i0 + (size_t)W * C, st, psx),
+                v3 = ew_ld(x, i0 + (size_t)W * C + C, st, psx);
+    ew_f4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaxf(v0[k], v1[k]), fmaxf(v2[k], v3[k]));
+    ew_st(y, t * 4, o, st, psy);
+  }
+}
+__global__ __launch_bounds__(256) void maxpool2_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dx, int B, int H, int W, int C, int st) {
+  const int OH = H / 2, OW = W / 2, cg = C / 4;
+  const size_t total = (size_t)B * OH * OW * cg, psx = (size_t)B * H * W * C, psy = total * 4;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % cg);
+    size_t p = t / cg;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const size_t b = p / OH;
+    const size_t i0 = ((b * H + 2 * oy) * W + 2 * ox) * (size_t)C + (size_t)g * 4;
+    const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+    ew_f4 v[4], o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = ew_ld(x, i0 + off[q], st, psx);
+    const ew_f4 gr = ew_ld(dy, t * 4, st, psy);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                     // the FIRST maximum in window order takes the gradient
+      int arg = 0;
+      float m = v[0][k];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) if (v[q][k] > m) { m = v[q][k]; arg = q; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q][k] = arg == q ? gr[k] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ew_st(dx, i0 + off[q], o[q], st, psx);
+  }
+}
+
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                           size_t n) {
+                           size_t n, int st) {
   typedef float f4 __attribute__((ext_vector_type(4)));
-  const size_t n4 = ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(out)) & 15) == 0
+  const size_t n4 = (st == 2 || ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(out)) & 15) == 0)
                         ? n / 4 : 0;
   const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  for (size_t i = i0; i < n4; i += stride) ((f4*)out)[i] = ((const f4*)a)[i] + ((const f4*)b)[i];
-  for (size_t i = n4 * 4 + i0; i < n; i += stride) out[i] = a[i] + b[i];
+  for (size_t i = i0; i < n4; i += stride) ew_st(out, i * 4, ew_ld(a, i * 4, st, n) + ew_ld(b, i * 4, st, n), st, n);
+  for (size_t i = n4 * 4 + i0; i < n && st != 2; i += stride) out[i] = a[i] + b[i];
 }
 
 // ---- ReflectionPad2d(p) backward: fold the gradient of the padded image back (resnet_generator.py:6,33,43,47)
@@ -784,26 +915,32 @@ int iprgan_cast_planes(const void* src, void* dst, size_t n, size_t pstride, int
 }
 
 int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const float* inv_scale, float* y,
-                    int B, int K, int x_bf16, void* stream) {
+                    int B, int K, int x_bf16, size_t x_pstride, void* stream) {
   IPR_CHECK(K % 4 == 0, "gemv_fwd: K=%d must be a multiple of 4", K);
   if (B == 0) return 0;
-  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(B), dim3(K >= 16384 ? 1024 : 256), 0, (hipStream_t)stream, x, w, bias, inv_scale, y, K, x_bf16);
+  const size_t ps = x_pstride ? x_pstride : (size_t)B * K;
+  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(B), dim3(K >= 16384 ? 1024 : 256), 0, (hipStream_t)stream, x, w, bias, inv_scale, y, K, x_bf16, ps);
   IPR_LAUNCH_CHECK();
   return 0;
 }
 int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float* inv_scale, float* dx,
                     float* dw, float* db, const float* prev_out, int prev_act, float prev_slope, int B,
-                    int K, int x_bf16, void* stream) {
+                    int K, int x_bf16, size_t x_pstride, size_t dx_pstride, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) return 0;
+  const size_t ps = x_pstride ? x_pstride : (size_t)B * K, ps_dx = dx_pstride ? dx_pstride : (size_t)B * K;
   if (dx) {
     IPR_CHECK(K % 4 == 0, "gemv_bwd: K=%d must be a multiple of 4", K);
     const int gx = cdiv(K / 4, 256) < 64 ? cdiv(K / 4, 256) : 64;
     hipLaunchKernelGGL(gemv_bwd_dx_kernel, dim3(gx, B), dim3(256), 0, st, w, dy,
-                       inv_scale, dx, prev_out, prev_act, prev_slope, B, K, x_bf16);
+                       inv_scale, dx, prev_out, prev_act, prev_slope, B, K, x_bf16, ps_dx, ps);
     IPR_LAUNCH_CHECK();
   }
   if (dw || db) {
+    if (x_bf16 == 2) {
+      IPR_CHECK(K % 4 == 0, "gemv_bwd: K=%d must be a multiple of 4", K);
+      hipLaunchKernelGGL(gemv_bwd_dw3_kernel, dim3(cdiv(K, 256)), dim3(64), 0, st, x, dy, dw, db, B, K, ps);
+    } else
     if (x_bf16) hipLaunchKernelGGL(gemv_bwd_dw_kernel<true>, dim3(cdiv(K, 512)), dim3(64), 0, st, x, dy, dw, db, B, K);
     else hipLaunchKernelGGL(gemv_bwd_dw_kernel<false>, dim3(cdiv(K, 256)), dim3(64), 0, st, x, dy, dw, db, B, K);
     IPR_LAUNCH_CHECK();
@@ -812,17 +949,21 @@ int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float
 }
 
 
-int iprgan_prelu_fwd(const float* x, const float* alpha, float* y, size_t n, void* stream) {
+#define IPR_ST_CHECK(st, n, what) \
+  IPR_CHECK((st) == 0 || ((st) == 2 && ((n) % 4) == 0), what ": storage kind %d (fp32 or three planes; three planes need n %% 4 == 0)", (int)(st))
+int iprgan_prelu_fwd(const float* x, const float* alpha, float* y, size_t n, int act_st, void* stream) {
   if (!n) return 0;
-  hipLaunchKernelGGL(prelu_fwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, n);
+  IPR_ST_CHECK(act_st, n, "prelu_fwd");
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, n, act_st);
   IPR_LAUNCH_CHECK();
   return 0;
 }
 int iprgan_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, float* ws,
-                     size_t n, void* stream) {
+                     size_t n, int act_st, void* stream) {
   if (!n) return 0;
+  IPR_ST_CHECK(act_st, n, "prelu_bwd");
   const int nb = grid_for(n, LOSS_BLOCKS);
-  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, dy, alpha, dx, ws, n);
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, dy, alpha, dx, ws, n, act_st);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, dalpha);
   IPR_LAUNCH_CHECK();
@@ -836,44 +977,62 @@ int iprgan_pixel_shuffle2(const float* src, float* dst, int B, int H, int W, int
   IPR_LAUNCH_CHECK();
   return 0;
 }
-int iprgan_pixel_shuffle2_prelu_fwd(const float* x, const float* alpha, float* y, int B, int H, int W, int C, void* stream) {
+int iprgan_pixel_shuffle2_prelu_fwd(const float* x, const float* alpha, float* y, int B, int H, int W, int C, int act_st,
+                                    void* stream) {
   IPR_CHECK(C > 0 && (C % 4) == 0, "pixel_shuffle2_prelu: %d output channels (a multiple of 4 is required)", C);
   const size_t n = (size_t)B * H * W * (C / 4);
   if (!n) return 0;
-  hipLaunchKernelGGL(ps2_prelu_fwd_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, B, H, W, C);
+  IPR_ST_CHECK(act_st, 4, "pixel_shuffle2_prelu_fwd");
+  hipLaunchKernelGGL(ps2_prelu_fwd_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, x, alpha, y, B, H, W, C, act_st);
   IPR_LAUNCH_CHECK();
   return 0;
 }
 int iprgan_pixel_shuffle2_prelu_bwd(const float* x, const float* dy, const float* alpha, float* dx, float* dalpha, float* ws,
-                                    int B, int H, int W, int C, void* stream) {
+                                    int B, int H, int W, int C, int act_st, void* stream) {
   IPR_CHECK(C > 0 && (C % 4) == 0, "pixel_shuffle2_prelu: %d output channels (a multiple of 4 is required)", C);
   const size_t n = (size_t)B * H * W * (C / 4);
   if (!n) return 0;
+  IPR_ST_CHECK(act_st, 4, "pixel_shuffle2_prelu_bwd");
   const int nb = grid_for(n, LOSS_BLOCKS);
-  hipLaunchKernelGGL(ps2_prelu_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, dy, alpha, dx, ws, B, H, W, C);
+  hipLaunchKernelGGL(ps2_prelu_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, dy, alpha, dx, ws, B, H, W, C, act_st);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, dalpha);
   IPR_LAUNCH_CHECK();
   return 0;
 }
-int iprgan_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+int iprgan_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, int act_st, void* stream) {
   const size_t n = (size_t)B * (H / 2) * (W / 2) * C;
   if (!n) return 0;
+  const bool vec = (C % 4) == 0 && (H % 2) == 0 && (W % 2) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+  IPR_CHECK(act_st == 0 || (act_st == 2 && vec), "maxpool2_fwd: three-plane tensors need even maps and C %% 4 == 0");
+  if (vec) {
+    hipLaunchKernelGGL(maxpool2_fwd4_kernel, dim3(grid_for(n / 4, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C, act_st);
+    IPR_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C);
   IPR_LAUNCH_CHECK();
   return 0;
 }
-int iprgan_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+int iprgan_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int act_st, void* stream) {
   const size_t n = (size_t)B * H * W * C;
   if (!n) return 0;
+  const bool vec = (C % 4) == 0 && (H % 2) == 0 && (W % 2) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+  IPR_CHECK(act_st == 0 || (act_st == 2 && vec), "maxpool2_bwd: three-plane tensors need even maps and C %% 4 == 0");
+  if (vec) {
+    hipLaunchKernelGGL(maxpool2_bwd4_kernel, dim3(grid_for(n / 16, 8192)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, B, H, W, C, act_st);
+    IPR_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, x, dy, dx,
                      B, H, W, C);
   IPR_LAUNCH_CHECK();
   return 0;
 }
-int iprgan_add(const float* a, const float* b, float* out, size_t n, void* stream) {
+int iprgan_add(const float* a, const float* b, float* out, size_t n, int act_st, void* stream) {
   if (!n) return 0;
-  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  IPR_ST_CHECK(act_st, n, "add");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, act_st);
   IPR_LAUNCH_CHECK();
   return 0;
 }

@@ -57,8 +57,8 @@ SIGNATURES = {
     'iprgan_cast': (_I, [_P, _P, _Z, _I, _I, _P]),
     'iprgan_cast_planes': (_I, [_P, _P, _Z, _Z, _I, _P]),
     'iprgan_conv_wgrad_takes_bf16': (_I, [_D]),
-    'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P]),
+    'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _Z, _P]),
+    'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _Z, _Z, _P]),
     'iprgan_bn_ws_floats': (_Z, [_I, _I]),
     'iprgan_bn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _P, _P, _P, _I, _P]),
     'iprgan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _F, _I, _P]),
@@ -68,14 +68,14 @@ SIGNATURES = {
     'iprgan_instnorm_ws_floats': (_Z, [_I, _I, _I]),
     'iprgan_instnorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, _P, _I, _P, _P, _I, _P]),
     'iprgan_instnorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _F, _I, _P]),
-    'iprgan_prelu_fwd': (_I, [_P, _P, _P, _Z, _P]),
-    'iprgan_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _P]),
+    'iprgan_prelu_fwd': (_I, [_P, _P, _P, _Z, _I, _P]),
+    'iprgan_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _P]),
     'iprgan_pixel_shuffle2': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    'iprgan_pixel_shuffle2_prelu_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    'iprgan_pixel_shuffle2_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    'iprgan_maxpool2_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    'iprgan_maxpool2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    'iprgan_add': (_I, [_P, _P, _P, _Z, _P]),
+    'iprgan_pixel_shuffle2_prelu_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'iprgan_pixel_shuffle2_prelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'iprgan_maxpool2_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'iprgan_maxpool2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'iprgan_add': (_I, [_P, _P, _P, _Z, _I, _P]),
     'iprgan_reflect_fold': (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _P]),
     'iprgan_sn_ws_floats': (_Z, [_I, _I]),
     'iprgan_sn_power_iter': (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),

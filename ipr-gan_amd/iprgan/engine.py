@@ -412,7 +412,7 @@ class GemvHead(Op):
         if getattr(self, '_perm_key', None) != key:
             self._perm, self._perm_key = ops.permute_021(self.weight, self.C, self.HW, 1), key
         wp = self._perm
-        x2 = ops.f32(x).view(B, K)          # (a three-plane input is joined once here: the head reads it once per pass)
+        x2 = x.view(B, K)
         if pair is not None:                # paired pass: each half-batch with its own sigma
             B2 = B // 2
             y = ops.empty((B,), x2)
@@ -431,7 +431,7 @@ class GemvHead(Op):
         if pair is not None:
             x2 = st['x']
             B2 = x2.shape[0] // 2
-            dx = torch.empty_like(x2) if need_dx else None
+            dx = ops._empty_like(x2) if need_dx else None          # (same storage kind as x: fp32, bf16 or three planes)
             entries, dbs = [], []
             for h, sl in enumerate((slice(0, B2), slice(B2, None))):
                 _, dwp, db = ops.gemv_bwd(x2[sl], st['wp'], dy[sl], pair[h], need_dx, need_w,

@@ -345,22 +345,21 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
 # ---- GEMV head ----------------------------------------------------------------------------------
 def gemv_fwd(x2d, w, bias, sigma, out=None):
     B, K = x2d.shape
-    x2d = f32(x2d) if is16(x2d) == ST_X3 else x2d          # (the head reads its 4 M elements once: joined on the way in)
     y = empty((B,), x2d) if out is None else out
-    call('iprgan_gemv_fwd', ptr(x2d), ptr(w), ptr(bias), ptr(sigma), ptr(y), B, K, is16(x2d), stream())
+    call('iprgan_gemv_fwd', ptr(x2d), ptr(w), ptr(bias), ptr(sigma), ptr(y), B, K, is16(x2d), pstride(x2d), stream())
     return y
 
 
 def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0, dx_out=None):
+    """prev_out, when given, is x2d itself (the fused derivative's operand is this layer's input)."""
     B, K = x2d.shape
-    if is16(x2d) == ST_X3:
-        x2d = f32(x2d)
-        prev_out = x2d if prev_out is not None else None      # (the fused derivative's operand is this layer's input)
     dx = (_empty_like(x2d) if dx_out is None else dx_out) if need_dx else None
+    if dx is not None and is16(dx) != is16(x2d):
+        raise RuntimeError('gemv_bwd: dx must have the storage kind of x')
     dw = empty((K,), x2d) if need_dw else None
     db = empty((1,), x2d) if need_dw else None
     call('iprgan_gemv_bwd', ptr(x2d), ptr(w), ptr(dy), ptr(sigma), ptr(dx), ptr(dw), ptr(db),
-         ptr(prev_out), prev_act, float(prev_slope), B, K, is16(x2d), stream())
+         ptr(prev_out), prev_act, float(prev_slope), B, K, is16(x2d), pstride(x2d), pstride(dx) if dx is not None else 0, stream())
     return dx, dw, db
 
 
@@ -674,21 +673,27 @@ def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias
     return dx, dgamma, dbeta
 
 
+def _same_kind(*ts):
+    """The tensors of one elementwise call in ONE storage kind (fp32 or, when every one of them is, three planes)."""
+    ks = {is16(t) for t in ts}
+    if ks == {ST_X3} and all(pstride(t) == t.numel() for t in ts):
+        return ST_X3, ts
+    return ST_F32, tuple(f32(t) for t in ts)
+
+
 def prelu_fwd(x, alpha):
-    x = f32(x) if L.act_x3() else x
-    _f32(x)
+    st, (x,) = _same_kind(x)
     y = _empty_like(x)
-    call('iprgan_prelu_fwd', ptr(x), ptr(alpha), ptr(y), x.numel(), stream())
+    call('iprgan_prelu_fwd', ptr(x), ptr(alpha), ptr(y), x.numel(), st, stream())
     return y
 
 
 def prelu_bwd(x, dy, alpha):
-    x, dy = (f32(x), f32(dy)) if L.act_x3() else (x, dy)
-    _f32(x, dy)
+    st, (x, dy) = _same_kind(x, dy)
     dx = _empty_like(x)
     dalpha = empty((1,), x)
     ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
-    call('iprgan_prelu_bwd', ptr(x), ptr(dy), ptr(alpha), ptr(dx), ptr(dalpha), ptr(ws), x.numel(), stream())
+    call('iprgan_prelu_bwd', ptr(x), ptr(dy), ptr(alpha), ptr(dx), ptr(dalpha), ptr(ws), x.numel(), st, stream())
     return dx, dalpha
 
 
@@ -710,48 +715,47 @@ def pixel_shuffle2(x, inverse=False):
 
 def pixel_shuffle2_prelu_fwd(x, alpha):
     """prelu(pixel_shuffle(x, 2)) in one pass: [B,H,W,4C] -> [B,2H,2W,C] (C % 4 == 0)."""
-    x = f32(x) if L.act_x3() else x
-    _f32(x)
+    st, (x,) = _same_kind(x)
     B, H, W, C4_ = x.shape
     Cc = C4_ // 4
-    y = empty((B, 2 * H, 2 * W, Cc), x)
-    call('iprgan_pixel_shuffle2_prelu_fwd', ptr(x), ptr(alpha), ptr(y), B, H, W, Cc, stream())
+    y = empty_kind((B, 2 * H, 2 * W, Cc), x, st)
+    call('iprgan_pixel_shuffle2_prelu_fwd', ptr(x), ptr(alpha), ptr(y), B, H, W, Cc, st, stream())
     return y
 
 
 def pixel_shuffle2_prelu_bwd(x, dy, alpha):
-    x, dy = (f32(x), f32(dy)) if L.act_x3() else (x, dy)
-    _f32(x, dy)
+    st, (x, dy) = _same_kind(x, dy)
     B, H, W, C4_ = x.shape
     Cc = C4_ // 4
     dx = _empty_like(x)
     dalpha = empty((1,), x)
     ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
-    call('iprgan_pixel_shuffle2_prelu_bwd', ptr(x), ptr(dy), ptr(alpha), ptr(dx), ptr(dalpha), ptr(ws), B, H, W, Cc, stream())
+    call('iprgan_pixel_shuffle2_prelu_bwd', ptr(x), ptr(dy), ptr(alpha), ptr(dx), ptr(dalpha), ptr(ws), B, H, W, Cc, st, stream())
     return dx, dalpha
 
 
 def maxpool2_fwd(x):
-    x = f32(x) if L.act_x3() else x
-    _f32(x)
+    st, (x,) = _same_kind(x)
     B, H, W, C_ = x.shape
-    y = empty((B, H // 2, W // 2, C_), x)
-    call('iprgan_maxpool2_fwd', ptr(x), ptr(y), B, H, W, C_, stream())
+    if st == ST_X3 and (H % 2 or W % 2):
+        st, x = ST_F32, f32(x)
+    y = empty_kind((B, H // 2, W // 2, C_), x, st)
+    call('iprgan_maxpool2_fwd', ptr(x), ptr(y), B, H, W, C_, st, stream())
     return y
 
 
 def maxpool2_bwd(x, dy):
-    x, dy = (f32(x), f32(dy)) if L.act_x3() else (x, dy)
-    _f32(x, dy)
+    st, (x, dy) = _same_kind(x, dy)
     B, H, W, C_ = x.shape
+    if st == ST_X3 and (H % 2 or W % 2):
+        st, x, dy = ST_F32, f32(x), f32(dy)
     dx = _empty_like(x)
-    call('iprgan_maxpool2_bwd', ptr(x), ptr(dy), ptr(dx), B, H, W, C_, stream())
+    call('iprgan_maxpool2_bwd', ptr(x), ptr(dy), ptr(dx), B, H, W, C_, st, stream())
     return dx
 
 
 def add(a, b):
-    a, b = (f32(a), f32(b)) if L.act_x3() else (a, b)
-    _f32(a, b)
+    st, (a, b) = _same_kind(a, b)
     out = _empty_like(a)
-    call('iprgan_add', ptr(a), ptr(b), ptr(out), a.numel(), stream())
+    call('iprgan_add', ptr(a), ptr(b), ptr(out), a.numel(), st, stream())
     return out
