@@ -390,6 +390,8 @@ int iprgan_get_math_mode(void);
  *                     CU), 128x64; bf16 operands in HBM, or fp32 operands with the exact fp32 MFMA
  *              18..25 three-plane ring tiles of conv_x3.hip (fp32x3 mode, three-plane operands): 256x128, 128x128,
  *                     128x64 (3 / 2 stages), 256x64, 64x64, 128x256, 128x128 (2 stages)
+ *              26, 27 their halo form for stride-1 gathers (k3 s1; the 2x2-tap sub-pixel phases of k4 s2): 256 positions x
+ *                     128 / 64 columns, the tile's halo staged once per 16-channel chunk, taps as row shifts
  *              14, 15 the persistent 256x128 / 256x64 form (bf16 operands)
  *              16     four sub-pixel phases per block (k4 s2 p1 backward-data forms, bf16 operands)
  *              17     256x256 with a half-tile ring: quadrant phases, five half-tiles of DMA in flight (bf16 operands)

@@ -42,6 +42,7 @@ static ProfSlot g_slots[] = {
     {"wgrad_halo_f32_kernel", 0, 0, 0}, {"gconv_pipe8_kernel", 0, 0, 0},
     {"gconv_x3_kernel", 0, 0, 0},       {"wgrad_x3_kernel", 0, 0, 0},
     {"gconv_x3p_kernel", 0, 0, 0},      {"wgrad_x3p_kernel", 0, 0, 0},
+    {"gconv_x3h_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; int tag; };
@@ -2027,6 +2028,8 @@ static int launch_gconv_bf16big(const GConvArgs& a, hipStream_t st) {
 static int launch_gconv(const GConvArgs& ain, hipStream_t st);
 int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_out);     // conv_pipe.hip
 int launch_gconv_x3p(const GConvArgs& a, int variant, hipStream_t st, int* bm_out);      // conv_x3.hip
+int launch_gconv_x3h(const GConvArgs& a, int variant, hipStream_t st, int* bm_out);      // conv_x3.hip: halo form
+int launch_gconv_x3p16(const GConvArgs& a, int variant, hipStream_t st, int* bm_out);    // conv_x3.hip: 16x16x32 MFMA form
 
 static bool smalln_eligible(const GConvArgs& a) {
   return g_smalln && !a.rs0 && !a.stat_part && a.Ns == 4 && a.nphase == 1 && a.isy == 1 && a.isx == 1 && a.osy == 1 && a.osx == 1 &&
@@ -2208,6 +2211,10 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
         return launch_gconv_pipe(a, tile - 8, st, &t_last_bm);
       case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25:                   // three-plane ring tiles (conv_x3.hip)
         return launch_gconv_x3p(a, tile - 18, st, &t_last_bm);
+      case 26: case 27:                                                                         // ... their halo form (stride-1 gathers)
+        return launch_gconv_x3h(a, tile - 26, st, &t_last_bm);
+      case 28: case 29: case 30: case 31:                                                       // ... on v_mfma_f32_16x16x32_bf16
+        return launch_gconv_x3p16(a, tile - 28, st, &t_last_bm);
       default: return launch_gconv_t<2, 2, 1, 1>(a, st);
     }
   };
@@ -2237,7 +2244,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   g_prof_on = false;
   float best_us = 0.f;
   int err = 0;
-  const int best = tune_pick(26, [&](int cand) -> int {
+  const int best = tune_pick(32, [&](int cand) -> int {
     if ((cand == 0 || cand == 3 || cand == 4) && N < 128) return -1;
     if ((cand == 6 || cand == 7) && (long long)cdiv(maxM, 256) * cdiv(N, 128) * a.nphase < 256) return -1;    // not even one block per CU
     return run(cand);

@@ -83,13 +83,16 @@ __device__ __forceinline__ void unpack_bf16x8(u32x4 r, f32x4& lo, f32x4& hi) {
 }
 
 // the fused-derivative operand (bf16 storage) of this thread's stores of column half h: NIT 16-byte loads
+// rowtab (optional, LDS): element offset (or OOB_OFFSET) of every tile row, for tiles whose rows are NOT consecutive
+// positions of the phase grid (the spatial-patch tiles of conv_x3.hip's halo kernel)
 template <class G>
-__device__ __forceinline__ void pipe_aux_load(const GConvArgs& a, int pz, int m0, int n0, int h, u32x4 (&v)[G::NIT]) {
+__device__ __forceinline__ void pipe_aux_load(const GConvArgs& a, int pz, int m0, int n0, int h, u32x4 (&v)[G::NIT],
+                                              const unsigned* rowtab = nullptr) {
   const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux_bytes, 0x00020000);
   const int tid = threadIdx.x, n = n0 + h * G::CN + (tid % G::OCT) * 8;
 #pragma unroll
   for (int it = 0; it < G::NIT; ++it) {
-    const unsigned e = pipe_row_elem(a, pz, m0 + it * G::RPI + tid / G::OCT);
+    const unsigned e = rowtab ? rowtab[it * G::RPI + tid / G::OCT] : pipe_row_elem(a, pz, m0 + it * G::RPI + tid / G::OCT);
     v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_aux, (e != OOB_OFFSET && n < a.Ns) ? (e + (unsigned)n) * 2u : OOB_OFFSET, 0, PIPE_NT);
   }
 }
@@ -97,11 +100,38 @@ __device__ __forceinline__ void pipe_aux_load(const GConvArgs& a, int pz, int m0
 // Same order of operations as gconv_epilogue (conv_shared.h): pair scale, [column sums of the accumulator], bias,
 // activation, fused derivative, residual, [column sums of the stored value], store.  Activations: none / ReLU /
 // LeakyReLU only (the launcher refuses the others).  T: the ring, free by now (all DMA landed, all fragment reads done).
+// accumulators of one wave -> the fp32 [rows][CN] tile in LDS.  32x32 MFMA blocks (C layout: column = lane & 31, row =
+// (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) or 16x16 blocks (v_mfma_f32_16x16x32: column = lane & 15, row = 4 (lane >> 4) + r;
+// the wave tile is [2 WM][2 WN] such blocks)
+template <int WM, int WN>
+__device__ __forceinline__ void pipe_acc_to_lds(const f32x16 (&acc)[WM][WN], float* T, int CN, int wm, int wnh, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        T[((wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CN + (wnh * WN + j) * 32 + l31] = acc[i][j][r];
+}
+template <int WM, int WN>
+__device__ __forceinline__ void pipe_acc_to_lds(const f32x4 (&acc)[2 * WM][2 * WN], float* T, int CN, int wm, int wnh, int lane) {
+  const int g = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 2 * WM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2 * WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        T[((wm * WM * 2 + i) * 16 + 4 * g + r) * CN + (wnh * WN * 2 + j) * 16 + l15] = acc[i][j][r];
+}
+
 // X3: out (and res) may be a three-plane tensor (GConvArgs::out16 == 2): the 8 values of a store are split into x = h + m + l
 // (exact) and leave as three 16-byte stores out_ps bytes apart; a three-plane residual is read back as h + (m + l) (exact).
-template <int WGM, int WGN, int WM, int WN, int RING_BYTES, bool STATS, bool PF, bool BNM = false, bool X3 = false>
-__device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[WM][WN], float* T, int pz, unsigned lq,
-                                              int m0, int n0, const u32x4* auxpf) {      // PF: [NH][NIT] prefetched
+template <int WGM, int WGN, int WM, int WN, int RING_BYTES, bool STATS, bool PF, bool BNM = false, bool X3 = false, class ACC = f32x16[WM][WN]>
+__device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, ACC& acc, float* T, int pz, unsigned lq,
+                                              int m0, int n0, const u32x4* auxpf,         // PF: [NH][NIT] prefetched
+                                              const unsigned* rowtab = nullptr) {
   using G = EpiGeom<WGM, WGN, WM, WN, RING_BYTES>;
   constexpr int CN = G::CN, OCT = G::OCT, RPI = G::RPI, NIT = G::NIT, NW = WGM * WGN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,17 +151,9 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
     const int n = n0 + h * CN + oct * 8;
     const bool nok = n < a.Ns;                        // Ns % 8 == 0 (launcher)
     u32x4 auxl[NIT];
-    if (!PF && a.aux && a.aux16) pipe_aux_load<G>(a, pz, m0, n0, h, auxl);      // in flight across the LDS round trip
+    if (!PF && a.aux && a.aux16) pipe_aux_load<G>(a, pz, m0, n0, h, auxl, rowtab);      // in flight across the LDS round trip
     if (h > 0) lds_barrier();                         // everybody is done reading the previous half
-    if (wn / WGN_H == h) {
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            T[((wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CN + ((wn % WGN_H) * WN + j) * 32 + l31] = acc[i][j][r];
-    }
+    if (wn / WGN_H == h) pipe_acc_to_lds<WM, WN>(acc, T, CN, wm, wn % WGN_H, lane);
     lds_barrier();
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
@@ -162,12 +184,12 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, f32x16 (&acc)[
     const bool lin = !a.linear_out && (RPI % ph.owg) == 0 && ((ph.ohg * ph.owg) % G::BM) == 0 && m0 + G::BM <= ph.M;
     const unsigned e_first = pipe_row_elem(a, pz, m0 + r0 < ph.M ? m0 + r0 : 0);
     const unsigned e_step = a.linear_out ? (unsigned)(RPI * a.Ns) : (unsigned)((RPI / (ph.owg > 0 ? ph.owg : 1)) * a.osy * a.OW * a.Ns);
-    const bool fast_rows = a.linear_out ? m0 + G::BM <= ph.M : lin;
+    const bool fast_rows = rowtab ? false : (a.linear_out ? m0 + G::BM <= ph.M : lin);
     const bool full = fast_rows && n0 + h * CN + CN <= a.Ns;         // no row or column of this tile is clipped
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int r = it * RPI + r0, m = m0 + r;
-      const unsigned e0 = fast_rows ? e_first + (unsigned)it * e_step : pipe_row_elem(a, pz, m);
+      const unsigned e0 = rowtab ? rowtab[r] : fast_rows ? e_first + (unsigned)it * e_step : pipe_row_elem(a, pz, m);
       const bool ok = e0 != OOB_OFFSET && nok;
       const unsigned e = e0 + (unsigned)n;
       f32x4 v0 = *(const f32x4*)(T + r * CN + oct * 8), v1 = *(const f32x4*)(T + r * CN + oct * 8 + 4);

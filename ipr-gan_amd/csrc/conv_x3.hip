@@ -256,6 +256,475 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
   pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf);
 }
 
+// ---- the same ring on v_mfma_f32_16x16x32_bf16 ------------------------------------------------------------------------
+// These kernels are POWER-bound: under gconv_x3p_kernel the chip clocks at 1.74 GHz (GRBM_GUI_ACTIVE / time, PMC pass) with
+// the matrix pipe 67 % busy - six MFMAs per product block leave no headroom.  MI355X_MICROARCH.md measures the 16x16x32 form
+// at 1.12-1.15x the FLOP/s of the 32x32x16 form at equal cycles per FLOP (operands re-read from LDS): less energy per FLOP,
+// higher clock.  Same stages, same DMA, same two accumulators; fragments are rows l & 15 x chunk l >> 4 (one MFMA covers
+// the whole 32-channel step), the LDS swizzle is the one that makes THOSE reads conflict-free.
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF>
+__global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p16_kernel(const GConvArgs a) {
+  constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NW = WGM * WGN;
+  constexpr bool FDB = NW <= 4;                  // one wave per SIMD: 512 registers
+  constexpr int RSA = BM / 16 / NW, RSB = BN / 16 / NW;        // 16-row pieces per plane this wave stages
+  constexpr int L = 3 * (RSA + RSB);                           // LDS-DMA instructions per wave and stage
+  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, A_BYTES = 3 * A_PLANE, STAGE_BYTES = 3 * (BM + BN) * 64;
+  static_assert(RSA >= 1 && RSB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "every wave stages whole 16-row pieces");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4 && L * (NSTAGE - 2) <= 63, "ring depth / vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+
+  // logical tile order as in gconv_kernel: n tiles fastest, then the sub-pixel phases, then m tiles
+  const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                gridDim.x * gridDim.y * gridDim.z);
+  const unsigned lq = lt / gridDim.y;
+  const int pz = (int)(lq % gridDim.z);
+  const int pM = a.ph[pz].M;
+  const int m0 = (int)(lq / gridDim.z) * BM, n0 = (int)(lt % gridDim.y) * BN;
+  if (m0 >= pM) {
+    if (STATS) {
+      for (int c = threadIdx.x; c < BN; c += NW * 64)
+        if (n0 + c < a.Ns) { a.stat_part[((size_t)lq * 2) * a.Ns + n0 + c] = 0.f; a.stat_part[((size_t)lq * 2 + 1) * a.Ns + n0 + c] = 0.f; }
+    }
+    return;
+  }
+  const int p_tw = a.ph[pz].tw, p_th = a.ph[pz].th;
+  const int nt = a.ph[pz].steps;                     // 32-deep K steps (Cs % 32 == 0: a step lies inside one tap)
+  const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
+  const int p_dy0 = a.ph[pz].dy0, p_dx0 = a.ph[pz].dx0, p_dys = a.ph[pz].dys, p_dxs = a.ph[pz].dxs;
+  const int p_wbase = a.ph[pz].wbase, p_wsy = a.ph[pz].wsy, p_wsx = a.ph[pz].wsx;
+  const int p_owg = a.ph[pz].owg, plane = a.ph[pz].ohg * a.ph[pz].owg;
+  const FastDiv d_plane = a.ph[pz].d_plane, d_owg = a.ph[pz].d_owg;
+  const int IH = a.IH, IW = a.IW, Cs = a.Cs;
+  const unsigned in_ps = a.in_ps, wt_ps = a.wt_ps;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform (LDS-DMA base, M0)
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lrow = lane >> 2;                                          // row of a 16-row piece this lane copies
+  // 16x16 fragments read rows l & 15, chunk l >> 4: chunk c of row r sits at position c ^ ((4 - (r >> 2)) & 3) - the four
+  // 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}: row quads 0, 3 at chunk 0 and 1, 2 at chunk 1) hit 16 slots
+  const unsigned sc = (unsigned)((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) * 16u;   // source chunk of this lane's position
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+
+  int aiy[RSA], aix[RSA];
+  unsigned arow[RSA], wrow[RSB];
+#pragma unroll
+  for (int i = 0; i < RSA; ++i) {
+    const int r = (i * NW + wave) * 16 + lrow;
+    const int m = m0 + r;
+    if (m < pM) {
+      const int b = fdiv(m, d_plane);
+      const int rem = m - b * plane;
+      const int y = fdiv(rem, d_owg);
+      const int x = rem - y * p_owg;
+      aiy[i] = y * a.isy;
+      aix[i] = x * a.isx;
+      arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * 2u + sc;
+    } else {
+      aiy[i] = ROW_INVALID; aix[i] = 0; arow[i] = 0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RSB; ++i) {
+    const int r = (i * NW + wave) * 16 + lrow;
+    wrow[i] = (unsigned)((n0 + r) * a.Kp) * 2u + sc;
+  }
+
+  // TWO accumulators per block: `acc` takes h h' only, `accs` the five small terms (<= 2^-7 of the product each).  The bf16
+  // MFMA aligns its 16 products to the exponent of the accumulator input and truncates: every MFMA into a LARGE accumulator
+  // costs about an ulp of it, however small its products (measured on K = 1152: one accumulator, six MFMAs per 16 k: rms
+  // error 5.1e-7 of the result, against 3.0e-7 for the fp32 MFMA).  With the small terms summed among themselves the large
+  // accumulator sees one MFMA per 16 k, the small one's roundings are 2^-7 of that, and the two meet once, in fp32, below.
+  f32x4 acc[2 * WM][2 * WN], accs[2 * WM][2 * WN];         // 16x16 blocks: v_mfma_f32_16x16x32_bf16
+#pragma unroll
+  for (int i = 0; i < 2 * WM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2 * WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = accs[i][j][r] = 0.f;
+
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+  // wave-uniform walk over (channel chunk, tap): taps inside a 32-channel chunk, so that consecutive K steps re-read the
+  // same pixels, shifted (they stay in L2)
+  int u_c = 0, u_ty = 0, u_tx = 0;
+  int w_dy = 0, w_dx = 0, w_tapoff = 0;
+  unsigned w_wk = 0, w_sbase = 0;
+  auto walk_begin = [&](int buf) {            // address pieces of the K step the walk points at, into stage `buf`
+    w_dy = p_dy0 + u_ty * p_dys; w_dx = p_dx0 + u_tx * p_dxs;
+    w_tapoff = ((w_dy * IW + w_dx) * Cs + u_c) * 2;
+    w_wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c) * 2u;
+    w_sbase = lds_base + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
+  };
+  auto walk_next = [&]() {
+    if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; u_c += 32; } }
+  };
+  // piece q of the stage: q < 3 * RSA: plane q / RSA of the activation rows of row set q % RSA; then the weight rows
+  auto piece = [&](int q) {
+    if (q < 3 * RSA) {
+      const int p = q / RSA, i = q % RSA;
+      const int iy = aiy[i] + w_dy, ix = aix[i] + w_dx;
+      bool ok;
+      unsigned off;
+      if (reflect) {              // wave-uniform branch: the mirrored pixel instead of a zero
+        ok = aiy[i] != ROW_INVALID;
+        const int ry = reflect_idx(iy, IH), rx = reflect_idx(ix, IW);
+        off = arow[i] + (unsigned)((((ry - aiy[i]) * IW + (rx - aix[i])) * Cs + u_c) * 2);
+      } else {
+        ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+        off = arow[i] + (unsigned)w_tapoff;
+      }
+      dma16(rs_in, w_sbase + (unsigned)p * A_PLANE + (unsigned)(i * NW) * 1024u, ok ? off + (unsigned)p * in_ps : OOB_OFFSET);
+    } else {
+      const int p = (q - 3 * RSA) / RSB, i = (q - 3 * RSA) % RSB;
+      dma16(rs_wt, w_sbase + A_BYTES + (unsigned)p * B_PLANE + (unsigned)(i * NW) * 1024u, wrow[i] + w_wk + (unsigned)p * wt_ps);
+    }
+  };
+  auto issue = [&](int buf) {
+    walk_begin(buf);
+#pragma unroll
+    for (int q = 0; q < L; ++q) piece(q);
+    walk_next();
+  };
+
+  // fragment read offsets inside a plane image: row (..) * 32 + l31, chunk (2 kk + half) ^ swz(l31)
+  const int l15 = lane & 15;
+  const unsigned foff = (unsigned)l15 * 64u + (unsigned)((lane >> 4) ^ ((4 - ((l15 >> 2) & 3)) & 3)) * 16u;      // + 1024 per 16-row block
+  const unsigned a_wave = (unsigned)(wm * WM) * 2048u, b_wave = A_BYTES + (unsigned)(wn * WN) * 2048u;
+  const char* ldsc = (const char*)lds;
+
+  // one K step on stage `cb`; ISS: the refill of stage `nb` is woven into the MFMA stream (one LDS-DMA instruction after
+  // every (SPREAD / L)-th MFMA), so that a wave waits for one slot of the CU's address path at a time while its (and its
+  // SIMD partner's) MFMAs run.  The fragments of sub-step 1 are read while sub-step 0 is multiplied.
+  // one K step (32 channels = ONE 16x16x32 MFMA per term and block pair) on stage `cb`; ISS: the refill of stage `nb` is
+  // woven into the MFMA stream.  The B fragments of the step stay in registers, the A fragments of a 16-row block are
+  // read right before its 6 x 2 WN MFMAs.
+  auto step = [&](int cb, int nb, auto ISS) {
+    constexpr bool iss = decltype(ISS)::value;
+    constexpr int NMF = 6 * 4 * WM * WN;                               // MFMAs per step
+    constexpr int SPREAD = NSTAGE >= 3 ? NMF : (3 * NMF) / 4;
+    const char* sb = ldsc + cb * STAGE_BYTES;
+    if constexpr (iss) walk_begin(nb);
+    bf16x8 bf[3][2 * WN];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < 2 * WN; ++j) bf[p][j] = *(const bf16x8*)(sb + b_wave + p * B_PLANE + j * 1024 + foff);
+    int q = 0, mi = 0;
+#pragma unroll
+    for (int i = 0; i < 2 * WM; ++i) {
+      bf16x8 af[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[p] = *(const bf16x8*)(sb + a_wave + p * A_PLANE + i * 1024 + foff);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {           // l h', h l', m m', m h', h m' into the small accumulator, h h' into the large one
+        const int pa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+        const int pb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 2 * WN; ++j) {
+          if (t < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa], bf[pb][j], accs[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa], bf[pb][j], acc[i][j], 0, 0, 0);
+          ++mi;
+          if constexpr (iss) {
+            if (q < L && q * SPREAD < mi * L) {
+              piece(q);
+              ++q;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      }
+    }
+    if constexpr (iss) {
+#pragma unroll
+      for (; q < L; ++q) piece(q);
+      walk_next();
+    }
+  };
+
+  // PREF: the fused-derivative operand of this thread's stores, loaded FIRST: vmcnt retires in order, so the wait for
+  // stage 0 covers these loads (the same latency, once per tile) and every later counted wait is unaffected
+  using G = EpiGeom<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES>;
+  u32x4 auxpf[PREF ? G::NIT : 1];
+  if constexpr (PREF) pipe_aux_load<G>(a, pz, m0, n0, 0, auxpf);
+
+  // ---- the ring
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nt) issue(s);
+  int cur = 0, nxt = NSTAGE - 1;                 // stage read at step t, stage refilled at step t (= read at t - 1)
+  int t = 0;
+  for (; t < nt - (NSTAGE - 1); ++t) {           // steps that refill a stage
+    wait_stages<L>(NSTAGE - 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads of step t - 1 are complete
+    __builtin_amdgcn_s_barrier();
+    step(cur, nxt, std::true_type{});
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+  }
+  for (; t < nt; ++t) {                          // the last NSTAGE - 1 steps drain the ring
+    const int rem = nt - 1 - t;
+    wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    step(cur, nxt, std::false_type{});
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                  // the epilogue reuses the ring
+#pragma unroll
+  for (int i = 0; i < 2 * WM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2 * WN; ++j) acc[i][j] += accs[i][j];
+
+  pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf);
+}
+
+
+// ---- halo form ------------------------------------------------------------------------------------------------
+// gconv_x3p_kernel above streams an im2col view of the activation: every tap of a K step re-fetches its 256 tile rows
+// from L2, the XCD's L2 delivers ~29 B/clk per CU, and a 256x128 tile needs 72 KB per 3072 MFMA cycles: the DMA path is
+// 80 % busy and its time ADDS to the matrix time (measured with K-loop probes: 216 TFLOP/s with both, 290 without the
+// refills).  For stride-1 gathers (Conv2d k3 s1 forward and backward-data; the sub-pixel phases of k4 s2 backward-data /
+// ConvTranspose2d forward, which are 2x2-tap stride-1 convolutions on the small grid) the taps of one channel chunk read
+// SHIFTED copies of the same pixels.  Here a tile is a spatial patch (16x16 positions of one image, or four whole 8x8
+// maps); per 16-channel chunk its halo ((16+2)^2 pixels x 3 planes = 31 KB) is staged ONCE, double-buffered a chunk
+// ahead, and every tap reads it at a row shift; only the weight rows of a tap (12 KB for 128 columns) stream through a
+// ring.  L2 -> LDS traffic per tap step: 12 + 31 / 9 = 16 KB per 1536 MFMA cycles (k3) - 10 B/clk instead of 24.
+//   * K step = one tap x 16 channels: LDS rows are 32 bytes (16 channels of one pixel / weight row of one plane), 8 rows per
+//     256-byte bank line: chunk c of row r sits at position c ^ ((r >> 3) & 1);
+//   * every wave issues exactly L = LB + LH LDS-DMA instructions per step (weight rows of step s + NSB - 1; a share of the
+//     next chunk's halo; dummies past the end go to a scratch row set) so that ONE counted vmcnt per step covers both rings:
+//     vmcnt retires in order, the wait for the weight stage of step s also covers every halo piece issued before it;
+//   * the epilogue is pipe_epilogue with a row table (tile row -> output element), since tile rows are not consecutive
+//     positions of the phase grid.
+struct X3HGeom {
+  int PH, PW, NI;            // patch rows x columns per image and images per tile: NI * PH * PW = 256
+  int lpw, lpp;              // log2(PW), log2(PH * PW)
+  int tpy, tpx;              // patches per image (phase grid / patch)
+  FastDiv d_tpi, d_tpx;      // / (tpy * tpx), / tpx
+};
+
+template <int WGN_, int WN, int NSB, int LH, int HSTEPS, bool STATS>
+__global__ __launch_bounds__(512) void gconv_x3h_kernel(const GConvArgs a, const X3HGeom g) {
+  constexpr int WGM = 4, WGN = WGN_, WM = 2, NW = 8, BM = 256, BN = WGN * WN * 32;
+  static_assert(WGM * WGN == NW, "eight waves");
+  constexpr int HP_MAX = 13, HPB = HP_MAX * 1024, HBUF = 3 * HPB;           // halo: <= 416 rows of 32 bytes per plane
+  constexpr int BPL = BN * 32, BSTAGE = 3 * BPL;                            // weight stage: [plane][BN rows][32 bytes]
+  constexpr int NBP = 3 * BN / 32, LB = (NBP + NW - 1) / NW, L = LB + LH;   // weight pieces per stage, per wave; slots per step
+  constexpr int OFF_B = 2 * HBUF, OFF_TRASH = OFF_B + NSB * BSTAGE, OFF_TAB = (OFF_TRASH + NW * 1024 > BM * BN * 4 ? OFF_TRASH + NW * 1024 : BM * BN * 4);
+  static_assert(OFF_TAB + 1024 <= 160 * 1024 && (NSB - 2) * L <= 63 && NSB >= 3, "LDS budget / vmcnt field / ring depth");
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  char* ldsc = (char*)lds;
+  unsigned* rowtab = (unsigned*)(ldsc + OFF_TAB);
+
+  const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                gridDim.x * gridDim.y * gridDim.z);
+  const unsigned lq = lt / gridDim.y;
+  const int pz = (int)(lq % gridDim.z), tile = (int)(lq / gridDim.z), n0 = (int)(lt % gridDim.y) * BN;
+  const Phase& ph = a.ph[pz];
+  const int th = ph.th, tw = ph.tw, ntap = th * tw;
+  const int dymin = ph.dys < 0 ? ph.dy0 + (th - 1) * ph.dys : ph.dy0, dxmin = ph.dxs < 0 ? ph.dx0 + (tw - 1) * ph.dxs : ph.dx0;
+  const int HHp = g.PH + th - 1, HWp = g.PW + tw - 1, hrows = g.NI * HHp * HWp, hp = (hrows + 31) >> 5;
+  const int bimg = (int)fdiv((unsigned)tile, g.d_tpi), trem = tile - bimg * (g.tpy * g.tpx);
+  const int tyy = (int)fdiv((unsigned)trem, g.d_tpx), txx = trem - tyy * g.tpx;
+  const int b0 = bimg * g.NI, y0 = tyy * g.PH, x0 = txx * g.PW;
+  const int IH = a.IH, IW = a.IW, Cs = a.Cs;
+  const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // ---- row table: tile row r = (image ni, patch row py, patch column px) -> element offset of the output pixel
+  if (tid < BM) {
+    const int ni = tid >> g.lpp, rr = tid & ((1 << g.lpp) - 1), py = rr >> g.lpw, px = rr & (g.PW - 1);
+    const int b = b0 + ni, y = y0 + py, x = x0 + px;
+    unsigned e = OOB_OFFSET;
+    if (b < a.B && y < ph.ohg && x < ph.owg) e = (unsigned)((b * a.OH + y * a.osy + ph.ooy) * a.OW + x * a.osx + ph.oox) * (unsigned)a.Ns;
+    rowtab[tid] = e;
+  }
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+
+  // ---- halo slots of this wave: slot t (t < HSLOTS) of a chunk carries piece id (t / LH * NW + wave) * LH + t % LH
+  // = (plane, 32 rows); the lane's source pixel does not depend on the chunk: byte offset of its channel 0, or OOB
+  constexpr int HSLOTS = HSTEPS * LH;            // the first HSTEPS = ntap - NSB + 1 steps of a chunk carry LH slots each
+  unsigned hsrc[HSLOTS];
+  int hdst[HSLOTS];                              // LDS byte offset inside a halo buffer, or -1 (dummy)
+#pragma unroll
+  for (int t = 0; t < HSLOTS; ++t) {
+    const int id = ((t / LH) * NW + wave) * LH + t % LH;
+    hsrc[t] = OOB_OFFSET; hdst[t] = -1;
+    if (id < 3 * hp) {
+      const int p = id / hp, pc = id - p * hp;
+      hdst[t] = p * HPB + pc * 1024;
+      const int hr = pc * 32 + (lane >> 1);
+      if (hr < hrows) {
+        const int ni = hr / (HHp * HWp), r2 = hr - ni * (HHp * HWp), hy = r2 / HWp, hx = r2 - hy * HWp;
+        int y = y0 + hy + dymin, x = x0 + hx + dxmin;
+        const int b = b0 + ni;
+        bool ok = b < a.B;
+        if (reflect) { y = reflect_idx(y, IH); x = reflect_idx(x, IW); }
+        ok = ok && (unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW;
+        if (ok) hsrc[t] = (unsigned)(((b * IH + y) * IW + x) * Cs) * 2u + (unsigned)p * a.in_ps +
+                          (unsigned)((lane & 1) ^ ((hr >> 3) & 1)) * 16u;
+      }
+    }
+  }
+  // ---- weight slots: slot j carries piece wave * LB + j = (plane, 32 rows) of the stage
+  unsigned wsrc[LB];
+  int wdst[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    const int id = wave * LB + j;
+    wsrc[j] = OOB_OFFSET; wdst[j] = -1;
+    if (id < NBP) {
+      const int p = id / (BN / 32), rs = id % (BN / 32), row = rs * 32 + (lane >> 1);
+      wdst[j] = p * BPL + rs * 1024;
+      wsrc[j] = (unsigned)((n0 + row) * a.Kp) * 2u + (unsigned)p * a.wt_ps + (unsigned)((lane & 1) ^ ((row >> 3) & 1)) * 16u;
+    }
+  }
+  const unsigned trash = lds_base + OFF_TRASH + (unsigned)wave * 1024u;
+
+  // fragment rows: A block i of this wave: tile row (wm * 2 + i) * 32 + l31 -> halo row of tap offset 0; B block j: weight row
+  int hbase[WM];
+  unsigned boff[WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int r = (wm * WM + i) * 32 + l31;
+    const int ni = r >> g.lpp, rr = r & ((1 << g.lpp) - 1), py = rr >> g.lpw, px = rr & (g.PW - 1);
+    hbase[i] = (ni * HHp + py) * HWp + px;
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int r = (wn * WN + j) * 32 + l31;
+    boff[j] = (unsigned)(r * 32) + (unsigned)(half ^ ((r >> 3) & 1)) * 16u;
+  }
+
+  f32x16 acc[WM][WN], accs[WM][WN];              // h h' | the five small terms (see gconv_x3p_kernel)
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = accs[i][j][r] = 0.f;
+
+  const int nchunk = Cs / 16, nsteps = nchunk * ntap;
+  const int hlast = HSTEPS - 1;                  // last step of a chunk that carries halo slots of the next one: its first
+                                                 // fragments are read one step before that chunk starts (host: ntap = NSB + HSTEPS - 1)
+  // weight walk (NSB - 1 steps ahead of the compute walk) and compute walk: (chunk, ty, tx)
+  int wc = 0, wty = 0, wtx = 0, ws_ = 0;
+  auto issue_w = [&](int j) __attribute__((always_inline)) {
+    const bool live = ws_ < nsteps && wdst[j] >= 0;
+    const unsigned wk = (unsigned)((ph.wbase + wty * ph.wsy + wtx * ph.wsx) * Cs + wc * 16) * 2u;
+    const unsigned dst = live ? lds_base + OFF_B + (unsigned)((ws_ % NSB) * BSTAGE + wdst[j]) : trash;
+    dma16(rs_wt, __builtin_amdgcn_readfirstlane(dst), live ? wsrc[j] + wk : OOB_OFFSET);
+  };
+  auto walk_w = [&]() __attribute__((always_inline)) {
+    ++ws_;
+    if (++wtx == tw) { wtx = 0; if (++wty == th) { wty = 0; ++wc; } }
+  };
+  auto issue_h = [&](int t, int chunk) __attribute__((always_inline)) {        // slot t of the halo of `chunk`
+    const bool live = chunk < nchunk && hdst[t] >= 0;
+    const unsigned dst = live ? lds_base + (unsigned)((chunk & 1) * HBUF + hdst[t]) : trash;
+    dma16(rs_in, __builtin_amdgcn_readfirstlane(dst), live && hsrc[t] != OOB_OFFSET ? hsrc[t] + (unsigned)(chunk * 32) : OOB_OFFSET);
+  };
+
+  // ---- prologue: the first chunk's halo and the first NSB - 1 weight stages, drained once (2 us per 100+ us tile)
+#pragma unroll
+  for (int t = 0; t < HSLOTS; ++t) issue_h(t, 0);
+#pragma unroll
+  for (int s = 0; s < NSB; ++s) {
+#pragma unroll
+    for (int j = 0; j < LB; ++j) issue_w(j);
+    walk_w();
+  }
+  wait_vmcnt<0>();
+  lds_barrier();
+
+  // Software pipeline: the fragments of step s + 1 are read (halo row shift + weight stage) while step s is multiplied, so
+  // the barrier at the top of step s hands over the stage of step s + 1 - and, since every wave has the stage of step s in
+  // registers by then, it is the slot of step s that is refilled (with step s + NSB).  The first version read its
+  // fragments right behind the barrier: all eight waves stalled on the same LDS round trip once per 24 MFMAs (205 TFLOP/s
+  // on the north-star shape, behind the im2col tile).
+  int cc = 0, cty = 0, ctx = 0, ck = 0;          // walk of the step whose fragments are read next
+  bf16x8 af[2][3][WM], bf[2][3][WN];
+  auto frags = [&](int sidx, int fb) __attribute__((always_inline)) {
+    const char* hb = ldsc + (cc & 1) * HBUF;
+    const char* sb = ldsc + OFF_B + (sidx % NSB) * BSTAGE;
+    const int tapoff = (ph.dy0 + cty * ph.dys - dymin) * HWp + (ph.dx0 + ctx * ph.dxs - dxmin);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int row = hbase[i] + tapoff;
+      const char* pa = hb + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[fb][p][i] = *(const bf16x8*)(pa + p * HPB);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[fb][p][j] = *(const bf16x8*)(sb + p * BPL + boff[j]);
+    if (++ctx == tw) { ctx = 0; if (++cty == th) { cty = 0; ++cc; } }
+  };
+  int kc = 0, kk = 0;                            // chunk / step-in-chunk of the step being MULTIPLIED (halo slot bookkeeping)
+  frags(0, 0);
+  auto one_step = [&](int s, auto FB) __attribute__((always_inline)) {
+    constexpr int fb = decltype(FB)::value;
+    // stage s + 1 has landed: it left at step s + 1 - NSB, the slots of the NSB - 2 steps since then may be in flight
+    wait_vmcnt<(NSB - 2) * L>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave holds the fragments of step s
+    __builtin_amdgcn_s_barrier();
+    if (s + 1 < nsteps) frags(s + 1, fb ^ 1);
+    int q = 0;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const int pa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+      const int pb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          if (t < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][pa][i], bf[fb][pb][j], accs[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[fb][pa][i], bf[fb][pb][j], acc[i][j], 0, 0, 0);
+        }
+      if (t < L) {                               // the step's L slots ride inside the MFMA stream
+        if (q < LB) issue_w(q);
+        else {
+          const int hslot = kk * LH + (q - LB);
+          bool done = false;
+#pragma unroll
+          for (int u = 0; u < HSLOTS; ++u)
+            if (!done && u == hslot) { issue_h(u, kk <= hlast ? kc + 1 : nchunk); done = true; }
+          if (!done) dma16(rs_in, __builtin_amdgcn_readfirstlane(trash), OOB_OFFSET);
+        }
+        ++q;
+      }
+    }
+    walk_w();
+    if (++kk == ntap) { kk = 0; ++kc; }
+  };
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    one_step(s, std::integral_constant<int, 0>{});
+    one_step(s + 1, std::integral_constant<int, 1>{});
+  }
+  if (s < nsteps) one_step(s, std::integral_constant<int, 0>{});
+  wait_vmcnt<0>();                               // (dummy slots of the draining steps: nothing may be in flight into the epilogue's tile)
+  lds_barrier();
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] += accs[i][j];
+
+  u32x4 nopf[1];
+  pipe_epilogue<WGM, WGN, WM, WN, BM * BN * 4, STATS, false, false, true>(a, acc, (float*)lds, pz, lq, 0, n0, nopf, rowtab);
+}
+
 // ---- storage conversion: fp32 <-> three planes (iprgan_cast with kind 2) -------------------------------------------
 // One thread per 8 elements: two 16-byte loads, three 16-byte stores (or the reverse); plane p at element offset p * ps.
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n8, size_t ps) {
@@ -356,6 +825,94 @@ static int launch_x3p_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   }
   IPR_LAUNCH_CHECK();
   return 0;
+}
+
+// ---- halo form: host side ----------------------------------------------------------------------------------------
+static bool x3h_geom(const GConvArgs& a, X3HGeom& g, int* ntap_out) {
+  if (a.in16 != 2 || a.isy != 1 || a.isx != 1 || a.ksplit > 1 || a.wmod > 0 || a.planar_M || a.rs0 || a.bn_mean) return false;
+  auto simple = [](int act) { return act == IPRGAN_ACT_NONE || act == IPRGAN_ACT_RELU || act == IPRGAN_ACT_LRELU; };
+  if ((a.Ns % 8) != 0 || (a.Cs % 16) != 0 || !simple(a.act) || (a.aux && (!simple(a.aux_act) || a.aux16 == 2))) return false;
+  const Phase& p0 = a.ph[0];
+  if (p0.M <= 0) return false;
+  for (int i = 0; i < a.nphase; ++i) {            // every phase: the same grid, the same (square) tap count, unit tap steps
+    const Phase& p = a.ph[i];
+    if (p.ohg != p0.ohg || p.owg != p0.owg || p.th != p0.th || p.tw != p0.tw || p.th != p.tw) return false;
+    if ((p.dys != 1 && p.dys != -1) || (p.dxs != 1 && p.dxs != -1)) return false;
+  }
+  const int k = p0.th;
+  if (k != 2 && k != 3) return false;
+  if (a.pad_mode == IPRGAN_PAD_REFLECT && (a.nphase != 1 || a.IH < 2 || a.IW < 2)) return false;
+  memset(&g, 0, sizeof(g));
+  if ((p0.ohg % 16) == 0 && (p0.owg % 16) == 0) { g.PH = 16; g.PW = 16; g.NI = 1; g.lpw = 4; g.lpp = 8; }
+  else if (p0.ohg == 8 && p0.owg == 8) { g.PH = 8; g.PW = 8; g.NI = 4; g.lpw = 3; g.lpp = 6; }
+  else return false;
+  g.tpy = p0.ohg / g.PH; g.tpx = p0.owg / g.PW;
+  g.d_tpi = make_fastdiv(g.tpy * g.tpx); g.d_tpx = make_fastdiv(g.tpx);
+  if (g.NI * (g.PH + k - 1) * (g.PW + k - 1) > 13 * 32) return false;
+  *ntap_out = k * k;
+  return true;
+}
+
+template <int WGN, int WN, int NSB, int LH, int HSTEPS>
+static int launch_x3h_t(const GConvArgs& a, const X3HGeom& g, hipStream_t st, int* bm_out) {
+  constexpr int BN = WGN * WN * 32, NBP = 3 * BN / 32, LB = (NBP + 7) / 8;
+  constexpr int OFF_TRASH = 2 * 3 * 13 * 1024 + NSB * 3 * BN * 32;
+  constexpr int OFF_TAB = OFF_TRASH + 8 * 1024 > 256 * BN * 4 ? OFF_TRASH + 8 * 1024 : 256 * BN * 4;
+  (void)LB;
+  const size_t smem = OFF_TAB + 1024;
+  const int mtiles = cdiv(a.B, g.NI) * g.tpy * g.tpx;
+  dim3 grid(mtiles, cdiv(a.Ns, BN), a.nphase);
+  *bm_out = 256;
+  auto go = [&](auto kern) {
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+    prof_launch(kern, grid, dim3(512), smem, st, 31, a.flops, a, g);
+  };
+  if (a.stat_part) go(gconv_x3h_kernel<WGN, WN, NSB, LH, HSTEPS, true>);
+  else go(gconv_x3h_kernel<WGN, WN, NSB, LH, HSTEPS, false>);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+
+// variant 0: 256 positions x 128 columns, 1: x 64 columns; 3x3 taps: 4 weight stages, the first 6 steps of a chunk carry one
+// halo slot per wave; 2x2 taps (sub-pixel phases of k4 s2): 3 stages, the first 2 steps carry three
+int launch_gconv_x3h(const GConvArgs& a, int variant, hipStream_t st, int* bm_out) {
+  X3HGeom g;
+  int ntap = 0;
+  if (!x3h_geom(a, g, &ntap)) return -1;
+  if (variant == 0) {
+    if (a.Ns < 128) return -1;
+    return ntap == 9 ? launch_x3h_t<2, 2, 4, 1, 6>(a, g, st, bm_out) : launch_x3h_t<2, 2, 3, 3, 2>(a, g, st, bm_out);
+  }
+  if (variant == 1) return ntap == 9 ? launch_x3h_t<2, 1, 4, 1, 6>(a, g, st, bm_out) : launch_x3h_t<2, 1, 3, 3, 2>(a, g, st, bm_out);
+  return -1;
+}
+
+template <int WGM, int WGN, int WM, int WN, int NSTAGE>
+static int launch_x3p16_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
+  constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+  int maxM = 0;
+  for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
+  if (maxM == 0) return 0;
+  const size_t smem = (size_t)NSTAGE * 3 * (BM + BN) * 64;
+  dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.nphase);
+  *bm_out = BM;
+  const dim3 block(WGM * WGN * 64);
+  if (a.stat_part) x3p_go<gconv_x3p16_kernel<WGM, WGN, WM, WN, NSTAGE, true, false>>(a, grid, block, smem, st);
+  else x3p_go<gconv_x3p16_kernel<WGM, WGN, WM, WN, NSTAGE, false, false>>(a, grid, block, smem, st);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+// the tiles of launch_gconv_x3p's variants 0, 1, 2, 4 on the 16x16x32 MFMA (variant 0..3 here)
+int launch_gconv_x3p16(const GConvArgs& a, int variant, hipStream_t st, int* bm_out) {
+  if (!gconv_x3p_eligible(a)) return -1;
+  switch (variant) {
+    case 0: return a.Ns >= 128 ? launch_x3p16_t<4, 2, 2, 2, 2>(a, st, bm_out) : -1;
+    case 1: return a.Ns >= 128 ? launch_x3p16_t<2, 2, 2, 2, 3>(a, st, bm_out) : -1;
+    case 2: return launch_x3p16_t<2, 2, 2, 1, 3>(a, st, bm_out);
+    case 3: return launch_x3p16_t<4, 1, 2, 2, 2>(a, st, bm_out);
+    default: return -1;
+  }
 }
 
 // variant: 0 = 256x128 (8 waves of 64x64, 2 stages, 144 KB), 1 = 128x128 (4 waves of 64x64, 3 stages, 144 KB),
