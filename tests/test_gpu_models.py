@@ -393,10 +393,12 @@ def test_cyclegan_steps_vs_reference_golden(golden, dev):
         if k.startswith(('step0/optD', 'step0/optG')):
             # The L1 cycle/identity terms have a sign() gradient: pixels where rec ~ real flip sign under
             # fp32 rounding noise, and at batch 1 the flips propagate through 12 InstanceNorm layers, so single
-            # gradient entries differ at the percent level between two correct implementations.  The moments
-            # are therefore compared by overall magnitude (10 %); every forward quantity (images, all 13
-            # losses), the weights after the step and the BER keep the tight tolerances.
-            return (0.1, 1e-3, 'scale')
+            # gradient entries differ at the percent level OF THEMSELVES between two correct implementations.  Measured
+            # against the float64 gradients (test_cyclegan_step0_moments_split_rounding_from_error): one boundary flip
+            # moves the tensors upstream of it by 0.5 % of their scale.  Every moment tensor: head, the 64 coarse and the
+            # 2048 dense samples (small tensors whole) within 2 % of the tensor's largest sample, asum and L2 within 4 %
+            # (round 3 compared these by overall magnitude only, 10 %).
+            return (2e-2, 2e-2, 'relmax')
         return base(k)
     compare(res, golden('cyclegan_steps_wbox'), policy=policy)
 
@@ -673,7 +675,7 @@ def _split_rounding_from_error(o64, res, ref, opts, net_factor, net_floor, tenso
     for net in opts:
         num_h = num_r = den = 0.0
         for k in sorted(o64):
-            if not (k.startswith(f'step0/{net}/') and k.endswith('::samp')):
+            if not (k.startswith(f'step0/{net}/') and k.endswith('::dense')):      # up to 2048 samples per tensor (small ones whole)
                 continue
             t = np.asarray(o64[k], np.float64)
             h, r = np.asarray(res[k], np.float64), np.asarray(ref[k], np.float64)

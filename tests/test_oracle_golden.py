@@ -38,18 +38,25 @@ def compare(res, ref, rtol=RTOL, atol=ATOL, policy=None):
             continue
         if len(pol) == 3 and pol[2] == 'relmax':      # (rtol, frac, 'relmax'): absolute slack = frac * max|sample|
             r, frac = pol[0], pol[1]
-            for f in ('head', 'samp'):
+            for f in ('head', 'samp', 'dense'):
+                if f'{p}::{f}' not in ref:
+                    continue
                 a, b = np.asarray(res[f'{p}::{f}']), ref[f'{p}::{f}']
                 np.testing.assert_allclose(a, b, rtol=r, atol=frac * float(np.abs(ref[f'{p}::samp']).max()) + 1e-6,
                                            err_msg=f'{p}::{f}')
-            a, b = float(res[f'{p}::asum']), float(ref[f'{p}::asum'])
-            assert abs(a - b) <= (r + frac) * abs(b) + 1e-6 * max(1.0, abs(b) / max(1e-30, float(np.abs(ref[f'{p}::samp']).mean()))), f'{p}::asum {a} vs {b}'
+            for f in ('asum', 'l2'):
+                if f'{p}::{f}' not in ref:
+                    continue
+                a, b = float(res[f'{p}::{f}']), float(ref[f'{p}::{f}'])
+                assert abs(a - b) <= (r + frac) * abs(b) + 1e-6 * max(1.0, abs(b) / max(1e-30, float(np.abs(ref[f'{p}::samp']).mean()))), f'{p}::{f} {a} vs {b}'
             continue
         r, t = pol
         n_est = max(1.0, float(ref[f'{p}::asum']) / max(1e-12, float(np.abs(ref[f'{p}::samp']).mean())))
-        for f in ('sum', 'asum', 'head', 'samp'):
+        for f in ('sum', 'asum', 'l2', 'head', 'samp', 'dense'):
+            if f'{p}::{f}' not in ref:        # (fixtures older than the L2 / dense-sample extension)
+                continue
             a, b = np.asarray(res[f'{p}::{f}']), ref[f'{p}::{f}']
-            if f in ('sum', 'asum'):      # element-wise slack accumulates like a random walk in the sums
+            if f in ('sum', 'asum', 'l2'):      # element-wise slack accumulates like a random walk in the sums (and in the norm)
                 at = t * np.sqrt(n_est) + r * float(ref[f'{p}::asum']) * (1.0 if f == 'sum' else 0.0)
             else:
                 # entries far below the tensor's own scale carry that scale's rounding noise
