@@ -36,14 +36,24 @@ def compare(res, ref, rtol=RTOL, atol=ATOL, policy=None):
             a, b = float(res[f'{p}::asum']), float(ref[f'{p}::asum'])
             assert abs(a - b) <= pol[0] * abs(b) + pol[1], f'{p}::asum {a} vs {b}'
             continue
-        if len(pol) == 3 and pol[2] == 'relmax':      # (rtol, frac, 'relmax'): absolute slack = frac * max|sample|
+        if len(pol) in (3, 5) and pol[2] == 'relmax':      # (rtol, frac, 'relmax'): absolute slack = frac * max|sample|
             r, frac = pol[0], pol[1]
+            # the tensor's scale: its largest sampled entry (the dense sample where the fixture has one)
+            big = float(max(np.abs(ref[f'{p}::samp']).max(), np.abs(ref[f'{p}::dense']).max() if f'{p}::dense' in ref else 0.0))
             for f in ('head', 'samp', 'dense'):
                 if f'{p}::{f}' not in ref:
                     continue
                 a, b = np.asarray(res[f'{p}::{f}']), ref[f'{p}::{f}']
-                np.testing.assert_allclose(a, b, rtol=r, atol=frac * float(np.abs(ref[f'{p}::samp']).max()) + 1e-6,
-                                           err_msg=f'{p}::{f}')
+                if len(pol) == 5:
+                    # (rtol, frac, 'relmax', share, frac2): up to `share` of a sample (at least one entry) may sit between frac and
+                    # frac2 of the tensor's scale away - the entries downstream of ONE activation-boundary element that the two fp32
+                    # evaluations round to different sides (named by the float64 test of the same fixture)
+                    d = np.abs(a.astype(np.float64) - b)
+                    out = d > r * np.abs(b) + frac * big + 1e-6
+                    assert out.sum() <= max(1, int(pol[3] * d.size)) and (d[out] <= pol[4] * big).all(), \
+                        f'{p}::{f}: {int(out.sum())} of {d.size} entries beyond {frac} of the scale, worst {float(d.max() / big):.3f}'
+                    continue
+                np.testing.assert_allclose(a, b, rtol=r, atol=frac * big + 1e-6, err_msg=f'{p}::{f}')
             for f in ('asum', 'l2'):
                 if f'{p}::{f}' not in ref:
                     continue
