@@ -1,17 +1,17 @@
 #!/bin/bash
 # One GPU-box pass that produces everything profiles/ holds for a round.  Run through gpurun from the repo root:
-#   gpurun --timeout 2700 -- 'bash scripts/gpu_round.sh r03'
+#   gpurun --timeout 2700 -- 'bash scripts/gpu_round.sh r04'
 # then, back in the build container:
 #   for w in "" srgan_ cyclegan_; do python scripts/summarize_profiles.py gpurun_out/prof <tag>_${w%_} profiles/<tag>_${w%_}; done
 # (scripts/collect_round.sh does that).  rocprofv3 rules of this pool: the program goes directly after "--", counters
 # are collected in their own passes (never together with a trace domain other than --kernel-trace).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O/prof
 cd $R
 if [ "$2" != "noprof-tests" ] && [ "$2" != "reprof" ]; then
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -3 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 fi
@@ -34,45 +34,50 @@ prof_workload () {   # $1 = workload, $2 = file tag, $3 = math mode, $4.. = step
 if [ "$2" = "reprof" ]; then      # only the profiler passes of the listed file tags ("" = headline): $3 = "headline srgan ..."
   for w in $3; do
     case $w in
-      headline) prof_workload dcgan64 ${TAG} fp32 --steps 20 --warmup 8; t=$TAG;;
-      srgan) prof_workload srgan ${TAG}_srgan fp32 --steps 8 --warmup 4; t=${TAG}_srgan;;
-      cyclegan) prof_workload cyclegan ${TAG}_cyclegan fp32 --steps 4 --warmup 2; t=${TAG}_cyclegan;;
+      headline) prof_workload dcgan64 ${TAG}_dcgan64_fp32x3 fp32x3 --steps 20 --warmup 8; t=${TAG}_dcgan64_fp32x3;;
+      fp32) prof_workload dcgan64 ${TAG} fp32 --steps 20 --warmup 8; t=$TAG;;
+      srgan) prof_workload srgan ${TAG}_srgan_fp32x3 fp32x3 --steps 8 --warmup 4; t=${TAG}_srgan_fp32x3;;
+      cyclegan) prof_workload cyclegan ${TAG}_cyclegan_fp32x3 fp32x3 --steps 4 --warmup 2; t=${TAG}_cyclegan_fp32x3;;
     esac
     python scripts/summarize_profiles.py $O/prof $t $O/$t > /dev/null 2>> $O/summarize.err
   done
   find $O/prof -name '*kernel_trace.csv' -delete; find $O/prof -name '*counter_collection.csv' -delete; find $O/prof -name '*agent_info.csv' -delete
   ls $O | grep -c .; exit 0
 fi
-prof_workload dcgan64 ${TAG} fp32 --steps 20 --warmup 8
-prof_workload srgan ${TAG}_srgan fp32 --steps 8 --warmup 4
-prof_workload cyclegan ${TAG}_cyclegan fp32 --steps 4 --warmup 2
-prof_workload dcgan128 ${TAG}_dcgan128_bf16act bf16act --steps 8 --warmup 4
+# headline math mode = fp32x3 (three-plane tensors); the exact-fp32 MFMA runs of the same workloads next to it
 prof_workload dcgan64 ${TAG}_dcgan64_fp32x3 fp32x3 --steps 20 --warmup 8
+prof_workload dcgan64 ${TAG} fp32 --steps 20 --warmup 8
+prof_workload srgan ${TAG}_srgan_fp32x3 fp32x3 --steps 8 --warmup 4
+prof_workload cyclegan ${TAG}_cyclegan_fp32x3 fp32x3 --steps 4 --warmup 2
+prof_workload dcgan128 ${TAG}_dcgan128_bf16act bf16act --steps 8 --warmup 4
 # the counters of THIS build first, so that the bench line's roofline.traffic (read from profiles/) matches it
-python scripts/summarize_profiles.py $O/prof $TAG $R/profiles/$TAG > /dev/null
-python scripts/summarize_profiles.py $O/prof ${TAG}_srgan $R/profiles/${TAG}_srgan > /dev/null
-python scripts/summarize_profiles.py $O/prof ${TAG}_cyclegan $R/profiles/${TAG}_cyclegan > /dev/null
-python scripts/summarize_profiles.py $O/prof ${TAG}_dcgan128_bf16act $R/profiles/${TAG}_dcgan128_bf16act > /dev/null
-python scripts/summarize_profiles.py $O/prof ${TAG}_dcgan64_fp32x3 $R/profiles/${TAG}_dcgan64_fp32x3 > /dev/null
+for t in ${TAG}_dcgan64_fp32x3 ${TAG} ${TAG}_srgan_fp32x3 ${TAG}_cyclegan_fp32x3 ${TAG}_dcgan128_bf16act; do
+  python scripts/summarize_profiles.py $O/prof $t $R/profiles/$t > /dev/null
+done
 cp $R/profiles/${TAG}*_pmc_traffic.json $R/profiles/${TAG}*_mfma_util.json $R/profiles/${TAG}*_bench_kernel_stats.csv $O/ 2>/dev/null
 timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err; cut -c1-400 $O/${TAG}_bench.json
+timeout 900 python bench.py --math fp32 --alt-math none --no-cpu-baseline > $O/${TAG}_bench_dcgan64_fp32.json 2>> $O/bench.err
 for w in srgan cyclegan dcgan128; do
   timeout 900 python bench.py --workload $w > $O/${TAG}_bench_$w.json 2> $O/bench_$w.err; cut -c1-200 $O/${TAG}_bench_$w.json
+  timeout 900 python bench.py --workload $w --math fp32 --alt-math none --no-cpu-baseline > $O/${TAG}_bench_${w}_fp32.json 2>> $O/bench_$w.err
 done
-timeout 900 python bench.py --workload dcgan128 --math bf16 --no-cpu-baseline > $O/${TAG}_bench_dcgan128_bf16.json 2>> $O/bench_dcgan128.err
-timeout 900 python bench.py --math bf16 --no-cpu-baseline > $O/${TAG}_bench_dcgan64_bf16.json 2>> $O/bench.err
 timeout 900 python bench.py --workload dcgan128 --math bf16act --no-cpu-baseline > $O/${TAG}_bench_dcgan128_bf16act.json 2>> $O/bench_dcgan128.err
 timeout 900 python bench.py --math bf16act --no-cpu-baseline > $O/${TAG}_bench_dcgan64_bf16act.json 2>> $O/bench.err
 timeout 600 python scripts/conv_bench.py > $O/${TAG}_conv_bench.jsonl 2> $O/conv_bench.err
-timeout 900 python bench.py --math fp32x3 --no-cpu-baseline > $O/${TAG}_bench_dcgan64_fp32x3.json 2>> $O/bench.err
-CONV_BENCH_MATH=fp32x3 timeout 600 python scripts/conv_bench.py > $O/${TAG}_conv_bench_fp32x3.jsonl 2>> $O/conv_bench.err
-# per-layer, per-tile table of the bf16 kernels at BASELINE config 5 sizes (forced tiles 8-16, halo / RGB backward-weight)
-CONV_BENCH_TILES=-1,8,10,11,12,16,17 CONV_BENCH_WGRAD=-1,0,61,67 timeout 900 python scripts/conv_bench_bf16.py > $O/${TAG}_conv_bench_bf16.jsonl 2> $O/conv_bench_bf16.err
-# per-layer tables (conv-family launches by pass + geometry) of the four workloads
+# three-plane tiles per layer (forward / backward-data by forced tile, backward-weight by candidate)
+X3P_TILES=-1,18,19,21,26,28 timeout 600 python scripts/x3p_check.py bench > $O/${TAG}_conv_bench_fp32x3.jsonl 2>> $O/conv_bench.err
+timeout 600 python scripts/probe/wgrad_x3_bench.py > $O/${TAG}_wgrad_bench_fp32x3.jsonl 2>> $O/conv_bench.err
+# per-layer tables (conv-family launches by pass + geometry) of the workloads, headline math mode and exact fp32
 for w in dcgan64 srgan cyclegan; do
-  IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload $w --no-cpu-baseline 2>&1 >/dev/null | grep -A200 "conv-family layers" | cut -c18- > $O/${TAG}_layers_$w.txt
+  IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload $w --alt-math none --no-cpu-baseline 2>&1 >/dev/null | grep -A200 "conv-family layers" | cut -c18- > $O/${TAG}_layers_${w}_fp32x3.txt
+  IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload $w --math fp32 --alt-math none --no-cpu-baseline 2>&1 >/dev/null | grep -A200 "conv-family layers" | cut -c18- > $O/${TAG}_layers_$w.txt
 done
 IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload dcgan128 --math bf16act --no-cpu-baseline 2>&1 >/dev/null | grep -A200 "conv-family layers" | cut -c18- > $O/${TAG}_layers_dcgan128_bf16act.txt
+# two ranks on this box's one GPU, the C ABI's communicator (test double tests/stub_rccl.cpp) carrying the buckets: step captured
+IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 600 python bench.py --gpus 2 --steps 20 --warmup 8 --no-cpu-baseline --alt-math none > $O/${TAG}_bench_2ranks_1gpu_stub.json 2> $O/bench_2ranks.err
+rm -f /tmp/iprgan_stub_rccl_*
+# the three-plane ring tile on the north-star shape: clock, MFMA-busy, LDS conflicts (scripts/probe/x3p_pmc.sh)
+bash scripts/probe/x3p_pmc.sh 18 > /dev/null 2>&1; cp $O/pmc_x3p18.txt $O/${TAG}_northstar_x3p_pmc.txt 2>/dev/null
 # north-star conv shape (3x3 256->256 @64x64, batch 64): counter passes for the per-kernel MFMA / LDS / VALU picture
 export IPRGAN_TUNE_CACHE=$O/tune_cache_ns.txt
 rm -f $IPRGAN_TUNE_CACHE
@@ -86,7 +91,7 @@ unset IPRGAN_TUNE_CACHE
 python scripts/summarize_ns_pmc.py $O/prof $O/${TAG} > /dev/null 2> $O/ns_pmc.err
 # Everything judged is summarised HERE (gpurun merges at most 64 MiB back): per-workload kernel stats, HBM traffic and
 # MFMA-busy summaries into $O, then the raw per-dispatch traces and counter dumps are dropped.
-for t in $TAG ${TAG}_srgan ${TAG}_cyclegan ${TAG}_dcgan128_bf16act ${TAG}_dcgan64_fp32x3; do
+for t in ${TAG}_dcgan64_fp32x3 $TAG ${TAG}_srgan_fp32x3 ${TAG}_cyclegan_fp32x3 ${TAG}_dcgan128_bf16act; do
   python scripts/summarize_profiles.py $O/prof $t $O/$t > /dev/null 2>> $O/summarize.err
 done
 find $O/prof -name '*kernel_trace.csv' -delete

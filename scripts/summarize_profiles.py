@@ -28,9 +28,11 @@ def short(k):
         if 'gconv_pipe_kernel' in k and m.group(8) == 'true':
             return 'gconv_pipe_f32_kernel'
         return 'gconv_pipe_kernel' if int(m.group(2)) * int(m.group(4)) * 32 >= 128 else 'gconv_pipe_kernel<256x64>'
-    m = re.match(r'void iprgan::(wgrad_halo_f32_kernel|wgrad_halo_kernel|gconv_phase4_kernel|gconv_pipe8_kernel)<', k)
+    m = re.match(r'void iprgan::(wgrad_halo_f32_kernel|wgrad_halo_kernel|gconv_phase4_kernel|gconv_pipe8_kernel|gconv_x3h_kernel|wgrad_x3h_kernel)<', k)
     if m:
         return m.group(1)
+    if re.match(r'void iprgan::gconv_x3p(16)?_kernel<', k):      # three-plane ring tiles (conv_x3.hip): profiling slot 29
+        return 'gconv_x3p_kernel'
     m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?(?:, (true|false))?(?:, (true|false))?>', k)
     if m:
         if m.group(9) == 'true':
