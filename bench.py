@@ -136,6 +136,12 @@ def make_workload(name, device, impl):
             model.update_g({'real_A': As[i % pool], 'real_B': Bs[i % pool]})
             model.update_d({'real_A': model.real_A, 'real_B': model.real_B,
                             'fake_A': model.fake_A.detach(), 'fake_B': model.fake_B.detach()})
+
+        def graph_body(s):          # capturable once both image pools are full (7 steps at batch 8, pool 50): models.CycleGAN.graph_*
+            model.update_g({'real_A': s['a'], 'real_B': s['b']})
+            model.update_d({'real_A': model.real_A, 'real_B': model.real_B,
+                            'fake_A': model.fake_A.detach(), 'fake_B': model.fake_B.detach()})
+        step.graph_spec = (graph_body, lambda i: {'a': As[i % pool], 'b': Bs[i % pool]})
     return model, step
 
 
@@ -272,14 +278,14 @@ def main():
                          "keeps activations with a multiple of 64 channels as bf16 in HBM")
     ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
                     help="capture the whole step in one HIP graph (iprgan/graphs.py): 'auto' = where the step is "
-                         "capturable (DCGAN, SRGAN; one GPU); steps sampled by the per-kernel timer run eagerly")
+                         "capturable (all workloads; N > 1 with the C ABI's communicator); steps sampled by the per-kernel timer run eagerly")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     heavy = args.workload in ('cyclegan', 'dcgan128')
     if args.steps is None:                  # >= 20 warm-up, >= 100 timed where a step is milliseconds
-        args.steps = 10 if heavy else 100
-    if args.warmup is None:
-        args.warmup = 4 if heavy else 20
+        args.steps = {'cyclegan': 20, 'dcgan128': 10}.get(args.workload, 100)
+    if args.warmup is None:             # (CycleGAN: its image pools fill during the first 7 steps; the step is captured after that)
+        args.warmup = {'cyclegan': 10, 'dcgan128': 4}.get(args.workload, 20)
     if args.alt_math == 'auto':
         args.alt_math = {'fp32': 'fp32x3', 'fp32x3': 'fp32'}.get(args.math, 'none')
 
@@ -365,12 +371,18 @@ def main():
     replays_before = graphed.replays if graphed is not None else 0
     t0 = time.perf_counter()
     stamps = []
+    host_replayed, n_replayed = 0.0, 0                 # host time of the steps that went out as one graph launch
     marks[0].record()
     for i in range(args.steps):
         sampled = every > 0 and i % every == 0
         _lib.prof_enable(sampled)
+        th = time.perf_counter()
         if graphed is not None:
+            r0 = graphed.replays
             step_fn(i, eager=sampled)
+            if graphed.replays > r0 and not sampled:
+                host_replayed += time.perf_counter() - th
+                n_replayed += 1
         else:
             step_fn(i)
         marks[i + 1].record()
@@ -506,6 +518,9 @@ def main():
                                            for k in kernels]},
             'alt_math': alt,
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
+            # ... of the steps replayed from the captured graph alone (the sampled steps of this run are enqueued kernel
+            # by kernel for the per-kernel timer; a training run replays every step)
+            'host_enqueue_ms_per_replayed_step': round(host_replayed / n_replayed * 1e3, 3) if n_replayed else None,
             'graph': ({'captured': graphed.graph is not None, 'replays_in_timed_region': replays_timed,
                        'eager_steps_in_timed_region': args.steps - replays_timed, 'failed': graphed.failed}
                       if graphed is not None else None),

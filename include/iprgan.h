@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 221
+#define IPRGAN_VERSION 222
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -249,6 +249,15 @@ int iprgan_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H
 int iprgan_add(const float* a, const float* b, float* out, size_t n, int act_st, void* stream);
 int iprgan_reflect_fold(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope,
                         const float* residual, int B, int H, int W, int C, int pad, void* stream);
+/* ImagePool's swap branch (models/util.py:27-34: `pool_images = self.images[index[prob]].clone(); self.images[index[prob]] =
+ * images[prob]; images[prob] = pool_images`) with the draws in device memory, so that a captured training step replays
+ * with new ones: image i of images[count][n] changes places with row index[i] of pool[..][n] when take[i] != 0.  The
+ * entries of index must be distinct (the reference takes a prefix of a permutation); fp32, any layout, n elements per
+ * image; both operands are updated in place. */
+/* n integers from HOST memory `values` into device memory `dst`, carried as kernel arguments: they are read before the
+ * call returns and land in stream order (the per-step draws of iprgan_pool_swap: no pinned buffer to keep alive). */
+int iprgan_write_ints(int* dst, const int* values, int n, void* stream);
+int iprgan_pool_swap(float* images, float* pool, const int* index, const int* take, int count, size_t n, void* stream);
 
 /* ---- spectral norm (torch.nn.utils.spectral_norm at networks/sn_discriminator.py:9,11,18,21) */
 size_t iprgan_sn_ws_floats(int rows, int cols);
@@ -392,6 +401,8 @@ int iprgan_get_math_mode(void);
  *                     128x64 (3 / 2 stages), 256x64, 64x64, 128x256, 128x128 (2 stages)
  *              26, 27 their halo form for stride-1 gathers (k3 s1; the 2x2-tap sub-pixel phases of k4 s2): 256 positions x
  *                     128 / 64 columns, the tile's halo staged once per 16-channel chunk, taps as row shifts
+ *              28..31 tiles 18, 19, 20, 22 on v_mfma_f32_16x16x32_bf16 (half the accumulator rows per instruction; measured
+ *                     on par, kept as autotune candidates)
  *              14, 15 the persistent 256x128 / 256x64 form (bf16 operands)
  *              16     four sub-pixel phases per block (k4 s2 p1 backward-data forms, bf16 operands)
  *              17     256x256 with a half-tile ring: quadrant phases, five half-tiles of DMA in flight (bf16 operands)

@@ -41,7 +41,7 @@ static ProfSlot g_slots[] = {
     {"gconv_pipe_f32_kernel", 0, 0, 0}, {"gconv_phase4_kernel", 0, 0, 0},
     {"wgrad_halo_f32_kernel", 0, 0, 0}, {"gconv_pipe8_kernel", 0, 0, 0},
     {"gconv_x3_kernel", 0, 0, 0},       {"wgrad_x3_kernel", 0, 0, 0},
-    {"gconv_x3p_kernel", 0, 0, 0},      {"wgrad_x3p_kernel", 0, 0, 0},
+    {"gconv_x3p_kernel", 0, 0, 0},      {"wgrad_x3h_kernel", 0, 0, 0},
     {"gconv_x3h_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
@@ -2274,7 +2274,9 @@ static size_t splitk_ws_floats(const GConvArgs& a) {
   return splitk_geom_ok(a) ? (size_t)SPLITK_MAX * (size_t)a.ph[0].M * a.Ns : 0;
 }
 static bool splitk_eligible(const GConvArgs& a, const float* ws) {
-  return ws && splitk_geom_ok(a) && !a.stat_part && !a.rs0 && !a.in16 && !a.out16 && !a.aux16 && !a.planar_M && !a.wmod &&
+  // storage kinds: all fp32, or all three-plane (the fused-derivative operand then arrives as its h plane: aux16 == 1)
+  const bool kinds = a.in16 == 2 ? (a.out16 == 2 && (!a.aux || a.aux16 == 1)) : (!a.in16 && !a.out16 && !a.aux16);
+  return ws && splitk_geom_ok(a) && !a.stat_part && !a.rs0 && kinds && !a.planar_M && !a.wmod &&
          a.ksplit <= 1 && a.res != a.out && a.aux != a.out && g_force_tile < 0;
 }
 static int gconv_splitk(const GConvArgs& a0, float* ws, hipStream_t st) {
@@ -2284,12 +2286,14 @@ static int gconv_splitk(const GConvArgs& a0, float* ws, hipStream_t st) {
     if (ks == 1) return launch_gconv(a0, st);
     GConvArgs a = a0;
     a.ksplit = ks; a.out = ws; a.bias = nullptr; a.act = IPRGAN_ACT_NONE; a.aux = nullptr; a.res = nullptr;
+    a.out16 = 0; a.aux16 = 0; a.out_ps = 0;              // the slabs are fp32 whatever the tensors' storage kind
     const int rc = launch_gconv(a, st);
     if (rc) return rc;
     const unsigned n4 = (unsigned)((size_t)M * a0.Ns / 4);
+    const size_t ps = a0.out_ps ? (size_t)a0.out_ps / 2 : (size_t)M * a0.Ns;       // plane stride of the output, elements
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int)n4, 256) < 2048 ? cdiv((int)n4, 256) : 2048), dim3(256), 0, st,
                        (const f32x4*)ws, a0.bias, (f32x4*)a0.out, n4, (unsigned)(a0.Ns / 4), a0.N, ks, a0.act, a0.slope,
-                       (const f32x4*)a0.aux, a0.aux_act, a0.aux_slope, (const f32x4*)a0.res);
+                       (const f32x4*)a0.aux, a0.aux_act, a0.aux_slope, (const f32x4*)a0.res, a0.out16 == 2 ? 2 : 0, ps);
     IPR_LAUNCH_CHECK();
     return 0;
   };

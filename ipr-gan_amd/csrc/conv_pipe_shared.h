@@ -131,7 +131,8 @@ __device__ __forceinline__ void pipe_acc_to_lds(const f32x4 (&acc)[2 * WM][2 * W
 template <int WGM, int WGN, int WM, int WN, int RING_BYTES, bool STATS, bool PF, bool BNM = false, bool X3 = false, class ACC = f32x16[WM][WN]>
 __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, ACC& acc, float* T, int pz, unsigned lq,
                                               int m0, int n0, const u32x4* auxpf,         // PF: [NH][NIT] prefetched
-                                              const unsigned* rowtab = nullptr) {
+                                              const unsigned* rowtab = nullptr,
+                                              unsigned slab_off = 0) {                    // split K: fp32 elements into a.out
   using G = EpiGeom<WGM, WGN, WM, WN, RING_BYTES>;
   constexpr int CN = G::CN, OCT = G::OCT, RPI = G::RPI, NIT = G::NIT, NW = WGM * WGN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,7 +143,7 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, ACC& acc, floa
   if (a.rs0) { rsc0 = 1.f / *a.rs0; rsc1 = 1.f / *a.rs1; }
   const float neg_act = a.act == IPRGAN_ACT_NONE ? 1.f : a.act == IPRGAN_ACT_RELU ? 0.f : a.slope;
   const float neg_aux = a.aux_act == IPRGAN_ACT_NONE ? 1.f : a.aux_act == IPRGAN_ACT_RELU ? 0.f : a.aux_slope;
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)((float*)a.out + slab_off), 0, a.out_bytes - slab_off * 4u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux ? a.aux_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? a.out_bytes : 0, 0x00020000);
   constexpr int WGN_H = WGN / G::NH;

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
   const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
                                 gridDim.x * gridDim.y * gridDim.z);
   const unsigned lq = lt / gridDim.y;
-  const int pz = (int)(lq % gridDim.z);
+  const int zi = (int)(lq % gridDim.z);
+  const int pz = a.ksplit > 1 ? 0 : zi;          // blockIdx.z: sub-pixel phase, or K split of a single-phase geometry
   const int pM = a.ph[pz].M;
   const int m0 = (int)(lq / gridDim.z) * BM, n0 = (int)(lt % gridDim.y) * BN;
   if (m0 >= pM) {
@@ -56,7 +57,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
     return;
   }
   const int p_tw = a.ph[pz].tw, p_th = a.ph[pz].th;
-  const int nt = a.ph[pz].steps;                     // 32-deep K steps (Cs % 32 == 0: a step lies inside one tap)
+  int nt = a.ph[pz].steps, s_begin = 0;              // 32-deep K steps (Cs % 32 == 0: a step lies inside one tap)
+  if (a.ksplit > 1) {                                // this block's share of the K walk; its partial tile goes to slab zi
+    const int per = (nt + a.ksplit - 1) / a.ksplit;
+    s_begin = zi * per;
+    const int s_end = s_begin + per < nt ? s_begin + per : nt;
+    nt = s_end > s_begin ? s_end - s_begin : 0;
+  }
   const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
   const int p_dy0 = a.ph[pz].dy0, p_dx0 = a.ph[pz].dx0, p_dys = a.ph[pz].dys, p_dxs = a.ph[pz].dxs;
   const int p_wbase = a.ph[pz].wbase, p_wsy = a.ph[pz].wsy, p_wsx = a.ph[pz].wsx;
@@ -115,6 +122,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
   // wave-uniform walk over (channel chunk, tap): taps inside a 32-channel chunk, so that consecutive K steps re-read the
   // same pixels, shifted (they stay in L2)
   int u_c = 0, u_ty = 0, u_tx = 0;
+  if (s_begin) {                              // (split K: the walk starts at step s_begin)
+    const int ntap = p_th * p_tw, ck = s_begin / ntap, tap = s_begin - ck * ntap;
+    u_c = ck * 32; u_ty = tap / p_tw; u_tx = tap - u_ty * p_tw;
+  }
   int w_dy = 0, w_dx = 0, w_tapoff = 0;
   unsigned w_wk = 0, w_sbase = 0;
   auto walk_begin = [&](int buf) {            // address pieces of the K step the walk points at, into stage `buf`
@@ -253,7 +264,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] += accs[i][j];
 
-  pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf);
+  const unsigned slab_off = a.ksplit > 1 ? (unsigned)zi * (unsigned)pM * (unsigned)a.Ns : 0u;      // elements (< 2^31: checked)
+  pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, slab_off);
 }
 
 // ---- the same ring on v_mfma_f32_16x16x32_bf16 ------------------------------------------------------------------------
@@ -499,6 +511,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p16_kernel(const GConv
 //     vmcnt retires in order, the wait for the weight stage of step s also covers every halo piece issued before it;
 //   * the epilogue is pipe_epilogue with a row table (tile row -> output element), since tile rows are not consecutive
 //     positions of the phase grid.
+// Measured and not kept (round 4): the same kernel for STRIDE-2 gathers of k4 p1 kernels (Conv2d k4 s2 forward, ConvT k4 s2
+// backward-data) - the 16 taps are 2 x 2 taps on each of the four residue images of the input, so the K walk becomes
+// (residue, 16-channel chunk) x (2 x 2 taps) with one (PH + 1) x (PW + 1) halo per residue and chunk.  Parity-green, but
+// slower than the im2col ring on every DCGAN layer (D.conv1 101 vs 107, D.conv3 115 vs 160, D.conv5 60 vs 174, G.up0
+// backward-data 119 vs 203 TFLOP/s): a 16-channel step of a 64-column tile is 12 MFMAs per wave between two barriers.
 struct X3HGeom {
   int PH, PW, NI;            // patch rows x columns per image and images per tile: NI * PH * PW = 256
   int lpw, lpp;              // log2(PW), log2(PH * PW)
@@ -788,8 +805,8 @@ int cast_planes(const void* src, void* dst, size_t n, size_t ps, bool to_planes,
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------
-bool gconv_x3p_eligible(const GConvArgs& a) {
-  if (a.in16 != 2 || a.ksplit > 1 || a.wmod > 0 || a.planar_M) return false;
+bool gconv_x3p_eligible(const GConvArgs& a, bool ksplit_ok = false) {
+  if (a.in16 != 2 || (a.ksplit > 1 && !ksplit_ok) || a.wmod > 0 || a.planar_M) return false;
   auto simple = [](int act) { return act == IPRGAN_ACT_NONE || act == IPRGAN_ACT_RELU || act == IPRGAN_ACT_LRELU; };
   if ((a.Ns % 8) != 0 || (a.Cs % 32) != 0 || !simple(a.act) || (a.aux && !simple(a.aux_act))) return false;    // pipe_epilogue
   if (a.bn_mean) return false;
@@ -811,7 +828,7 @@ static int launch_x3p_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
   for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
   if (maxM == 0) return 0;
   const size_t smem = (size_t)NSTAGE * 3 * (BM + BN) * 64;
-  dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.nphase);
+  dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.ksplit > 1 ? a.ksplit : a.nphase);
   *bm_out = BM;
   constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * 3 * (BM + BN) * 64>::PF_FIRST;
   const bool pref = a.aux && a.aux16 == 1 && can_pf;
@@ -921,7 +938,7 @@ int launch_gconv_x3p16(const GConvArgs& a, int variant, hipStream_t st, int* bm_
 //          6 = 128x256 (4 waves of 64x128, 2 stages, 144 KB), 7 = 128x128 (2 stages, 96 KB)
 // returns -1 when the variant does not apply to the geometry
 int launch_gconv_x3p(const GConvArgs& a, int variant, hipStream_t st, int* bm_out) {
-  if (!gconv_x3p_eligible(a)) return -1;
+  if (!gconv_x3p_eligible(a, true)) return -1;          // (the 32x32x16 ring takes a K split: blockIdx.z, partial tiles into slabs)
   switch (variant) {
     case 0: return a.Ns >= 128 ? launch_x3p_t<4, 2, 2, 2, 2>(a, st, bm_out) : -1;
     case 1: return a.Ns >= 128 ? launch_x3p_t<2, 2, 2, 2, 3>(a, st, bm_out) : -1;

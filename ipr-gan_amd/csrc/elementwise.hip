@@ -648,6 +648,32 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
   for (size_t i = n4 * 4 + i0; i < n && st != 2; i += stride) out[i] = a[i] + b[i];
 }
 
+// ---- ImagePool's swap branch (models/util.py:27-34) with the decisions read from DEVICE memory, so that a captured step
+// replays with new draws: image i changes places with history slot index[i] when take[i] != 0.  The slots of one call are
+// distinct (a prefix of a permutation), so the swaps are independent: blockIdx.y = image.
+// a few integers from the host into device memory AS KERNEL ARGUMENTS: read at call time, ordered on the stream like
+// any launch, no host buffer that a later call could overwrite under a copy still in flight
+struct IntsArg { static constexpr int N = 64; int v[N]; };
+__global__ void write_ints_kernel(int* __restrict__ dst, IntsArg t, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = t.v[threadIdx.x];
+}
+__global__ void pool_swap_kernel(float* __restrict__ images, float* __restrict__ pool, const int* __restrict__ index,
+                                 const int* __restrict__ take, size_t n) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int i = blockIdx.y;
+  if (!take[i]) return;
+  float* a = images + (size_t)i * n;
+  float* b = pool + (size_t)index[i] * n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t n4 = (((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b)) & 15) == 0) ? n / 4 : 0;
+  for (size_t e = i0; e < n4; e += stride) {
+    const f4 va = reinterpret_cast<f4*>(a)[e], vb = reinterpret_cast<f4*>(b)[e];
+    reinterpret_cast<f4*>(a)[e] = vb;
+    reinterpret_cast<f4*>(b)[e] = va;
+  }
+  for (size_t e = n4 * 4 + i0; e < n; e += stride) { const float va = a[e]; a[e] = b[e]; b[e] = va; }
+}
+
 // ---- ReflectionPad2d(p) backward: fold the gradient of the padded image back (resnet_generator.py:6,33,43,47)
 __device__ __forceinline__ int refl_pre(int i, int n, int p, int* out) {
   // padded-coordinate preimages (0-based in the padded image) of interior index i
@@ -1033,6 +1059,23 @@ int iprgan_add(const float* a, const float* b, float* out, size_t n, int act_st,
   if (!n) return 0;
   IPR_ST_CHECK(act_st, n, "add");
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, act_st);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_write_ints(int* dst, const int* values, int n, void* stream) {
+  for (int off = 0; off < n; off += IntsArg::N) {
+    IntsArg t;
+    const int cnt = n - off < IntsArg::N ? n - off : IntsArg::N;
+    for (int i = 0; i < cnt; ++i) t.v[i] = values[off + i];
+    hipLaunchKernelGGL(write_ints_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst + off, t, cnt);
+    IPR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+int iprgan_pool_swap(float* images, float* pool, const int* index, const int* take, int count, size_t n, void* stream) {
+  if (!n || count <= 0) return 0;
+  IPR_CHECK(count <= 65535, "pool_swap: %d images in one call (limit 65535)", count);
+  hipLaunchKernelGGL(pool_swap_kernel, dim3(grid_for(n, 8192), count), dim3(256), 0, (hipStream_t)stream, images, pool, index, take, n);
   IPR_LAUNCH_CHECK();
   return 0;
 }

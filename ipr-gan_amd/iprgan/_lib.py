@@ -76,6 +76,8 @@ SIGNATURES = {
     'iprgan_maxpool2_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     'iprgan_maxpool2_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'iprgan_add': (_I, [_P, _P, _P, _Z, _I, _P]),
+    'iprgan_pool_swap': (_I, [_P, _P, _P, _P, _I, _Z, _P]),
+    'iprgan_write_ints': (_I, [_P, _P, _I, _P]),
     'iprgan_reflect_fold': (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _P]),
     'iprgan_sn_ws_floats': (_Z, [_I, _I]),
     'iprgan_sn_power_iter': (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),

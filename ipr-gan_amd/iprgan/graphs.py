@@ -11,8 +11,7 @@ Data-parallel runs (N > 1) capture the same way when the buckets travel through 
 (``iprgan_allreduce_bucket`` on the reducer's side stream: forked off and joined back inside the capture); with
 torch.distributed as the transport the step stays eager.
 
-What makes the step capturable (all of it already true for the DCGAN / VAE models, none of it for CycleGAN, whose
-ImagePool and LR schedule decide on the host):
+What makes the step capturable:
   * inputs live in static device tensors (``copy_`` before each replay);
   * no host decision inside the step depends on device data; metrics are read after the step, from tensors the graph
     wrote (their Python bindings are restored after each replay, because an eager step in between rebinds them);
@@ -20,6 +19,11 @@ ImagePool and LR schedule decide on the host):
     kernel arguments of the captured call, so a host-computed bias correction would be frozen;
   * host bookkeeping that the skipped Python would have done is redone per replay: optimizer step counts for
     ``state_dict()``, parameter version counters (operand caches and the stale-graph check key on them).
+  * host decisions that do NOT depend on device data are made before the replay and handed over in device memory:
+    CycleGAN's ImagePool (models/util.py:27-34) draws its swap decisions from the CPU generator; the model exposes
+    ``graph_ready()`` (pools full: fixed buffers), ``graph_before_replay()`` (draw + write the tables) and
+    ``graph_signature()`` (buffers the graph has baked in); hyper-parameters that travel by value (a scheduler's learning
+    rate) are compared before every replay and a change captures the step again.
 
 Capturing does not execute: the captured call's device work happens at the first replay, its host side effects happened
 during the capture - together they are exactly one step.  If the capture fails (an op that may not be captured), the
@@ -65,6 +69,8 @@ class GraphedStep:
         for o in self.opts:
             o.device_step = True
         self._bound = []
+        # models with host-side decisions inside the step (looked up on the class: the wrappers' __getattr__ delegates)
+        self.hooks = [m for m in _chain(model) if callable(getattr(type(m), 'graph_before_replay', None))]
 
     def _snapshot(self):
         self._bound = [(m, k, v) for m in _chain(self.model) for k, v in m.__dict__.items() if isinstance(v, torch.Tensor)]
@@ -105,26 +111,31 @@ class GraphedStep:
     def _hyper(self):
         """Hyper-parameters that travel BY VALUE in the captured Adam launches: a change (SRGAN's lr *= 0.1, a scheduler)
         must not be replayed over - the step is captured again."""
-        return [(g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']) for o in self.opts for g in o.param_groups]
+        return ([(g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']) for o in self.opts for g in o.param_groups]
+                + [m.graph_signature() for m in self.hooks])
 
     def __call__(self, inputs=None, eager=False):
         if inputs is not None:
             for k, v in inputs.items():
                 if v is not self.static[k]:
                     self.static[k].copy_(v, non_blocking=True)
-        if eager or self.failed is not None or self.warm > 0:
+        if eager or self.failed is not None or self.warm > 0 or not all(m.graph_ready() for m in self.hooks):
             if self.warm > 0 and not eager:
                 self.warm -= 1
             return self.body(self.static)
         if self.graph is None:
             if not self._capture():
                 return self.body(self.static)
+            for m in self.hooks:
+                m.graph_before_replay()
             self.graph.replay()                   # the captured call's device work (its host side ran during the capture)
             self.replays += 1
             return None
-        if self._hyper() != self._lrs:            # learning rate (...) changed since the capture: capture this call afresh
+        if self._hyper() != self._lrs:            # learning rate, pool buffers (...) changed since the capture: capture afresh
             self.graph = None
             return self.__call__(None, eager=False)
+        for m in self.hooks:
+            m.graph_before_replay()
         self.graph.replay()
         self.replays += 1
         for o in self.opts:

@@ -13,7 +13,7 @@ from itertools import chain
 import torch
 
 from . import _lib as L
-from . import networks, optim, tools
+from . import networks, ops, optim, tools
 from .parallel import GradReducer, Replica, broadcast_module
 from .tools import loss_sum, loss_value
 
@@ -333,18 +333,58 @@ class ImagePool(torch.nn.Module):
         # once per step to compare a device scalar (it cost one full synchronisation per CycleGAN step)
         if getattr(self, '_host_counts', None) is None:
             self._host_counts = float(self.counts)
+        self._last_n = images.size(0)
         if self._host_counts < self.pool_size:
             self.images = torch.cat([self.images.to(images.device), images.detach()], dim=0)[:self.pool_size, ...]
             self.counts += images.size(0)
             self._host_counts += images.size(0)
             return images.detach()
         images = images.detach()
-        prob = torch.rand(images.size(0)) > 0.5
-        index = torch.randperm(self.pool_size)[:images.size(0)]
-        pool_images = self.images[index[prob]].clone()
-        self.images[index[prob]] = images[prob].detach()
-        images[prob] = pool_images
-        return images.detach()
+        if not images.is_cuda:              # (host tensors: the reference's own indexing form)
+            prob = torch.rand(images.size(0)) > 0.5
+            index = torch.randperm(self.pool_size)[:images.size(0)]
+            pool_images = self.images[index[prob]].clone()
+            self.images[index[prob]] = images[prob].detach()
+            images[prob] = pool_images
+            return images.detach()
+        # The swap itself reads its decisions from device memory (iprgan_pool_swap), so a captured step can replay it with
+        # new draws: eager calls draw here, a replay draws in graphs.GraphedStep's pre-replay hook (``draw``) - the same
+        # two CPU-RNG calls in the same order either way.
+        if not torch.cuda.is_current_stream_capturing():
+            self.draw(images.size(0))
+        if not self.images.is_contiguous():
+            self.images = self.images.contiguous()
+        if images.is_contiguous():
+            ops.pool_swap(images, self.images, self._draws[0], self._draws[1])
+            return images
+        out = images.contiguous()           # (a permuted view: the swapped batch is returned, the view keeps its values)
+        ops.pool_swap(out, self.images, self._draws[0], self._draws[1])
+        return out
+
+    def full(self):
+        """True once every call takes the swap branch (fixed buffers: the step can be captured)."""
+        if self.pool_size <= 0:
+            return True
+        if getattr(self, '_host_counts', None) is None:
+            self._host_counts = float(self.counts)
+        return self._host_counts >= self.pool_size
+
+    def draw(self, n):
+        """The swap decisions of one call, drawn from torch's CPU generator exactly as models/util.py:28-29 does, written to
+        this pool's device table in stream order."""
+        prob = torch.rand(n) > 0.5
+        index = torch.randperm(self.pool_size)[:n]
+        assert index.numel() == n, f'ImagePool: batch {n} exceeds pool_size {self.pool_size}'
+        t = self.table(n)
+        ops.write_ints(t[0], index.tolist())
+        ops.write_ints(t[1], [int(p) for p in prob.tolist()])
+
+    def table(self, n):
+        """int32 [2, >= n] on the pool's device: row 0 = history slot per image, row 1 = swap / keep."""
+        dev = self.images.device
+        if getattr(self, '_draws', None) is None or self._draws.shape[1] < n or self._draws.device != dev:
+            self._draws = torch.zeros(2, max(n, 8), dtype=torch.int32, device=dev)
+        return self._draws
 
 
 class CycleGAN(Model):
@@ -463,6 +503,28 @@ class CycleGAN(Model):
     def update_lr(self):
         self.schedulerG.step()
         self.schedulerD.step()
+
+    # ---- hooks of graphs.GraphedStep: what decides on the host in this model and how a captured step is fed
+    def graph_ready(self):
+        """Capturable once both history pools are full: while they fill, ``images`` is re-allocated by every call."""
+        if not (self.poolA.full() and self.poolB.full()):
+            return False
+        for pool in (self.poolA, self.poolB):       # the tables exist before a capture could allocate them in its own pool
+            if pool.pool_size > 0:
+                pool.table(pool._last_n)
+        return True
+
+    def graph_before_replay(self):
+        """The per-step host decisions of update_d (models/util.py:28-29), in the order forward_d consumes them."""
+        for pool in (self.poolA, self.poolB):
+            if pool.pool_size > 0:
+                pool.draw(pool._last_n)
+
+    def graph_signature(self):
+        """What a captured step has baked in besides the optimizers' hyper-parameters: the pools' buffers (a loaded
+        checkpoint replaces them) - a change makes GraphedStep capture again."""
+        return tuple((p.images.data_ptr(), getattr(p, '_draws', None) is not None and p._draws.data_ptr())
+                     for p in (self.poolA, self.poolB) if p.pool_size > 0)
 
     def update_g(self, data, update=True):
         self.forward_g(data)

@@ -759,3 +759,22 @@ def add(a, b):
     out = _empty_like(a)
     call('iprgan_add', ptr(a), ptr(b), ptr(out), a.numel(), st, stream())
     return out
+
+
+def write_ints(dst, values):
+    """A short list of Python ints into the int32 device tensor ``dst`` in stream order (travels as kernel arguments)."""
+    assert dst.is_cuda and dst.dtype == torch.int32 and dst.is_contiguous() and dst.numel() >= len(values)
+    arr = (C.c_int * len(values))(*[int(v) for v in values])
+    call('iprgan_write_ints', C.c_void_p(dst.data_ptr()), C.cast(arr, C.c_void_p), len(values), stream())
+
+
+def pool_swap(images, pool, index, take):
+    """ImagePool's swap branch (models/util.py:27-34) in place on both tensors, the draws read from device memory:
+    images[i] <-> pool[index[i]] where take[i] != 0 (index: distinct int32 rows of ``pool``)."""
+    assert images.is_contiguous() and pool.is_contiguous() and images.dtype == pool.dtype == torch.float32
+    assert index.dtype == take.dtype == torch.int32 and index.numel() >= images.shape[0] <= take.numel()
+    n = images[0].numel()
+    assert pool[0].numel() == n
+    assert index.is_cuda and take.is_cuda and index.is_contiguous() and take.is_contiguous()
+    call('iprgan_pool_swap', ptr(images), ptr(pool), C.c_void_p(index.data_ptr()), C.c_void_p(take.data_ptr()), images.shape[0], n,
+         stream())

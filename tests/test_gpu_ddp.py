@@ -406,5 +406,8 @@ def test_bench_two_ranks_capture_the_step_with_the_exchange_inside():
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['transport'] == 'rccl-abi' and r['comm_nranks'] == 2, r
     assert r['graph'] and r['graph']['captured'] and r['graph']['failed'] is None and r['graph']['replays_in_timed_region'] >= 6, r['graph']
-    assert r['host_enqueue_ms_per_step'] < 0.5 * r['ms_per_step'], (r['host_enqueue_ms_per_step'], r['ms_per_step'])
+    # every fourth timed step is enqueued kernel by kernel for the per-kernel timer: the replayed steps are the ones a training
+    # run consists of; over the whole window (eager steps included) the host still has to stay ahead of the device
+    assert r['host_enqueue_ms_per_replayed_step'] < 0.25 * r['ms_per_step'], (r['host_enqueue_ms_per_replayed_step'], r['ms_per_step'])
+    assert r['host_enqueue_ms_per_step'] < 0.75 * r['ms_per_step'], (r['host_enqueue_ms_per_step'], r['ms_per_step'])
     assert all(v == v for v in r['metrics_last_step'].values())

@@ -143,10 +143,10 @@ def test_bn_backward_fusion_matches_the_separate_passes(dev, monkeypatch, math_m
     assert n > 50
 
 
-def _state_fingerprint(model):
+def _state_fingerprint(model, nets=('G', 'D')):
     out = {}
     sd = model.state_dict()
-    for net in ('G', 'D'):
+    for net in nets:
         for k, v in sd[net].items():
             out[f'{net}/{k}'] = v.detach().cpu().clone()
     for opt in ('optG', 'optD'):
@@ -223,6 +223,64 @@ def test_graphed_srgan_step_is_bit_identical_to_eager(dev):
     bad = [(k, float((fa[k].double() - fb[k].double()).abs().max())) for k in fa if not torch.equal(fa[k], fb[k])]
     assert not bad, f'{len(bad)} of {len(fa)} tensors differ: {bad[:12]}'
     assert ma == mb, (ma, mb)
+
+
+def test_graphed_cyclegan_step_is_bit_identical_to_eager(dev):
+    """CycleGAN's step (update_g, then update_d through the image pools) captured and replayed (missing #2):
+    what decides on the host in the reference's step - ImagePool's swap draws (models/util.py:27-34) and the LambdaLR
+    schedule (models/cyclegan.py:50-56,145-147) - stays on the host and is handed to the graph: the draws go into a
+    device table before each replay (iprgan_pool_swap reads them), a changed learning rate captures the step again.
+    Pool of 4 at batch 2 (full after two steps), epoch 8 with update_lr() after every step from the third on (the rate
+    moves for the last two steps): nine steps - three eager, capture, three replays, two re-captures - leave the four
+    networks, both Adam states, both pools and the metrics BIT-IDENTICAL to nine eager steps."""
+    from iprgan import Config, graphs, models
+    n_steps, B = 9, 2
+    As = [torch.tanh(recipe.tensor(57, 200 + s, (B, 3, 64, 64))).to(dev) for s in range(n_steps)]
+    Bs = [torch.tanh(recipe.tensor(57, 300 + s, (B, 3, 64, 64))).to(dev) for s in range(n_steps)]
+
+    def build():
+        m = models.CycleGAN(Config(dict(cases.CYCLEGAN_CFG, pool_size=4, epoch=8)), device=[dev])
+        for i, n in enumerate((m.GA, m.GB, m.DA, m.DB)):
+            recipe.fill(n.module, 57 + i)
+            n.to(dev)
+        return models.WhiteBoxWrapper(m, Config(dict(cases.WBOX_CFG, target='GB')))
+
+    def body_of(m):
+        def body(s):
+            m.update_g({'real_A': s['a'], 'real_B': s['b']})
+            m.update_d({'real_A': m.real_A, 'real_B': m.real_B, 'fake_A': m.fake_A.detach(), 'fake_B': m.fake_B.detach()})
+        return body
+
+    def run(m, call):
+        lrs = []
+        for s in range(n_steps):
+            torch.manual_seed(900 + s)                   # ImagePool draws from the CPU generator
+            call({'a': As[s], 'b': Bs[s]})
+            lrs.append(m.optG.param_groups[0]['lr'])
+            if s >= 2:
+                m.update_lr()
+        fp = _state_fingerprint(m, ('GA', 'GB', 'DA', 'DB'))
+        sd = m.state_dict()
+        for p in ('poolA', 'poolB'):
+            fp[f'{p}/images'] = sd[p]['images'].detach().cpu().clone()
+            fp[f'{p}/counts'] = sd[p]['counts'].detach().cpu().clone()
+        return fp, m.get_metrics(), lrs
+
+    a = build()
+    for o in graphs._optimizers(a):
+        o.device_step = True
+    fa, ma, lra = run(a, body_of(a))
+    assert lra[-1] < lra[-2] < lra[0], lra                # the schedule did move inside the run
+    b = build()
+    step = graphs.GraphedStep(b, body_of(b), {'a': As[0], 'b': Bs[0]}, warmup=3)
+    fb, mb, lrb = run(b, step)
+    assert step.failed is None and step.graph is not None and step.replays == 6, (step.failed, step.replays)
+    assert lra == lrb
+    bad = [(k, float((fa[k].double() - fb[k].double()).abs().max())) for k in fa if not torch.equal(fa[k], fb[k])]
+    assert not bad, f'{len(bad)} of {len(fa)} tensors differ: {bad[:12]}'
+    assert ma == mb, (ma, mb)
+    # the pools did swap (a run whose draws all said "keep" would prove nothing): some history image is a later step's
+    assert float(fa['poolA/counts']) == 4.0
 
 
 def _graphed_vs_eager(dev, mode, n_steps, eager_at, replays):
@@ -436,6 +494,9 @@ class _Ref:
 
     def __getitem__(self, k):
         return np.asarray(self.d[k])
+
+    def __contains__(self, k):
+        return k in self.d
 
 
 def _logo(tmp_path):
