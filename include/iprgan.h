@@ -424,7 +424,9 @@ int iprgan_cast(const float* src, float* dst, size_t n, int src_bf16, int dst_bf
  * dst + p * pstride (bf16 elements, p = 0, 1, 2); otherwise src is the h plane of a three-plane tensor with that plane
  * stride and dst receives h + (m + l).  pstride >= n (a batch slice of a larger tensor keeps the larger stride). */
 int iprgan_cast_planes(const void* src, void* dst, size_t n, size_t pstride, int to_planes, void* stream);
-/* 1 if iprgan_conv_bwd_weight consumes bf16 x / dy of this layer directly (desc flags set), 0 if it wants fp32 copies */
+/* 1 if iprgan_conv_bwd_weight consumes x / dy of this layer in the storage kinds the descriptor names (bf16; three planes on
+ * both sides; or ONE three-plane operand next to an fp32 one - the 64-channel side of an RGB stem / head, summed h + (m + l)
+ * as it is loaded), 0 if it wants fp32 copies */
 int iprgan_conv_wgrad_takes_bf16(const iprgan_conv_desc* d);
 int iprgan_axpy(float* y, const float* x, float a, size_t n, void* stream);   /* y += a*x */
 /* y_t += a*x_t for n tensors in one launch (HOST arrays of DEVICE pointers / element counts): the small

@@ -983,7 +983,9 @@ struct WGradArgs {
   int xcd;                   // wgrad_t_kernel: XCD-contiguous tile order
   int in16;                  // 1: P and Q are bf16 tensors and the bf16 image applies (host-side: picks the IN16 kernel)
                              // 2: P and Q are three-plane tensors (plane strides p_ps / q_ps bytes): the IN3P split kernel
-  int p16, q16;              // storage type of P / Q (kernels without IN16 widen bf16 chunks on arrival)
+  int p16, q16;              // storage kind of P / Q (kernels without IN16 widen on arrival: 1 = bf16 chunks; 2 = three
+                             // planes, summed h + (m + l) exactly - the 64-channel side of an RGB stem / head in fp32x3 mode,
+                             // whose other operand is an fp32 image: wgrad_kernel only)
   unsigned p_ps, q_ps;
   unsigned bstep0, bstep1;   // byte step of the image base for db32 / db32+1 images
   double flops;
@@ -1080,6 +1082,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
   const unsigned pes = IN16 ? 2u : (a.p16 ? 2u : 4u), qes = IN16 ? 2u : (a.q16 ? 2u : 4u);
   const int Qs4 = a.Qs * (int)qes, dx32 = a.dx32, dy32 = a.dy32;          // bytes per Q pixel
   const unsigned pstep = 32u * (unsigned)a.Ps * pes, bstep0 = a.bstep0, bstep1 = a.bstep1;
+  const unsigned p_plane = (unsigned)a.M * (unsigned)a.Ps * 2u;           // bytes of one plane of a three-plane P
 
   // Running state of this thread's rows, advanced by 32 rows of m per chunk with adds and selects only.
   // The integer work of the loader competes with the MFMAs for issue slots (the waves of a block are
@@ -1118,6 +1121,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
         if (po[i] != OOB_OFFSET) po[i] += pstep;
         continue;
       }
+      if (!IN16 && a.p16 == 2) {       // (rows past M of plane h are plane m's memory: po < bytes of one plane)
+        const bool okp = po[i] < p_plane;
+        rP[0][i] = buf_load4_bf16(rs_p, okp ? po[i] : OOB_OFFSET) + (buf_load4_bf16(rs_p, okp ? po[i] + a.p_ps : OOB_OFFSET) +
+                                                                     buf_load4_bf16(rs_p, okp ? po[i] + 2u * a.p_ps : OOB_OFFSET));
+        if (po[i] != OOB_OFFSET) po[i] += pstep;
+        continue;
+      }
       rP[0][i] = (!IN16 && a.p16) ? buf_load4_bf16(rs_p, po[i]) : buf_load4(rs_p, po[i]);
       po[i] += pstep;
     }
@@ -1135,6 +1145,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_kernel(const WGradArgs a
       if (IN3P) {
 #pragma unroll
         for (int p = 0; p < NLD; ++p) rQ[p][i] = buf_load4(rs_q, ok && qb[i] < OOB_OFFSET ? off + (unsigned)p * a.q_ps : OOB_OFFSET);
+      } else if (!IN16 && a.q16 == 2) {
+        const bool okq = ok && qb[i] < OOB_OFFSET;
+        rQ[0][i] = buf_load4_bf16(rs_q, okq ? off : OOB_OFFSET) + (buf_load4_bf16(rs_q, okq ? off + a.q_ps : OOB_OFFSET) +
+                                                                   buf_load4_bf16(rs_q, okq ? off + 2u * a.q_ps : OOB_OFFSET));
       } else
       rQ[0][i] = (!IN16 && a.q16) ? buf_load4_bf16(rs_q, ok ? off : OOB_OFFSET) : buf_load4(rs_q, ok ? off : OOB_OFFSET);
       int x = qx[i] + dx32, y = qy[i] + dy32;
@@ -1632,7 +1646,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const f32x4* __restr
 // x[B][H][W][C4] -> xp[B][H+2p][W+2p][C4] with ReflectionPad2d borders (only for the swapped-role wgrad of the
 // reflect-padded RGB heads, see WGeom)
 __global__ void reflect_pad_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ xp, int B, int H, int W,
-                                   int C4n, int pad) {
+                                   int C4n, int pad, size_t x_ps = 0) {        // x_ps != 0: x is a three-plane tensor
   const int HP = H + 2 * pad, WP = W + 2 * pad;
   const size_t total = (size_t)B * HP * WP * C4n;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -1642,7 +1656,13 @@ __global__ void reflect_pad_kernel(const f32x4* __restrict__ x, f32x4* __restric
     const int yq = (int)(r % HP);
     const int b = (int)(r / HP);
     const int sy = reflect_idx(yq - pad, H), sx = reflect_idx(xq - pad, W);
-    xp[i] = x[(((size_t)b * H + sy) * W + sx) * C4n + c];
+    const size_t e = (((size_t)b * H + sy) * W + sx) * C4n + c;
+    if (x_ps) {
+      const size_t e4 = e * 4;
+      xp[i] = ld_bf16x4((const float*)x, e4) + (ld_bf16x4((const float*)x, e4 + x_ps) + ld_bf16x4((const float*)x, e4 + 2 * x_ps));
+    } else {
+      xp[i] = x[e];
+    }
   }
 }
 
@@ -2407,7 +2427,10 @@ static bool wgrad_plan_c(const iprgan_conv_desc* d, int cand, WGradPlan& p) {
   cand %= WGRAD_NBASE;
   if (p.variant && (g.N <= 32 || g_math == IPRGAN_MATH_BF16)) return false;   // the 32-row tile and the bf16 image exist in the first form only
   if (p.variant && (d->x_bf16 || d->y_bf16)) return false;      // the transposed-image kernel reads fp32 tensors only
-  if (wgrad_has_planes(d) && (!wgrad_in3p(d) || g.swap || (cand % WGRAD_NSHAPE != 0 && cand % WGRAD_NSHAPE != 3))) return false;
+  if (wgrad_in3p(d) && (g.swap || (cand % WGRAD_NSHAPE != 0 && cand % WGRAD_NSHAPE != 3))) return false;
+  // one three-plane operand next to an fp32 one (RGB stems / heads in fp32x3 mode): the fp32 tiles of the first form
+  // widen it on arrival (WGradArgs::p16 / q16 = 2); a bf16 operand next to it has no form
+  if (wgrad_has_planes(d) && !wgrad_in3p(d) && (d->x_bf16 == 1 || d->y_bf16 == 1)) return false;
   p.N = g.N;
   p.Cq = g.Cq;
   p.Ps = c4(p.N); p.Qs = c4(p.Cq);
@@ -2901,9 +2924,13 @@ int iprgan_conv_wgrad_takes_bf16(const iprgan_conv_desc* d) {
   // bf16 x and / or dy (desc flags) are read directly by every backward-weight kernel except the reflect-padded
   // swapped form (which copies x into a padded fp32 image first): there the caller hands an fp32 x (iprgan_cast)
   const WGeom g = wgrad_geom(d);
-  if (wgrad_has_planes(d)) {      // three planes: both tensors, a regular (not role-swapped) layer with a 128x128 split tile
+  if (wgrad_in3p(d)) {            // three planes, both tensors: a regular (not role-swapped) layer with a 128x128 split tile
     WGradPlan p;
-    return wgrad_in3p(d) && !g.swap && (wgrad_plan_c(d, 0, p) || wgrad_plan_c(d, 3, p) || wgrad_x3h_ok(d)) ? 1 : 0;
+    return !g.swap && (wgrad_plan_c(d, 0, p) || wgrad_plan_c(d, 3, p) || wgrad_x3h_ok(d)) ? 1 : 0;
+  }
+  if (wgrad_has_planes(d)) {      // one three-plane operand, the other fp32 (RGB stems / heads): widened on arrival by the
+    WGradPlan p;                  // fp32 tiles; the reflect-padded swapped form pads an fp32 copy of x, joined on the way
+    return d->x_bf16 != 1 && d->y_bf16 != 1 && (wgrad_plan_c(d, 0, p) || wgrad_plan_c(d, 1, p) || wgrad_plan_c(d, 2, p)) ? 1 : 0;
   }
   return !(g.padded && d->x_bf16);
 }
@@ -2919,8 +2946,9 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   if (g.padded) {             // reflect-padded copy of x behind the slabs and the bias partials
     float* xp = ws + rup4(wgrad_slab_floats(d) + colsum_ws_floats(d->B * s.OH * s.OW, c4(d->Cout)));
     const size_t n4 = wgrad_padded_floats(d) / 4;
+    const size_t xps = d->x_bf16 == 2 ? (d->x_pstride ? (size_t)d->x_pstride : (size_t)d->B * d->H * d->W * c4(d->Cin)) : 0;
     hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256)),
-                       dim3(256), 0, st, (const f32x4*)x, (f32x4*)xp, d->B, d->H, d->W, c4(d->Cin) / 4, d->pad);
+                       dim3(256), 0, st, (const f32x4*)x, (f32x4*)xp, d->B, d->H, d->W, c4(d->Cin) / 4, d->pad, xps);
     IPR_LAUNCH_CHECK();
     xin = xp;
   }
@@ -2975,18 +3003,18 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     a.pad_mode = g.swap ? IPRGAN_PAD_ZERO : d->pad_mode;      // swapped + reflect runs on the padded copy
     a.Kw = p.Kw; a.Nrows = p.Nrows; a.chunks_per_split = p.cps;
     const bool p_is_x = d->transposed || g.swap;
-    a.p16 = (p_is_x ? d->x_bf16 : d->y_bf16) != 0;
-    a.q16 = (p_is_x ? d->y_bf16 : d->x_bf16) != 0;
+    a.p16 = p_is_x ? (g.padded ? 0 : d->x_bf16) : d->y_bf16;       // (the padded copy of x is fp32 whatever x is)
+    a.q16 = p_is_x ? d->y_bf16 : d->x_bf16;
     a.in16 = wgrad_in3p(d) ? 2 : (wgrad_in16(d) && p.bn == 128 && p.bk == 128) ? 1 : 0;
+    if (!a.in16 && (a.p16 == 2 || a.q16 == 2) && p.variant) return -1;        // widened on arrival by wgrad_kernel only
     const unsigned long long pesz = a.p16 ? 2ull : 4ull, esz = a.q16 ? 2ull : 4ull;
     unsigned long long pb = (unsigned long long)a.M * a.Ps * pesz;
     unsigned long long qb = (unsigned long long)d->B * a.QH * a.QW * a.Qs * esz;
-    if (a.in16 == 2) {
+    {
       const long long pps = p_is_x ? d->x_pstride : d->y_pstride, qps = p_is_x ? d->y_pstride : d->x_pstride;
-      IPR_CHECK(pb < 0x2fffffffull && qb < 0x2fffffffull, "conv_bwd_weight: three-plane tensor larger than 2 GiB");
-      a.p_ps = pps ? (unsigned)(pps * 2) : (unsigned)pb;
-      a.q_ps = qps ? (unsigned)(qps * 2) : (unsigned)qb;
-      pb += 2ull * a.p_ps; qb += 2ull * a.q_ps;
+      IPR_CHECK((a.p16 != 2 || pb < 0x2fffffffull) && (a.q16 != 2 || qb < 0x2fffffffull), "conv_bwd_weight: three-plane tensor larger than 2 GiB");
+      if (a.p16 == 2) { a.p_ps = pps ? (unsigned)(pps * 2) : (unsigned)pb; pb += 2ull * a.p_ps; }
+      if (a.q16 == 2) { a.q_ps = qps ? (unsigned)(qps * 2) : (unsigned)qb; qb += 2ull * a.q_ps; }
     }
     IPR_CHECK(pb < 0x7fffffffull && qb < 0x7fffffffull, "conv_bwd_weight: tensor larger than 2 GiB");
     a.p_bytes = (unsigned)pb; a.q_bytes = (unsigned)qb;
@@ -3029,7 +3057,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   int cand = 0;
   {
     WGradPlan p0;
-    if (!wgrad_plan_c(d, 0, p0)) cand = !wgrad_has_planes(d) ? 1 : wgrad_plan_c(d, 3, p0) ? 3 : WGRAD_X3H0;
+    if (!wgrad_plan_c(d, 0, p0)) cand = !wgrad_in3p(d) ? 1 : wgrad_plan_c(d, 3, p0) ? 3 : WGRAD_X3H0;
   }
   if (g_force_wgrad >= 0) {
     WGradPlan pf;
@@ -3060,6 +3088,7 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
   }
   {
     const int rc = run_to(cand, dw, beta);
+    IPR_CHECK(rc != -1, "conv_bwd_weight: candidate %d does not apply to this layer (storage kinds x %d / dy %d)", cand, d->x_bf16, d->y_bf16);
     if (rc) return rc;
   }
   if (db) {

@@ -324,12 +324,11 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
     if ST_X3 in (is16(x), is16(dy)) and is16(x) != is16(dy):
         if c4(spec.cin) % 32 == 0 and c4(spec.cout) % 32 == 0 and ST_BF16 not in (is16(x), is16(dy)):
             x, dy = to_kind(x, ST_X3), to_kind(dy, ST_X3)      # (a gradient that arrived as fp32: split, not the other side joined)
-        else:
-            x, dy = f32(x), f32(dy)                            # (RGB stems / heads: one side is an fp32 image)
+        # (else RGB stems / heads: one side is an fp32 image, the kernel widens the three-plane side on arrival)
     d.x_bf16, d.y_bf16 = is16(x), is16(dy)            # the kernels read either storage type (include/iprgan.h)
     d.x_pstride, d.y_pstride = pstride(x), pstride(dy)
-    if d.x_bf16 and not query('iprgan_conv_wgrad_takes_bf16', C.byref(d)):
-        x, dy = (f32(x), f32(dy)) if d.x_bf16 == ST_X3 else (cast(x, torch.float32), dy)
+    if (d.x_bf16 or d.y_bf16 == ST_X3) and not query('iprgan_conv_wgrad_takes_bf16', C.byref(d)):
+        x, dy = (f32(x), f32(dy)) if ST_X3 in (d.x_bf16, d.y_bf16) else (cast(x, torch.float32), dy)
         d.x_bf16, d.y_bf16 = is16(x), is16(dy)
         d.x_pstride = d.y_pstride = 0
     if dw is None:

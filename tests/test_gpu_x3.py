@@ -211,6 +211,63 @@ def test_wgrad_halo_for_three_plane_tensors(shape, cand, dev):
         _lib.set_math('fp32')
 
 
+RGB_SHAPES = [  # B, cin, cout, k, stride, pad, H, W, transposed, reflect: one side RGB (fp32), the other 64 channels (planes)
+    (6, 3, 64, 3, 1, 1, 24, 20, False, False),      # SNDiscriminator stem (sn_discriminator.py:9): dy is the three-plane side
+    (4, 64, 3, 3, 1, 1, 16, 24, True, False),       # ConvGenerator head (conv_generator.py:21): x is
+    (2, 64, 3, 7, 1, 3, 20, 18, False, True),       # ResnetGenerator head (resnet_generator.py:43-44): role-swapped, padded fp32 copy of x
+    (2, 3, 64, 7, 1, 3, 18, 20, False, True),       # ResnetGenerator stem (resnet_generator.py:6-7): reflection in the gather
+    (3, 64, 3, 9, 1, 4, 16, 16, False, False),      # SRResNet head (sr_resnet.py:17)
+]
+
+
+@pytest.mark.parametrize('cand', [-1, 0, 1])
+@pytest.mark.parametrize('shape', RGB_SHAPES, ids=lambda c: '-'.join(map(str, c)))
+def test_wgrad_of_rgb_layers_reads_the_three_plane_side_directly(shape, cand, dev):
+    """Backward-weight of RGB stems / heads in 'fp32x3' mode: the 64-channel operand is a three-plane tensor, the image side
+    fp32; the fp32 tiles sum the planes h + (m + l) - exactly - as they load them (WGradArgs p16 / q16 = 2; the reflect-padded
+    role-swapped form joins while it pads), so no fp32 copy of the large tensor is made.  The result must equal, bit for
+    bit, what the same candidate computes from the joined fp32 tensor, and sit at the fp32 distance from float64."""
+    import ctypes as C
+    from iprgan import ops, _lib
+    B, cin, cout, k, s, p, H, W, tr, refl = shape
+    g = torch.Generator().manual_seed(7 + cin + cout + H + k)
+    spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr, pad_mode=1 if refl else 0)
+    OH, OW = spec.out_hw(H, W)
+    x = torch.randn(B, H, W, ops.c4(cin), generator=g).to(dev)
+    dy = torch.randn(B, OH, OW, ops.c4(cout), generator=g).to(dev)
+    x[..., cin:] = 0
+    dy[..., cout:] = 0
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    x64 = x[..., :cin].double().cpu().permute(0, 3, 1, 2)
+    if refl:
+        x64 = F.pad(x64, (p, p, p, p), mode='reflect')
+    w64 = torch.zeros(*wshape, dtype=torch.float64, requires_grad=True)
+    y64 = F.conv_transpose2d(x64, w64, None, s, p) if tr else F.conv2d(x64, w64, None, s, 0 if refl else p)
+    y64.backward(dy[..., :cout].double().cpu().permute(0, 3, 1, 2))
+    want = w64.grad
+    rel = lambda got, ref: float((got.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())      # noqa: E731
+    try:
+        # the same values as fp32 tensors on both sides through the same candidate (the exact fp32 tiles of mode 'fp32')
+        _lib.set_math('fp32')
+        _lib.call('iprgan_debug_force_tiles', -1, cand)
+        ref32, db32 = ops.conv_bwd_weight(spec, spec.desc(B, H, W), x, dy, wshape, True)
+        _lib.set_math('fp32x3')
+        d = spec.desc(B, H, W)
+        assert sorted((d.x_bf16, d.y_bf16)) == [0, 2]
+        assert _lib.query('iprgan_conv_wgrad_takes_bf16', C.byref(d)) == 1
+        xk, dyk = ops.to_kind(x, d.x_bf16), ops.to_kind(dy, d.y_bf16)
+        got, db = ops.conv_bwd_weight(spec, d, xk, dyk, wshape, True)
+        assert cand < 0 or torch.equal(got, ref32), f'cand {cand}: differs from the joined operands by {float((got - ref32).abs().max()):.3e}'
+        assert rel(got, want) < 4e-7
+        dy64 = dy[..., :cout].double().cpu()
+        tol = 1e-6 * float(dy64.abs().sum((0, 1, 2)).max())          # (a sum of B * OH * OW signed terms: cancellation)
+        assert float((db.double().cpu() - dy64.sum((0, 1, 2))).abs().max()) <= tol
+        assert float((db.double().cpu() - db32.double().cpu()).abs().max()) <= tol
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
+        _lib.set_math('fp32')
+
+
 @pytest.mark.parametrize('name', [n for n in T.HIP_NETS if n != 'Discriminator96'])
 def test_networks_vs_reference_golden_through_split_tiles(name, golden, dev, via_x3):
     T.test_net_vs_reference_golden(name, golden, dev)
