@@ -455,8 +455,9 @@ def main():
             r = parallel.owner_of(p)
             if r is not None:
                 reducers[id(r)] = r
-    comm = {'transport': parallel.transport_name() if world > 1 else 'none', 'nranks': parallel.comm_nranks(),
-            'exposed_ms': round(sum(r.exposed_ms() for r in reducers.values()), 4) if world > 1 else 0.0}
+    forced = world == 1 and os.environ.get('IPRGAN_FORCE_COMM') == '1'       # one rank through the library's RCCL communicator
+    comm = {'transport': parallel.transport_name() if (world > 1 or forced) else 'none', 'nranks': parallel.comm_nranks(),
+            'exposed_ms': round(sum(r.exposed_ms() for r in reducers.values()), 4) if (world > 1 or forced) else 0.0}
 
     if rank == 0:
         B = wl['batch']

@@ -82,6 +82,24 @@ def _no_param_grads(*nets):
             p.requires_grad_(True)
 
 
+_CONST = {}
+
+
+def _const(value, like):
+    """A cached device scalar (the seed of ``loss.backward`` and the zero of an inhibited / absent loss term): autograd and
+    ``zeros_like`` would fill a fresh one per call - a kernel launch each, inside the training step."""
+    key = (float(value), like.device, like.dtype)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full([], float(value), device=like.device, dtype=like.dtype)
+    return t
+
+
+def _backward(loss):
+    """``loss.backward()`` with the cached seed."""
+    loss.backward(_const(1.0, loss))
+
+
 def _step(opt, reducer):
     reducer.reduce()
     reducer.wait()
@@ -154,7 +172,7 @@ class DCGAN(Model):
         self.compute_d_loss()
         self.optD.zero_grad()
         self.reduceD.arm()
-        self.LossD.backward()
+        _backward(self.LossD)
         _step(self.optD, self.reduceD)
 
     def update_g(self, data, update=True):
@@ -163,7 +181,7 @@ class DCGAN(Model):
         if update:
             self.optG.zero_grad()
             self.reduceG.arm()
-            self.LossG.backward()
+            _backward(self.LossG)
             _step(self.optG, self.reduceG)
 
 
@@ -219,7 +237,7 @@ class VAE(Model):
         if update:
             self.optG.zero_grad()
             self.reduceG.arm()
-            self.LossG.backward()
+            _backward(self.LossG)
             _step(self.optG, self.reduceG)
 
 
@@ -296,7 +314,7 @@ class SRGAN(Model):
         self.compute_d_loss()
         self.optD.zero_grad()
         self.reduceD.arm()
-        self.LossD.backward()
+        _backward(self.LossD)
         _step(self.optD, self.reduceD)
 
     def update_g(self, data, update=True):
@@ -305,7 +323,7 @@ class SRGAN(Model):
         if update:
             self.optG.zero_grad()
             self.reduceG.arm()
-            self.LossG.backward()
+            _backward(self.LossG)
             _step(self.optG, self.reduceG)
 
 
@@ -532,7 +550,7 @@ class CycleGAN(Model):
         if update:
             self.optG.zero_grad()
             self.reduceG.arm()
-            self.LossG.backward()
+            _backward(self.LossG)
             _step(self.optG, self.reduceG)
 
     def update_d(self, data):
@@ -540,8 +558,8 @@ class CycleGAN(Model):
         self.compute_d_loss()
         self.optD.zero_grad()
         self.reduceD.arm()
-        self.LossDA.backward()
-        self.LossDB.backward()
+        _backward(self.LossDA)
+        _backward(self.LossDB)
         _step(self.optD, self.reduceD)
 
 
@@ -612,7 +630,7 @@ class BlackBoxWrapper(Wrapper):
 
     def compute_g_loss(self):
         self.LossG = self.model.LossG
-        self.LossW = torch.zeros_like(self.LossG) if self.inhibit else self.loss_fn(self.Gxwm, self.ywm)
+        self.LossW = _const(0.0, self.LossG) if self.inhibit else self.loss_fn(self.Gxwm, self.ywm)
 
     def forward_g(self, data):
         self.inhibit = data.get('inhibit_bbox', False)
@@ -644,7 +662,7 @@ class BlackBoxWrapper(Wrapper):
             loss = self.LossG + self.Lambda * self.LossW
             red = self.model.reduceG
             red.arm()
-            loss.backward()
+            _backward(loss)
             _step(self.model.optG, red)
 
 
@@ -666,11 +684,11 @@ class WhiteBoxWrapper(Wrapper):
     def compute_g_loss(self):
         target = getattr(self.model, self.config.target)
         self.LossG = self.model.LossG
-        self.LossS = torch.zeros_like(self.LossG) if self.inhibit else self.loss_model(target)
+        self.LossS = _const(0.0, self.LossG) if self.inhibit else self.loss_model(target)
         if hasattr(self.model, 'LossW'):
             self.Lambda, self.LossW = self.model.Lambda, self.model.LossW
         else:
-            self.Lambda, self.LossW = 0, torch.zeros_like(self.LossS)
+            self.Lambda, self.LossW = 0, _const(0.0, self.LossS)
 
     def get_metrics(self):
         metrics = self.model.get_metrics()
@@ -686,8 +704,9 @@ class WhiteBoxWrapper(Wrapper):
         self.compute_g_loss()
         if update:
             self.model.optG.zero_grad()
-            loss = self.LossG + self.Lambda * self.LossW + self.LossS
+            # (a term with weight 0 adds exactly nothing: skipped, not multiplied)
+            loss = self.LossG + self.LossS if self.Lambda == 0 else self.LossG + self.Lambda * self.LossW + self.LossS
             red = self.model.reduceG
             red.arm()
-            loss.backward()
+            _backward(loss)
             _step(self.model.optG, red)

@@ -406,8 +406,25 @@ def test_bench_two_ranks_capture_the_step_with_the_exchange_inside():
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['transport'] == 'rccl-abi' and r['comm_nranks'] == 2, r
     assert r['graph'] and r['graph']['captured'] and r['graph']['failed'] is None and r['graph']['replays_in_timed_region'] >= 6, r['graph']
-    # every fourth timed step is enqueued kernel by kernel for the per-kernel timer: the replayed steps are the ones a training
-    # run consists of; over the whole window (eager steps included) the host still has to stay ahead of the device
-    assert r['host_enqueue_ms_per_replayed_step'] < 0.25 * r['ms_per_step'], (r['host_enqueue_ms_per_replayed_step'], r['ms_per_step'])
-    assert r['host_enqueue_ms_per_step'] < 0.75 * r['ms_per_step'], (r['host_enqueue_ms_per_step'], r['ms_per_step'])
+    # the host stays ahead of the device (the step is device-bound).  How far ahead says little here: the stub's exchange is a
+    # HOST node inside the graph (hipLaunchHostFunc), which makes hipGraphLaunch wait for the previous replay's host nodes -
+    # the real RCCL records kernels; the 1-rank communicator run below measures the launch cost of such a graph
+    assert r['host_enqueue_ms_per_step'] < 0.8 * r['ms_per_step'], (r['host_enqueue_ms_per_step'], r['ms_per_step'])
+
+
+def test_bench_with_the_library_communicator_replays_in_a_fraction_of_the_step():
+    """``IPRGAN_FORCE_COMM=1 bench.py``: one rank, but the gradient buckets go through the real RCCL communicator of the C ABI
+    (fork to the side stream, ncclAllReduce, join - all inside the captured step, as at N > 1).  A replayed step then costs
+    the host one graph launch: under a tenth of the step time."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'IPRGAN_RCCL_LIB')}
+    env.update(IPRGAN_FORCE_COMM='1')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '16', '--warmup', '6', '--no-cpu-baseline',
+                        '--alt-math', 'none'], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert r['transport'] == 'rccl-abi' and r['comm_nranks'] == 1, (r['transport'], r['comm_nranks'])
+    assert r['graph'] and r['graph']['captured'] and r['graph']['failed'] is None and r['graph']['replays_in_timed_region'] >= 8, r['graph']
+    assert r['host_enqueue_ms_per_replayed_step'] < 0.1 * r['ms_per_step'], (r['host_enqueue_ms_per_replayed_step'], r['ms_per_step'])
     assert all(v == v for v in r['metrics_last_step'].values())
