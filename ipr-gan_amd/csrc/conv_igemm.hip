@@ -2288,7 +2288,9 @@ static int g_force_splitk = -1;
 static bool splitk_geom_ok(const GConvArgs& a) {
   if (a.nphase != 1 || a.osy != 1 || a.osx != 1 || a.ph[0].ooy || a.ph[0].oox) return false;
   const long long M = a.ph[0].M, blocks = (long long)cdiv((int)M, 64) * cdiv(a.Ns, 64);
-  return a.Ns >= 64 && (a.Cs % 32) == 0 && blocks <= 1280 && a.ph[0].steps >= 32 && M * a.Ns <= (5ll << 20);
+  const long long lim_blocks = getenv("IPRGAN_SPLITK_BLOCKS") ? atoll(getenv("IPRGAN_SPLITK_BLOCKS")) : 1280;
+  const long long lim_out = getenv("IPRGAN_SPLITK_OUT") ? atoll(getenv("IPRGAN_SPLITK_OUT")) : (5ll << 20);
+  return a.Ns >= 64 && (a.Cs % 32) == 0 && blocks <= lim_blocks && a.ph[0].steps >= 32 && M * a.Ns <= lim_out;
 }
 static size_t splitk_ws_floats(const GConvArgs& a) {
   return splitk_geom_ok(a) ? (size_t)SPLITK_MAX * (size_t)a.ph[0].M * a.Ns : 0;

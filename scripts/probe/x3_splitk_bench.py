@@ -21,7 +21,13 @@ LAYERS = [  # name, cin, cout, k, s, p, transposed, H, B
     ('VGG 512->512 k3 @12 B64', 512, 512, 3, 1, 1, False, 12, 64),
     ('VGG 256->512 k3 @12 B64', 256, 512, 3, 1, 1, False, 12, 64),
     ('D96 512->512 k3s2 @12 B64', 512, 512, 3, 2, 1, False, 12, 64),
+    ('VGG 256->256 k3 @24 B64', 256, 256, 3, 1, 1, False, 24, 64),
+    ('VGG 128->256 k3 @24 B64', 128, 256, 3, 1, 1, False, 24, 64),
+    ('D.conv4 128->256 k3 @16 B256', 128, 256, 3, 1, 1, False, 16, 256),
+    ('D.conv6 256->512 k3 @8 B256', 256, 512, 3, 1, 1, False, 8, 256),
 ]
+if len(sys.argv) > 1:
+    LAYERS = [l for l in LAYERS if any(a in l[0] for a in sys.argv[1:])]
 _lib.set_math('fp32x3')
 for name, cin, cout, k, s, p, tr, H, B in LAYERS:
     spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr)
