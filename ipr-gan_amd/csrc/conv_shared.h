@@ -28,13 +28,27 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 f) {      // round-to-nearest-
   return v;
 }
 // x = h + m + l, three bf16 terms (nearest-even each; the two subtractions are exact in fp32): t[0] = h, t[1] = m, t[2] = l
+// (written on PAIRS: one v_cvt_pk_bf16_f32 per two elements and plane, widening = one shift / one mask per element;
+// element-wise conversions cost the compiler a convert per element plus the re-packing: 60 instead of 44 instructions per 8)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {          // {bf16(a), bf16(b)}, nearest-even
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hp, unsigned& mp, unsigned& lp) {
+  hp = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __builtin_bit_cast(float, hp << 16), r1 = x1 - __builtin_bit_cast(float, hp & 0xffff0000u);
+  mp = cvt_pk_bf16(r0, r1);
+  lp = cvt_pk_bf16(r0 - __builtin_bit_cast(float, mp << 16), r1 - __builtin_bit_cast(float, mp & 0xffff0000u));
+}
 __device__ __forceinline__ void split3_bf16(f32x4 f, bf16x4 (&t)[3]) {
-  t[0] = to_bf16x4(f);
-  const f32x4 h = {(float)t[0].x, (float)t[0].y, (float)t[0].z, (float)t[0].w};
-  const f32x4 r1 = f - h;
-  t[1] = to_bf16x4(r1);
-  const f32x4 m = {(float)t[1].x, (float)t[1].y, (float)t[1].z, (float)t[1].w};
-  t[2] = to_bf16x4(r1 - m);
+  typedef unsigned int u32pair __attribute__((ext_vector_type(2)));
+  unsigned w0[3], w1[3];
+  split3_pair(f.x, f.y, w0[0], w0[1], w0[2]);
+  split3_pair(f.z, f.w, w1[0], w1[1], w1[2]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) t[p] = __builtin_bit_cast(bf16x4, u32pair{w0[p], w1[p]});
 }
 // 4 consecutive bf16 elements (element index idx of a tensor whose storage type is bf16) -> 4 floats
 __device__ __forceinline__ f32x4 ld_bf16x4(const float* base, size_t idx) {
