@@ -77,7 +77,7 @@ IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload dcgan128 --math bf1
 IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 600 python bench.py --gpus 2 --steps 20 --warmup 8 --no-cpu-baseline --alt-math none > $O/${TAG}_bench_2ranks_1gpu_stub.json 2> $O/bench_2ranks.err
 rm -f /tmp/iprgan_stub_rccl_*
 # one rank, the buckets through the real RCCL communicator of the C ABI (fork / ncclAllReduce / join inside the captured step)
-IPRGAN_FORCE_COMM=1 timeout 600 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --alt-math none > $O/${TAG}_bench_1rank_rccl.json 2> $O/bench_1rank.err
+IPRGAN_FORCE_COMM=1 timeout 600 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --alt-math none 2> $O/bench_1rank.err | grep '^{' > $O/${TAG}_bench_1rank_rccl.json      # (RCCL prints its version banner to stdout)
 # the three-plane ring tile on the north-star shape: clock, MFMA-busy, LDS conflicts (scripts/probe/x3p_pmc.sh)
 bash scripts/probe/x3p_pmc.sh 18 > /dev/null 2>&1; cp $O/pmc_x3p18.txt $O/${TAG}_northstar_x3p_pmc.txt 2>/dev/null
 # north-star conv shape (3x3 256->256 @64x64, batch 64): counter passes for the per-kernel MFMA / LDS / VALU picture
