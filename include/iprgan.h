@@ -62,7 +62,11 @@ typedef struct {
  * its bf16 rounding (same sign: activation masks read only that plane).  The pointer handed to an entry point is plane h.
  * Producers split ONCE per element; the convolution kernels then move the planes to LDS by DMA and multiply plane pairs
  * on the bf16 matrix pipe (csrc/conv_x3.hip) with no vector-ALU work in their K loops. */
-enum { IPRGAN_ST_F32 = 0, IPRGAN_ST_BF16 = 1, IPRGAN_ST_X3 = 2 };
+enum { IPRGAN_ST_F32 = 0, IPRGAN_ST_BF16 = 1, IPRGAN_ST_X3 = 2,
+       /* the `act_bf16` argument of the norm entry points (iprgan_bn_*, iprgan_instnorm_*, iprgan_bn_prelu_*) only: the layer's
+        * INPUT x is fp32 while y, dy, dx and the residual are three-plane tensors - the convolution in front of a norm layer
+        * then writes 4 instead of 6 bytes per element (y_bf16 = IPRGAN_ST_F32 in its descriptor) and x is read three times */
+       IPRGAN_ST_X3_XF32 = 3 };
 /* bf16 activations ("bf16 in HBM", BASELINE config 5): only with IPRGAN_MATH_BF16 and only for tensors whose padded
  * channel count is a multiple of 64; such a tensor is bf16 for EVERY entry point that touches it (element offsets and
  * shapes are unchanged, the `float*` in the signatures is then a bf16 buffer).  Prepared weights follow the operand

@@ -50,8 +50,13 @@ __device__ __forceinline__ void stv(float* base, size_t e, const f32x4& v, size_
     *(f32x4*)(base + e) = v;
   }
 }
+// Storage kind 3 (norm entry points only, IPRGAN_ST_X3_XF32): the layer's INPUT x is fp32 - the convolution in front of a norm
+// layer writes 4 instead of 6 bytes per element, and x is read three times (apply, backward reduction, backward apply) -
+// while y, dy, dx and the residual are three-plane tensors.  SX / SY: the kind of x / of every other tensor.
+#define SX (ST == 3 ? 0 : ST)
+#define SY (ST == 3 ? 2 : ST)
 // launch-time choice of a kernel instantiation by storage kind
-#define ST_PICK(kind, K, ...) ((kind) == 2 ? K<__VA_ARGS__, 2> : (kind) == 1 ? K<__VA_ARGS__, 1> : K<__VA_ARGS__, 0>)
+#define ST_PICK(kind, K, ...) ((kind) == 3 ? K<__VA_ARGS__, 3> : (kind) == 2 ? K<__VA_ARGS__, 2> : (kind) == 1 ? K<__VA_ARGS__, 1> : K<__VA_ARGS__, 0>)
 
 struct ColGeom {
   int TC, TR, gy, NB, rows_per_block;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   if (ok) {
     f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {1.f, 1.f, 1.f, 1.f};
-    if (MODE == 1) p0 = ldv<ST>(x, gofs + cq * 4, ps);
+    if (MODE == 1) p0 = ldv<SX>(x, gofs + cq * 4, ps);
     f32x4 pg = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 2) {
       p0 = *(const f32x4*)(mean + cq * 4); p1 = *(const f32x4*)(invstd + cq * 4);
@@ -147,18 +152,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t off = gofs + (size_t)(r + u * TR) * C + cq * 4;
-        xv[u] = ldv<ST>(x, off, ps);
-        if (MODE == 2) gv[u] = ldv<ST>(dy, off, ps);
-        if (need_y) yv[u] = ldv<ST>(y, off, ps);
+        xv[u] = ldv<SX>(x, off, ps);
+        if (MODE == 2) gv[u] = ldv<SY>(dy, off, ps);
+        if (need_y) yv[u] = ldv<SY>(y, off, ps);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) accumulate(xv[u], MODE == 2 ? gv[u] : xv[u], need_y ? yv[u] : xv[u]);   // same row order as below
     }
     for (; r < r1; r += TR) {
       const size_t off = gofs + (size_t)r * C + cq * 4;
-      const f32x4 xv = ldv<ST>(x, off, ps);
-      const f32x4 gv = MODE == 2 ? ldv<ST>(dy, off, ps) : xv;
-      const f32x4 yv = need_y ? ldv<ST>(y, off, ps) : xv;
+      const f32x4 xv = ldv<SX>(x, off, ps);
+      const f32x4 gv = MODE == 2 ? ldv<SY>(dy, off, ps) : xv;
+      const f32x4 yv = need_y ? ldv<SY>(y, off, ps) : xv;
       accumulate(xv, gv, yv);
     }
   }
@@ -338,12 +343,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const size_t base = (size_t)blockIdx.y * n4;        // n4 = 16-byte quads per group here
 #pragma unroll 4
     for (; i < n4; i += stride) {
-      const f32x4 v = ldv<ST>(x, (base + i) * 4, ps);
+      const f32x4 v = ldv<SX>(x, (base + i) * 4, ps);
       f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = act_apply((v[k] - m[k]) * is[k] * g[k] + b[k], act, slope);
-      if (residual) o += ldv<ST>(residual, (base + i) * 4, ps);
-      stv<ST>(y, (base + i) * 4, o, ps);
+      if (residual) o += ldv<SY>(residual, (base + i) * 4, ps);
+      stv<SY>(y, (base + i) * 4, o, ps);
     }
     return;
   }
@@ -351,12 +356,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const int c = (int)(i - fdiv(i, d_c4n) * (unsigned)C4n) * 4;
     const size_t go = (size_t)fdiv(i, d_group4) * (size_t)C4n * 4;     // group offset into mean/invstd
     const f32x4 g = ld4(gamma, c, 1.f), b = ld4(beta, c, 0.f), m = ld4(mean + go, c, 0.f), is = ld4(invstd + go, c, 1.f);
-    const f32x4 v = ldv<ST>(x, (size_t)i * 4, ps);
+    const f32x4 v = ldv<SX>(x, (size_t)i * 4, ps);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = act_apply((v[k] - m[k]) * is[k] * g[k] + b[k], act, slope);
-    if (residual) o += ldv<ST>(residual, (size_t)i * 4, ps);
-    stv<ST>(y, (size_t)i * 4, o, ps);
+    if (residual) o += ldv<SY>(residual, (size_t)i * 4, ps);
+    stv<SY>(y, (size_t)i * 4, o, ps);
   }
 }
 
@@ -400,9 +405,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   auto body = [&](size_t idx, const f32x4& g, const f32x4& b, const f32x4& m, const f32x4& is, const f32x4& s1,
                   const f32x4& s2) {
-    const f32x4 xv = ldv<ST>(x, idx * 4, ps), gv = ldv<ST>(dy, idx * 4, ps);
+    const f32x4 xv = ldv<SX>(x, idx * 4, ps), gv = ldv<SY>(dy, idx * 4, ps);
     f32x4 yv = {0.f, 0.f, 0.f, 0.f};
-    if (!from_x && !no_act) yv = ldv<ST>(y, idx * 4, ps);
+    if (!from_x && !no_act) yv = ldv<SY>(y, idx * 4, ps);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       const float dz = no_act ? gv[k] : gv[k] * act_grad_from_out(from_x ? v : yv[k], act, slope);
       o[k] = g[k] * is[k] * (dz - s1[k] * invM - t * s2[k] * invM);
     }
-    stv<ST>(dx, idx * 4, o, ps);
+    stv<SY>(dx, idx * 4, o, ps);
     csum += o;
   };
   if (FIXED) {               // see bn_apply_kernel: blockIdx.y = group, n4 = quads per group
@@ -520,7 +525,7 @@ static int norm_fwd(const float* x, float* y, const float* gamma, const float* b
                        x, nullptr, nullptr, nullptr, nullptr, ws, M, C, g.TC, g.rows_per_block, 0, 0.f, nullptr, nullptr, nullptr, ps);
     IPR_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64), G), dim3(64 * FL), 0, st, ws, x, g.NB, M, C,
-                       eps, momentum, running_mean, running_var, save_mean, save_invstd, 0, counter, b16, ps);
+                       eps, momentum, running_mean, running_var, save_mean, save_invstd, 0, counter, b16 == 3 ? 0 : b16, ps);
   }
   IPR_LAUNCH_CHECK();
   const size_t n4 = (size_t)G * M * C / 4;
@@ -607,7 +612,7 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
                          dbias_prev, dbias_beta);
       IPR_LAUNCH_CHECK();
     } else {                 // channel counts that do not divide the block: the separate column-sum pass
-      const int rc = colsum_launch(dx, dbias_prev, ws, G * M, C, dbias_n, st, dbias_beta, b16, ps);
+      const int rc = colsum_launch(dx, dbias_prev, ws, G * M, C, dbias_n, st, dbias_beta, b16 == 3 ? 2 : b16, ps);
       if (rc) return rc;
     }
   }

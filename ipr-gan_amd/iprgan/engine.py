@@ -134,7 +134,9 @@ class Conv(Op):
     def forward(self, x, st, train):
         sp = self.spec
         B, H, W, _ = x.shape
-        d = sp.desc(B, H, W)
+        # y_f32 (set by the chain): the consumer is a norm layer - in 'fp32x3' mode the output leaves as fp32 (4 instead of 6
+        # bytes per element) and the norm layer, which reads it three times, is where the tensor is split (ops._norm_fwd_kinds)
+        d = sp.desc(B, H, W, y16=ops.ST_F32 if st.get('y_f32') else None)
         sigma = st.get('sigma')             # set by Chain's batched spectral-norm pre-pass
         if self.sn is not None and sigma is None and st.get('pair') is None:
             u, v = self.sn
@@ -171,6 +173,8 @@ class Conv(Op):
 
     def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
         sp, d, sigma = self.spec, st['d'], st['sigma']
+        if d.y_bf16 == ops.ST_F32 and ops.is16(dy) == ops.ST_X3:    # (y_f32: the forward output left as fp32, its gradient
+            d = ops._desc_with(d, y_bf16=ops.ST_X3)                  # arrives from the norm layer as a three-plane tensor)
         if sp.act != L.ACT_NONE and not st.get('dy_is_preact', False):
             dy = ops.act_bwd(dy, st['y'], sp.act, sp.slope)
         grads = []
@@ -673,6 +677,9 @@ class ChainFn(torch.autograd.Function):
                 if (per_inst or (isinstance(nxt, BatchNorm) and (train or not nxt.m.track_running_stats))) \
                         and op.can_emit_stats(h.shape[1], h.shape[2], per_inst):
                     st['emit_stats'] = True
+            if isinstance(op, Conv) and i + 1 < n_ops and isinstance(chain.ops[i + 1], (BatchNorm, InstanceNorm)) and not pair \
+                    and h.dim() == 4 and ops._NORM_XF32 and op.spec.act == L.ACT_NONE and ops.act_kind(op.spec.cout) == ops.ST_X3:
+                st['y_f32'] = True
             if _FUSE_STATS and isinstance(op, (BatchNorm, InstanceNorm)) and i + 1 < n_ops and isinstance(chain.ops[i + 1], SkipEnd):
                 st['close_skip'] = True
             h = op.forward(h, st, train)

@@ -363,23 +363,53 @@ def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_
 
 
 # ---- batch norm -----------------------------------------------------------------------------------
+ST_X3_XF32 = 3          # norm entry points only (include/iprgan.h): x fp32; y, dy, dx, residual three planes
+_NORM_XF32 = os.environ.get('IPRGAN_NORM_XF32', '1') != '0'
+
+
+def _norm_fwd_kinds(x):
+    """(storage-kind argument of the norm entry point, kind of its output y).  In 'fp32x3' mode an fp32 input whose channel
+    count allows three planes gets a three-plane output: the convolution in front of a norm layer writes fp32 (4 instead
+    of 6 bytes per element; engine.Conv: y_f32) and the norm layer is where the tensor is split."""
+    k = is16(x)
+    if k == ST_F32 and _NORM_XF32 and L.act_x3() and x.dim() == 4 and x.shape[-1] % 32 == 0:
+        return ST_X3_XF32, ST_X3
+    return k, k
+
+
+def _norm_bwd_kinds(x, dy, y=None):
+    """(storage-kind argument, dy, y) of a norm backward: the saved fp32 x of a layer whose output is three planes stays
+    fp32 (ST_X3_XF32); otherwise dy (and y) follow x."""
+    k = is16(x)
+    if k == ST_F32 and is16(dy) == ST_X3 and pstride(dy) == dy.numel():
+        if y is not None and is16(y) != ST_X3:
+            y = to_kind(y, ST_X3)
+        return ST_X3_XF32, dy, y
+    if is16(dy) != k:
+        dy = to_kind(dy, k)
+    if y is not None and is16(y) != k:
+        y = to_kind(y, k)
+    return k, dy, y
+
+
 def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, act, slope=0.0, conv_stats=None,
            conv_bias=None, counter=None, residual=None):
     """conv_stats = (partials, rows) from conv_fwd(stats=True): the statistics are taken from them instead of a pass
     over x.  counter: the module's int64 num_batches_tracked, incremented on the device."""
     C_ = x.shape[-1]
     M = x.numel() // C_
-    y = _empty_like(x)
-    if residual is not None and is16(residual) != is16(x):
-        residual = to_kind(residual, is16(x))
+    st, ky = _norm_fwd_kinds(x)
+    y = empty_kind(x.shape, x, ky)
+    if residual is not None and is16(residual) != ky:
+        residual = to_kind(residual, ky)
     mean, invstd = empty((C_,), x), empty((C_,), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
     call('iprgan_bn_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
          ptr(mean), ptr(invstd), ptr(ws), M, C_, float(eps), float(momentum), 0 if training else 1,
          act, float(slope), ptr(part), int(rows), ptr(conv_bias) if part is not None else None,
-         counter.data_ptr() if counter is not None else None, ptr(residual), is16(x), stream())
-    return y, mean, invstd
+         counter.data_ptr() if counter is not None else None, ptr(residual), st, stream())
+    return _out(y), mean, invstd
 
 
 def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None, dbias_beta=0.0):
@@ -387,15 +417,14 @@ def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None,
     that produced x."""
     C_ = x.shape[-1]
     M = x.numel() // C_
-    if dy.dtype != x.dtype:
-        dy = cast(dy, x.dtype)
-    dx = _empty_like(x)
+    st, dy, y = _norm_bwd_kinds(x, dy, y)
+    dx = _empty_like(dy)
     dgamma, dbeta = empty((C_,), x), empty((C_,), x)
     ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
     call('iprgan_bn_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
          ptr(dgamma), ptr(dbeta), ptr(ws), M, C_, act, float(slope), ptr(dbias), dbias.numel() if dbias is not None else 0,
-         float(dbias_beta), is16(x), stream())
-    return dx, dgamma, dbeta
+         float(dbias_beta), st, stream())
+    return _out(dx), dgamma, dbeta
 
 
 def bn_prelu_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, slope_t, conv_stats=None,
@@ -403,31 +432,31 @@ def bn_prelu_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, train
     """BatchNorm + PReLU (``slope_t``: the PReLU parameter, one float on the device) in the norm's own passes."""
     C_ = x.shape[-1]
     M = x.numel() // C_
-    y = _empty_like(x)
-    if residual is not None and is16(residual) != is16(x):
-        residual = to_kind(residual, is16(x))
+    st, ky = _norm_fwd_kinds(x)
+    y = empty_kind(x.shape, x, ky)
+    if residual is not None and is16(residual) != ky:
+        residual = to_kind(residual, ky)
     mean, invstd = empty((C_,), x), empty((C_,), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
     call('iprgan_bn_prelu_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(mean),
          ptr(invstd), ptr(ws), M, C_, float(eps), float(momentum), 0 if training else 1, ptr(slope_t), ptr(part), int(rows),
          ptr(conv_bias) if part is not None else None, counter.data_ptr() if counter is not None else None, ptr(residual),
-         is16(x), stream())
-    return y, mean, invstd
+         st, stream())
+    return _out(y), mean, invstd
 
 
 def bn_prelu_bwd(x, dy, gamma, beta, mean, invstd, slope_t, dbias=None, dbias_beta=0.0):
     C_ = x.shape[-1]
     M = x.numel() // C_
-    if dy.dtype != x.dtype:
-        dy = cast(dy, x.dtype)
-    dx = _empty_like(x)
+    st, dy, _ = _norm_bwd_kinds(x, dy)
+    dx = _empty_like(dy)
     dgamma, dbeta, dslope = empty((C_,), x), empty((C_,), x), empty((1,), x)
     ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
     call('iprgan_bn_prelu_bwd', ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(slope_t), ptr(dx),
          ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(ws), M, C_, ptr(dbias), dbias.numel() if dbias is not None else 0,
-         float(dbias_beta), is16(x), stream())
-    return dx, dgamma, dbeta, dslope
+         float(dbias_beta), st, stream())
+    return _out(dx), dgamma, dbeta, dslope
 
 
 def bn_bwd_pre(x, dz, gamma, mean, invstd, partials, dbias=None, dbias_beta=0.0):
@@ -644,32 +673,30 @@ def fill(t, value=0.0):
 # ---- instance norm / PReLU / pixel shuffle / max pool / residual add ---------------------------------
 def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias=None, residual=None):
     B, H, W, C_ = x.shape
-    y = _empty_like(x)
-    if residual is not None and is16(residual) != is16(x):
-        residual = to_kind(residual, is16(x))
+    st, ky = _norm_fwd_kinds(x)
+    y = empty_kind(x.shape, x, ky)
+    if residual is not None and is16(residual) != ky:
+        residual = to_kind(residual, ky)
     mean, invstd = empty((B, C_), x), empty((B, C_), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
     call('iprgan_instnorm_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(ws),
          B, H * W, C_, float(eps), act, float(slope), ptr(part), int(rows),
-         ptr(conv_bias) if part is not None else None, ptr(residual), is16(x), stream())
-    return y, mean, invstd
+         ptr(conv_bias) if part is not None else None, ptr(residual), st, stream())
+    return _out(y), mean, invstd
 
 
 def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None, dbias_beta=0.0):
     B, H, W, C_ = x.shape
-    if is16(dy) != is16(x):
-        dy = to_kind(dy, is16(x))
-    if y is not None and is16(y) != is16(x):
-        y = to_kind(y, is16(x))
-    dx = _empty_like(x)
+    st, dy, y = _norm_bwd_kinds(x, dy, y)
+    dx = _empty_like(dy)
     dgamma = empty((C_,), x) if gamma is not None else None
     dbeta = empty((C_,), x) if gamma is not None else None
     ws = empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
     call('iprgan_instnorm_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
          ptr(dgamma), ptr(dbeta), ptr(ws), B, H * W, C_, act, float(slope), ptr(dbias),
-         dbias.numel() if dbias is not None else 0, float(dbias_beta), is16(x), stream())
-    return dx, dgamma, dbeta
+         dbias.numel() if dbias is not None else 0, float(dbias_beta), st, stream())
+    return _out(dx), dgamma, dbeta
 
 
 def _same_kind(*ts):

@@ -45,11 +45,13 @@ def both_math_modes(names=None):
     return hook
 
 
-def math_mode_fixture():
+def math_mode_fixture(io_f32=True):
     @pytest.fixture(autouse=True)
     def math_mode(request):
-        """'fp32x3': every 'fp32' request of the test (and the library default) runs as 'fp32x3'; direct calls of the conv
-        ops hand back fp32 tensors (ops.io_f32: the kernels still run on three-plane operands and results)."""
+        """'fp32x3': every 'fp32' request of the test (and the library default) runs as 'fp32x3'.  io_f32 (op-level test
+        modules): direct calls of the conv / norm ops hand back fp32 copies of their three-plane results (ops.io_f32: the
+        kernels still run on three-plane operands and results); model-level modules leave it off - the networks run exactly
+        as in production, three-plane tensors from layer to layer."""
         mode = getattr(request, 'param', 'fp32')
         from iprgan import _lib, ops
         if mode == 'fp32x3':
@@ -58,7 +60,7 @@ def math_mode_fixture():
                 pytest.skip('a bf16-mode case: one math mode of its own')
             _lib._FP32_VIA_X3 = True
             _lib.set_math('fp32')
-            ops.io_f32(True)
+            ops.io_f32(io_f32)
             assert _lib.get_math() == 'fp32x3'
         try:
             yield mode

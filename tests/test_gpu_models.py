@@ -19,7 +19,7 @@ import conftest
 pytestmark = pytest.mark.gpu
 # every test of this file runs in both math modes ('fp32' and 'fp32x3'), same tolerances (conftest.both_math_modes)
 pytest_generate_tests = conftest.both_math_modes()
-math_mode = conftest.math_mode_fixture()
+math_mode = conftest.math_mode_fixture(io_f32=False)
 RTOL, ATOL = 5e-4, 5e-5
 HIP_NETS = list(cases.NET_CASES)
 
@@ -646,12 +646,12 @@ def test_conv_linearity_at_full_size(dev):
         wf, wb = ops.conv_prep(spec, d, w, None, True, True)
         x1 = torch.randn(128, H, H, cin, generator=g).to(dev)
         x2 = torch.randn(128, H, H, cin, generator=g).to(dev)
-        f = lambda t: ops.conv_fwd(spec, d, t, wf, None)
+        f = lambda t: ops.f32(ops.conv_fwd(spec, d, t, wf, None))        # (a three-plane result in 'fp32x3' mode: joined, exactly)
         lhs, rhs = f(0.5 * x1 - 2.0 * x2), 0.5 * f(x1) - 2.0 * f(x2)
         assert float((lhs - rhs).abs().max()) <= 2e-5 * float(rhs.abs().max())
         g1 = torch.randn(128, OH, OW, cout, generator=g).to(dev)
         g2 = torch.randn(128, OH, OW, cout, generator=g).to(dev)
-        b = lambda t: ops.conv_bwd_data(spec, d, t, wb)
+        b = lambda t: ops.f32(ops.conv_bwd_data(spec, d, t, wb))
         lhs, rhs = b(0.5 * g1 - 2.0 * g2), 0.5 * b(g1) - 2.0 * b(g2)
         assert float((lhs - rhs).abs().max()) <= 2e-5 * float(rhs.abs().max())
         wg = lambda xx, gg: ops.conv_bwd_weight(spec, d, xx, gg, w.shape, False)[0]

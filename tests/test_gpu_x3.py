@@ -211,6 +211,48 @@ def test_wgrad_halo_for_three_plane_tensors(shape, cand, dev):
         _lib.set_math('fp32')
 
 
+@pytest.mark.parametrize('shape', [(6, 12, 10, 64), (3, 16, 16, 96), (2, 9, 7, 256)], ids=lambda c: 'x'.join(map(str, c)))
+@pytest.mark.parametrize('layer', ['bn', 'bn_prelu', 'in'])
+def test_norm_layers_take_an_fp32_input_next_to_three_plane_tensors(layer, shape, dev):
+    """Storage kind IPRGAN_ST_X3_XF32 of the norm entry points: the layer's input x stays fp32 (the convolution in front of it
+    writes 4 instead of 6 bytes per element) while y, the residual, dy and dx are three-plane tensors.  Same arithmetic,
+    same summation order as the all-fp32 kernels: forward output, statistics, dx, dgamma, dbeta (and the PReLU slope
+    gradient) must be BIT-identical to the fp32 mode's."""
+    from iprgan import ops, _lib
+    B, H, W, C_ = shape
+    g = torch.Generator().manual_seed(5 + C_ + H)
+    x = (torch.randn(B, H, W, C_, generator=g) * 1.5 + 0.3).to(dev)
+    res = torch.randn(B, H, W, C_, generator=g).to(dev)
+    dy = torch.randn(B, H, W, C_, generator=g).to(dev)
+    gamma, beta = (torch.rand(C_, generator=g) + 0.5).to(dev), torch.randn(C_, generator=g).to(dev)
+    slope = torch.tensor([0.25], device=dev)
+
+    def run(planes):
+        rm, rv = torch.zeros(C_, device=dev), torch.ones(C_, device=dev)
+        r, d_ = (ops.to_kind(res, 2), ops.to_kind(dy, 2)) if planes else (res, dy)
+        if layer == 'bn':
+            y, mean, invstd = ops.bn_fwd(x, gamma, beta, rm, rv, 1e-5, 0.1, True, _lib.ACT_RELU, residual=r)
+            out = ops.bn_bwd(x, y, d_, gamma, mean, invstd, _lib.ACT_RELU, beta=beta)
+        elif layer == 'bn_prelu':
+            y, mean, invstd = ops.bn_prelu_fwd(x, gamma, beta, rm, rv, 1e-5, 0.1, True, slope, residual=r)
+            out = ops.bn_prelu_bwd(x, d_, gamma, beta, mean, invstd, slope)
+        else:
+            y, mean, invstd = ops.instnorm_fwd(x, gamma, beta, 1e-5, _lib.ACT_RELU, residual=r)
+            out = ops.instnorm_bwd(x, y, d_, gamma, mean, invstd, _lib.ACT_RELU, beta=beta)
+        if planes:
+            assert ops.is16(y) == 2 and ops.is16(out[0]) == 2 and ops.is16(x) == 0
+        return [ops.f32(y), mean, invstd, rm, rv, ops.f32(out[0])] + list(out[1:])
+    try:
+        _lib.set_math('fp32')
+        want = run(False)
+        _lib.set_math('fp32x3')
+        got = run(True)
+    finally:
+        _lib.set_math('fp32')
+    for i, (a_, b_) in enumerate(zip(got, want)):
+        assert torch.equal(a_, b_), f'output {i}: max diff {float((a_ - b_).abs().max()):.3e}'
+
+
 RGB_SHAPES = [  # B, cin, cout, k, stride, pad, H, W, transposed, reflect: one side RGB (fp32), the other 64 channels (planes)
     (6, 3, 64, 3, 1, 1, 24, 20, False, False),      # SNDiscriminator stem (sn_discriminator.py:9): dy is the three-plane side
     (4, 64, 3, 3, 1, 1, 16, 24, True, False),       # ConvGenerator head (conv_generator.py:21): x is
