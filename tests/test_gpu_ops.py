@@ -1216,3 +1216,27 @@ def test_integration_md_ctypes_stub(dev):
     y = ns['sn_conv3x3_lrelu'](x.to(dev), w0.to(dev), u0.to(dev), v0.to(dev), conv.bias.detach().to(dev))
     torch.cuda.synchronize()
     close(from_nhwc(y.cpu(), 16), ref, what='INTEGRATION.md stub')
+
+
+@pytest.mark.parametrize('n_img,pool_n,shape', [(8, 50, (3, 32, 32)), (1, 4, (3, 7, 5)), (70, 80, (1, 3, 3))])
+def test_pool_swap_and_write_ints(dev, n_img, pool_n, shape):
+    """iprgan_write_ints + iprgan_pool_swap (ImagePool's swap branch, models/util.py:27-34, with the draws in device memory):
+    the same result as the reference's three indexed copies, for odd sizes (scalar tail) and more than 64 entries (two
+    launches of the by-value writer)."""
+    from iprgan import ops
+    g = torch.Generator().manual_seed(11 + n_img)
+    images = torch.randn(n_img, *shape, generator=g)
+    pool = torch.randn(pool_n, *shape, generator=g)
+    prob = torch.rand(n_img, generator=g) > 0.5
+    index = torch.randperm(pool_n, generator=g)[:n_img]
+    want_img, want_pool = images.clone(), pool.clone()
+    taken = want_pool[index[prob]].clone()
+    want_pool[index[prob]] = want_img[prob]
+    want_img[prob] = taken
+    img_d, pool_d = images.to(dev), pool.to(dev)
+    tbl = torch.zeros(2, n_img + 3, dtype=torch.int32, device=dev)
+    ops.write_ints(tbl[0], index.tolist())
+    ops.write_ints(tbl[1], [int(p) for p in prob.tolist()])
+    assert tbl[0, :n_img].cpu().tolist() == index.tolist() and tbl[1, :n_img].cpu().tolist() == [int(p) for p in prob.tolist()]
+    ops.pool_swap(img_d, pool_d, tbl[0], tbl[1])
+    assert torch.equal(img_d.cpu(), want_img) and torch.equal(pool_d.cpu(), want_pool)
