@@ -94,7 +94,11 @@ class GraphedStep:
         # device never executed (a checkpoint written later would resume with bias corrections one step ahead)
         saved = [(sh, sh['step']) for o in self.opts for sh in getattr(o, '_fast', {}).values()]
         try:
-            with torch.cuda.graph(g):
+            # N > 1: RCCL's proxy threads make runtime calls of their own while this thread captures; in the default 'global'
+            # mode any such call from ANY thread invalidates the capture ("operation not permitted when stream is capturing"),
+            # 'thread_local' only polices the capturing thread (what PyTorch prescribes for NCCL inside graphs)
+            mode = 'thread_local' if nranks > 1 else 'global'
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 self.body(self.static)
         except Exception as e:                    # not capturable here: stay eager (the half-captured call did no device work)
             self.failed = f'{type(e).__name__}: {e}'
