@@ -52,7 +52,7 @@ PEAK_BF16_MFMA = 2500e12          # dense bf16 MFMA (MI355X_MICROARCH.md); only 
 # --math fp32x3: an fp32 product block is SIX bf16 MFMAs (operands split into three bf16 terms, conv_igemm.hip SPLIT), so
 # the matrix pipe bounds the fp32-equivalent rate at a sixth of the dense bf16 peak
 PEAK_X3_MFMA = PEAK_BF16_MFMA / 6
-PROF_EVERY = int(os.environ.get('IPRGAN_BENCH_PROF_EVERY', '4'))
+PROF_STEPS = int(os.environ.get('IPRGAN_BENCH_PROF_STEPS', '0'))    # eager, instrumented steps AFTER the timed region (0 = K / 4, 2 ... 25)
 WBOX_CFG = {'gamma_0': 0.1, 'string': 'EXAMPLE A'}
 ADAM_GAN = {'lr': 2.0e-4, 'betas': [0.5, 0.999]}
 
@@ -278,7 +278,7 @@ def main():
                          "keeps activations with a multiple of 64 channels as bf16 in HBM")
     ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
                     help="capture the whole step in one HIP graph (iprgan/graphs.py): 'auto' = where the step is "
-                         "capturable (all workloads; N > 1 with the C ABI's communicator); steps sampled by the per-kernel timer run eagerly")
+                         "capturable (all workloads; N > 1: opt-in with 'on', through the C ABI's communicator); the per-kernel timer's steps run eagerly AFTER the timed region")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     heavy = args.workload in ('cyclegan', 'dcgan128')
@@ -324,15 +324,15 @@ def main():
     model, step_fn = make_workload(args.workload, [device], (Config, models))
     graphed = None
     # (auto: only when the capture - two eager calls, then the capturing one - fits inside the warm-up)
-    # (N > 1: the gradient exchange is captured with the step when it goes through the C ABI's communicator; GraphedStep
-    # stays eager - `failed` says why - when the transport turns out to be torch.distributed)
+    # (N > 1: capture is opt-in, `--graph on` - the exchange is then captured with the step when it goes through the C ABI's
+    # communicator; GraphedStep stays eager on every rank - `failed` says why - otherwise)
     if args.graph != 'off' and hasattr(step_fn, 'graph_spec') and (args.graph == 'on' or args.warmup >= 4):
         from iprgan import graphs
         body, inputs_of = step_fn.graph_spec
-        graphed = graphs.GraphedStep(model, body, inputs_of(0), warmup=max(2, args.warmup - 2))
+        graphed = graphs.GraphedStep(model, body, inputs_of(0), warmup=max(2, args.warmup - 2), allow_ddp=(args.graph == 'on'))
         eager_step = step_fn
 
-        def step_fn(i, eager=False):              # noqa: F811  (sampled steps carry HIP events: they cannot be replayed)
+        def step_fn(i, eager=False):              # noqa: F811  (the instrumented steps carry HIP events: they cannot be replayed)
             graphed(inputs_of(i), eager=eager)
     elif args.graph == 'on':
         raise SystemExit(f'bench.py: --graph on is not available for {args.workload}')
@@ -345,6 +345,11 @@ def main():
             step_fn(i, eager=(i == args.warmup - 1))
         else:
             step_fn(i)
+        if world > 1 and i == 0:
+            # every layer geometry of the step has been autotuned by now: all ranks adopt rank 0's choices, so that the
+            # replicas run the same tiles (summation orders) whatever their own timings said
+            from iprgan import parallel
+            parallel.sync_autotune()
     _lib.prof_enable(False)
     _lib.prof_results()
     torch.cuda.synchronize()
@@ -360,13 +365,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Per-kernel HIP events ride on the conv-family dispatches of every PROF_EVERY-th step of the timed region
-    # (all steps when K < 2 * PROF_EVERY): timing every launch costs ~0.3 ms of a 12 ms step in completion-signal
-    # handling, and the headline value should not pay for its own instrumentation.
-    every = PROF_EVERY if (args.steps >= 2 * PROF_EVERY or PROF_EVERY <= 0) else 1
-    # one device timestamp per step boundary (an event on the launch stream: torch's current stream is the one the library
-    # launches on): median / p10 / p90 of the per-step device times next to the mean of the window
+    # The timed region holds NOTHING but the K steps (replays of the captured step where the step is capturable): the
+    # per-kernel HIP events of `roofline` / `conv_kernels` are taken in a SECOND window of eager steps behind the closing
+    # fence (`value` no longer pays for its own instrumentation).
+    # One device timestamp per step boundary (an event on the launch stream: torch's current stream is the one the library
+    # launches on): median / p10 / p90 of the per-step device times next to the mean of the window.
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    _lib.prof_enable(False)
     fence()
     replays_before = graphed.replays if graphed is not None else 0
     t0 = time.perf_counter()
@@ -374,13 +379,11 @@ def main():
     host_replayed, n_replayed = 0.0, 0                 # host time of the steps that went out as one graph launch
     marks[0].record()
     for i in range(args.steps):
-        sampled = every > 0 and i % every == 0
-        _lib.prof_enable(sampled)
         th = time.perf_counter()
         if graphed is not None:
             r0 = graphed.replays
-            step_fn(i, eager=sampled)
-            if graphed.replays > r0 and not sampled:
+            step_fn(i)
+            if graphed.replays > r0:
                 host_replayed += time.perf_counter() - th
                 n_replayed += 1
         else:
@@ -391,14 +394,23 @@ def main():
     replays_timed = (graphed.replays - replays_before) if graphed is not None else 0
     fence()
     elapsed = time.perf_counter() - t0
-    _lib.prof_enable(False)
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]          # noqa: E731
-    prof_steps = len(range(0, args.steps, every)) if every > 0 else 1
     log(f'timed {args.steps} steps in {elapsed:.3f}s')
     if os.environ.get('IPRGAN_BENCH_STAMPS'):
         log('per-step host ms: ' + ' '.join(f'{(b - a) * 1e3:.1f}' for a, b in zip([t0] + stamps[:-1], stamps)) +
             f' | final sync {(t0 + elapsed - stamps[-1]) * 1e3:.1f}')
+    # second window: the same steps enqueued kernel by kernel with a HIP-event pair on every conv-family dispatch
+    prof_steps = PROF_STEPS if PROF_STEPS > 0 else max(2, min(25, args.steps // 4))
+    _lib.prof_results()
+    _lib.prof_enable(True)
+    for i in range(prof_steps):
+        if graphed is not None:
+            step_fn(args.steps + i, eager=True)
+        else:
+            step_fn(args.steps + i)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
     kernels = [k for k in _lib.prof_results() if k['launches']]
     if os.environ.get('IPRGAN_BENCH_LAYERS') and rank == 0:     # per-layer table of the sampled steps, to stderr
         rows = sorted(_lib.prof_layers(), key=lambda r: -r['ms'])
@@ -492,7 +504,8 @@ def main():
                     'peak': round(peak / 1e12, 1), 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                     'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
-                    'source': 'HIP events on the launch stream, this run'}
+                    'source': f'HIP events on the launch stream, this run: second window of {prof_steps} eager steps behind '
+                              'the closing fence of the timed region (no instrumented step inside `value`)'}
         conv_ms = sum(k['ms'] for k in kernels)
         conv_flops = sum(k['flops'] for k in kernels)
         out = {
@@ -502,6 +515,9 @@ def main():
             'ms_per_step_p90': round(pct(0.9), 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.math in ('fp32', 'fp32x3') else 'bf16',
+            # which arithmetic produced `value` (r03 and earlier: 'fp32' = the exact fp32 MFMA; since r04 the default is
+            # 'fp32x3'; the other fp32 mode of the same run is under `alt_math`)
+            'math_mode': args.math,
             'data': 'synthetic',
             'config': {'workload': wl['text'] + ', ' +
                                    {'fp32': 'fp32 (exact fp32 MFMA)', 'fp32x3': 'fp32 tensors stored as three exact bf16 planes (x = h + m + l), fp32-grade products from six bf16 MFMAs per block with fp32 accumulation', 'bf16': 'bf16 MFMA tiles (fp32 accumulate, fp32 tensors and master weights)',
@@ -519,8 +535,7 @@ def main():
                                            for k in kernels]},
             'alt_math': alt,
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
-            # ... of the steps replayed from the captured graph alone (the sampled steps of this run are enqueued kernel
-            # by kernel for the per-kernel timer; a training run replays every step)
+            # ... of the steps replayed from the captured graph alone (= all timed steps once the step is captured)
             'host_enqueue_ms_per_replayed_step': round(host_replayed / n_replayed * 1e3, 3) if n_replayed else None,
             'graph': ({'captured': graphed.graph is not None, 'replays_in_timed_region': replays_timed,
                        'eager_steps_in_timed_region': args.steps - replays_timed, 'failed': graphed.failed}

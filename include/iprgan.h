@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 222
+#define IPRGAN_VERSION 223
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -419,6 +419,14 @@ int iprgan_debug_force_tiles(int gconv_tile, int wgrad_cand);
 /* test hook: force the split count (1..4) of the split-K path that convolutions with few output tiles take when their
  * workspace is passed (iprgan_conv_fwd_ws_floats / iprgan_conv_bwd_data_ws_floats); -1 = autotuned. */
 int iprgan_debug_force_splitk(int splits);
+/* The autotuner's table (process-global, mutex-guarded) as flat records of IPRGAN_TUNE_RECORD_INTS ints each (16 ints of
+ * geometry key + the chosen tile / candidate), HOST memory.  export: *count = records in the table; up to cap_records are
+ * written when `records` is not NULL.  import: inserts / overwrites (replace != 0: the table is cleared first).  The ranks of
+ * a data-parallel job adopt rank 0's table after the first step (iprgan/parallel.py: sync_autotune), so that every replica
+ * runs the same tiles; the reference's counterpart is cudnn.benchmark = True deciding per process (train.py:44-45). */
+#define IPRGAN_TUNE_RECORD_INTS 17
+int iprgan_tune_export(int* records, size_t cap_records, size_t* count);
+int iprgan_tune_import(const int* records, size_t n_records, int replace);
 
 /* ---- misc elementwise ----------------------------------------------------------------------- */
 int iprgan_fill(float* p, float v, size_t n, void* stream);

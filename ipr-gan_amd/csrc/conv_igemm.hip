@@ -3120,6 +3120,35 @@ int iprgan_debug_force_splitk(int splits) {
   return 0;
 }
 
+// The autotuner's table as flat records of IPRGAN_TUNE_RECORD_INTS ints (16 key ints + the choice), so that the ranks of a
+// data-parallel job can adopt ONE rank's choices (iprgan/parallel.py: sync_autotune): every replica then runs the same tiles
+// - the same summation orders - whatever its own timings said.
+int iprgan_tune_export(int* records, size_t cap_records, size_t* count) {
+  IPR_CHECK(count, "tune_export: null count");
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  tune_load();
+  *count = g_tune.size();
+  if (!records) return 0;
+  size_t i = 0;
+  for (auto it = g_tune.begin(); it != g_tune.end() && i < cap_records; ++it, ++i) {
+    memcpy(records + i * IPRGAN_TUNE_RECORD_INTS, it->first.v, sizeof(it->first.v));
+    records[i * IPRGAN_TUNE_RECORD_INTS + 16] = it->second;
+  }
+  return 0;
+}
+int iprgan_tune_import(const int* records, size_t n_records, int replace) {
+  IPR_CHECK(records || !n_records, "tune_import: null records");
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  tune_load();
+  if (replace) g_tune.clear();
+  for (size_t i = 0; i < n_records; ++i) {
+    TuneKey k;
+    memcpy(k.v, records + i * IPRGAN_TUNE_RECORD_INTS, sizeof(k.v));
+    g_tune[k] = records[i * IPRGAN_TUNE_RECORD_INTS + 16];
+  }
+  return 0;
+}
+
 int iprgan_prof_enable(int on) {
   if (on) {
     for (int i = 0; i < g_nslots; ++i) { g_slots[i].launches = 0; g_slots[i].ms = 0; g_slots[i].flops = 0; }

@@ -121,9 +121,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
   const unsigned lds_base = (unsigned)(uintptr_t)lds;
   // wave-uniform walk over (channel chunk, tap): taps inside a 32-channel chunk, so that consecutive K steps re-read the
   // same pixels, shifted (they stay in L2)
+  // korder bit 0 (A/B, IPRGAN_X3P_KORDER): channel chunks inside a tap - consecutive steps read the two (or more) 64-byte
+  // pieces of the SAME 128-byte lines of a pixel's channel vector, one after the other
+  const bool chunk_fast = (a.korder & 1) != 0;
   int u_c = 0, u_ty = 0, u_tx = 0;
   if (s_begin) {                              // (split K: the walk starts at step s_begin)
-    const int ntap = p_th * p_tw, ck = s_begin / ntap, tap = s_begin - ck * ntap;
+    const int ntap = p_th * p_tw, nck = Cs / 32;
+    const int ck = chunk_fast ? s_begin % nck : s_begin / ntap, tap = chunk_fast ? s_begin / nck : s_begin - ck * ntap;
     u_c = ck * 32; u_ty = tap / p_tw; u_tx = tap - u_ty * p_tw;
   }
   int w_dy = 0, w_dx = 0, w_tapoff = 0;
@@ -135,7 +139,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
     w_sbase = lds_base + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
   };
   auto walk_next = [&]() {
-    if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; u_c += 32; } }
+    if (chunk_fast) {
+      u_c += 32;
+      if (u_c == Cs) { u_c = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
+    } else if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; u_c += 32; } }
   };
   // piece q of the stage: q < 3 * RSA: plane q / RSA of the activation rows of row set q % RSA; then the weight rows
   auto piece = [&](int q) {
@@ -833,14 +840,17 @@ static void x3p_go(const GConvArgs& a, dim3 grid, dim3 block, size_t smem, hipSt
 }
 
 template <int WGM, int WGN, int WM, int WN, int NSTAGE>
-static int launch_x3p_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
+static int launch_x3p_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   int maxM = 0;
-  for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
+  for (int i = 0; i < a_in.nphase; ++i) maxM = a_in.ph[i].M > maxM ? a_in.ph[i].M : maxM;
   if (maxM == 0) return 0;
   const size_t smem = (size_t)NSTAGE * 3 * (BM + BN) * 64;
-  dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.ksplit > 1 ? a.ksplit : a.nphase);
+  dim3 grid(cdiv(maxM, BM), cdiv(a_in.Ns, BN), a_in.ksplit > 1 ? a_in.ksplit : a_in.nphase);
   *bm_out = BM;
+  static const int korder = getenv("IPRGAN_X3P_KORDER") ? atoi(getenv("IPRGAN_X3P_KORDER")) : 0;
+  GConvArgs a = a_in;
+  a.korder = korder;
   constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * 3 * (BM + BN) * 64>::PF_FIRST;
   const bool pref = a.aux && a.aux16 == 1 && can_pf;
   const dim3 block(WGM * WGN * 64);

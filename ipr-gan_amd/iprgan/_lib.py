@@ -108,6 +108,8 @@ SIGNATURES = {
                              _P, C.c_double, _P]),
     'iprgan_debug_force_tiles': (_I, [_I, _I]),
     'iprgan_debug_force_splitk': (_I, [_I]),
+    'iprgan_tune_export': (_I, [_P, _Z, _P]),
+    'iprgan_tune_import': (_I, [_P, _Z, _I]),
     'iprgan_set_math_mode': (_I, [_I]),
     'iprgan_get_math_mode': (_I, []),
     'iprgan_prof_enable': (_I, [_I]),

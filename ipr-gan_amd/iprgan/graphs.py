@@ -9,7 +9,10 @@ autograd engine's backward thread inherits it - and from then on replays the gra
 
 Data-parallel runs (N > 1) capture the same way when the buckets travel through the C ABI's communicator
 (``iprgan_allreduce_bucket`` on the reducer's side stream: forked off and joined back inside the capture); with
-torch.distributed as the transport the step stays eager.
+torch.distributed as the transport the step stays eager.  Capture at N > 1 is OPT-IN (``allow_ddp``: bench.py ``--graph on``,
+train.py ``engine: {graph_ddp: true}``) until it has run on a real multi-GPU communicator: on this 1-GPU pool only a test
+double (tests/stub_rccl.cpp) and the 1-rank real communicator have exercised it.  The outcome of a capture is AGREED across
+ranks (all-reduce MIN of the success flag over torch.distributed): every rank replays or every rank stays eager.
 
 What makes the step capturable:
   * inputs live in static device tensors (``copy_`` before each replay);
@@ -58,8 +61,9 @@ class GraphedStep:
     then as a captured graph.  ``body`` takes the dict of STATIC input tensors and performs one whole training step on
     ``model`` (e.g. ``update_d`` then ``update_g``).  ``step(inputs, eager=True)`` forces an eager step (profiling runs)."""
 
-    def __init__(self, model, body, inputs, warmup=3):
+    def __init__(self, model, body, inputs, warmup=3, allow_ddp=False):
         self.model, self.body = model, body
+        self.allow_ddp = bool(allow_ddp)
         self.static = {k: v.detach().clone() for k, v in inputs.items()}
         self.warm = int(warmup)
         self.graph, self.failed, self.replays = None, None, 0
@@ -78,12 +82,19 @@ class GraphedStep:
     def _capture(self):
         from . import parallel
         rank, nranks = parallel.world()
+        # (both refusals below are decided from facts every rank shares - the flag, the collectively chosen transport - so
+        # no rank enters the agreement collective further down alone)
+        if nranks > 1 and not self.allow_ddp:
+            self.failed = 'capture at N > 1 is opt-in (bench.py --graph on / engine.graph_ddp): unproven on a real multi-GPU communicator'
+            return False
         if nranks > 1 and parallel.transport_name() != 'rccl-abi':
             # the gradient exchange is part of the step: through the C ABI's communicator it is forked / joined inside the
             # capture (parallel.GradReducer._launch); torch.distributed's collectives (gloo test path, fallback) are not
             self.failed = f'gradient exchange over {parallel.transport_name()} cannot be captured'
             return False
         torch.cuda.synchronize()
+        if nranks > 1:
+            parallel.sync_autotune()              # the tiles the graph bakes in are the same on every rank
         # version-keyed operand caches must not be HIT inside the capture (engine.drop_operand_caches)
         for m in _chain(self.model):
             for sub in (m.__dict__.get('_modules') or {}).values():
@@ -102,15 +113,55 @@ class GraphedStep:
                 self.body(self.static)
         except Exception as e:                    # not capturable here: stay eager (the half-captured call did no device work)
             self.failed = f'{type(e).__name__}: {e}'
+        if self.failed is None:
+            # every optimizer the replay will book-keep for must have stepped on the device-counter path inside the capture:
+            # a group the body never steps (or stepped on the host path) would make every replay advance device state and
+            # then fail in Adam.replayed() on the host - decided HERE, once, not after the first replay
+            missing = [i for i, o in enumerate(self.opts) for gr in o.param_groups
+                       if gr['params'] and 'step_dev' not in getattr(o, '_fast', {}).get(id(gr), {})]
+            if missing:
+                self.failed = f'optimizer(s) {sorted(set(missing))} have a parameter group without a device-side step counter after the capture'
+        if nranks > 1:
+            # one rank eager while its peers replay would still exchange matching buckets, but a rank that aborted mid-capture
+            # and one that did not must not disagree about WHAT the next call does: agree on the outcome
+            ok = parallel._all_ranks_ok(self.failed is None, self._agree_device())
+            if not ok and self.failed is None:
+                self.failed = 'a peer rank could not capture the step'
+        if self.failed is not None:
+            del g
             for sh, step in saved:
                 sh['step'] = step
                 sh['step_t'].fill_(step)
+            self._reset_reducers()
             torch.cuda.synchronize()
             return False
         self.graph = g
         self._lrs = self._hyper()
         self._snapshot()
         return True
+
+    def _agree_device(self):
+        """Device of the flag tensor of the agreement collective: the GPU under torch.distributed's nccl backend, the host
+        under gloo (test ranks sharing one GPU)."""
+        import torch.distributed as dist
+        return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+
+    def _reset_reducers(self):
+        """After an aborted capture: the reducers' per-step state belongs to the dead capture (a pending-pass count that
+        never counted down, bucket events recorded into the discarded graph).  The next eager step arms them afresh."""
+        from . import parallel
+        seen = {}
+        for o in self.opts:
+            for gr in o.param_groups:
+                for p in gr['params']:
+                    r = parallel.owner_of(p)
+                    if r is not None:
+                        seen[id(r)] = r
+        for r in seen.values():
+            r.armed, r.in_final, r.pending = False, False, 0
+            for b in (r.buckets or ()):
+                b['left'], b['launched'], b['done'] = 0, False, None
+                b.pop('ready', None)
 
     def _hyper(self):
         """Hyper-parameters that travel BY VALUE in the captured Adam launches: a change (SRGAN's lr *= 0.1, a scheduler)

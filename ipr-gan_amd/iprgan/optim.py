@@ -79,8 +79,11 @@ class Adam(Optimizer):
         for group in self.param_groups:
             sh = getattr(self, '_fast', {}).get(id(group))
             if sh is None or 'step_dev' not in sh:
-                raise RuntimeError('optim.Adam.replayed(): a parameter group has no device-side step counter - its step was '
-                                   'captured on the slow path (frozen bias corrections); the graph must not be replayed')
+                # not part of the captured step (an empty group, an optimizer the body never steps): nothing moved on the
+                # device, nothing to book-keep.  graphs.GraphedStep._capture refuses, ONCE, a capture that leaves a
+                # non-empty group of its optimizers without a device counter - never a crash behind a replay that has
+                # already advanced device state
+                continue
             sh['step'] += 1
             sh['step_t'].fill_(sh['step'])
             torch.autograd.graph.increment_version(group['params'])

@@ -451,6 +451,40 @@ class GradReducer:
                 del _owner[id(p)]
 
 
+def tune_table():
+    """The library's autotune table as a list of 17-int records (include/iprgan.h: iprgan_tune_export)."""
+    from . import _lib as L
+    n = C.c_size_t(0)
+    L.call('iprgan_tune_export', None, 0, C.byref(n))
+    if not n.value:
+        return []
+    buf = (C.c_int * (17 * n.value))()
+    L.call('iprgan_tune_export', buf, n.value, C.byref(n))
+    return [list(buf[i * 17:(i + 1) * 17]) for i in range(n.value)]
+
+
+def tune_adopt(records, replace=True):
+    from . import _lib as L
+    flat = [v for r in records for v in r]
+    buf = (C.c_int * max(1, len(flat)))(*flat)
+    L.call('iprgan_tune_import', buf, len(records), 1 if replace else 0)
+
+
+def sync_autotune(src=0):
+    """Every rank adopts rank ``src``'s autotune table (call after the first step(s), when every layer geometry of the step
+    has been tuned, and before a graph capture): the replicas then launch the same tiles - the same summation orders -
+    whatever their own timings said (VERDICT r04 next #6c; the reference's cudnn.benchmark decides per process).  Geometries
+    first met later are tuned per rank again until the next call.  No-op with one rank."""
+    rank, w = world()
+    if w == 1:
+        return 0
+    box = [tune_table() if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    if rank != src:
+        tune_adopt(box[0], replace=True)
+    return len(box[0])
+
+
 def broadcast_module(module, src=0):
     """Make every rank start from rank-``src``'s parameters and buffers (replicas live for the run)."""
     _, w = world()

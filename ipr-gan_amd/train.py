@@ -138,7 +138,8 @@ class Experiment:
                 def body(s):
                     m.update_d({'real_sample': s['x'], 'latent': s['z']})
                     m.update_g({'fake_sample': m.fake_sample})
-                self._graphed = graphs.GraphedStep(m, body, {'x': x.to(dev), 'z': z.to(dev)}, warmup=3)
+                self._graphed = graphs.GraphedStep(m, body, {'x': x.to(dev), 'z': z.to(dev)}, warmup=3,
+                                                   allow_ddp=bool(self.engine.get('graph_ddp')))
             self._graphed({'x': x, 'z': z})
         elif self.kind == 'generation':
             for _ in range(d_iter):
@@ -201,6 +202,9 @@ class Experiment:
         for step in range(self.init_step, last + 1):
             self._step = step
             self.train()
+            if step == self.init_step:
+                from iprgan import parallel
+                parallel.sync_autotune()          # N > 1: every rank adopts rank 0's tile choices (no-op on one rank)
             if step == self.init_step + 1:
                 # long-lived objects out of the cyclic collector's sight: a generation-2 pass over torch's ~1 M objects
                 # stalls the enqueueing thread for ~100 ms every few dozen iterations otherwise

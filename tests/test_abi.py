@@ -23,7 +23,7 @@ def test_library_exports_every_symbol():
     lib = _lib.load()                      # raises if the .so is missing: there is no fallback
     for name in header_symbols():
         assert hasattr(lib, name), name
-    assert lib.iprgan_version() == 222
+    assert lib.iprgan_version() == 223
     assert lib.iprgan_last_error() is not None
 
 
@@ -37,3 +37,17 @@ def test_size_queries_run_without_gpu():
     assert _lib.query('iprgan_conv_wgrad_ws_floats', C.byref(d)) > 512 * 9 * 256
     d3 = ops.ConvSpec(3, 64, 3, 1, 1).desc(2, 16, 16)
     assert _lib.query('iprgan_conv_wfwd_floats', C.byref(d3)) == 128 * 64     # K = 9 taps x 4 ch -> 64
+
+
+def test_tune_table_round_trips_without_gpu():
+    """iprgan_tune_export / iprgan_tune_import (host-only): what parallel.sync_autotune ships from rank 0 to its peers."""
+    from iprgan import parallel
+    before = parallel.tune_table()
+    rec = [[7, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 21], [7, 9, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 18]]
+    parallel.tune_adopt(rec, replace=False)
+    after = parallel.tune_table()
+    assert all(r in after for r in rec) and len(after) == len(before) + 2
+    parallel.tune_adopt([[7, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 30]], replace=False)      # overwrite by key
+    assert [r[16] for r in parallel.tune_table() if r[:2] == [7, 1]] == [30]
+    parallel.tune_adopt(before, replace=True)
+    assert parallel.tune_table() == before

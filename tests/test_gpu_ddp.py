@@ -397,7 +397,7 @@ def test_bench_two_ranks_capture_the_step_with_the_exchange_inside():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(IPRGAN_SHARE_DEVICE='1', IPRGAN_DIST_BACKEND='gloo', IPRGAN_RCCL_LIB=STUB)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '12', '--warmup', '6',
-                        '--no-cpu-baseline', '--alt-math', 'none'], env=env, capture_output=True, text=True, timeout=900)
+                        '--graph', 'on', '--no-cpu-baseline', '--alt-math', 'none'], env=env, capture_output=True, text=True, timeout=900)
     for f in __import__('glob').glob('/tmp/iprgan_stub_rccl_*'):
         os.remove(f)
     assert p.returncode == 0, p.stderr[-2000:]

@@ -345,3 +345,165 @@ def test_bench_roofline_of_split_mode_is_priced_against_a_sixth_of_the_bf16_peak
     import bench
     assert bench.PEAK_X3_MFMA == pytest.approx(bench.PEAK_BF16_MFMA / 6)
     assert np.isclose(bench.PEAK_X3_MFMA / 1e12, 416.7, atol=0.1)
+
+
+# ---- the ends of fp32's exponent range (VERDICT r04 next #8a; the contract is written down in include/iprgan.h next to
+# IPRGAN_ST_X3): where "x = h + (m + l) exactly" holds, what happens below and above it, and that a convolution on
+# operands out there is still as close to float64 as the fp32 MFMA's.
+def _round_trip(x):
+    """fp32 -> three planes -> fp32 through iprgan_cast_planes (a bf16 tensor is a three-plane tensor only in 'fp32x3' mode)."""
+    from iprgan import ops, _lib
+    try:
+        _lib.set_math('fp32x3')
+        return ops.f32(ops.to_kind(x, ops.ST_X3))
+    finally:
+        _lib.set_math('fp32')
+
+
+def _mantissas(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    m = 1.0 + torch.randint(0, 1 << 23, (n,), generator=g).double() / float(1 << 23)      # 24 significant bits, all used
+    return m * torch.where(torch.rand(n, generator=g) < 0.5, -1.0, 1.0).double()
+
+
+@pytest.mark.parametrize('exp', [-110, -105, -100, -90, -30, 0, 60, 100, 120, 126])
+def test_planes_are_exact_down_to_2_to_the_minus_110_and_up_to_the_bf16_maximum(exp, dev):
+    """Every fp32 value with 2^-110 <= |x| <= 0x7F7F0000 (the largest finite bf16, 3.3895e38) round-trips bit for bit:
+    the low plane's least significant bit is x's, and bf16 reaches down to 2^-133 (subnormal)."""
+    from iprgan import ops
+    x = (_mantissas(4096, exp) * 2.0 ** exp).float()
+    x = x[x.abs() <= 3.3895313892515355e38]
+    assert x.numel() > 2000 and bool((x.double().abs() >= 2.0 ** -110).all())
+    xd = x.to(dev)
+    back = _round_trip(xd)
+    assert torch.equal(back, xd), f'2^{exp}: {int((back != xd).sum())} of {x.numel()} values changed'
+
+
+@pytest.mark.parametrize('exp', [-111, -118, -126, -130, -140, -149])
+def test_planes_below_2_to_the_minus_110_keep_the_bf16_subnormal_grid(exp, dev):
+    """Below 2^-110 the planes run out of exponent range before fp32 does: the stored value is x rounded to a multiple of
+    2^-133 (bf16's subnormal spacing) - absolute error at most 2^-134 per plane rounding, i.e. 24 significant bits at 2^-110,
+    8 at 2^-126.  Nothing becomes non-finite and signs are kept."""
+    from iprgan import ops
+    x = (_mantissas(2048, 7 - exp) * 2.0 ** exp).float()               # (fp32 subnormals below 2^-126 included)
+    xd = x.to(dev)
+    back = _round_trip(xd)
+    assert bool(torch.isfinite(back).all())
+    err = (back.double() - xd.double()).abs().max().item()
+    assert err <= 2.0 ** -133, f'2^{exp}: worst absolute error 2^{np.log2(max(err, 1e-300)):.1f}'
+    assert bool(((back == 0) | (torch.sign(back) == torch.sign(xd))).all())
+
+
+def test_planes_never_turn_a_non_finite_or_over_range_value_into_a_finite_one(dev):
+    """NaN stays NaN.  +-inf and finite values beyond the largest bf16 (|x| > 0x7F7F7FFF: h rounds to inf, the residual
+    planes are inf - inf) come back NON-FINITE (NaN) - never as a finite number, so a diverged run is still detected by
+    the finiteness checks that the fp32 mode would trip (bench.py asserts on the metrics; models/base.py has none)."""
+    from iprgan import ops
+    big = torch.tensor([0x7F7F8000, 0x7F7FFFFF, 0xFF7F8000, 0xFF7FFFFF], dtype=torch.int64).to(torch.int32).view(torch.float32)
+    x = torch.cat([torch.tensor([float('inf'), float('-inf'), float('nan')]), big, torch.tensor([1.0, -2.5, 3.3895313892515355e38])]).to(dev)
+    x = x.repeat(8)[:64].contiguous()
+    back = _round_trip(x)
+    fin = torch.isfinite(x) & (x.abs() <= 3.3895313892515355e38)
+    assert torch.equal(back[fin], x[fin])
+    assert not bool(torch.isfinite(back[~fin]).any()), back[~fin]
+
+
+@pytest.mark.parametrize('xs,ws', [(-100, 60), (-60, -40), (100, -80), (60, 40), (-110, 100)])
+def test_conv_at_the_ends_of_the_exponent_range_is_as_close_to_float64_as_the_fp32_mfma(xs, ws, dev):
+    """64 -> 128 k3 with activations at 2^xs and weights at 2^ws (products between 2^-100 and 2^100): relative rms distance to
+    the float64 convolution at or below the exact fp32 MFMA's, for y, dx and dw - the planes carry the full mantissa over
+    the whole range the product itself survives in."""
+    from iprgan import ops, _lib
+    g = torch.Generator().manual_seed(99 + xs)
+    B, cin, cout, H = 4, 64, 128, 16
+    spec = ops.ConvSpec(cin, cout, 3, 1, 1, 0, False)
+    x = (torch.randn(B, H, H, cin, generator=g).double() * 2.0 ** xs).float().to(dev)
+    dys = -(xs + ws) // 2              # gradients scaled so that dx = dy * w and dw = x * dy stay inside fp32's range too
+    dy = (torch.randn(B, H, H, cout, generator=g).double() * 2.0 ** dys).float().to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g).double() * 0.05 * 2.0 ** ws).float().to(dev)
+    x64, w64 = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True), w.double().cpu().requires_grad_(True)
+    F.conv2d(x64, w64, None, 1, 1).backward(dy.double().cpu().permute(0, 3, 1, 2))
+    with torch.no_grad():
+        ref = (F.conv2d(x64, w64, None, 1, 1).permute(0, 2, 3, 1), x64.grad.permute(0, 2, 3, 1), w64.grad)
+    err = {}
+    try:
+        for mode in ('fp32', 'fp32x3'):
+            _lib.set_math(mode)
+            d = spec.desc(B, H, H)
+            xk, dyk = ops.to_kind(x, d.x_bf16), ops.to_kind(dy, d.y_bf16)
+            wf, wb = ops.conv_prep(spec, d, w, None, True, True)
+            y = ops.conv_fwd(spec, d, xk, wf, None)
+            dx = ops.conv_bwd_data(spec, d, dyk, wb)
+            dw = ops.conv_bwd_weight(spec, d, xk, dyk, tuple(w.shape), False)
+            dw = dw[0] if isinstance(dw, tuple) else dw
+            got = [ops.f32(t).double().cpu() for t in (y, dx, dw)]
+            assert all(bool(torch.isfinite(t).all()) for t in got)
+            err[mode] = [float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()) for a, b in zip(got, ref)]
+    finally:
+        _lib.set_math('fp32')
+    for name, e32, ex3 in zip(('y', 'dx', 'dw'), err['fp32'], err['fp32x3']):
+        assert ex3 <= e32 + 2e-8 and ex3 < 1.5e-6, f'{name} at 2^{xs} x 2^{ws}: fp32x3 {ex3:.3e} vs fp32 {e32:.3e}'
+
+
+def test_conv_under_heavy_cancellation_of_the_leading_terms(dev):
+    """The h x h' products - everything the first accumulator of the six-MFMA form holds - cancel EXACTLY (activations +-A in
+    bf16-representable pairs against one bf16-representable weight), so the result is made of the five small terms alone:
+    x = +-A (1 + d), d ~ 2^-10, lands in the m / l planes.  The distance to float64 relative to the (tiny) result must not
+    exceed the exact fp32 MFMA's, which rounds every partial sum at the magnitude of A."""
+    from iprgan import ops, _lib
+    g = torch.Generator().manual_seed(4242)
+    B, cin, cout, H = 2, 64, 64, 12
+    spec = ops.ConvSpec(cin, cout, 3, 1, 0, 0, False)             # no padding: every output sums all 576 taps
+    sign = torch.tensor([1.0, -1.0]).repeat(cin // 2)               # channel pairs (+A, -A)
+    A = 3.0
+    delta = (torch.randn(B, H, H, cin, generator=g) * 2.0 ** -10).clamp(-2.0 ** -9, 2.0 ** -9)      # |A d| < half a bf16 ulp of A: h = +-A
+    x = (A * sign * (1.0 + delta)).float().to(dev)
+    wcol = (torch.randint(1, 8, (cout, 1, 1, 1), generator=g).float() * 0.25)           # bf16-representable, one value per output channel
+    w = wcol.expand(cout, cin, 3, 3).contiguous().to(dev)
+    x64 = x.double().cpu().permute(0, 3, 1, 2)
+    ref = F.conv2d(x64, w.double().cpu(), None, 1, 0).permute(0, 2, 3, 1)
+    lead = F.conv2d((A * sign).double().view(1, cin, 1, 1).expand(1, cin, H, H), w.double().cpu(), None, 1, 0)
+    assert float(lead.abs().max()) == 0.0                            # the leading terms really cancel
+    assert float(ref.abs().mean()) < 0.05 * A                        # ... and what is left is small against A
+    err = {}
+    try:
+        for mode in ('fp32', 'fp32x3'):
+            _lib.set_math(mode)
+            d = spec.desc(B, H, H)
+            wf, _ = ops.conv_prep(spec, d, w, None, True, False)
+            y = ops.f32(ops.conv_fwd(spec, d, ops.to_kind(x, d.x_bf16), wf, None)).double().cpu()
+            err[mode] = float((y - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    finally:
+        _lib.set_math('fp32')
+    assert err['fp32x3'] <= err['fp32'] + 2e-8, err
+
+
+def test_conv_with_a_non_finite_input_gives_non_finite_outputs_exactly_where_fp32_does(dev):
+    """One +inf and one NaN element in the activations: every output whose receptive field contains one of them is
+    non-finite in BOTH modes (the three-plane mode yields NaN where the fp32 mode yields inf: inf x 0 in the residual
+    planes), every other output is finite and equal within the fp32 tolerance."""
+    from iprgan import ops, _lib
+    g = torch.Generator().manual_seed(11)
+    B, cin, cout, H = 1, 64, 64, 16
+    spec = ops.ConvSpec(cin, cout, 3, 1, 1, 0, False)
+    x = torch.randn(B, H, H, cin, generator=g)
+    x[0, 4, 5, 7] = float('inf')
+    x[0, 11, 9, 40] = float('nan')
+    x = x.to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev)
+    out = {}
+    try:
+        for mode in ('fp32', 'fp32x3'):
+            _lib.set_math(mode)
+            d = spec.desc(B, H, H)
+            wf, _ = ops.conv_prep(spec, d, w, None, True, False)
+            out[mode] = ops.f32(ops.conv_fwd(spec, d, ops.to_kind(x, d.x_bf16), wf, None)).cpu()
+    finally:
+        _lib.set_math('fp32')
+    bad = torch.zeros(H, H, dtype=torch.bool)
+    bad[3:6, 4:7] = True
+    bad[10:13, 8:11] = True
+    for mode in out:
+        fin = torch.isfinite(out[mode][0]).all(dim=-1)
+        assert torch.equal(fin, ~bad), mode
+    np.testing.assert_allclose(out['fp32x3'][0][~bad].numpy(), out['fp32'][0][~bad].numpy(), rtol=2e-4, atol=2e-5)

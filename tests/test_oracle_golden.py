@@ -205,3 +205,14 @@ def test_ms_ssim_restatement_known_answers():
     assert 0.0 < v <= 1.0
     lossn = ssim.ms_ssim_loss(normalized=True)(x * 2 - 1, y * 2 - 1)
     assert abs(float(lossn) - (1 - float(ssim.ms_ssim(x, y)))) < 1e-5
+
+
+def test_late_step_pair_plumbing_is_exact_oracle_to_oracle():
+    """cases.run_late_step_pair (the harness of tests/test_gpu_models.py::test_late_step_moments_from_a_common_state): with the
+    oracle on both sides, the follower that loaded the leader's state reproduces the next step bit for bit - weights, buffers,
+    both Adam moments, step counts and sign buffers all travel through the reference's state_dict layout."""
+    A, B, ma, mb = cases.run_late_step_pair('dcgan', (gan.Cfg, gan, gan.CPU), (gan.Cfg, gan, gan.CPU), lead_steps=2)
+    assert ma == mb and len(A) == 84
+    for k in A:
+        assert np.array_equal(A[k], B[k]), k
+    assert all(float(A[k]) == 3.0 for k in A if k.endswith('/step'))
