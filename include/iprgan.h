@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 223
+#define IPRGAN_VERSION 224
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -440,6 +440,23 @@ int iprgan_cast_planes(const void* src, void* dst, size_t n, size_t pstride, int
  * both sides; or ONE three-plane operand next to an fp32 one - the 64-channel side of an RGB stem / head, summed h + (m + l)
  * as it is loaded), 0 if it wants fp32 copies */
 int iprgan_conv_wgrad_takes_bf16(const iprgan_conv_desc* d);
+/* Backward-weight with its slab reduce DEFERRED.  iprgan_conv_bwd_weight runs two kernels: the tiles, which leave partial
+ * weight gradients in slabs of `ws`, and a fixed-order reduce + scatter into dw (PyTorch layout; dw = beta * dw + sum).  The
+ * deferred form enqueues the tiles (and the bias gradient, if asked for) and fills *rec (HOST memory) with what the reduce needs
+ * instead of launching it; iprgan_wgrad_reduce_multi then runs the reduces of up to 24 records per launch - one launch for all
+ * layers of a backward pass instead of one per layer (19 per DCGAN-64 step), bit-identical to the undeferred results (every block
+ * performs the same additions in the same order).  The caller keeps `ws` and `dw` of every pending record alive and unmodified
+ * until the multi-reduce has been enqueued on the SAME stream; rec->pending == 0 after the call means nothing is owed (the layer
+ * took a form without slabs).  Autotuning trial launches of a first call reduce at once into their scratch area. */
+typedef struct {
+  const float* ws; float* dw;
+  int32_t nsplit, Nrows, Kw, N, C, Qs, ntap, pending;
+  int64_t sn, sc;
+  float beta;
+} iprgan_wgrad_reduce_rec;
+int iprgan_conv_bwd_weight_deferred(const iprgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db, float* ws,
+                                    float beta, void* stream, iprgan_wgrad_reduce_rec* rec);
+int iprgan_wgrad_reduce_multi(const iprgan_wgrad_reduce_rec* recs, int n, void* stream);
 int iprgan_axpy(float* y, const float* x, float a, size_t n, void* stream);   /* y += a*x */
 /* y_t += a*x_t for n tensors in one launch (HOST arrays of DEVICE pointers / element counts): the small
  * gradients of a pass (biases, norm scales, PReLU slopes) into their gradient-bucket views */

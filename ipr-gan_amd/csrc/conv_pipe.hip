@@ -115,6 +115,29 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   // XCD then fetch different 128-byte columns of the NHWC rows instead of all camping on the L2 channels of one column
   const int nchunk = Cs / KSTEP;
   int u_c = krot ? (int)(lq % (unsigned)nchunk) * KSTEP : 0, u_ty = 0, u_tx = 0, u_n = 0;
+  // korder bit 6: a stride-2 gather walks its taps grouped by parity, channel chunks innermost - the four taps through which
+  // one input pixel meets its four output positions follow each other, so its re-reads are L2 hits (conv_x3.hip:
+  // gconv_x3p_kernel; measured there: bytes from beyond L2 / 5.8 on D.conv1)
+  const bool s2walk = (a.korder & 64) != 0 && a.isy == 2 && a.isx == 2 && (p_th & 1) == 0 && (p_tw & 1) == 0;
+  const int p_hx = p_tw >> 1, p_hy = p_th >> 1;
+  int q_cls = 0, q_dy = 0, q_dx = 0;
+  if (s2walk) u_c = 0;
+  auto walk_adv = [&]() {
+    if (s2walk) {
+      u_c += KSTEP;
+      if (u_c >= Cs) {
+        u_c = 0;
+        if (++q_dx == p_hx) { q_dx = 0; if (++q_dy == p_hy) { q_dy = 0; ++q_cls; } }
+        u_ty = (q_cls >> 1) + 2 * q_dy; u_tx = (q_cls & 1) + 2 * q_dx;
+      }
+    } else if (korder) {          // taps inside a channel chunk: consecutive K steps re-read the same pixels, shifted
+      if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; u_c += KSTEP; if (u_c >= Cs) u_c = 0; } }
+    } else {
+      u_c += KSTEP;
+      if (u_c >= Cs) u_c = 0;
+      if (++u_n == nchunk) { u_n = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
+    }
+  };
   // issue the LDS-DMA of the next K step of the walk into stage buffer `buf`
   auto issue = [&](int buf) {
     const int dy = p_dy0 + u_ty * p_dys, dx = p_dx0 + u_tx * p_dxs;
@@ -139,13 +162,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
 #pragma unroll
     for (int i = 0; i < LB; ++i)
       dma16(rs_wt, sbase + A_BYTES + (unsigned)(i * NW) * 1024u, wrow[i] + wk);
-    if (korder) {                 // taps inside a channel chunk: consecutive K steps re-read the same pixels, shifted
-      if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; u_c += KSTEP; if (u_c >= Cs) u_c = 0; } }
-    } else {
-      u_c += KSTEP;
-      if (u_c >= Cs) u_c = 0;
-      if (++u_n == nchunk) { u_n = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
-    }
+    walk_adv();
   };
 
   // fragment read offsets: row (wm*WM+i)*32 + l31 of A / (wn*WN+j)*32 + l31 of B, chunk (2 kk + half) ^ swz(l31)
@@ -278,13 +295,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
     if constexpr (iss) {
 #pragma unroll
       for (; q < L; ++q) piece(q);
-      if (korder) {
-        if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; u_c += KSTEP; if (u_c >= Cs) u_c = 0; } }
-      } else {
-        u_c += KSTEP;
-        if (u_c >= Cs) u_c = 0;
-        if (++u_n == nchunk) { u_n = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
-      }
+      walk_adv();
     }
   };
 
@@ -1222,7 +1233,8 @@ static int launch_phase4(const GConvArgs& a, hipStream_t st, int* bm_out) {
 // A/B switch (GConvArgs::korder): bit 0 = taps inside a channel chunk, bit 1 = tile rows start at different chunks (measured
 // neutral: the L2 channels are not the limit), bit 4 = refill pieces woven into the MFMA stream (+5-10 % on the 8-wave bf16
 // tiles), bit 5 = the same for the fp32 tiles (+1-3 %)
-static int g_pipe_korder = getenv("IPRGAN_PIPE_KORDER") ? atoi(getenv("IPRGAN_PIPE_KORDER")) : 49;
+// bit 6 = stride-2 gathers walk their taps grouped by parity with the channel chunks innermost (round 5)
+static int g_pipe_korder = getenv("IPRGAN_PIPE_KORDER") ? atoi(getenv("IPRGAN_PIPE_KORDER")) : 49 + 64;
 
 int launch_gconv_pipe(const GConvArgs& a0, int variant, hipStream_t st, int* bm_out) {
   if (!gconv_pipe_eligible(a0)) return -1;

@@ -121,14 +121,37 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
   const unsigned lds_base = (unsigned)(uintptr_t)lds;
   // wave-uniform walk over (channel chunk, tap): taps inside a 32-channel chunk, so that consecutive K steps re-read the
   // same pixels, shifted (they stay in L2)
-  // korder bit 0 (A/B, IPRGAN_X3P_KORDER): channel chunks inside a tap - consecutive steps read the two (or more) 64-byte
-  // pieces of the SAME 128-byte lines of a pixel's channel vector, one after the other
+  // K-walk order (A/B: IPRGAN_X3P_KORDER).  bit 0: channel chunks inside a tap - consecutive steps read the 64-byte pieces of
+  // the SAME 128-byte lines of a pixel's channel vector, one after the other.  bit 1: taps of a stride-2 gather grouped by
+  // parity - (ty, tx), (ty, tx + 2), (ty + 2, tx), (ty + 2, tx + 2) are the four taps through which ONE input pixel meets the
+  // four output positions that use it; walked back to back, the re-reads of a pixel are 1-3 steps apart instead of 2 / 8 / 10
+  // (an XCD's 4 MiB L2 is turned over by its 32 CUs' stages every ~2 steps: only near re-reads are L2 hits)
   const bool chunk_fast = (a.korder & 1) != 0;
+  const int p_ntap = p_th * p_tw;
+  const bool parity = (a.korder & 2) != 0 && a.isy == 2 && a.isx == 2 && (p_th & 1) == 0 && (p_tw & 1) == 0;
+  const int p_hx = p_tw >> 1, p_hy = p_th >> 1;
   int u_c = 0, u_ty = 0, u_tx = 0;
+  int q_cls = 0, q_dy = 0, q_dx = 0;          // parity walk: class (ty & 1, tx & 1), then (ty >> 1, tx >> 1) inside it
+  auto tap_next = [&]() -> bool {             // next tap of the walk (counters only: no division in the K loop); true = wrapped
+    bool wrapped = false;
+    if (parity) {
+      if (++q_dx == p_hx) { q_dx = 0; if (++q_dy == p_hy) { q_dy = 0; if (++q_cls == 4) { q_cls = 0; wrapped = true; } } }
+      u_ty = (q_cls >> 1) + 2 * q_dy; u_tx = (q_cls & 1) + 2 * q_dx;
+    } else if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; wrapped = true; } }
+    return wrapped;
+  };
   if (s_begin) {                              // (split K: the walk starts at step s_begin)
-    const int ntap = p_th * p_tw, nck = Cs / 32;
-    const int ck = chunk_fast ? s_begin % nck : s_begin / ntap, tap = chunk_fast ? s_begin / nck : s_begin - ck * ntap;
-    u_c = ck * 32; u_ty = tap / p_tw; u_tx = tap - u_ty * p_tw;
+    const int nck = Cs / 32;
+    const int ck = chunk_fast ? s_begin % nck : s_begin / p_ntap;
+    const int j = chunk_fast ? s_begin / nck : s_begin - ck * p_ntap;
+    u_c = ck * 32;
+    if (parity) {
+      const int hq = p_hx * p_hy, r = j % hq;
+      q_cls = j / hq; q_dy = r / p_hx; q_dx = r - q_dy * p_hx;
+      u_ty = (q_cls >> 1) + 2 * q_dy; u_tx = (q_cls & 1) + 2 * q_dx;
+    } else {
+      u_ty = j / p_tw; u_tx = j - u_ty * p_tw;
+    }
   }
   int w_dy = 0, w_dx = 0, w_tapoff = 0;
   unsigned w_wk = 0, w_sbase = 0;
@@ -141,8 +164,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
   auto walk_next = [&]() {
     if (chunk_fast) {
       u_c += 32;
-      if (u_c == Cs) { u_c = 0; if (++u_tx == p_tw) { u_tx = 0; ++u_ty; } }
-    } else if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; u_c += 32; } }
+      if (u_c == Cs) { u_c = 0; tap_next(); }
+    } else if (tap_next()) u_c += 32;
   };
   // piece q of the stage: q < 3 * RSA: plane q / RSA of the activation rows of row set q % RSA; then the weight rows
   auto piece = [&](int q) {
@@ -378,7 +401,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p16_kernel(const GConv
   const unsigned lds_base = (unsigned)(uintptr_t)lds;
   // wave-uniform walk over (channel chunk, tap): taps inside a 32-channel chunk, so that consecutive K steps re-read the
   // same pixels, shifted (they stay in L2)
+  // K-walk order: GConvArgs::korder as in gconv_x3p_kernel (bit 0: channel chunks inside a tap; bit 1: the taps of a
+  // stride-2 gather grouped by parity)
+  const bool chunk_fast = (a.korder & 1) != 0;
+  const bool parity = (a.korder & 2) != 0 && a.isy == 2 && a.isx == 2 && (p_th & 1) == 0 && (p_tw & 1) == 0;
+  const int p_hx = p_tw >> 1, p_hy = p_th >> 1;
   int u_c = 0, u_ty = 0, u_tx = 0;
+  int q_cls = 0, q_dy = 0, q_dx = 0;
+  auto tap_next = [&]() -> bool {
+    bool wrapped = false;
+    if (parity) {
+      if (++q_dx == p_hx) { q_dx = 0; if (++q_dy == p_hy) { q_dy = 0; if (++q_cls == 4) { q_cls = 0; wrapped = true; } } }
+      u_ty = (q_cls >> 1) + 2 * q_dy; u_tx = (q_cls & 1) + 2 * q_dx;
+    } else if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; wrapped = true; } }
+    return wrapped;
+  };
   int w_dy = 0, w_dx = 0, w_tapoff = 0;
   unsigned w_wk = 0, w_sbase = 0;
   auto walk_begin = [&](int buf) {            // address pieces of the K step the walk points at, into stage `buf`
@@ -388,7 +425,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p16_kernel(const GConv
     w_sbase = lds_base + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
   };
   auto walk_next = [&]() {
-    if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; u_c += 32; } }
+    if (chunk_fast) {
+      u_c += 32;
+      if (u_c == Cs) { u_c = 0; tap_next(); }
+    } else if (tap_next()) u_c += 32;
   };
   // piece q of the stage: q < 3 * RSA: plane q / RSA of the activation rows of row set q % RSA; then the weight rows
   auto piece = [&](int q) {
@@ -848,9 +888,14 @@ static int launch_x3p_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
   const size_t smem = (size_t)NSTAGE * 3 * (BM + BN) * 64;
   dim3 grid(cdiv(maxM, BM), cdiv(a_in.Ns, BN), a_in.ksplit > 1 ? a_in.ksplit : a_in.nphase);
   *bm_out = BM;
-  static const int korder = getenv("IPRGAN_X3P_KORDER") ? atoi(getenv("IPRGAN_X3P_KORDER")) : 0;
+  static const int korder = getenv("IPRGAN_X3P_KORDER") ? atoi(getenv("IPRGAN_X3P_KORDER")) : -1;      // A/B override
   GConvArgs a = a_in;
-  a.korder = korder;
+  // K-walk order (gconv_x3p_kernel: korder).  Stride-2 gathers (Conv2d k4 s2 forward, ConvTranspose2d k4 s2 backward-data)
+  // walk their taps grouped by parity with the channel chunks innermost: measured on D.conv1 (64 -> 64 k4 s2 @64x64, batch
+  // 128; profiles/r05_dconv1_korder_tcc.txt) bytes fetched from beyond the XCD's L2 803 -> 138 MB per launch (the tensor is
+  // 201 MB: every pixel used to arrive four times), forward 99 -> 144 TFLOP/s; G.up2's backward-data 135 -> 188.  Stride-1
+  // gathers keep taps-inside-chunk (chunks innermost costs the 64-column k3 layers 5-30 %).
+  a.korder = korder >= 0 ? korder : ((a.isy == 2 && a.isx == 2) ? 3 : 0);
   constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * 3 * (BM + BN) * 64>::PF_FIRST;
   const bool pref = a.aux && a.aux16 == 1 && can_pf;
   const dim3 block(WGM * WGN * 64);
@@ -927,15 +972,18 @@ int launch_gconv_x3h(const GConvArgs& a, int variant, hipStream_t st, int* bm_ou
 }
 
 template <int WGM, int WGN, int WM, int WN, int NSTAGE>
-static int launch_x3p16_t(const GConvArgs& a, hipStream_t st, int* bm_out) {
+static int launch_x3p16_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   int maxM = 0;
-  for (int i = 0; i < a.nphase; ++i) maxM = a.ph[i].M > maxM ? a.ph[i].M : maxM;
+  for (int i = 0; i < a_in.nphase; ++i) maxM = a_in.ph[i].M > maxM ? a_in.ph[i].M : maxM;
   if (maxM == 0) return 0;
   const size_t smem = (size_t)NSTAGE * 3 * (BM + BN) * 64;
-  dim3 grid(cdiv(maxM, BM), cdiv(a.Ns, BN), a.nphase);
+  dim3 grid(cdiv(maxM, BM), cdiv(a_in.Ns, BN), a_in.nphase);
   *bm_out = BM;
   const dim3 block(WGM * WGN * 64);
+  static const int korder = getenv("IPRGAN_X3P_KORDER") ? atoi(getenv("IPRGAN_X3P_KORDER")) : -1;
+  GConvArgs a = a_in;
+  a.korder = korder >= 0 ? korder : ((a.isy == 2 && a.isx == 2) ? 3 : 0);       // (launch_x3p_t)
   if (a.stat_part) x3p_go<gconv_x3p16_kernel<WGM, WGN, WM, WN, NSTAGE, true, false>>(a, grid, block, smem, st);
   else x3p_go<gconv_x3p16_kernel<WGM, WGN, WM, WN, NSTAGE, false, false>>(a, grid, block, smem, st);
   IPR_LAUNCH_CHECK();

@@ -26,6 +26,12 @@ class ConvDesc(C.Structure):
                                                      ('x_pstride', C.c_int64), ('y_pstride', C.c_int64)]
 
 
+class WGradReduceRec(C.Structure):
+    """iprgan_wgrad_reduce_rec (include/iprgan.h): what a deferred backward-weight call owes."""
+    _fields_ = [('ws', C.c_void_p), ('dw', C.c_void_p)] + [(n, C.c_int32) for n in
+                ('nsplit', 'Nrows', 'Kw', 'N', 'C', 'Qs', 'ntap', 'pending')] + [('sn', C.c_int64), ('sc', C.c_int64), ('beta', C.c_float)]
+
+
 _P, _F, _I, _Z, _LL = C.c_void_p, C.c_float, C.c_int, C.c_size_t, C.c_longlong
 _D = C.POINTER(ConvDesc)
 
@@ -57,6 +63,8 @@ SIGNATURES = {
     'iprgan_cast': (_I, [_P, _P, _Z, _I, _I, _P]),
     'iprgan_cast_planes': (_I, [_P, _P, _Z, _Z, _I, _P]),
     'iprgan_conv_wgrad_takes_bf16': (_I, [_D]),
+    'iprgan_conv_bwd_weight_deferred': (_I, [_D, _P, _P, _P, _P, _P, _F, _P, _P]),
+    'iprgan_wgrad_reduce_multi': (_I, [_P, _I, _P]),
     'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _Z, _P]),
     'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _Z, _Z, _P]),
     'iprgan_bn_ws_floats': (_Z, [_I, _I]),

@@ -186,8 +186,8 @@ class Conv(Op):
             B2 = d.B // 2
             dh = sp.desc(B2, d.H, d.W)
             x_ = st['x']
-            dwa, _ = ops.conv_bwd_weight(sp, dh, x_[:B2], dy[:B2], self.weight.shape, False)
-            dwb, _ = ops.conv_bwd_weight(sp, dh, x_[B2:], dy[B2:], self.weight.shape, False)
+            dwa, _ = ops.conv_bwd_weight(sp, dh, x_[:B2], dy[:B2], self.weight.shape, False, defer=st.get('wg_defer'))
+            dwb, _ = ops.conv_bwd_weight(sp, dh, x_[B2:], dy[B2:], self.weight.shape, False, defer=st.get('wg_defer'))
             st['dwsn'] = [(dwa, st['uv'][0][0], st['uv'][0][1], pair[0]), (dwb, st['uv'][1][0], st['uv'][1][1], pair[1])]
             dbp = st.get('db_part')
             db = (ops.colsum_partials(dbp[0], dbp[1], dy.shape[-1], sp.cout) if dbp is not None
@@ -206,12 +206,12 @@ class Conv(Op):
             want_b = has_b and db_done is None
             if sink is not None and self.sn is None:
                 ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, want_b, dw=sink.view_of(self.weight),
-                                    db=sink.view_of(self.bias) if want_b else None, beta=1.0)
+                                    db=sink.view_of(self.bias) if want_b else None, beta=1.0, defer=st.get('wg_defer'))
                 grads = [DIRECT] + ([DIRECT] if has_b else [])
             else:
                 # (spectral norm: dW_sn is a temporary - the batched SN backward accumulates dW_orig into the view -
                 # and the bias gradient joins the pass's small-gradient add)
-                dw, db = ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, want_b)
+                dw, db = ops.conv_bwd_weight(sp, d, st['x'], dy, self.weight.shape, want_b, defer=st.get('wg_defer'))
                 grads = [dw] + ([db if want_b else db_done] if has_b else [])
             if self.sn is not None:         # spectral-norm backward of all layers is batched by ChainFn.backward
                 st['dwsn'] = [(dw, st['u'], st['v'], st['sigma'])]
@@ -730,13 +730,16 @@ class ChainFn(torch.autograd.Function):
             red.params_done([p for p in red.params if p not in mine])
         grads_per_op = [None] * len(ops_list)
         small_dst, small_src, sn_wait = [], [], []
+        wg_wait = []        # slab reduces the convolutions of this pass owe (ops.conv_bwd_weight(defer=...)): one launch in flush()
 
         small_seen = set()
 
         def flush():
             """deferred writes into the bucket views: spectral-norm backward of the layers seen so far (batched; a paired
             pass has two (dW_sn, u, v, sigma) entries per layer: two rounds, the second accumulating) and the small
-            gradients (one multi-tensor add)"""
+            gradients (one multi-tensor add); first of all the slab reduces of the weight gradients, which the spectral-norm
+            backward reads"""
+            ops.wgrad_reduce_flush(wg_wait)
             if sn_wait:
                 out_of = {i: (red.view_of(ops_list[i].weight) if sink is not None else torch.empty_like(ops_list[i].weight))
                           for i in sn_wait}
@@ -799,6 +802,8 @@ class ChainFn(torch.autograd.Function):
                     and i - 1 >= first_needed):
                 pst = stash[i - 1]
                 st['bn_fuse'] = (pst['x'], pst['mean'], pst['invstd'], prev.m.weight, prev.m.bias, prev.act, prev.slope)
+            if isinstance(op, Conv):
+                st['wg_defer'] = wg_wait
             g, pg = op.backward(g, st, need_dx, op_need_w[i], fuse, sink)
             if 'bn_partials' in st:
                 stash[i - 1]['dz_partials'] = st.pop('bn_partials')

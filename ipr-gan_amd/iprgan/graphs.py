@@ -61,9 +61,12 @@ class GraphedStep:
     then as a captured graph.  ``body`` takes the dict of STATIC input tensors and performs one whole training step on
     ``model`` (e.g. ``update_d`` then ``update_g``).  ``step(inputs, eager=True)`` forces an eager step (profiling runs)."""
 
-    def __init__(self, model, body, inputs, warmup=3, allow_ddp=False):
+    def __init__(self, model, body, inputs, warmup=3, allow_ddp=False, capture_mode=None):
         self.model, self.body = model, body
         self.allow_ddp = bool(allow_ddp)
+        # 'global' / 'thread_local' / None = by rank count (see _capture); IPRGAN_GRAPH_CAPTURE_MODE overrides None
+        import os
+        self.capture_mode = capture_mode or os.environ.get('IPRGAN_GRAPH_CAPTURE_MODE') or None
         self.static = {k: v.detach().clone() for k, v in inputs.items()}
         self.warm = int(warmup)
         self.graph, self.failed, self.replays = None, None, 0
@@ -108,7 +111,7 @@ class GraphedStep:
             # N > 1: RCCL's proxy threads make runtime calls of their own while this thread captures; in the default 'global'
             # mode any such call from ANY thread invalidates the capture ("operation not permitted when stream is capturing"),
             # 'thread_local' only polices the capturing thread (what PyTorch prescribes for NCCL inside graphs)
-            mode = 'thread_local' if nranks > 1 else 'global'
+            mode = self.capture_mode or ('thread_local' if nranks > 1 else 'global')
             with torch.cuda.graph(g, capture_error_mode=mode):
                 self.body(self.static)
         except Exception as e:                    # not capturable here: stay eager (the half-captured call did no device work)

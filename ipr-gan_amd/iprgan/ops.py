@@ -317,9 +317,26 @@ def colsum(x2d_like, channels, out=None, beta=0.0):
     return res
 
 
-def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0.0):
+_DEFER_WGRAD = os.environ.get('IPRGAN_DEFER_WGRAD_REDUCE', '1') != '0'     # A/B switch: one slab reduce launch per backward pass
+
+
+def wgrad_reduce_flush(pending):
+    """The slab reduces that ``conv_bwd_weight(..., defer=pending)`` calls of a backward pass owe, in ONE launch per 24 layers
+    (iprgan_wgrad_reduce_multi; bit-identical to the per-layer launches).  ``pending`` = [(record, workspace, dw)]: the
+    tensors are kept alive until the launch is enqueued."""
+    if not pending:
+        return
+    n = len(pending)
+    arr = (L.WGradReduceRec * n)(*[p[0] for p in pending])
+    call('iprgan_wgrad_reduce_multi', arr, n, stream())
+    del pending[:]
+
+
+def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0.0, defer=None):
     """dw, db given (gradient-bucket views): ``dw = beta*dw + grad`` written in place, no temporary.
-    bf16 x / dy are consumed directly where the 128x128 bf16 tile applies, through fp32 copies elsewhere."""
+    bf16 x / dy are consumed directly where the 128x128 bf16 tile applies, through fp32 copies elsewhere.
+    ``defer`` (a list): the slab reduce into dw is NOT launched - it is appended to the list and runs with the other layers'
+    in ``wgrad_reduce_flush(defer)``; until then dw is not valid."""
     d = ConvDesc(*[getattr(d, f) for f, _ in ConvDesc._fields_])
     if ST_X3 in (is16(x), is16(dy)) and is16(x) != is16(dy):
         if c4(spec.cin) % 32 == 0 and c4(spec.cout) % 32 == 0 and ST_BF16 not in (is16(x), is16(dy)):
@@ -336,6 +353,13 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
     if db is None and want_bias:
         db = empty((spec.cout,), x)
     ws = empty((query('iprgan_conv_wgrad_ws_floats', C.byref(d)),), x)
+    if defer is not None and _DEFER_WGRAD:
+        rec = L.WGradReduceRec()
+        call('iprgan_conv_bwd_weight_deferred', C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db) if want_bias else None, ptr(ws),
+             float(beta), stream(), C.byref(rec))
+        if rec.pending:
+            defer.append((rec, ws, dw))
+        return dw, (db if want_bias else None)
     call('iprgan_conv_bwd_weight', C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db) if want_bias else None, ptr(ws),
          float(beta), stream())
     return dw, (db if want_bias else None)

@@ -15,7 +15,7 @@ pytest_generate_tests = conftest.both_math_modes({
     'test_conv_fwd_bwd', 'test_conv_dgrad_fused_prev_act', 'test_conv_sn_scale', 'test_reflect_pad_conv',
     'test_every_gconv_tile_variant', 'test_every_wgrad_candidate', 'test_north_star_conv_shapes_full_size',
     'test_conv_epilogue_column_sums', 'test_fused_norm_statistics_with_large_mean_channels', 'test_conv_splitk',
-    'test_batchnorm', 'test_instance_norm'})
+    'test_batchnorm', 'test_instance_norm', 'test_deferred_wgrad_reduce_is_bit_identical'})
 math_mode = conftest.math_mode_fixture()
 
 
@@ -1240,3 +1240,37 @@ def test_pool_swap_and_write_ints(dev, n_img, pool_n, shape):
     assert tbl[0, :n_img].cpu().tolist() == index.tolist() and tbl[1, :n_img].cpu().tolist() == [int(p) for p in prob.tolist()]
     ops.pool_swap(img_d, pool_d, tbl[0], tbl[1])
     assert torch.equal(img_d.cpu(), want_img) and torch.equal(pool_d.cpu(), want_pool)
+
+
+@pytest.mark.parametrize('cand', [-1, 0, 22, 45, 61, 72, 74, 76])
+def test_deferred_wgrad_reduce_is_bit_identical(dev, cand):
+    """iprgan_conv_bwd_weight_deferred + ONE iprgan_wgrad_reduce_multi over several layers against the per-layer form
+    (tiles + reduce in one call): the same bits, with beta = 0 and accumulating into a pre-filled gradient (beta = 1), for the
+    split-M GEMM forms, the halo forms of every storage kind and the autotuner's own choice (-1).  Every block of the multi
+    kernel performs the additions of its single-layer counterpart in the same order (csrc/conv_igemm.hip: wgrad_reduce_block)."""
+    from iprgan import _lib, ops
+    layers = [(64, 64, 4, 2, 1, False, 32, 6), (64, 128, 3, 1, 1, False, 16, 5), (128, 64, 4, 2, 1, True, 8, 4),
+              (96, 160, 3, 1, 1, False, 12, 3), (3, 64, 3, 1, 1, False, 16, 4)]
+    try:
+        _lib.call('iprgan_debug_force_tiles', -1, cand)
+        for beta in (0.0, 1.0):
+            pending, want, got = [], [], []
+            for li, (cin, cout, k, s, p, tr, H, B) in enumerate(layers):
+                spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr)
+                d = spec.desc(B, H, H)
+                OH, OW = spec.out_hw(H, H)
+                x = ops.to_kind(to_nhwc(rnd(B, cin, H, H, seed=10 + li)).to(dev), d.x_bf16)
+                dy = ops.to_kind(to_nhwc(rnd(B, cout, OH, OW, seed=20 + li)).to(dev), d.y_bf16)
+                wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+                base = rnd(*wshape, seed=30 + li).to(dev)
+                a, b = base.clone(), base.clone()
+                ops.conv_bwd_weight(spec, d, x, dy, wshape, False, dw=a, beta=beta)
+                ops.conv_bwd_weight(spec, d, x, dy, wshape, False, dw=b, beta=beta, defer=pending)
+                want.append(a); got.append(b)
+            assert len(pending) >= 3, 'these layers run slab kernels: their reduces must have been deferred'
+            ops.wgrad_reduce_flush(pending)
+            assert not pending
+            for li, (a, b) in enumerate(zip(want, got)):
+                assert torch.equal(a, b), f'layer {li}, beta {beta}, cand {cand}: deferred reduce differs (max {float((a - b).abs().max()):.3e})'
+    finally:
+        _lib.call('iprgan_debug_force_tiles', -1, -1)
