@@ -20,6 +20,11 @@ int cast_planes(const void* src, void* dst, size_t n, size_t ps, bool to_planes,
 int reflect_fold_launch(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope,
                         const float* residual, int B, int H, int W, int C, int pad, int okind, size_t ps, hipStream_t stream);
 
+// elementwise.hip: the mirror terms of a ReflectionPad2d gradient (border strips of the padded grid, fp32 `dxp`) added to the
+// ring pixels of dx, which already holds the zero-padded backward-data result (conv_igemm.hip: conv_bwd_data_reflect_direct)
+int reflect_ring_fix_launch(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope, int B, int H,
+                            int W, int C, int pad, int okind, size_t ps, hipStream_t stream);
+
 #define IPR_CHECK(cond, ...)                 \
   do {                                       \
     if (!(cond)) {                           \

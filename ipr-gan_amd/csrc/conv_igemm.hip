@@ -2316,8 +2316,8 @@ static int g_force_splitk = -1;
 static bool splitk_geom_ok(const GConvArgs& a) {
   if (a.nphase != 1 || a.osy != 1 || a.osx != 1 || a.ph[0].ooy || a.ph[0].oox) return false;
   const long long M = a.ph[0].M, blocks = (long long)cdiv((int)M, 64) * cdiv(a.Ns, 64);
-  const long long lim_blocks = getenv("IPRGAN_SPLITK_BLOCKS") ? atoll(getenv("IPRGAN_SPLITK_BLOCKS")) : 1280;
-  const long long lim_out = getenv("IPRGAN_SPLITK_OUT") ? atoll(getenv("IPRGAN_SPLITK_OUT")) : (5ll << 20);
+  static const long long lim_blocks = getenv("IPRGAN_SPLITK_BLOCKS") ? atoll(getenv("IPRGAN_SPLITK_BLOCKS")) : 1280;     // (read once)
+  static const long long lim_out = getenv("IPRGAN_SPLITK_OUT") ? atoll(getenv("IPRGAN_SPLITK_OUT")) : (5ll << 20);
   return a.Ns >= 64 && (a.Cs % 32) == 0 && blocks <= lim_blocks && a.ph[0].steps >= 32 && M * a.Ns <= lim_out;
 }
 static size_t splitk_ws_floats(const GConvArgs& a) {
@@ -2879,6 +2879,63 @@ int iprgan_conv_bwd_data_bn(const iprgan_conv_desc* d, const float* dy, const fl
                             nullptr, stream, &bn);
 }
 
+// ReflectionPad2d(p) + Conv2d(k = 2p + 1, stride 1) backward-data WITHOUT the padded grid (round 5).
+// The padded form (a zero-pad pass over (H + 2p) x (W + 2p) into an fp32 workspace, then iprgan_reflect_fold) costs the extra
+// rows, 8 bytes per element of workspace traffic and - what hurt most - the tile count of the padded grid: 34 848 rows instead
+// of 32 768 at batch 8 are 274 tiles instead of 256 on 256 CUs (dgrad 140 TFLOP/s where the forward pass runs at 217).  Here:
+//   1. the border STRIPS of the padded gradient - positions outside the image, the only ones that fold onto other pixels - as
+//      four phases of one small launch into `ws` (top / bottom: p rows of W + 2p; left / right: p columns of H), each with
+//      only the taps that can reach the image (p of the 2p + 1 rows or columns of the kernel);
+//   2. the image itself as an ordinary zero-padded backward-data pass straight into dx (every epilogue feature);
+//   3. reflect_ring_fix_kernel adds the strips to the ring pixels they mirror, inside the activation derivative.
+// (acc + mirror) * act' + residual becomes (acc * act' + residual) + mirror * act': one fp32 rounding apart.
+static int g_reflect_direct = getenv("IPRGAN_REFLECT_DIRECT") ? atoi(getenv("IPRGAN_REFLECT_DIRECT")) : 1;
+static bool reflect_direct_ok(const iprgan_conv_desc* d) {
+  const int P = d->pad;
+  return g_reflect_direct && d->pad_mode == IPRGAN_PAD_REFLECT && !d->transposed && d->stride == 1 && P >= 1 && d->KH == 2 * P + 1 &&
+         d->KW == 2 * P + 1 && 2 * P + 2 <= d->H && 2 * P + 2 <= d->W && (c4(d->Cout) % 32) == 0 && c4(d->Cin) >= 32 &&
+         d->x_bf16 != 1 && d->y_bf16 != 1;
+}
+static int conv_bwd_data_reflect_direct(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
+                                        const float* prev_out, int prev_act, float prev_slope, const float* residual,
+                                        hipStream_t st) {
+  const Shape s = out_shape(d);
+  const int P = d->pad, H = d->H, W = d->W, HP = H + 2 * P, WP = W + 2 * P;
+  {
+    GConvArgs b;
+    memset(&b, 0, sizeof(b));
+    geom_bwd_form(b, d->B, s.OH, s.OW, d->Cout, HP, WP, d->Cin, d->KH, d->KW, 1, 0);     // source pixel = padded position - tap
+    const Phase base = b.ph[0];
+    b.nphase = 4;
+    for (int i = 0; i < 4; ++i) b.ph[i] = base;
+    Phase& top = b.ph[0];        // rows 0 .. P-1 of the padded grid: kernel rows 0 .. P-1 reach the image
+    top.th = P; top.ohg = P; top.owg = WP; top.ooy = 0; top.oox = 0; top.dy0 = 0; top.dx0 = 0; top.wbase = 0;
+    Phase& bot = b.ph[1];        // rows H+P .. H+2P-1: kernel rows P+1 .. 2P
+    bot.th = P; bot.ohg = P; bot.owg = WP; bot.ooy = H + P; bot.oox = 0; bot.dy0 = H - 1; bot.dx0 = 0; bot.wbase = (P + 1) * d->KW;
+    Phase& lef = b.ph[2];        // columns 0 .. P-1 of the rows in between: kernel columns 0 .. P-1
+    lef.tw = P; lef.ohg = H; lef.owg = P; lef.ooy = P; lef.oox = 0; lef.dy0 = P; lef.dx0 = 0; lef.wbase = 0;
+    Phase& rig = b.ph[3];        // columns W+P .. W+2P-1: kernel columns P+1 .. 2P
+    rig.tw = P; rig.ohg = H; rig.owg = P; rig.ooy = P; rig.oox = W + P; rig.dy0 = P; rig.dx0 = W - 1; rig.wbase = P + 1;
+    for (int i = 0; i < 4; ++i) finish_phase(b.ph[i], d->B, b.Cs);
+    b.in = dy; b.wt = wbwd; b.out = ws;
+    b.in16 = d->y_bf16; b.in_ps = (unsigned)(d->y_pstride * 2);
+    b.flops = 0.0;               // (the layer's algorithmic FLOPs are accounted once, by the pass over the image)
+    const int rc = launch_gconv(b, st);
+    if (rc) return rc;
+  }
+  GConvArgs a;
+  memset(&a, 0, sizeof(a));
+  geom_bwd_form(a, d->B, s.OH, s.OW, d->Cout, H, W, d->Cin, d->KH, d->KW, 1, P);
+  a.in = dy; a.wt = wbwd; a.out = dx;
+  a.in16 = d->y_bf16; a.out16 = d->x_bf16; a.aux16 = d->x_bf16 != 0;
+  a.in_ps = (unsigned)(d->y_pstride * 2); a.out_ps = (unsigned)(d->x_pstride * 2);
+  a.aux = prev_out; a.aux_act = prev_act; a.aux_slope = prev_slope; a.res = residual;
+  a.flops = 2.0 * d->B * (double)s.OH * s.OW * d->Cout * d->Cin * d->KH * d->KW;
+  const int rc = launch_gconv(a, st);
+  if (rc) return rc;
+  return reflect_ring_fix_launch(ws, dx, prev_out, prev_act, prev_slope, d->B, H, W, c4(d->Cin), P, d->x_bf16, (size_t)d->x_pstride, st);
+}
+
 static int conv_bwd_data_impl(const iprgan_conv_desc* d, const float* dy, const float* wbwd, float* dx, float* ws,
                               const float* prev_out, int prev_act, float prev_slope, const float* pair_sigma0,
                               const float* pair_sigma1, float* stat_part, int* stat_rows, const float* residual,
@@ -2908,6 +2965,8 @@ static int conv_bwd_data_impl(const iprgan_conv_desc* d, const float* dy, const 
     a.flops = 2.0 * d->B * (double)d->Cout * d->Cin * ntap;
     return launch_gconv(a, (hipStream_t)stream);
   }
+  if (reflect && ws && !bn && reflect_direct_ok(d))
+    return conv_bwd_data_reflect_direct(d, dy, wbwd, dx, ws, prev_out, prev_act, prev_slope, residual, (hipStream_t)stream);
   if (reflect) {
     // gradient w.r.t. the reflection-padded image (a zero-pad conv with pad 0 over H+2p), then fold
     IPR_CHECK(!d->transposed && ws, "conv_bwd_data: reflect pad needs a Conv2d and a workspace");

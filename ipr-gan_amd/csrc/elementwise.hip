@@ -733,6 +733,69 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const rf_f4* __restri
   }
 }
 
+// ---- ReflectionPad2d(p) backward without the padded grid (round 5; conv_igemm.hip: conv_bwd_data_reflect_direct) ----------
+// The interior of the gradient is an ordinary zero-padded backward-data pass straight into dx (fused derivative, residual,
+// three-plane split: the full-speed tile kernels, and a tile count that is not inflated by (H + 2p)(W + 2p) / HW - 274 tiles
+// instead of 256 on 256 CUs made the batch-8 layers of CycleGAN 1.5x slower than their forward).  What the reflection adds
+// lives on the four border STRIPS of the padded grid (rows / columns outside the image: 6 % of the positions), computed by one
+// small launch into `dxp`; this kernel adds every strip position to the interior pixel it mirrors:
+//   dx[y][x] += act'(prev[y][x]) * sum over the preimages (yq, xq) != (y, x) of dxp[yq][xq]
+// for the "ring" pixels only (rows 1..p and H-1-p..H-2, columns likewise): 2p (W + H - 2p) pixels per image.
+__global__ __launch_bounds__(256) void reflect_ring_fix_kernel(const rf_f4* __restrict__ dxp, rf_f4* __restrict__ dx,
+                                                               const rf_f4* __restrict__ prev_out, int prev_act, float prev_slope,
+                                                               unsigned total4, int H, int W, int C4n, int p, int ring,
+                                                               FastDiv d_c4n, FastDiv d_ring, FastDiv d_w, FastDiv d_2p,
+                                                               int okind, size_t ps) {
+  typedef __bf16 rf_b4 __attribute__((ext_vector_type(4)));
+  auto ldb = [](const void* base, size_t e) {
+    const rf_b4 h = *(const rf_b4*)((const __bf16*)base + e);
+    const rf_f4 v = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    return v;
+  };
+  const int HP = H + 2 * p, WP = W + 2 * p;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+    const unsigned rp = fdiv(i, d_c4n), c = i - rp * (unsigned)C4n;
+    const unsigned b = fdiv(rp, d_ring);
+    const int r = (int)(rp - b * (unsigned)ring);
+    int y, x;
+    if (r < 2 * p * W) {                       // the 2p ring ROWS, whole
+      const int iy = (int)fdiv((unsigned)r, d_w);
+      x = r - iy * W;
+      y = iy < p ? 1 + iy : H - 1 - p + (iy - p);
+    } else {                                   // the other H - 2p rows: their 2p ring COLUMNS
+      const int r2 = r - 2 * p * W, j = (int)fdiv((unsigned)r2, d_2p), ix = r2 - j * 2 * p;
+      y = j == 0 ? 0 : (j == H - 2 * p - 1 ? H - 1 : p + j);
+      x = ix < p ? 1 + ix : W - 1 - p + (ix - p);
+    }
+    int ys[3], xs[3];
+    const int ny = refl_pre(y, H, p, ys), nx = refl_pre(x, W, p, xs);
+    rf_f4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < ny; ++a)
+      for (int q = 0; q < nx; ++q)
+        if (a | q) s += dxp[((size_t)((int)b * HP + ys[a]) * WP + xs[q]) * C4n + c];      // (a, q) = (0, 0): the pixel itself
+    const size_t e = ((size_t)((int)b * H + y) * W + x) * C4n * 4 + (size_t)c * 4;
+    if (prev_out) {
+      const rf_f4 o = okind == 2 ? ldb(prev_out, e) : prev_out[e / 4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] *= act_grad_from_out(o[k], prev_act, prev_slope);
+    }
+    if (okind == 2) {
+      s += ldb(dx, e) + (ldb(dx, e + ps) + ldb(dx, e + 2 * ps));
+      const rf_b4 h = {(__bf16)s.x, (__bf16)s.y, (__bf16)s.z, (__bf16)s.w};
+      const rf_f4 hf = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+      const rf_f4 r1 = s - hf;
+      const rf_b4 m = {(__bf16)r1.x, (__bf16)r1.y, (__bf16)r1.z, (__bf16)r1.w};
+      const rf_f4 mf = {(float)m.x, (float)m.y, (float)m.z, (float)m.w};
+      const rf_f4 r2 = r1 - mf;
+      const rf_b4 l = {(__bf16)r2.x, (__bf16)r2.y, (__bf16)r2.z, (__bf16)r2.w};
+      __bf16* o = (__bf16*)dx + e;
+      *(rf_b4*)o = h; *(rf_b4*)(o + ps) = m; *(rf_b4*)(o + 2 * ps) = l;
+    } else {
+      dx[e / 4] += s;
+    }
+  }
+}
+
 // ---- sign loss / BER (multi-tensor: pointer table travels in the kernel arguments) ----------
 #define SIGN_MAX_LAYERS 64
 struct SignTable {
@@ -1097,6 +1160,20 @@ int reflect_fold_launch(const float* dxp, float* dx, const float* prev_out, int 
                      (const rf_f4*)dxp, (rf_f4*)dx, (const rf_f4*)prev_out, prev_act, prev_slope, (const rf_f4*)residual,
                      (unsigned)(n / 4), H, W,
                      C / 4, pad, make_fastdiv(C / 4), make_fastdiv(W), make_fastdiv(H), okind, ps);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int reflect_ring_fix_launch(const float* dxp, float* dx, const float* prev_out, int prev_act, float prev_slope, int B, int H,
+                            int W, int C, int pad, int okind, size_t ps, hipStream_t stream) {
+  IPR_CHECK(pad >= 1 && 2 * pad + 2 <= H && 2 * pad + 2 <= W && C % 4 == 0, "reflect_ring_fix: pad %d on a %dx%d image", pad, H, W);
+  const int ring = 2 * pad * W + (H - 2 * pad) * 2 * pad;
+  const size_t n4 = (size_t)B * ring * (C / 4);
+  IPR_CHECK(n4 < 0x7fffffffull, "reflect_ring_fix: too many elements");
+  if (okind == 2 && !ps) ps = (size_t)B * H * W * C;
+  if (!n4) return 0;
+  hipLaunchKernelGGL(reflect_ring_fix_kernel, dim3(grid_for(n4, 8192)), dim3(256), 0, stream, (const rf_f4*)dxp, (rf_f4*)dx,
+                     (const rf_f4*)prev_out, prev_act, prev_slope, (unsigned)n4, H, W, C / 4, pad, ring, make_fastdiv(C / 4),
+                     make_fastdiv(ring), make_fastdiv(W), make_fastdiv(2 * pad), okind, ps);
   IPR_LAUNCH_CHECK();
   return 0;
 }

@@ -48,8 +48,11 @@ class Config(object):
 #     fuse_stats: true       # norm statistics / bias gradients from conv epilogues (IPRGAN_FUSE_STATS)
 #     pair_d: true           # D(real) and D(fake) as one paired pass              (IPRGAN_PAIR_D)
 #     batch_passes: true     # same-network passes of CycleGAN batched             (IPRGAN_BATCH_PASSES)
-#     graph: true            # ImageGeneration on one GPU: the whole step as one captured HIP graph (graphs.py)
-ENGINE_KEYS = ('math', 'bucket_mb', 'comm', 'comm_timeout', 'tune_cache', 'fuse_stats', 'pair_d', 'batch_passes', 'graph')
+#     graph: true            # ImageGeneration: the whole step as one captured HIP graph (graphs.py); one rank only, unless
+#     graph_ddp: true        #   ... this opts a data-parallel run in (the exchange through the C ABI's communicator is captured
+#                            #   with the step; every rank captures or every rank stays eager; unproven on real multi-GPU RCCL)
+ENGINE_KEYS = ('math', 'bucket_mb', 'comm', 'comm_timeout', 'tune_cache', 'fuse_stats', 'pair_d', 'batch_passes', 'graph',
+               'graph_ddp')
 
 
 def apply_engine(config, set_math=True):

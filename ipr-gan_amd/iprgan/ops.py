@@ -196,6 +196,14 @@ class ConvSpec:
         """x16 / y16: storage type of the layer's input / output activation (default: the bf16act rule)."""
         x16 = act_kind(self.cin) if x16 is None else x16
         y16 = act_kind(self.cout) if y16 is None else y16
+        # a three-plane tensor is 6 bytes per element behind ONE 32-bit buffer descriptor (include/iprgan.h: tensors < 2 GiB):
+        # past 357 M elements it stays fp32 (4 bytes: the limit of the fp32 mode, 536 M) instead of failing inside a launch;
+        # the kind depends on the tensor's own shape only, so producer and consumer agree (ADVICE r04)
+        OH, OW = self.out_hw(H, W)
+        if x16 == ST_X3 and B * H * W * c4(self.cin) * 6 >= 0x7fffffff:
+            x16 = ST_F32
+        if y16 == ST_X3 and B * OH * OW * c4(self.cout) * 6 >= 0x7fffffff:
+            y16 = ST_F32
         return ConvDesc(B, H, W, self.cin, self.cout, self.k, self.k, self.stride, self.pad,
                         self.outpad, int(self.transposed), self.pad_mode, self.act, float(self.slope), int(x16), int(y16))
 
@@ -391,6 +399,15 @@ ST_X3_XF32 = 3          # norm entry points only (include/iprgan.h): x fp32; y, 
 _NORM_XF32 = os.environ.get('IPRGAN_NORM_XF32', '1') != '0'
 
 
+def _whole3(t):
+    """A three-plane tensor whose planes are NOT its own element count apart (a batch slice of a larger tensor keeps the
+    parent's plane stride) re-packed into a contiguous one: the norm kernels address the planes at G*M*C (csrc/norm.hip),
+    so a sliced operand would have its m and l planes read / written at the wrong offsets."""
+    if t is not None and is16(t) == ST_X3 and pstride(t) != t.numel():
+        return to_kind(f32(t), ST_X3)
+    return t
+
+
 def _norm_fwd_kinds(x):
     """(storage-kind argument of the norm entry point, kind of its output y).  In 'fp32x3' mode an fp32 input whose channel
     count allows three planes gets a three-plane output: the convolution in front of a norm layer writes fp32 (4 instead
@@ -404,8 +421,11 @@ def _norm_fwd_kinds(x):
 def _norm_bwd_kinds(x, dy, y=None):
     """(storage-kind argument, dy, y) of a norm backward: the saved fp32 x of a layer whose output is three planes stays
     fp32 (ST_X3_XF32); otherwise dy (and y) follow x."""
+    x_, dy, y = x, _whole3(dy), _whole3(y)
     k = is16(x)
-    if k == ST_F32 and is16(dy) == ST_X3 and pstride(dy) == dy.numel():
+    if k == ST_X3 and pstride(x_) != x_.numel():
+        raise RuntimeError('norm backward: the saved input is a batch slice of a three-plane tensor (plane stride != element count)')
+    if k == ST_F32 and is16(dy) == ST_X3:
         if y is not None and is16(y) != ST_X3:
             y = to_kind(y, ST_X3)
         return ST_X3_XF32, dy, y
@@ -422,10 +442,12 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, a
     over x.  counter: the module's int64 num_batches_tracked, incremented on the device."""
     C_ = x.shape[-1]
     M = x.numel() // C_
+    x = _whole3(x)
     st, ky = _norm_fwd_kinds(x)
     y = empty_kind(x.shape, x, ky)
     if residual is not None and is16(residual) != ky:
         residual = to_kind(residual, ky)
+    residual = _whole3(residual)
     mean, invstd = empty((C_,), x), empty((C_,), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
@@ -456,10 +478,12 @@ def bn_prelu_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, train
     """BatchNorm + PReLU (``slope_t``: the PReLU parameter, one float on the device) in the norm's own passes."""
     C_ = x.shape[-1]
     M = x.numel() // C_
+    x = _whole3(x)
     st, ky = _norm_fwd_kinds(x)
     y = empty_kind(x.shape, x, ky)
     if residual is not None and is16(residual) != ky:
         residual = to_kind(residual, ky)
+    residual = _whole3(residual)
     mean, invstd = empty((C_,), x), empty((C_,), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
@@ -697,10 +721,12 @@ def fill(t, value=0.0):
 # ---- instance norm / PReLU / pixel shuffle / max pool / residual add ---------------------------------
 def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias=None, residual=None):
     B, H, W, C_ = x.shape
+    x = _whole3(x)
     st, ky = _norm_fwd_kinds(x)
     y = empty_kind(x.shape, x, ky)
     if residual is not None and is16(residual) != ky:
         residual = to_kind(residual, ky)
+    residual = _whole3(residual)
     mean, invstd = empty((B, C_), x), empty((B, C_), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
     ws = None if part is not None else empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)

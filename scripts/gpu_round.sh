@@ -5,7 +5,7 @@
 #   for w in "" srgan_ cyclegan_; do python scripts/summarize_profiles.py gpurun_out/prof <tag>_${w%_} profiles/<tag>_${w%_}; done
 # (scripts/collect_round.sh does that).  rocprofv3 rules of this pool: the program goes directly after "--", counters
 # are collected in their own passes (never together with a trace domain other than --kernel-trace).
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O/prof
@@ -74,12 +74,27 @@ for w in dcgan64 srgan cyclegan; do
 done
 IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload dcgan128 --math bf16act --no-cpu-baseline 2>&1 >/dev/null | grep -A200 "conv-family layers" | cut -c18- > $O/${TAG}_layers_dcgan128_bf16act.txt
 # two ranks on this box's one GPU, the C ABI's communicator (test double tests/stub_rccl.cpp) carrying the buckets: step captured
-IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 600 python bench.py --gpus 2 --steps 20 --warmup 8 --no-cpu-baseline --alt-math none > $O/${TAG}_bench_2ranks_1gpu_stub.json 2> $O/bench_2ranks.err
+# (capture at N > 1 is opt-in since round 5: --graph on)
+IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 600 python bench.py --gpus 2 --graph on --steps 20 --warmup 8 --no-cpu-baseline --alt-math none > $O/${TAG}_bench_2ranks_1gpu_stub.json 2> $O/bench_2ranks.err
+rm -f /tmp/iprgan_stub_rccl_*
+# EIGHT ranks on this box's one GPU over the same test double (VERDICT r04 next #6a): the bucket protocol, the rank-0 tile
+# table adopted by every rank, the agreed capture of the step and rank 0's JSON line at N = 8 (the eight replicas share 256 CUs:
+# the img/s of this line says nothing about an 8-GPU node)
+IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 1200 python bench.py --gpus 8 --graph on --steps 12 --warmup 6 --no-cpu-baseline --alt-math none > $O/${TAG}_bench_8ranks_1gpu_stub.json 2> $O/bench_8ranks.err
+rm -f /tmp/iprgan_stub_rccl_*
+# ... and eagerly (the default of --graph auto at N > 1): what the driver's multi-GPU command runs
+IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 1200 python bench.py --gpus 8 --steps 12 --warmup 6 --no-cpu-baseline --alt-math none > $O/${TAG}_bench_8ranks_1gpu_stub_eager.json 2> $O/bench_8ranks_eager.err
 rm -f /tmp/iprgan_stub_rccl_*
 # one rank, the buckets through the real RCCL communicator of the C ABI (fork / ncclAllReduce / join inside the captured step)
 IPRGAN_FORCE_COMM=1 timeout 600 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --alt-math none 2> $O/bench_1rank.err | grep '^{' > $O/${TAG}_bench_1rank_rccl.json      # (RCCL prints its version banner to stdout)
 # the three-plane ring tile on the north-star shape: clock, MFMA-busy, LDS conflicts (scripts/probe/x3p_pmc.sh)
 bash scripts/probe/x3p_pmc.sh 18 > /dev/null 2>&1; cp $O/pmc_x3p18.txt $O/${TAG}_northstar_x3p_pmc.txt 2>/dev/null
+# ... and the clocks / power rocm-smi reports while that tile runs back to back (the power-bound reading as an observation)
+bash scripts/probe/smi_log.sh $O/${TAG}_northstar_x3p_smi.txt > /dev/null 2>&1
+# D.conv1 (64 -> 64 k4 s2 @64x64, batch 128) through the 256x64 tile: bytes from beyond L2 and L2 hit rate by K-walk order
+# (0 = taps inside a chunk, row-major; 3 = the default for stride-2 gathers since round 5: parity-grouped taps, chunks innermost)
+for K in 0 3; do IPRGAN_X3P_KORDER=$K bash scripts/probe/x3p_tcc.sh 22 2 tcck$K > /dev/null 2>&1; done
+( echo "# IPRGAN_X3P_KORDER=0"; cat $O/pmc_tcck022_2.txt; echo "# IPRGAN_X3P_KORDER=3 (default for stride-2 gathers)"; cat $O/pmc_tcck322_2.txt ) > $O/${TAG}_dconv1_korder_tcc.txt 2>/dev/null
 # north-star conv shape (3x3 256->256 @64x64, batch 64): counter passes for the per-kernel MFMA / LDS / VALU picture
 export IPRGAN_TUNE_CACHE=$O/tune_cache_ns.txt
 rm -f $IPRGAN_TUNE_CACHE

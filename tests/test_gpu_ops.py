@@ -15,7 +15,8 @@ pytest_generate_tests = conftest.both_math_modes({
     'test_conv_fwd_bwd', 'test_conv_dgrad_fused_prev_act', 'test_conv_sn_scale', 'test_reflect_pad_conv',
     'test_every_gconv_tile_variant', 'test_every_wgrad_candidate', 'test_north_star_conv_shapes_full_size',
     'test_conv_epilogue_column_sums', 'test_fused_norm_statistics_with_large_mean_channels', 'test_conv_splitk',
-    'test_batchnorm', 'test_instance_norm', 'test_deferred_wgrad_reduce_is_bit_identical'})
+    'test_batchnorm', 'test_instance_norm', 'test_deferred_wgrad_reduce_is_bit_identical',
+    'test_reflect_pad_dgrad_without_the_padded_grid'})
 math_mode = conftest.math_mode_fixture()
 
 
@@ -1274,3 +1275,30 @@ def test_deferred_wgrad_reduce_is_bit_identical(dev, cand):
                 assert torch.equal(a, b), f'layer {li}, beta {beta}, cand {cand}: deferred reduce differs (max {float((a - b).abs().max()):.3e})'
     finally:
         _lib.call('iprgan_debug_force_tiles', -1, -1)
+
+
+@pytest.mark.parametrize('cfg', [(64, 64, 3, 1, 16, 16, 3), (64, 128, 3, 1, 9, 11, 2), (128, 64, 5, 2, 12, 10, 2), (32, 64, 7, 3, 16, 9, 2),
+                                 (256, 256, 3, 1, 64, 64, 2)], ids=lambda c: '-'.join(map(str, c)))
+def test_reflect_pad_dgrad_without_the_padded_grid(dev, cfg):
+    """conv_bwd_data_reflect_direct (csrc/conv_igemm.hip): the border strips of the padded gradient as four phases of one small
+    launch, the image as an ordinary zero-padded backward-data pass with the fused LeakyReLU derivative and the skip-connection
+    residual in its epilogue, reflect_ring_fix_kernel adding the mirrored strips to the ring pixels - against torch's gradient
+    of ReflectionPad2d(p) + Conv2d(k = 2p + 1) in float64, for p = 1, 2, 3, ragged maps and the CycleGAN layer at full size."""
+    from iprgan import _lib, ops
+    cin, cout, k, p, H, W, B = cfg
+    x = rnd(B, cin, H, W, seed=1)
+    w = rnd(cout, cin, k, k, seed=2, scale=(cin * k * k) ** -0.5)
+    prev = rnd(B, cin, H, W, seed=5)                     # the producer's output: its LeakyReLU derivative is fused into the epilogue
+    res = rnd(B, cin, H, W, seed=6)
+    xr = x.double().requires_grad_()
+    yr = F.conv2d(F.pad(xr, (p, p, p, p), mode='reflect'), w.double(), None)
+    g = rnd(*yr.shape, seed=4)
+    yr.backward(g.double())
+    want = xr.grad * torch.where(prev.double() > 0, 1.0, 0.2) + res.double()
+    spec = ops.ConvSpec(cin, cout, k, 1, p, pad_mode=1)
+    d = spec.desc(B, H, W)
+    _, wb = ops.conv_prep(spec, d, w.to(dev), None, False, True)
+    dx = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb, to_nhwc(prev).to(dev), _lib.ACT_LRELU, 0.2, residual=to_nhwc(res).to(dev))
+    close(from_nhwc(ops.f32(dx).cpu(), cin), want, what='reflect dgrad, direct form')
+    dx0 = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb)
+    close(from_nhwc(ops.f32(dx0).cpu(), cin), xr.grad, what='reflect dgrad, direct form, plain')
