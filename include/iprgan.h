@@ -62,6 +62,18 @@ typedef struct {
  * its bf16 rounding (same sign: activation masks read only that plane).  The pointer handed to an entry point is plane h.
  * Producers split ONCE per element; the convolution kernels then move the planes to LDS by DMA and multiply plane pairs
  * on the bf16 matrix pipe (csrc/conv_x3.hip) with no vector-ALU work in their K loops. */
+/* RANGE of the three-plane storage (tests/test_gpu_x3.py: "the ends of fp32's exponent range"; measured on gfx950):
+ *   - 2^-110 <= |x| <= 0x7F7F0000 (3.3895e38, the largest finite bf16): the round trip fp32 -> planes -> fp32 is BIT-EXACT;
+ *   - |x| < 2^-110: the planes run out of exponent range before fp32 does.  The stored value is x rounded to the bf16 subnormal
+ *     grid (absolute error <= 2^-133): 24 significant bits at 2^-110, 8 at 2^-126 (only h is left); signs are kept, nothing
+ *     becomes non-finite.  fp32 subnormals flush the same way;
+ *   - NaN stays NaN.  +-inf and finite |x| > 0x7F7F7FFF (h rounds to inf, the residual planes are inf - inf) come back as NaN:
+ *     a non-finite or over-range value NEVER turns into a finite one, so a diverged run trips the same finiteness checks as
+ *     in the fp32 mode - but an inf is not preserved as an inf;
+ *   - products: a convolution whose operands are in the exact range is as close to the float64 result as the fp32 MFMA's over
+ *     the whole range the PRODUCT survives in (operands at 2^-110 x 2^100, 2^100 x 2^-80, ...: test_conv_at_the_ends_of_the_
+ *     exponent_range), also when the leading h x h' terms cancel and the result is made of the small terms alone; an output whose
+ *     receptive field contains a non-finite input is non-finite in both modes (NaN here where the fp32 mode gives +-inf). */
 enum { IPRGAN_ST_F32 = 0, IPRGAN_ST_BF16 = 1, IPRGAN_ST_X3 = 2,
        /* the `act_bf16` argument of the norm entry points (iprgan_bn_*, iprgan_instnorm_*, iprgan_bn_prelu_*) only: the layer's
         * INPUT x is fp32 while y, dy, dx and the residual are three-plane tensors - the convolution in front of a norm layer

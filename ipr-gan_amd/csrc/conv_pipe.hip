@@ -118,8 +118,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
   // korder bit 6: a stride-2 gather walks its taps grouped by parity, channel chunks innermost - the four taps through which
   // one input pixel meets its four output positions follow each other, so its re-reads are L2 hits (conv_x3.hip:
   // gconv_x3p_kernel; measured there: bytes from beyond L2 / 5.8 on D.conv1)
-  const bool s2walk = (a.korder & 64) != 0 && a.isy == 2 && a.isx == 2 && (p_th & 1) == 0 && (p_tw & 1) == 0;
-  const int p_hx = p_tw >> 1, p_hy = p_th >> 1;
+  const bool s2walk = (a.korder & 64) != 0 && a.isy == 2 && a.isx == 2 && p_th >= 2 && p_tw >= 2;
   int q_cls = 0, q_dy = 0, q_dx = 0;
   if (s2walk) u_c = 0;
   auto walk_adv = [&]() {
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_pipe_kernel(const GConvA
       u_c += KSTEP;
       if (u_c >= Cs) {
         u_c = 0;
-        if (++q_dx == p_hx) { q_dx = 0; if (++q_dy == p_hy) { q_dy = 0; ++q_cls; } }
+        if (++q_dx == ((p_tw - (q_cls & 1) + 1) >> 1)) { q_dx = 0; if (++q_dy == ((p_th - (q_cls >> 1) + 1) >> 1)) { q_dy = 0; ++q_cls; } }
         u_ty = (q_cls >> 1) + 2 * q_dy; u_tx = (q_cls & 1) + 2 * q_dx;
       }
     } else if (korder) {          // taps inside a channel chunk: consecutive K steps re-read the same pixels, shifted

@@ -128,14 +128,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
   // (an XCD's 4 MiB L2 is turned over by its 32 CUs' stages every ~2 steps: only near re-reads are L2 hits)
   const bool chunk_fast = (a.korder & 1) != 0;
   const int p_ntap = p_th * p_tw;
-  const bool parity = (a.korder & 2) != 0 && a.isy == 2 && a.isx == 2 && (p_th & 1) == 0 && (p_tw & 1) == 0;
-  const int p_hx = p_tw >> 1, p_hy = p_th >> 1;
+  const bool parity = (a.korder & 2) != 0 && a.isy == 2 && a.isx == 2 && p_th >= 2 && p_tw >= 2;
+  // taps of parity class (cy, cx): ty = cy, cy + 2, ... < th (k4: two per class and axis; k3: two even, one odd)
   int u_c = 0, u_ty = 0, u_tx = 0;
   int q_cls = 0, q_dy = 0, q_dx = 0;          // parity walk: class (ty & 1, tx & 1), then (ty >> 1, tx >> 1) inside it
   auto tap_next = [&]() -> bool {             // next tap of the walk (counters only: no division in the K loop); true = wrapped
     bool wrapped = false;
     if (parity) {
-      if (++q_dx == p_hx) { q_dx = 0; if (++q_dy == p_hy) { q_dy = 0; if (++q_cls == 4) { q_cls = 0; wrapped = true; } } }
+      if (++q_dx == ((p_tw - (q_cls & 1) + 1) >> 1)) {
+        q_dx = 0;
+        if (++q_dy == ((p_th - (q_cls >> 1) + 1) >> 1)) { q_dy = 0; if (++q_cls == 4) { q_cls = 0; wrapped = true; } }
+      }
       u_ty = (q_cls >> 1) + 2 * q_dy; u_tx = (q_cls & 1) + 2 * q_dx;
     } else if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; wrapped = true; } }
     return wrapped;
@@ -146,9 +149,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
     const int j = chunk_fast ? s_begin / nck : s_begin - ck * p_ntap;
     u_c = ck * 32;
     if (parity) {
-      const int hq = p_hx * p_hy, r = j % hq;
-      q_cls = j / hq; q_dy = r / p_hx; q_dx = r - q_dy * p_hx;
-      u_ty = (q_cls >> 1) + 2 * q_dy; u_tx = (q_cls & 1) + 2 * q_dx;
+      for (int i = 0; i < j; ++i) tap_next();             // (once per block, at most th * tw - 1 steps)
     } else {
       u_ty = j / p_tw; u_tx = j - u_ty * p_tw;
     }
@@ -309,6 +310,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
   pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, slab_off);
 }
 
+// Measured and not kept (round 5): the same ring as a PERSISTENT kernel (gconv_x3pp_kernel: grid = resident slots, each block walks
+// its tile list through the same XCD map and never drains the ring - the LDS-DMA "fill" side runs NSTAGE - 1 steps ahead of the
+// multiply side and switches to the next tile's rows when its walk is exhausted, the epilogue stages through the one stage that
+// is free between a tile's last step and the next refill (EpiGeom with one stage's bytes: 128x128 in two column halves), so no
+// block turnover and no exposed prologue).  128x128 / 3 stages, 128x64 / 2 stages and 64x64 / 3 stages on four waves, bit-identical
+// to tiles 19 / 21 / 23 on 80-image layers with multi-phase geometries and ragged tiles; the 256x128 tile on eight waves needs 327
+// spilled registers next to the fill state.  Slower than the plain tiles on every DCGAN / north-star layer but two
+// (profiles/r05_persistent_ring_bench.jsonl: north-star 184 -> 177, 175 -> 167, 144 -> 134 TFLOP/s; D.conv1 forward 144 -> 112):
+// the hardware's block dispatch balances tiles of uneven duration better than a static tile list, and the first wait behind an
+// epilogue has to drain its stores (vmcnt retires in order).  One finding worth keeping: two instantiations of the step lambda
+// (refilling / draining) inside ONE loop make the register allocator shuttle the accumulators between AGPRs and VGPRs (128
+// v_accvgpr moves per 48 MFMAs, 15-35 % slower) - a single always-refilling instantiation whose slots past the end carry
+// zero-fill dummies has none.
+
 // ---- the same ring on v_mfma_f32_16x16x32_bf16 ------------------------------------------------------------------------
 // These kernels are POWER-bound: under gconv_x3p_kernel the chip clocks at 1.74 GHz (GRBM_GUI_ACTIVE / time, PMC pass) with
 // the matrix pipe 67 % busy - six MFMAs per product block leave no headroom.  MI355X_MICROARCH.md measures the 16x16x32 form
@@ -404,14 +419,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p16_kernel(const GConv
   // K-walk order: GConvArgs::korder as in gconv_x3p_kernel (bit 0: channel chunks inside a tap; bit 1: the taps of a
   // stride-2 gather grouped by parity)
   const bool chunk_fast = (a.korder & 1) != 0;
-  const bool parity = (a.korder & 2) != 0 && a.isy == 2 && a.isx == 2 && (p_th & 1) == 0 && (p_tw & 1) == 0;
-  const int p_hx = p_tw >> 1, p_hy = p_th >> 1;
+  const bool parity = (a.korder & 2) != 0 && a.isy == 2 && a.isx == 2 && p_th >= 2 && p_tw >= 2;
+  // taps of parity class (cy, cx): ty = cy, cy + 2, ... < th (k4: two per class and axis; k3: two even, one odd)
   int u_c = 0, u_ty = 0, u_tx = 0;
   int q_cls = 0, q_dy = 0, q_dx = 0;
   auto tap_next = [&]() -> bool {
     bool wrapped = false;
     if (parity) {
-      if (++q_dx == p_hx) { q_dx = 0; if (++q_dy == p_hy) { q_dy = 0; if (++q_cls == 4) { q_cls = 0; wrapped = true; } } }
+      if (++q_dx == ((p_tw - (q_cls & 1) + 1) >> 1)) {
+        q_dx = 0;
+        if (++q_dy == ((p_th - (q_cls >> 1) + 1) >> 1)) { q_dy = 0; if (++q_cls == 4) { q_cls = 0; wrapped = true; } }
+      }
       u_ty = (q_cls >> 1) + 2 * q_dy; u_tx = (q_cls & 1) + 2 * q_dx;
     } else if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; wrapped = true; } }
     return wrapped;

@@ -75,15 +75,15 @@ done
 IPRGAN_BENCH_LAYERS=1 timeout 600 python bench.py --workload dcgan128 --math bf16act --no-cpu-baseline 2>&1 >/dev/null | grep -A200 "conv-family layers" | cut -c18- > $O/${TAG}_layers_dcgan128_bf16act.txt
 # two ranks on this box's one GPU, the C ABI's communicator (test double tests/stub_rccl.cpp) carrying the buckets: step captured
 # (capture at N > 1 is opt-in since round 5: --graph on)
-IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 600 python bench.py --gpus 2 --graph on --steps 20 --warmup 8 --no-cpu-baseline --alt-math none > $O/${TAG}_bench_2ranks_1gpu_stub.json 2> $O/bench_2ranks.err
+IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 600 python bench.py --gpus 2 --graph on --steps 20 --warmup 8 --no-cpu-baseline --alt-math none 2> $O/bench_2ranks.err | grep '^{' > $O/${TAG}_bench_2ranks_1gpu_stub.json       # (gloo prints its connection banner to stdout)
 rm -f /tmp/iprgan_stub_rccl_*
 # EIGHT ranks on this box's one GPU over the same test double (VERDICT r04 next #6a): the bucket protocol, the rank-0 tile
 # table adopted by every rank, the agreed capture of the step and rank 0's JSON line at N = 8 (the eight replicas share 256 CUs:
 # the img/s of this line says nothing about an 8-GPU node)
-IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 1200 python bench.py --gpus 8 --graph on --steps 12 --warmup 6 --no-cpu-baseline --alt-math none > $O/${TAG}_bench_8ranks_1gpu_stub.json 2> $O/bench_8ranks.err
+IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 1200 python bench.py --gpus 8 --graph on --steps 12 --warmup 6 --no-cpu-baseline --alt-math none 2> $O/bench_8ranks.err | grep '^{' > $O/${TAG}_bench_8ranks_1gpu_stub.json
 rm -f /tmp/iprgan_stub_rccl_*
 # ... and eagerly (the default of --graph auto at N > 1): what the driver's multi-GPU command runs
-IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 1200 python bench.py --gpus 8 --steps 12 --warmup 6 --no-cpu-baseline --alt-math none > $O/${TAG}_bench_8ranks_1gpu_stub_eager.json 2> $O/bench_8ranks_eager.err
+IPRGAN_SHARE_DEVICE=1 IPRGAN_DIST_BACKEND=gloo IPRGAN_RCCL_LIB=$R/tests/_build/libstub_rccl.so timeout 1200 python bench.py --gpus 8 --steps 12 --warmup 6 --no-cpu-baseline --alt-math none 2> $O/bench_8ranks_eager.err | grep '^{' > $O/${TAG}_bench_8ranks_1gpu_stub_eager.json
 rm -f /tmp/iprgan_stub_rccl_*
 # one rank, the buckets through the real RCCL communicator of the C ABI (fork / ncclAllReduce / join inside the captured step)
 IPRGAN_FORCE_COMM=1 timeout 600 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --alt-math none 2> $O/bench_1rank.err | grep '^{' > $O/${TAG}_bench_1rank_rccl.json      # (RCCL prints its version banner to stdout)

@@ -507,3 +507,4 @@ def test_conv_with_a_non_finite_input_gives_non_finite_outputs_exactly_where_fp3
         fin = torch.isfinite(out[mode][0]).all(dim=-1)
         assert torch.equal(fin, ~bad), mode
     np.testing.assert_allclose(out['fp32x3'][0][~bad].numpy(), out['fp32'][0][~bad].numpy(), rtol=2e-4, atol=2e-5)
+
