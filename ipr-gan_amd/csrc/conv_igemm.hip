@@ -2078,6 +2078,7 @@ int launch_gconv_pipe(const GConvArgs& a, int variant, hipStream_t st, int* bm_o
 int launch_gconv_x3p(const GConvArgs& a, int variant, hipStream_t st, int* bm_out);      // conv_x3.hip
 int launch_gconv_x3h(const GConvArgs& a, int variant, hipStream_t st, int* bm_out);      // conv_x3.hip: halo form
 int launch_gconv_x3p16(const GConvArgs& a, int variant, hipStream_t st, int* bm_out);    // conv_x3.hip: 16x16x32 MFMA form
+int launch_gconv_x3ws(const GConvArgs& a, int variant, hipStream_t st, int* bm_out);     // conv_x3.hip: loader waves + multiplying waves
 
 static bool smalln_eligible(const GConvArgs& a) {
   return g_smalln && !a.rs0 && !a.stat_part && a.Ns == 4 && a.nphase == 1 && a.isy == 1 && a.isx == 1 && a.osy == 1 && a.osx == 1 &&
@@ -2263,6 +2264,8 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
         return launch_gconv_x3h(a, tile - 26, st, &t_last_bm);
       case 28: case 29: case 30: case 31:                                                       // ... on v_mfma_f32_16x16x32_bf16
         return launch_gconv_x3p16(a, tile - 28, st, &t_last_bm);
+      case 32: case 33: case 34:                                                                // ... with dedicated loader waves (round 5)
+        return launch_gconv_x3ws(a, tile - 32, st, &t_last_bm);
       default: return launch_gconv_t<2, 2, 1, 1>(a, st);
     }
   };
@@ -2292,7 +2295,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   g_prof_on = false;
   float best_us = 0.f;
   int err = 0;
-  const int best = tune_pick(32, [&](int cand) -> int {
+  const int best = tune_pick(35, [&](int cand) -> int {
     if ((cand == 0 || cand == 3 || cand == 4) && N < 128) return -1;
     if ((cand == 6 || cand == 7) && (long long)cdiv(maxM, 256) * cdiv(N, 128) * a.nphase < 256) return -1;    // not even one block per CU
     return run(cand);

@@ -310,6 +310,209 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
   pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, slab_off);
 }
 
+// ---- the ring with DEDICATED LOADER WAVES (round 5) -----------------------------------------------------------------------
+// conv_pipe.hip's K-loop probes measured the DMA-only and the MFMA-only time of a ring step ADDING: a wave that issues an
+// LDS-DMA piece sits in its issue slot until the CU's address path has taken it (60-185 cycles per piece beside MFMAs and
+// fragment reads), and an in-order wave issues no MFMA meanwhile.  A four-wave 256x64 tile - the 64-column layers: D.conv1,
+// G.up2, every backward-data pass into 64 channels - issues 15 pieces per wave and step against 48 MFMAs (1 536 cycles): the
+// matrix pipe starves on issue stalls (20-30 % busy), not on bytes (L2 at 7.7 of 34 TB/s).  Here the block has EIGHT waves:
+// waves 0-3 multiply (one per SIMD, 64x64 accumulators each, fragments from LDS, NO vector-memory instruction in their K
+// loop), waves 4-7 do nothing but issue the stage refills (a loader wave alone issues a piece in ~25 cycles:
+// MI355X_MICROARCH.md, ldsdma-fill) and wait for them to land.  Same LDS image, same ring, same counted waits (kept by the
+// loaders), ONE s_barrier per K step shared by both roles; the loaders match the epilogue's barriers and leave.
+// Staging layout = the four-wave tile's (loader l owns the 16-row pieces l, l + 4, ... of every plane).
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF, int MINW = 2>
+__global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a) {      // MINW = 4: two blocks per CU (128 registers)
+  constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NW = WGM * WGN;
+  static_assert(NW == 4, "four multiplying waves + four loader waves");
+  constexpr int RSA = BM / 16 / NW, RSB = BN / 16 / NW;
+  constexpr int L = 3 * (RSA + RSB);
+  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, A_BYTES = 3 * A_PLANE, STAGE_BYTES = 3 * (BM + BN) * 64;
+  static_assert(RSA >= 1 && RSB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "every loader stages whole 16-row pieces");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 3 && L * (NSTAGE - 2) <= 63, "ring depth / vmcnt field");
+  using G = EpiGeom<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES>;
+  static_assert(G::NH == 1, "the loaders match the barriers of a one-round epilogue");
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+
+  const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                gridDim.x * gridDim.y * gridDim.z);
+  const unsigned lq = lt / gridDim.y;
+  const int pz = (int)(lq % gridDim.z);
+  const int pM = a.ph[pz].M;
+  const int m0 = (int)(lq / gridDim.z) * BM, n0 = (int)(lt % gridDim.y) * BN;
+  if (m0 >= pM) {
+    if (STATS) {
+      for (int c = threadIdx.x; c < BN; c += 512)
+        if (n0 + c < a.Ns) { a.stat_part[((size_t)lq * 2) * a.Ns + n0 + c] = 0.f; a.stat_part[((size_t)lq * 2 + 1) * a.Ns + n0 + c] = 0.f; }
+    }
+    return;
+  }
+  const int nt = a.ph[pz].steps;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* ldsc = (const char*)lds;
+
+  if (wave8 >= NW) {
+    // ================================================= loader waves =================================================
+    const int wave = wave8 - NW;                                     // loader index = the staging role of wave `wave` of the 4-wave tile
+    const int p_tw = a.ph[pz].tw, p_th = a.ph[pz].th;
+    const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
+    const int p_dy0 = a.ph[pz].dy0, p_dx0 = a.ph[pz].dx0, p_dys = a.ph[pz].dys, p_dxs = a.ph[pz].dxs;
+    const int p_wbase = a.ph[pz].wbase, p_wsy = a.ph[pz].wsy, p_wsx = a.ph[pz].wsx;
+    const int p_owg = a.ph[pz].owg, plane = a.ph[pz].ohg * a.ph[pz].owg;
+    const FastDiv d_plane = a.ph[pz].d_plane, d_owg = a.ph[pz].d_owg;
+    const int IH = a.IH, IW = a.IW, Cs = a.Cs;
+    const unsigned in_ps = a.in_ps, wt_ps = a.wt_ps;
+    const int lrow = lane >> 2;
+    const unsigned sc = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+    int aiy[RSA], aix[RSA];
+    unsigned arow[RSA], wrow[RSB];
+#pragma unroll
+    for (int i = 0; i < RSA; ++i) {
+      const int m = m0 + (i * NW + wave) * 16 + lrow;
+      if (m < pM) {
+        const int b = fdiv(m, d_plane);
+        const int rem = m - b * plane;
+        const int y = fdiv(rem, d_owg);
+        const int x = rem - y * p_owg;
+        aiy[i] = y * a.isy;
+        aix[i] = x * a.isx;
+        arow[i] = (unsigned)(((b * IH + aiy[i]) * IW + aix[i]) * Cs) * 2u + sc;
+      } else {
+        aiy[i] = ROW_INVALID; aix[i] = 0; arow[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RSB; ++i) wrow[i] = (unsigned)((n0 + (i * NW + wave) * 16 + lrow) * a.Kp) * 2u + sc;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    const bool chunk_fast = (a.korder & 1) != 0;
+    const bool parity = (a.korder & 2) != 0 && a.isy == 2 && a.isx == 2 && p_th >= 2 && p_tw >= 2;
+    int u_c = 0, u_ty = 0, u_tx = 0, q_cls = 0, q_dy = 0, q_dx = 0;
+    auto tap_next = [&]() -> bool {
+      bool wrapped = false;
+      if (parity) {
+        if (++q_dx == ((p_tw - (q_cls & 1) + 1) >> 1)) {
+          q_dx = 0;
+          if (++q_dy == ((p_th - (q_cls >> 1) + 1) >> 1)) { q_dy = 0; if (++q_cls == 4) { q_cls = 0; wrapped = true; } }
+        }
+        u_ty = (q_cls >> 1) + 2 * q_dy; u_tx = (q_cls & 1) + 2 * q_dx;
+      } else if (++u_tx == p_tw) { u_tx = 0; if (++u_ty == p_th) { u_ty = 0; wrapped = true; } }
+      return wrapped;
+    };
+    auto issue = [&](int buf) {
+      const int w_dy = p_dy0 + u_ty * p_dys, w_dx = p_dx0 + u_tx * p_dxs;
+      const int w_tapoff = ((w_dy * IW + w_dx) * Cs + u_c) * 2;
+      const unsigned w_wk = (unsigned)((p_wbase + u_ty * p_wsy + u_tx * p_wsx) * Cs + u_c) * 2u;
+      const unsigned w_sbase = lds_base + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
+#pragma unroll
+      for (int q = 0; q < L; ++q) {
+        if (q < 3 * RSA) {
+          const int p = q / RSA, i = q % RSA;
+          const int iy = aiy[i] + w_dy, ix = aix[i] + w_dx;
+          bool ok;
+          unsigned off;
+          if (reflect) {
+            ok = aiy[i] != ROW_INVALID;
+            const int ry = reflect_idx(iy, IH), rx = reflect_idx(ix, IW);
+            off = arow[i] + (unsigned)((((ry - aiy[i]) * IW + (rx - aix[i])) * Cs + u_c) * 2);
+          } else {
+            ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+            off = arow[i] + (unsigned)w_tapoff;
+          }
+          dma16(rs_in, w_sbase + (unsigned)p * A_PLANE + (unsigned)(i * NW) * 1024u, ok ? off + (unsigned)p * in_ps : OOB_OFFSET);
+        } else {
+          const int p = (q - 3 * RSA) / RSB, i = (q - 3 * RSA) % RSB;
+          dma16(rs_wt, w_sbase + A_BYTES + (unsigned)p * B_PLANE + (unsigned)(i * NW) * 1024u, wrow[i] + w_wk + (unsigned)p * wt_ps);
+        }
+      }
+      if (chunk_fast) {
+        u_c += 32;
+        if (u_c == Cs) { u_c = 0; tap_next(); }
+      } else if (tap_next()) u_c += 32;
+    };
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < nt) issue(s);
+    int nxt = NSTAGE - 1;
+    for (int t = 0; t < nt; ++t) {
+      const int rem = nt - 1 - t;
+      wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);   // this loader's share of stage t has landed
+      __builtin_amdgcn_s_barrier();                            // ... and every multiplying wave is done with stage t - 1
+      if (t + NSTAGE - 1 < nt) issue(nxt);
+      nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+    }
+    __builtin_amdgcn_s_barrier();                              // "the epilogue reuses the ring"
+    constexpr int EPI_BARRIERS = 1 + (STATS ? 2 : 0);          // pipe_epilogue with one column round: see its lds_barrier() calls
+#pragma unroll
+    for (int i = 0; i < EPI_BARRIERS; ++i) __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // =================================================== multiplying waves ===================================================
+  const int wave = wave8;
+  const int wm = wave / WGN, wn = wave % WGN;
+  f32x16 acc[WM][WN], accs[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = accs[i][j][r] = 0.f;
+  const int half = lane >> 5, l31 = lane & 31;
+  unsigned foff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) foff[kk] = (unsigned)l31 * 64u + (unsigned)((2 * kk + half) ^ ((l31 >> 2) & 3)) * 16u;
+  const unsigned a_wave = (unsigned)(wm * WM) * 2048u, b_wave = A_BYTES + (unsigned)(wn * WN) * 2048u;
+  u32x4 auxpf[PREF ? G::NIT : 1];
+  if constexpr (PREF) pipe_aux_load<G>(a, pz, m0, n0, 0, auxpf);       // (nothing else of this wave is ever in the vmcnt queue)
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's fragment reads of step t - 1 are complete
+    __builtin_amdgcn_s_barrier();
+    const char* sb = ldsc + cur * STAGE_BYTES;
+    constexpr int NFB = MINW <= 2 ? 2 : 1;       // fragment buffers: both sub-steps up front where 256 registers allow
+    bf16x8 af[NFB][3][WM], bf[NFB][3][WN];
+    auto frags = [&](int kk) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[kk % NFB][p][i] = *(const bf16x8*)(sb + a_wave + p * A_PLANE + i * 2048 + foff[kk]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[kk % NFB][p][j] = *(const bf16x8*)(sb + b_wave + p * B_PLANE + j * 2048 + foff[kk]);
+      }
+    };
+    frags(0);
+    if (NFB == 2) frags(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (NFB == 1 && kk == 1) frags(1);
+#pragma unroll
+      for (int tt = 0; tt < 6; ++tt) {
+        const int pa = tt == 0 ? 2 : (tt == 2 || tt == 3) ? 1 : 0;
+        const int pb = tt == 1 ? 2 : (tt == 2 || tt == 4) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            if (tt < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk % NFB][pa][i], bf[kk % NFB][pb][j], accs[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk % NFB][pa][i], bf[kk % NFB][pb][j], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                  // the epilogue reuses the ring
+  if constexpr (PREF) wait_vmcnt<0>();           // the prefetched operand of the fused derivative
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] += accs[i][j];
+  pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, 0u);
+}
+
 // Measured and not kept (round 5): the same ring as a PERSISTENT kernel (gconv_x3pp_kernel: grid = resident slots, each block walks
 // its tile list through the same XCD map and never drains the ring - the LDS-DMA "fill" side runs NSTAGE - 1 steps ahead of the
 // multiply side and switches to the next tile's rows when its walk is exhausted, the epilogue stages through the one stage that
@@ -926,6 +1129,48 @@ static int launch_x3p_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
   }
   IPR_LAUNCH_CHECK();
   return 0;
+}
+
+// warp-specialized form (gconv_x3ws_kernel): variant 0 = 256x64 (2 stages, 120 KB), 1 = 128x128 (3 stages, 144 KB),
+// 2 = 128x64 (2 stages, 72 KB, two blocks per CU)
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, int MINW = 2>
+static int launch_x3ws_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
+  constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+  int maxM = 0;
+  for (int i = 0; i < a_in.nphase; ++i) maxM = a_in.ph[i].M > maxM ? a_in.ph[i].M : maxM;
+  if (maxM == 0) return 0;
+  const size_t smem = (size_t)NSTAGE * 3 * (BM + BN) * 64;
+  dim3 grid(cdiv(maxM, BM), cdiv(a_in.Ns, BN), a_in.nphase);
+  *bm_out = BM;
+  static const int korder = getenv("IPRGAN_X3P_KORDER") ? atoi(getenv("IPRGAN_X3P_KORDER")) : -1;
+  GConvArgs a = a_in;
+  a.korder = korder >= 0 ? korder : ((a.isy == 2 && a.isx == 2) ? 3 : 0);       // (launch_x3p_t)
+  constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * 3 * (BM + BN) * 64>::PF_FIRST;
+  const bool pref = a.aux && a.aux16 == 1 && can_pf;
+  auto go = [&](auto kern) {
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+    prof_launch(kern, grid, dim3(512), smem, st, 29, a.flops, a);
+  };
+  if (a.stat_part) {
+    if constexpr (can_pf) { if (pref) { go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, true, MINW>); IPR_LAUNCH_CHECK(); return 0; } }
+    go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, MINW>);
+  } else {
+    if constexpr (can_pf) { if (pref) { go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, false, true, MINW>); IPR_LAUNCH_CHECK(); return 0; } }
+    go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, false, false, MINW>);
+  }
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int launch_gconv_x3ws(const GConvArgs& a, int variant, hipStream_t st, int* bm_out) {
+  static const bool enabled = !getenv("IPRGAN_X3WS") || atoi(getenv("IPRGAN_X3WS")) != 0;       // A/B switch
+  if (!enabled || !gconv_x3p_eligible(a)) return -1;
+  switch (variant) {
+    case 0: return launch_x3ws_t<4, 1, 2, 2, 2>(a, st, bm_out);
+    case 1: return a.Ns >= 128 ? launch_x3ws_t<2, 2, 2, 2, 3>(a, st, bm_out) : -1;
+    case 2: return launch_x3ws_t<2, 2, 2, 1, 2, 4>(a, st, bm_out);             // 128x64, 72 KB: two blocks (sixteen waves) per CU
+    default: return -1;
+  }
 }
 
 // ---- halo form: host side ----------------------------------------------------------------------------------------
