@@ -1070,6 +1070,13 @@ __global__ __launch_bounds__(512) void gconv_phase4_kernel(const GConvArgs a) {
 
 // ---- host side -----------------------------------------------------------------------------------------------
 static int g_pipe_f32 = getenv("IPRGAN_PIPE_F32") ? atoi(getenv("IPRGAN_PIPE_F32")) : 1;     // A/B switch: LDS-DMA ring tiles for fp32 layers
+// Measured and not kept (round 5): the bf16 ring with DEDICATED LOADER WAVES (four multiplying waves without vector-memory
+// instructions + four waves that only issue the refills: what conv_x3.hip's gconv_x3ws_kernel does for three-plane operands,
+// +10-27 % there).  256x128 (4 x 128x64, 3 stages), 128x128 (2 stages, two blocks per CU) and 256x64 tiles, parity-green:
+// +2-7 % over the plain tiles of the same shape, behind the autotuner's picks on every DCGAN-128 layer, config 5 unchanged
+// (17.3 ms; profiles/r05_bf16_loader_wave_tiles.jsonl).  A bf16 step moves the same bytes as a three-plane step for a sixth
+// of the matrix work: these tiles are bound by the bytes a CU can pull from L2 (~70 GB/s), not by the issue slots.
+
 bool gconv_pipe_eligible(const GConvArgs& a) {
   if (a.ksplit > 1 || a.wmod > 0 || a.planar_M || a.in16 == 2 || a.out16 == 2) return false;      // (three planes: conv_x3.hip)
   auto simple = [](int act) { return act == IPRGAN_ACT_NONE || act == IPRGAN_ACT_RELU || act == IPRGAN_ACT_LRELU; };
