@@ -420,7 +420,7 @@ int iprgan_get_math_mode(void);
  *              28..31 tiles 18, 19, 20, 22 on v_mfma_f32_16x16x32_bf16 (half the accumulator rows per instruction; measured
  *                     on par, kept as autotune candidates)
  *              32..34 the three-plane ring with DEDICATED LOADER WAVES (round 5): 256x64, 128x128, 128x64 (two blocks per CU) -
- *                     four waves multiply, four waves only issue the stage refills
+ *                     four waves multiply, four waves only issue the stage refills; 35..37 the same on v_mfma_f32_16x16x32_bf16
  *              14, 15 the persistent 256x128 / 256x64 form (bf16 operands)
  *              16     four sub-pixel phases per block (k4 s2 p1 backward-data forms, bf16 operands)
  *              17     256x256 with a half-tile ring: quadrant phases, five half-tiles of DMA in flight (bf16 operands)

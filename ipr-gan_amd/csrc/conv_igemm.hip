@@ -2264,7 +2264,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
         return launch_gconv_x3h(a, tile - 26, st, &t_last_bm);
       case 28: case 29: case 30: case 31:                                                       // ... on v_mfma_f32_16x16x32_bf16
         return launch_gconv_x3p16(a, tile - 28, st, &t_last_bm);
-      case 32: case 33: case 34:                                                                // ... with dedicated loader waves (round 5)
+      case 32: case 33: case 34: case 35: case 36: case 37:                                     // ... with dedicated loader waves (round 5)
         return launch_gconv_x3ws(a, tile - 32, st, &t_last_bm);
       default: return launch_gconv_t<2, 2, 1, 1>(a, st);
     }
@@ -2295,7 +2295,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
   g_prof_on = false;
   float best_us = 0.f;
   int err = 0;
-  const int best = tune_pick(35, [&](int cand) -> int {
+  const int best = tune_pick(38, [&](int cand) -> int {
     if ((cand == 0 || cand == 3 || cand == 4) && N < 128) return -1;
     if ((cand == 6 || cand == 7) && (long long)cdiv(maxM, 256) * cdiv(N, 128) * a.nphase < 256) return -1;    // not even one block per CU
     return run(cand);

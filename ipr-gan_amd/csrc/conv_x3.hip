@@ -321,7 +321,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p_kernel(const GConvAr
 // MI355X_MICROARCH.md, ldsdma-fill) and wait for them to land.  Same LDS image, same ring, same counted waits (kept by the
 // loaders), ONE s_barrier per K step shared by both roles; the loaders match the epilogue's barriers and leave.
 // Staging layout = the four-wave tile's (loader l owns the 16-row pieces l, l + 4, ... of every plane).
-template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF, int MINW = 2>
+// M16: the multiplying waves use v_mfma_f32_16x16x32_bf16 (gconv_x3p16_kernel's fragments and LDS swizzle: less energy per FLOP on
+// a chip that sits on its power cap under these kernels)
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, bool STATS, bool PREF, int MINW = 2, bool M16 = false>
 __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a) {      // MINW = 4: two blocks per CU (128 registers)
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NW = WGM * WGN;
   static_assert(NW == 4, "four multiplying waves + four loader waves");
@@ -364,7 +366,8 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
     const int IH = a.IH, IW = a.IW, Cs = a.Cs;
     const unsigned in_ps = a.in_ps, wt_ps = a.wt_ps;
     const int lrow = lane >> 2;
-    const unsigned sc = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
+    // source chunk of this lane's LDS position: the swizzle that makes the multiplying waves' fragment reads conflict-free
+    const unsigned sc = M16 ? (unsigned)((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) * 16u : (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
     int aiy[RSA], aix[RSA];
@@ -453,6 +456,57 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
   // =================================================== multiplying waves ===================================================
   const int wave = wave8;
   const int wm = wave / WGN, wn = wave % WGN;
+  const unsigned a_wave = (unsigned)(wm * WM) * 2048u, b_wave = A_BYTES + (unsigned)(wn * WN) * 2048u;
+  u32x4 auxpf[PREF ? G::NIT : 1];
+  if constexpr (PREF) pipe_aux_load<G>(a, pz, m0, n0, 0, auxpf);       // (nothing else of this wave is ever in the vmcnt queue)
+  if constexpr (M16) {
+    f32x4 acc[2 * WM][2 * WN], accs[2 * WM][2 * WN];
+#pragma unroll
+    for (int i = 0; i < 2 * WM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = accs[i][j][r] = 0.f;
+    const int l15 = lane & 15;
+    const unsigned foff = (unsigned)l15 * 64u + (unsigned)((lane >> 4) ^ ((4 - ((l15 >> 2) & 3)) & 3)) * 16u;      // + 1024 per 16-row block
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const char* sb = ldsc + cur * STAGE_BYTES;
+      bf16x8 bf[3][2 * WN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < 2 * WN; ++j) bf[p][j] = *(const bf16x8*)(sb + b_wave + p * B_PLANE + j * 1024 + foff);
+#pragma unroll
+      for (int i = 0; i < 2 * WM; ++i) {
+        bf16x8 af[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[p] = *(const bf16x8*)(sb + a_wave + p * A_PLANE + i * 1024 + foff);
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt) {
+          const int pa = tt == 0 ? 2 : (tt == 2 || tt == 3) ? 1 : 0;
+          const int pb = tt == 1 ? 2 : (tt == 2 || tt == 4) ? 1 : 0;
+#pragma unroll
+          for (int j = 0; j < 2 * WN; ++j) {
+            if (tt < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa], bf[pb][j], accs[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa], bf[pb][j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // the epilogue reuses the ring
+    if constexpr (PREF) wait_vmcnt<0>();
+#pragma unroll
+    for (int i = 0; i < 2 * WM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * WN; ++j) acc[i][j] += accs[i][j];
+    pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, 0u);
+    return;
+  }
   f32x16 acc[WM][WN], accs[WM][WN];
 #pragma unroll
   for (int i = 0; i < WM; ++i)
@@ -464,9 +518,6 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
   unsigned foff[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) foff[kk] = (unsigned)l31 * 64u + (unsigned)((2 * kk + half) ^ ((l31 >> 2) & 3)) * 16u;
-  const unsigned a_wave = (unsigned)(wm * WM) * 2048u, b_wave = A_BYTES + (unsigned)(wn * WN) * 2048u;
-  u32x4 auxpf[PREF ? G::NIT : 1];
-  if constexpr (PREF) pipe_aux_load<G>(a, pz, m0, n0, 0, auxpf);       // (nothing else of this wave is ever in the vmcnt queue)
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's fragment reads of step t - 1 are complete
@@ -1133,7 +1184,7 @@ static int launch_x3p_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
 
 // warp-specialized form (gconv_x3ws_kernel): variant 0 = 256x64 (2 stages, 120 KB), 1 = 128x128 (3 stages, 144 KB),
 // 2 = 128x64 (2 stages, 72 KB, two blocks per CU)
-template <int WGM, int WGN, int WM, int WN, int NSTAGE, int MINW = 2>
+template <int WGM, int WGN, int WM, int WN, int NSTAGE, int MINW = 2, bool M16 = false>
 static int launch_x3ws_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
   constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
   int maxM = 0;
@@ -1153,11 +1204,11 @@ static int launch_x3ws_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
     prof_launch(kern, grid, dim3(512), smem, st, 29, a.flops, a);
   };
   if (a.stat_part) {
-    if constexpr (can_pf) { if (pref) { go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, true, MINW>); IPR_LAUNCH_CHECK(); return 0; } }
-    go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, MINW>);
+    if constexpr (can_pf) { if (pref) { go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, true, MINW, M16>); IPR_LAUNCH_CHECK(); return 0; } }
+    go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, MINW, M16>);
   } else {
-    if constexpr (can_pf) { if (pref) { go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, false, true, MINW>); IPR_LAUNCH_CHECK(); return 0; } }
-    go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, false, false, MINW>);
+    if constexpr (can_pf) { if (pref) { go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, false, true, MINW, M16>); IPR_LAUNCH_CHECK(); return 0; } }
+    go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, false, false, MINW, M16>);
   }
   IPR_LAUNCH_CHECK();
   return 0;
@@ -1169,6 +1220,9 @@ int launch_gconv_x3ws(const GConvArgs& a, int variant, hipStream_t st, int* bm_o
     case 0: return launch_x3ws_t<4, 1, 2, 2, 2>(a, st, bm_out);
     case 1: return a.Ns >= 128 ? launch_x3ws_t<2, 2, 2, 2, 3>(a, st, bm_out) : -1;
     case 2: return launch_x3ws_t<2, 2, 2, 1, 2, 4>(a, st, bm_out);             // 128x64, 72 KB: two blocks (sixteen waves) per CU
+    case 3: return launch_x3ws_t<4, 1, 2, 2, 2, 2, true>(a, st, bm_out);       // 3-5: the same tiles on v_mfma_f32_16x16x32_bf16
+    case 4: return a.Ns >= 128 ? launch_x3ws_t<2, 2, 2, 2, 3, 2, true>(a, st, bm_out) : -1;
+    case 5: return launch_x3ws_t<2, 2, 2, 1, 2, 4, true>(a, st, bm_out);
     default: return -1;
   }
 }
