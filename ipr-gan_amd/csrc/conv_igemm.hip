@@ -43,6 +43,7 @@ static ProfSlot g_slots[] = {
     {"gconv_x3_kernel", 0, 0, 0},       {"wgrad_x3_kernel", 0, 0, 0},
     {"gconv_x3p_kernel", 0, 0, 0},      {"wgrad_x3h_kernel", 0, 0, 0},
     {"gconv_x3h_kernel", 0, 0, 0},
+    {"gconv_x3p16_kernel", 0, 0, 0},    {"gconv_x3ws_kernel", 0, 0, 0},
 };
 static const int g_nslots = sizeof(g_slots) / sizeof(g_slots[0]);
 struct ProfRec { hipEvent_t a, b; int slot; double flops; int tag; };

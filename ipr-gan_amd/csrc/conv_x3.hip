@@ -459,6 +459,7 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
   const unsigned a_wave = (unsigned)(wm * WM) * 2048u, b_wave = A_BYTES + (unsigned)(wn * WN) * 2048u;
   u32x4 auxpf[PREF ? G::NIT : 1];
   if constexpr (PREF) pipe_aux_load<G>(a, pz, m0, n0, 0, auxpf);       // (nothing else of this wave is ever in the vmcnt queue)
+  if (a.korder & 128) __builtin_amdgcn_s_setprio(3);                   // (A/B: the multiplying wave ahead of its SIMD's loader wave)
   if constexpr (M16) {
     f32x4 acc[2 * WM][2 * WN], accs[2 * WM][2 * WN];
 #pragma unroll
@@ -474,16 +475,22 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       const char* sb = ldsc + cur * STAGE_BYTES;
-      bf16x8 bf[3][2 * WN];
+      // read order = the order the six terms need them: the first MFMA (l h') waits for the three A planes of block row 0 and
+      // the h' fragments only, the l' and m' fragments arrive under the first MFMAs
+      bf16x8 bf[3][2 * WN], af0[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < 3; ++p) af0[p] = *(const bf16x8*)(sb + a_wave + (2 - p) * A_PLANE + foff);       // l, m, h of block row 0
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) {
+        const int p = pp == 0 ? 0 : pp == 1 ? 2 : 1;                   // h', l', m'
 #pragma unroll
         for (int j = 0; j < 2 * WN; ++j) bf[p][j] = *(const bf16x8*)(sb + b_wave + p * B_PLANE + j * 1024 + foff);
+      }
 #pragma unroll
       for (int i = 0; i < 2 * WM; ++i) {
         bf16x8 af[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[p] = *(const bf16x8*)(sb + a_wave + p * A_PLANE + i * 1024 + foff);
+        for (int p = 0; p < 3; ++p) af[p] = i == 0 ? af0[2 - p] : *(const bf16x8*)(sb + a_wave + p * A_PLANE + i * 1024 + foff);
 #pragma unroll
         for (int tt = 0; tt < 6; ++tt) {
           const int pa = tt == 0 ? 2 : (tt == 2 || tt == 3) ? 1 : 0;
@@ -1144,11 +1151,11 @@ bool gconv_x3p_eligible(const GConvArgs& a, bool ksplit_ok = false) {
   return true;
 }
 
-template <void (*KERN)(const GConvArgs)>
+template <void (*KERN)(const GConvArgs), int SLOT = 29>
 static void x3p_go(const GConvArgs& a, dim3 grid, dim3 block, size_t smem, hipStream_t st) {
   static bool attr_set = false;            // per kernel instantiation
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
-  prof_launch(KERN, grid, block, smem, st, 29, a.flops, a);
+  prof_launch(KERN, grid, block, smem, st, SLOT, a.flops, a);      // bench.py's roofline slots: one per __global__ name
 }
 
 template <int WGM, int WGN, int WM, int WN, int NSTAGE>
@@ -1196,12 +1203,14 @@ static int launch_x3ws_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
   static const int korder = getenv("IPRGAN_X3P_KORDER") ? atoi(getenv("IPRGAN_X3P_KORDER")) : -1;
   GConvArgs a = a_in;
   a.korder = korder >= 0 ? korder : ((a.isy == 2 && a.isx == 2) ? 3 : 0);       // (launch_x3p_t)
+  static const int prio = getenv("IPRGAN_X3WS_PRIO") ? atoi(getenv("IPRGAN_X3WS_PRIO")) : 0;
+  if (prio) a.korder |= 128;
   constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * 3 * (BM + BN) * 64>::PF_FIRST;
   const bool pref = a.aux && a.aux16 == 1 && can_pf;
   auto go = [&](auto kern) {
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
-    prof_launch(kern, grid, dim3(512), smem, st, 29, a.flops, a);
+    prof_launch(kern, grid, dim3(512), smem, st, 33, a.flops, a);
   };
   if (a.stat_part) {
     if constexpr (can_pf) { if (pref) { go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, true, MINW, M16>); IPR_LAUNCH_CHECK(); return 0; } }
@@ -1301,8 +1310,8 @@ static int launch_x3p16_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
   static const int korder = getenv("IPRGAN_X3P_KORDER") ? atoi(getenv("IPRGAN_X3P_KORDER")) : -1;
   GConvArgs a = a_in;
   a.korder = korder >= 0 ? korder : ((a.isy == 2 && a.isx == 2) ? 3 : 0);       // (launch_x3p_t)
-  if (a.stat_part) x3p_go<gconv_x3p16_kernel<WGM, WGN, WM, WN, NSTAGE, true, false>>(a, grid, block, smem, st);
-  else x3p_go<gconv_x3p16_kernel<WGM, WGN, WM, WN, NSTAGE, false, false>>(a, grid, block, smem, st);
+  if (a.stat_part) x3p_go<gconv_x3p16_kernel<WGM, WGN, WM, WN, NSTAGE, true, false>, 32>(a, grid, block, smem, st);
+  else x3p_go<gconv_x3p16_kernel<WGM, WGN, WM, WN, NSTAGE, false, false>, 32>(a, grid, block, smem, st);
   IPR_LAUNCH_CHECK();
   return 0;
 }

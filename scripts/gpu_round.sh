@@ -65,7 +65,7 @@ timeout 900 python bench.py --workload dcgan128 --math bf16act --no-cpu-baseline
 timeout 900 python bench.py --math bf16act --no-cpu-baseline > $O/${TAG}_bench_dcgan64_bf16act.json 2>> $O/bench.err
 timeout 600 python scripts/conv_bench.py > $O/${TAG}_conv_bench.jsonl 2> $O/conv_bench.err
 # three-plane tiles per layer (forward / backward-data by forced tile, backward-weight by candidate)
-X3P_TILES=-1,18,19,21,26,28 timeout 600 python scripts/x3p_check.py bench > $O/${TAG}_conv_bench_fp32x3.jsonl 2>> $O/conv_bench.err
+X3P_TILES=-1,18,19,21,26,28,32,33,34,36,37 timeout 900 python scripts/x3p_check.py bench > $O/${TAG}_conv_bench_fp32x3.jsonl 2>> $O/conv_bench.err
 timeout 600 python scripts/probe/wgrad_x3_bench.py > $O/${TAG}_wgrad_bench_fp32x3.jsonl 2>> $O/conv_bench.err
 # per-layer tables (conv-family launches by pass + geometry) of the workloads, headline math mode and exact fp32
 for w in dcgan64 srgan cyclegan; do

@@ -31,8 +31,9 @@ def short(k):
     m = re.match(r'void iprgan::(wgrad_halo_f32_kernel|wgrad_halo_kernel|gconv_phase4_kernel|gconv_pipe8_kernel|gconv_x3h_kernel|wgrad_x3h_kernel)<', k)
     if m:
         return m.group(1)
-    if re.match(r'void iprgan::gconv_x3p(16)?_kernel<', k):      # three-plane ring tiles (conv_x3.hip): profiling slot 29
-        return 'gconv_x3p_kernel'
+    m = re.match(r'void iprgan::(gconv_x3p_kernel|gconv_x3p16_kernel|gconv_x3ws_kernel)<', k)      # three-plane ring tiles (conv_x3.hip):
+    if m:                                                                                           # profiling slots 29 / 32 / 33
+        return m.group(1)
     m = re.match(r'void iprgan::wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)(?:, (true|false))?(?:, (true|false))?(?:, (true|false))?>', k)
     if m:
         if m.group(9) == 'true':

@@ -1065,7 +1065,10 @@ def test_conv_epilogue_column_sums(dev, shape, tile):
         xd = to_nhwc(x).to(dev)
         y0 = ops.conv_fwd(spec, d, xd, wf, b.to(dev))
         y, (part, rows) = ops.conv_fwd(spec, d, xd, wf, b.to(dev), stats=True)
-        assert torch.equal(y, y0)
+        if tile >= 0:
+            assert torch.equal(y, y0)
+        else:   # the tuner times the two epilogues apart and may pick tiles whose MFMA shapes sum a K step in a different order
+            assert float((y - y0).abs().max()) <= 2e-6 * float(y0.abs().max())
         Cs = ops.c4(cout)
         pr = part[:rows * 2 * Cs].view(rows, 2, Cs).double().sum(0).cpu()
         ref1, ref2 = acc.double().sum((0, 2, 3)), (acc.double() ** 2).sum((0, 2, 3))
@@ -1079,7 +1082,10 @@ def test_conv_epilogue_column_sums(dev, shape, tile):
         xin_d = to_nhwc(xin.detach()).to(dev)
         dx0 = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb, xin_d, 2, 0.1)
         dx, (part, rows) = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb, xin_d, 2, 0.1, colsums=True)
-        assert torch.equal(dx, dx0)
+        if tile >= 0:
+            assert torch.equal(dx, dx0)
+        else:
+            assert float((dx - dx0).abs().max()) <= 2e-6 * float(dx0.abs().max())
         cs = ops.colsum_partials(part, rows, ops.c4(cin), cin).cpu().double()
         refc = want.double().sum((0, 2, 3))
         assert float((cs - refc).abs().max()) <= 2e-4 * float(want.abs().max()) * want[:, 0].numel() ** 0.5
