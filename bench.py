@@ -506,6 +506,15 @@ def main():
                     'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
                     'source': f'HIP events on the launch stream, this run: second window of {prof_steps} eager steps behind '
                               'the closing fence of the timed region (no instrumented step inside `value`)'}
+            # the three-plane ring exists under three __global__ names (same stages, same six-MFMA product block, same epilogue;
+            # four multiplying+loading waves / the 16x16x32 form / dedicated loader waves): the tuner deals a layer to whichever
+            # is fastest, so one name alone shows the layers it was dealt, not the algorithm - report the three together as well
+            ring = [k for k in kernels if k['name'] in ('gconv_x3p_kernel', 'gconv_x3p16_kernel', 'gconv_x3ws_kernel') and k['ms'] > 0]
+            if dom['name'] in [k['name'] for k in ring] and len(ring) > 1:
+                rms, rfl = sum(k['ms'] for k in ring), sum(k['flops'] for k in ring)
+                roof['ring_family'] = {'kernels': {k['name']: {'launches': k['launches'], 'ms': round(k['ms'], 3),
+                                                                 'tflops': round(k['flops'] / (k['ms'] * 1e-3) / 1e12, 2)} for k in ring},
+                                       'achieved': round(rfl / (rms * 1e-3) / 1e12, 2), 'frac': round(rfl / (rms * 1e-3) / peak, 4)}
         conv_ms = sum(k['ms'] for k in kernels)
         conv_flops = sum(k['flops'] for k in kernels)
         out = {

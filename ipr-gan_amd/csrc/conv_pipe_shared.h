@@ -48,9 +48,11 @@ __device__ __forceinline__ void wait_stages(int stages) {
 }
 
 // ---- row-major epilogue through LDS ---------------------------------------------------------------------------
-template <int WGM, int WGN, int WM, int WN, int RING_BYTES>
+// XW: waves of the block beyond the WGM x WGN multiplying ones that take a share of the row passes (the loader waves of
+// conv_x3.hip's gconv_x3ws_kernel: the passes are latency chains - LDS read, split, stores - that one wave per SIMD does not hide)
+template <int WGM, int WGN, int WM, int WN, int RING_BYTES, int XW = 0>
 struct EpiGeom {
-  static constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NT = WGM * WGN * 64;
+  static constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32, NT = (WGM * WGN + XW) * 64;
   static constexpr int NH = (BM * BN * 4 > RING_BYTES) ? 2 : 1;     // column halves (256x256: two rounds of 128 columns)
   static constexpr int CN = BN / NH;        // columns per round
   static constexpr int OCT = CN / 8;        // threads per tile row (8 channels each)
@@ -128,13 +130,15 @@ __device__ __forceinline__ void pipe_acc_to_lds(const f32x4 (&acc)[2 * WM][2 * W
 
 // X3: out (and res) may be a three-plane tensor (GConvArgs::out16 == 2): the 8 values of a store are split into x = h + m + l
 // (exact) and leave as three 16-byte stores out_ps bytes apart; a three-plane residual is read back as h + (m + l) (exact).
-template <int WGM, int WGN, int WM, int WN, int RING_BYTES, bool STATS, bool PF, bool BNM = false, bool X3 = false, class ACC = f32x16[WM][WN]>
+// XW / HAS_ACC: see EpiGeom - the extra waves call this with HAS_ACC = false (they hold no accumulators) and run the same barriers
+template <int WGM, int WGN, int WM, int WN, int RING_BYTES, bool STATS, bool PF, bool BNM = false, bool X3 = false, class ACC = f32x16[WM][WN],
+          int XW = 0, bool HAS_ACC = true>
 __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, ACC& acc, float* T, int pz, unsigned lq,
                                               int m0, int n0, const u32x4* auxpf,         // PF: [NH][NIT] prefetched
                                               const unsigned* rowtab = nullptr,
                                               unsigned slab_off = 0) {                    // split K: fp32 elements into a.out
-  using G = EpiGeom<WGM, WGN, WM, WN, RING_BYTES>;
-  constexpr int CN = G::CN, OCT = G::OCT, RPI = G::RPI, NIT = G::NIT, NW = WGM * WGN;
+  using G = EpiGeom<WGM, WGN, WM, WN, RING_BYTES, XW>;
+  constexpr int CN = G::CN, OCT = G::OCT, RPI = G::RPI, NIT = G::NIT, NW = WGM * WGN + XW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN, half = lane >> 5, l31 = lane & 31;
   const int oct = tid % OCT, r0 = tid / OCT;
@@ -154,7 +158,7 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, ACC& acc, floa
     u32x4 auxl[NIT];
     if (!PF && a.aux && a.aux16) pipe_aux_load<G>(a, pz, m0, n0, h, auxl, rowtab);      // in flight across the LDS round trip
     if (h > 0) lds_barrier();                         // everybody is done reading the previous half
-    if (wn / WGN_H == h) pipe_acc_to_lds<WM, WN>(acc, T, CN, wm, wn % WGN_H, lane);
+    if constexpr (HAS_ACC) { if (wn / WGN_H == h) pipe_acc_to_lds<WM, WN>(acc, T, CN, wm, wn % WGN_H, lane); }
     lds_barrier();
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) {

@@ -332,8 +332,8 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
   constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, A_BYTES = 3 * A_PLANE, STAGE_BYTES = 3 * (BM + BN) * 64;
   static_assert(RSA >= 1 && RSB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "every loader stages whole 16-row pieces");
   static_assert(NSTAGE >= 2 && NSTAGE <= 3 && L * (NSTAGE - 2) <= 63, "ring depth / vmcnt field");
-  using G = EpiGeom<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES>;
-  static_assert(G::NH == 1, "the loaders match the barriers of a one-round epilogue");
+  using G = EpiGeom<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, NW>;      // all eight waves share the epilogue's row passes
+  static_assert(G::NH == 1, "one column round");
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
 
   const unsigned lt = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
@@ -390,6 +390,9 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
 #pragma unroll
     for (int i = 0; i < RSB; ++i) wrow[i] = (unsigned)((n0 + (i * NW + wave) * 16 + lrow) * a.Kp) * 2u + sc;
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    u32x4 auxpf[PREF ? G::NIT : 1];
+    if constexpr (PREF) pipe_aux_load<G>(a, pz, m0, n0, 0, auxpf);     // ahead of every LDS-DMA piece in this wave's vmcnt queue: the counted waits
+                                                                       // ("at most N outstanding") never see it
     const bool chunk_fast = (a.korder & 1) != 0;
     const bool parity = (a.korder & 2) != 0 && a.isy == 2 && a.isx == 2 && p_th >= 2 && p_tw >= 2;
     int u_c = 0, u_ty = 0, u_tx = 0, q_cls = 0, q_dy = 0, q_dx = 0;
@@ -447,9 +450,14 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
       nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
     __builtin_amdgcn_s_barrier();                              // "the epilogue reuses the ring"
-    constexpr int EPI_BARRIERS = 1 + (STATS ? 2 : 0);          // pipe_epilogue with one column round: see its lds_barrier() calls
-#pragma unroll
-    for (int i = 0; i < EPI_BARRIERS; ++i) __builtin_amdgcn_s_barrier();
+    // the loaders take half of the epilogue's row passes (LDS -> split -> stores): same barriers, no accumulators
+    if constexpr (M16) {
+      f32x4 none[2 * WM][2 * WN];
+      pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true, f32x4[2 * WM][2 * WN], NW, false>(a, none, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, 0u);
+    } else {
+      f32x16 none[WM][WN];
+      pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true, f32x16[WM][WN], NW, false>(a, none, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, 0u);
+    }
     return;
   }
 
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
   const unsigned a_wave = (unsigned)(wm * WM) * 2048u, b_wave = A_BYTES + (unsigned)(wn * WN) * 2048u;
   u32x4 auxpf[PREF ? G::NIT : 1];
   if constexpr (PREF) pipe_aux_load<G>(a, pz, m0, n0, 0, auxpf);       // (nothing else of this wave is ever in the vmcnt queue)
-  if (a.korder & 128) __builtin_amdgcn_s_setprio(3);                   // (A/B: the multiplying wave ahead of its SIMD's loader wave)
+  // (s_setprio(3) on the multiplying waves: no effect on any layer - 8.125 / 8.136 ms per DCGAN step)
   if constexpr (M16) {
     f32x4 acc[2 * WM][2 * WN], accs[2 * WM][2 * WN];
 #pragma unroll
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
     for (int i = 0; i < 2 * WM; ++i)
 #pragma unroll
       for (int j = 0; j < 2 * WN; ++j) acc[i][j] += accs[i][j];
-    pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, 0u);
+    pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true, f32x4[2 * WM][2 * WN], NW>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, 0u);
     return;
   }
   f32x16 acc[WM][WN], accs[WM][WN];
@@ -568,9 +576,22 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] += accs[i][j];
-  pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, 0u);
+  pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true, f32x16[WM][WN], NW>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, 0u);
 }
 
+// Measured and not kept (round 5): the loader-wave ring in PERSISTENT blocks (gconv_x3wp_kernel: a block stays on its CU and walks a
+// tile list in the XCD map's order; the loader waves see one unbroken stream of K steps and refill across tile boundaries, so the
+// next tile's first stages land while the multiplying waves are in the epilogue; the epilogue stages through the one ring buffer
+// that is free between a tile's last step and the refill behind the next tile's first barrier - 128x128 in two column halves;
+// past the last tile the loaders issue zero-fill dummies so that the counted wait is one instruction on every step).  Bit-identical
+// to tiles 36 / 37 on multi-round, multi-phase, ragged layers - and exactly as fast: scripts/probe/tile_overhead.py fits
+// (time per tile) = a + b (K steps) with a = 8.3 us, b = 1.15 us against a = 9.7 us, b = 1.10 us for tile 36 (north-star layer
+// 218.6 vs 219.7 TFLOP/s, D.conv4 198 vs 201).  What the fit says about a: the same probe without the epilogue
+// (accumulators dropped) leaves a = 3.7 us, i.e. 4.4-6 us of every 128x128 tile are the epilogue itself - one wave per SIMD
+// running 8 dependent passes of (LDS read, ~70 VALU instructions of three-plane split, three 16-byte stores) with the matrix
+// pipe idle - and a persistent block only hides the ~2 us around it.  Over a DCGAN step that is ~27 k tile epilogues = 0.5 ms
+// (6 %).  Hiding it needs the accumulators parked in LDS while the next tile multiplies (64 KB beside the ring: only a two-stage
+// ring fits, and the two-stage 128x128 tile measures b = 1.17 us, 3-7 % slower on every layer) - not built.
 // Measured and not kept (round 5): the same ring as a PERSISTENT kernel (gconv_x3pp_kernel: grid = resident slots, each block walks
 // its tile list through the same XCD map and never drains the ring - the LDS-DMA "fill" side runs NSTAGE - 1 steps ahead of the
 // multiply side and switches to the next tile's rows when its walk is exhausted, the epilogue stages through the one stage that
@@ -1203,9 +1224,7 @@ static int launch_x3ws_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
   static const int korder = getenv("IPRGAN_X3P_KORDER") ? atoi(getenv("IPRGAN_X3P_KORDER")) : -1;
   GConvArgs a = a_in;
   a.korder = korder >= 0 ? korder : ((a.isy == 2 && a.isx == 2) ? 3 : 0);       // (launch_x3p_t)
-  static const int prio = getenv("IPRGAN_X3WS_PRIO") ? atoi(getenv("IPRGAN_X3WS_PRIO")) : 0;
-  if (prio) a.korder |= 128;
-  constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * 3 * (BM + BN) * 64>::PF_FIRST;
+  constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * 3 * (BM + BN) * 64, WGM * WGN>::PF_FIRST;
   const bool pref = a.aux && a.aux16 == 1 && can_pf;
   auto go = [&](auto kern) {
     static bool attr_set = false;

@@ -16,7 +16,7 @@ SMALL = [  # B, cin, cout, k, stride, pad, H, transposed, reflect
     (8, 64, 64, 4, 2, 1, 64, False, False), (8, 256, 128, 4, 2, 1, 16, True, False), (2, 256, 256, 3, 2, 1, 24, False, False),
     (4, 96, 160, 3, 1, 1, 20, False, False), (2, 128, 128, 3, 1, 1, 16, False, True), (3, 64, 192, 3, 1, 1, 20, False, False),
 ]
-TILES = [-1, 0, 18, 26, 27, 28, 29, 30, 31, 32, 33]
+TILES = [-1, 0, 18, 26, 27, 28, 29, 30, 31, 32, 33, 36, 37]
 
 
 def relerr(got, want):
@@ -64,7 +64,7 @@ def acc():
             print(json.dumps(dict(layer=[B, cin, cout, k, s, p, H, tr, refl], tile=tile, y=ey, dx=edx, y32=e32[0], dx32=e32[1], ok=ok)), flush=True)
         # statistics + fused derivative + residual through the three-plane epilogue (tile 18 and the register-staged tile 0)
         if not tr and not refl and s == 1:
-            for tile in (18, 26, 28, 30, 32, 33, 0):
+            for tile in (18, 26, 28, 30, 32, 33, 36, 0):
                 _lib.call('iprgan_debug_force_tiles', tile, -1)
                 y, stats = ops.conv_fwd(spec, d, xp, wf, bias, stats=True)
                 yf = ops.to_kind(y, 0)
