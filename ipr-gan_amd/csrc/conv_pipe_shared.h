@@ -37,6 +37,13 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef IPRGAN_X3WS_TIMING      // debug build only (scripts/probe/ws_phase_times.sh): shader-clock stamps of one multiplying wave per block
+static __device__ unsigned long long g_x3ws_ts[8192 * 8];
+#define X3WS_STAMP(k) do { if (threadIdx.x == 0) { const unsigned bl = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+    if (bl < 8192) g_x3ws_ts[bl * 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define X3WS_STAMP(k) do { } while (0)
+#endif
 // wait until at most `stages` x L of this wave's LDS-DMA instructions are outstanding (stages: wave-uniform, 0..3)
 template <int L>
 __device__ __forceinline__ void wait_stages(int stages) {
@@ -160,6 +167,7 @@ __device__ __forceinline__ void pipe_epilogue(const GConvArgs& a, ACC& acc, floa
     if (h > 0) lds_barrier();                         // everybody is done reading the previous half
     if constexpr (HAS_ACC) { if (wn / WGN_H == h) pipe_acc_to_lds<WM, WN>(acc, T, CN, wm, wn % WGN_H, lane); }
     lds_barrier();
+    if constexpr (X3 && HAS_ACC && XW > 0) X3WS_STAMP(4);
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
 #pragma unroll

@@ -479,9 +479,11 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
     const int l15 = lane & 15;
     const unsigned foff = (unsigned)l15 * 64u + (unsigned)((lane >> 4) ^ ((4 - ((l15 >> 2) & 3)) & 3)) * 16u;      // + 1024 per 16-row block
     int cur = 0;
+    X3WS_STAMP(0);
     for (int t = 0; t < nt; ++t) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      if (t == 0) X3WS_STAMP(1);
       const char* sb = ldsc + cur * STAGE_BYTES;
       // read order = the order the six terms need them: the first MFMA (l h') waits for the three A planes of block row 0 and
       // the h' fragments only, the l' and m' fragments arrive under the first MFMAs
@@ -512,6 +514,7 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
       }
       cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
+    X3WS_STAMP(2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // the epilogue reuses the ring
     if constexpr (PREF) wait_vmcnt<0>();
@@ -519,7 +522,11 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
     for (int i = 0; i < 2 * WM; ++i)
 #pragma unroll
       for (int j = 0; j < 2 * WN; ++j) acc[i][j] += accs[i][j];
+    X3WS_STAMP(3);
     pipe_epilogue<WGM, WGN, WM, WN, NSTAGE * STAGE_BYTES, STATS, PREF, false, true, f32x4[2 * WM][2 * WN], NW>(a, acc, (float*)lds, pz, lq, m0, n0, auxpf, nullptr, 0u);
+    X3WS_STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    X3WS_STAMP(6);
     return;
   }
   f32x16 acc[WM][WN], accs[WM][WN];
@@ -586,12 +593,17 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
 // past the last tile the loaders issue zero-fill dummies so that the counted wait is one instruction on every step).  Bit-identical
 // to tiles 36 / 37 on multi-round, multi-phase, ragged layers - and exactly as fast: scripts/probe/tile_overhead.py fits
 // (time per tile) = a + b (K steps) with a = 8.3 us, b = 1.15 us against a = 9.7 us, b = 1.10 us for tile 36 (north-star layer
-// 218.6 vs 219.7 TFLOP/s, D.conv4 198 vs 201).  What the fit says about a: the same probe without the epilogue
-// (accumulators dropped) leaves a = 3.7 us, i.e. 4.4-6 us of every 128x128 tile are the epilogue itself - one wave per SIMD
-// running 8 dependent passes of (LDS read, ~70 VALU instructions of three-plane split, three 16-byte stores) with the matrix
-// pipe idle - and a persistent block only hides the ~2 us around it.  Over a DCGAN step that is ~27 k tile epilogues = 0.5 ms
-// (6 %).  Hiding it needs the accumulators parked in LDS while the next tile multiplies (64 KB beside the ring: only a two-stage
-// ring fits, and the two-stage 128x128 tile measures b = 1.17 us, 3-7 % slower on every layer) - not built.
+// 218.6 vs 219.7 TFLOP/s, D.conv4 198 vs 201; 4 % faster at 18 K steps, 2 % slower at 72: its two-half epilogue costs what the
+// hidden prologue saves, and its K step measured 3 % longer).  Where a tile's time goes, from s_memtime stamps inside the
+// 128x128 tile (scripts/probe/ws_phase_times.sh, profiles/r05_ws_phase_cycles.jsonl; shader cycles): K step 1 900 (the six-MFMA
+// block alone: 1 536 - the loaders need ~155 cycles per LDS-DMA piece beside the multiplying waves, 12 pieces per step; the 256x64
+// tile has 15 and steps in 2 600), entry -> first stage landed 5 700 (64-channel inputs: 10 900), accumulators -> LDS + barrier
+// 1 760, row passes 4 000 with all eight waves (was ~6 000 with four), store acknowledge 600-1 200: 12 500 cycles = 6.5 K steps per
+// tile outside the K loop, 8 % of a 72-step tile, 16 % at 36 steps, 34 % at 18.  Tried on the epilogue without effect on `a`:
+// every pass's LDS row read ahead of the first pass, a padded LDS pitch (the 16x16 accumulator layout writes 4-way bank
+// conflicts), s_setprio on the multiplying waves, HIP_FORCE_DEV_KERNARG.  Hiding the epilogue needs the accumulators parked in
+// LDS while the next tile multiplies (64 KB beside the ring: only a two-stage ring fits, and the two-stage 128x128 tile steps in
+// 1.17 instead of 1.09 us) - not built.
 // Measured and not kept (round 5): the same ring as a PERSISTENT kernel (gconv_x3pp_kernel: grid = resident slots, each block walks
 // its tile list through the same XCD map and never drains the ring - the LDS-DMA "fill" side runs NSTAGE - 1 steps ahead of the
 // multiply side and switches to the next tile's rows when its walk is exhausted, the epilogue stages through the one stage that
@@ -1372,3 +1384,9 @@ int launch_gconv_x3p(const GConvArgs& a, int variant, hipStream_t st, int* bm_ou
 }
 
 }  // namespace iprgan
+
+#ifdef IPRGAN_X3WS_TIMING
+extern "C" int iprgan_debug_x3ws_ts(unsigned long long* out, size_t n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(iprgan::g_x3ws_ts), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
