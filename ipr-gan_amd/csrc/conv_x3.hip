@@ -414,6 +414,9 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
       const unsigned w_sbase = lds_base + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
 #pragma unroll
       for (int q = 0; q < L; ++q) {
+#ifdef IPRGAN_X3WS_HALFDMA      // debug build only (ws_phase_times.sh halfdma): every other piece is not issued - is the K step bound by DMA intake?
+        if (q & 1) continue;
+#endif
         if (q < 3 * RSA) {
           const int p = q / RSA, i = q % RSA;
           const int iy = aiy[i] + w_dy, ix = aix[i] + w_dx;
@@ -444,7 +447,11 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
     int nxt = NSTAGE - 1;
     for (int t = 0; t < nt; ++t) {
       const int rem = nt - 1 - t;
+#ifdef IPRGAN_X3WS_HALFDMA
+      wait_stages<(L + 1) / 2>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+#else
       wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);   // this loader's share of stage t has landed
+#endif
       __builtin_amdgcn_s_barrier();                            // ... and every multiplying wave is done with stage t - 1
       if (t + NSTAGE - 1 < nt) issue(nxt);
       nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
@@ -604,6 +611,13 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
 // conflicts), s_setprio on the multiplying waves, HIP_FORCE_DEV_KERNARG.  Hiding the epilogue needs the accumulators parked in
 // LDS while the next tile multiplies (64 KB beside the ring: only a two-stage ring fits, and the two-stage 128x128 tile steps in
 // 1.17 instead of 1.09 us) - not built.
+// What bounds the K step (same stamps; IPRGAN_X3WS_HALFDMA: the loaders skip every other piece): the 128x128 tile steps in 1 894
+// cycles with HALF the pieces as with all of them (1 905) - its K step is the multiplying waves' own (1 546 cycles of MFMA + operand
+// fragments: 96 KB of LDS reads beside 48 KB of DMA writes per step are 1 152 cycles of the LDS pipe, bunched behind the barrier) -
+// while the 256x64 tile drops from 2 600-2 900 to 1 900-2 200: THAT tile is bound by its loaders (12 gathered activation pieces at
+// ~190 cycles + 3 weight pieces at ~100 per loader and step; 128x128: 6 + 6).  With half the DMA the same cycles pass 14 % faster
+// in wall time (1 705 -> 1 465 us on the north-star layer): the DMA's watts come out of the clock.  Reading the next step's first
+// fragments under the last MFMAs of a step (unsynchronised timing probe) made the step LONGER (2 090).
 // Measured and not kept (round 5): the same ring as a PERSISTENT kernel (gconv_x3pp_kernel: grid = resident slots, each block walks
 // its tile list through the same XCD map and never drains the ring - the LDS-DMA "fill" side runs NSTAGE - 1 steps ahead of the
 // multiply side and switches to the next tile's rows when its walk is exhausted, the epilogue stages through the one stage that
