@@ -414,8 +414,10 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
       const unsigned w_sbase = lds_base + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
 #pragma unroll
       for (int q = 0; q < L; ++q) {
-#ifdef IPRGAN_X3WS_HALFDMA      // debug build only (ws_phase_times.sh halfdma): every other piece is not issued - is the K step bound by DMA intake?
-        if (q & 1) continue;
+#ifdef IPRGAN_X3WS_HALFDMA      // debug build only (ws_phase_times.sh): 1 = every other piece is not issued - is the K step bound by DMA intake?
+        if (IPRGAN_X3WS_HALFDMA == 1 && (q & 1)) continue;          // 2 = no weight pieces, 3 = no activation pieces (what does each kind cost?)
+        if (IPRGAN_X3WS_HALFDMA == 2 && q >= 3 * RSA) continue;
+        if (IPRGAN_X3WS_HALFDMA == 3 && q < 3 * RSA) continue;
 #endif
         if (q < 3 * RSA) {
           const int p = q / RSA, i = q % RSA;
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
     for (int t = 0; t < nt; ++t) {
       const int rem = nt - 1 - t;
 #ifdef IPRGAN_X3WS_HALFDMA
-      wait_stages<(L + 1) / 2>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
+      wait_stages<(IPRGAN_X3WS_HALFDMA == 1 ? (L + 1) / 2 : IPRGAN_X3WS_HALFDMA == 2 ? 3 * RSA : 3 * RSB)>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);
 #else
       wait_stages<L>(rem < NSTAGE - 2 ? rem : NSTAGE - 2);   // this loader's share of stage t has landed
 #endif
@@ -614,10 +616,18 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
 // What bounds the K step (same stamps; IPRGAN_X3WS_HALFDMA: the loaders skip every other piece): the 128x128 tile steps in 1 894
 // cycles with HALF the pieces as with all of them (1 905) - its K step is the multiplying waves' own (1 546 cycles of MFMA + operand
 // fragments: 96 KB of LDS reads beside 48 KB of DMA writes per step are 1 152 cycles of the LDS pipe, bunched behind the barrier) -
-// while the 256x64 tile drops from 2 600-2 900 to 1 900-2 200: THAT tile is bound by its loaders (12 gathered activation pieces at
-// ~190 cycles + 3 weight pieces at ~100 per loader and step; 128x128: 6 + 6).  With half the DMA the same cycles pass 14 % faster
-// in wall time (1 705 -> 1 465 us on the north-star layer): the DMA's watts come out of the clock.  Reading the next step's first
-// fragments under the last MFMAs of a step (unsynchronised timing probe) made the step LONGER (2 090).
+// while the 256x64 tile drops from 2 600-2 900 to 1 900-2 200: THAT tile is bound by what its loaders move.  Pieces by kind (=2: no
+// weight pieces, =3: no activation pieces): 256x64 steps in 2 590-2 640 with its 12 + 3 pieces per loader, 2 050-2 150 with the
+// 12 activation pieces alone (3 120 for the stride-2 gather of D.conv1: 260 cycles per piece), 1 881 with the 3 weight pieces
+// alone (= the multiplying waves' floor): ~170 cycles per piece of either kind, one 1 KB piece per ~40 cycles per CU from four
+// loaders = 25 B/cycle = 43 GB/s at the 1.73 GHz these kernels clock at; two blocks per CU (eight loaders) reach 52 GB/s.
+// MI355X_MICROARCH.md has the ceiling: rows gathered from the XCD's L2 at 66-73 GB/s per CU by a CU that does nothing else,
+// 52-62 % of the stream-alone rate beside computing waves - the 64-column tiles sit ON it, and the 128x128 tile (48 KB per step
+// against 60) is balanced between it and its multiplying waves.  Only fewer bytes per MAC move these tiles (the halo form reads
+// a 3x3 layer's activations once instead of nine times, but steps 16 channels per barrier: 80-115 TFLOP/s on the same layers).
+// With half the DMA the same cycles pass 14 % faster in wall time (1 705 -> 1 465 us on the north-star layer): the DMA's watts
+// come out of the clock.  Reading the next step's first fragments under the last MFMAs of a step (unsynchronised timing probe)
+// made the step LONGER (2 090); 64x64 tiles at two or three blocks per CU: slower on every layer.
 // Measured and not kept (round 5): the same ring as a PERSISTENT kernel (gconv_x3pp_kernel: grid = resident slots, each block walks
 // its tile list through the same XCD map and never drains the ring - the LDS-DMA "fill" side runs NSTAGE - 1 steps ahead of the
 // multiply side and switches to the next tile's rows when its walk is exhausted, the epilogue stages through the one stage that
@@ -1277,6 +1287,8 @@ int launch_gconv_x3ws(const GConvArgs& a, int variant, hipStream_t st, int* bm_o
     case 3: return launch_x3ws_t<4, 1, 2, 2, 2, 2, true>(a, st, bm_out);       // 3-5: the same tiles on v_mfma_f32_16x16x32_bf16
     case 4: return a.Ns >= 128 ? launch_x3ws_t<2, 2, 2, 2, 3, 2, true>(a, st, bm_out) : -1;
     case 5: return launch_x3ws_t<2, 2, 2, 1, 2, 4, true>(a, st, bm_out);
+    // (64x64 tiles on this kernel, three or two blocks per CU so that co-resident blocks overlap each other's prologue and epilogue:
+    // 68-78 registers, parity-green, slower on every layer - "SR 64->64 @24x24" 96-101 against 109 TFLOP/s for the 128x64 tile)
     default: return -1;
   }
 }
