@@ -1136,6 +1136,17 @@ __global__ __launch_bounds__(512) void gconv_x3h_kernel(const GConvArgs a, const
   pipe_epilogue<WGM, WGN, WM, WN, BM * BN * 4, STATS, false, false, true>(a, acc, (float*)lds, pz, lq, 0, n0, nopf, rowtab);
 }
 
+// Measured and not kept (round 5): the halo form WITH LOADER WAVES (gconv_x3wh_kernel: 128 positions - 8x16, 16x8 or two 8x8 maps - x
+// 128 / 64 columns, the halo staged once per 32-channel chunk and double-buffered, 64-byte LDS rows in gconv_x3p16_kernel's swizzle
+// computed per lane from the shifted halo row, one v_mfma_f32_16x16x32_bf16 per block, plane pair and (tap, chunk) step = 96 per wave
+// between two barriers, four loaders issuing L = LB + LH pieces per step under one counted vmcnt; 28 instead of 48 KB from L2 per
+// step of a 128x128 tile).  Correct at the first run (as close to float64 as every other tile, statistics and fused derivative
+// included) and NOT faster: north-star layer 216-219 against 225-227 TFLOP/s for the im2col loader-wave tile, D.conv4 178 / 197
+// against 211 / 220, the 64-column form 184 against 190 (two blocks per CU) - the 128x128 K step is the multiplying waves' own
+// (half-DMA probe above) and the shifted halo reads cost them more than the aligned stage reads; with 118-154 KB of LDS only one
+// block fits a CU.  What the bytes saved do buy is clock (the reflect-padded north-star layer, where the im2col tile pays for its
+// reflected gathers: 214 against 210).
+
 // ---- storage conversion: fp32 <-> three planes (iprgan_cast with kind 2) -------------------------------------------
 // One thread per 8 elements: two 16-byte loads, three 16-byte stores (or the reverse); plane p at element offset p * ps.
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n8, size_t ps) {
