@@ -494,31 +494,41 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
       __builtin_amdgcn_s_barrier();
       if (t == 0) X3WS_STAMP(1);
       const char* sb = ldsc + cur * STAGE_BYTES;
-      // read order = the order the six terms need them: the first MFMA (l h') waits for the three A planes of block row 0 and
-      // the h' fragments only, the l' and m' fragments arrive under the first MFMAs
-      bf16x8 bf[3][2 * WN], af0[3];
+      // Order of the 16 product blocks of this wave: along the "staircase" (0,0) (0,1) (1,0) (1,1) (0,2) (1,2) (2,0) ... so that
+      // every group of blocks needs ONE new fragment triple (three planes of one A block row or one B block column).  Walking
+      // whole rows instead needs all twelve B fragments inside the first row: the four multiplying waves then pull 60 KB
+      // out of LDS right behind the barrier (480 cycles of the LDS pipe) while their MFMAs wait for operands.
+      bf16x8 af[2 * WM][3], bf[3][2 * WN];
+      auto load_a = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af0[p] = *(const bf16x8*)(sb + a_wave + (2 - p) * A_PLANE + foff);       // l, m, h of block row 0
+        for (int p = 0; p < 3; ++p) af[i][p] = *(const bf16x8*)(sb + a_wave + p * A_PLANE + i * 1024 + foff);
+      };
+      auto load_b = [&](int j) __attribute__((always_inline)) {
 #pragma unroll
-      for (int pp = 0; pp < 3; ++pp) {
-        const int p = pp == 0 ? 0 : pp == 1 ? 2 : 1;                   // h', l', m'
-#pragma unroll
-        for (int j = 0; j < 2 * WN; ++j) bf[p][j] = *(const bf16x8*)(sb + b_wave + p * B_PLANE + j * 1024 + foff);
-      }
-#pragma unroll
-      for (int i = 0; i < 2 * WM; ++i) {
-        bf16x8 af[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) af[p] = i == 0 ? af0[2 - p] : *(const bf16x8*)(sb + a_wave + p * A_PLANE + i * 1024 + foff);
+        for (int p = 0; p < 3; ++p) bf[p][j] = *(const bf16x8*)(sb + b_wave + p * B_PLANE + j * 1024 + foff);
+      };
+      auto block = [&](int i, int j) __attribute__((always_inline)) {
 #pragma unroll
         for (int tt = 0; tt < 6; ++tt) {
           const int pa = tt == 0 ? 2 : (tt == 2 || tt == 3) ? 1 : 0;
           const int pb = tt == 1 ? 2 : (tt == 2 || tt == 4) ? 1 : 0;
+          if (tt < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][pa], bf[pb][j], accs[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][pa], bf[pb][j], acc[i][j], 0, 0, 0);
+        }
+      };
+      constexpr int NR = 2 * WM, NC = 2 * WN, ND = NR > NC ? NR : NC;
+      load_a(0); load_b(0);
 #pragma unroll
-          for (int j = 0; j < 2 * WN; ++j) {
-            if (tt < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa], bf[pb][j], accs[i][j], 0, 0, 0);
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa], bf[pb][j], acc[i][j], 0, 0, 0);
-          }
+      for (int d = 0; d < ND; ++d) {          // ring d: column d against the rows above it, then row d up to the diagonal
+        if (d + 1 < NC) load_b(d + 1);        // (the fragments of ring d + 1 are on their way while ring d multiplies)
+        if (d + 1 < NR) load_a(d + 1);
+        if (d < NC) {
+#pragma unroll
+          for (int i = 0; i < (d < NR ? d : NR); ++i) block(i, d);
+        }
+        if (d < NR) {
+#pragma unroll
+          for (int j = 0; j <= (d < NC ? d : NC - 1); ++j) block(d, j);
         }
       }
       cur = cur + 1 == NSTAGE ? 0 : cur + 1;
