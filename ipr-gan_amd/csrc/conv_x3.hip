@@ -822,34 +822,47 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gconv_x3p16_kernel(const GConv
     constexpr int SPREAD = NSTAGE >= 3 ? NMF : (3 * NMF) / 4;
     const char* sb = ldsc + cb * STAGE_BYTES;
     if constexpr (iss) walk_begin(nb);
-    bf16x8 bf[3][2 * WN];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int j = 0; j < 2 * WN; ++j) bf[p][j] = *(const bf16x8*)(sb + b_wave + p * B_PLANE + j * 1024 + foff);
+    // the product blocks along the staircase of gconv_x3ws_kernel's multiplying waves (one new fragment triple per group of blocks)
+    bf16x8 af[2 * WM][3], bf[3][2 * WN];
     int q = 0, mi = 0;
+    auto load_a = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2 * WM; ++i) {
-      bf16x8 af[3];
+      for (int p = 0; p < 3; ++p) af[i][p] = *(const bf16x8*)(sb + a_wave + p * A_PLANE + i * 1024 + foff);
+    };
+    auto load_b = [&](int j) __attribute__((always_inline)) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[p] = *(const bf16x8*)(sb + a_wave + p * A_PLANE + i * 1024 + foff);
+      for (int p = 0; p < 3; ++p) bf[p][j] = *(const bf16x8*)(sb + b_wave + p * B_PLANE + j * 1024 + foff);
+    };
+    auto block = [&](int i, int j) __attribute__((always_inline)) {
 #pragma unroll
       for (int t = 0; t < 6; ++t) {           // l h', h l', m m', m h', h m' into the small accumulator, h h' into the large one
         const int pa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
         const int pb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
-#pragma unroll
-        for (int j = 0; j < 2 * WN; ++j) {
-          if (t < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa], bf[pb][j], accs[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa], bf[pb][j], acc[i][j], 0, 0, 0);
-          ++mi;
-          if constexpr (iss) {
-            if (q < L && q * SPREAD < mi * L) {
-              piece(q);
-              ++q;
-              __builtin_amdgcn_sched_barrier(0);
-            }
+        if (t < 5) accs[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][pa], bf[pb][j], accs[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][pa], bf[pb][j], acc[i][j], 0, 0, 0);
+        ++mi;
+        if constexpr (iss) {
+          if (q < L && q * SPREAD < mi * L) {
+            piece(q);
+            ++q;
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
+      }
+    };
+    constexpr int NR = 2 * WM, NC = 2 * WN, ND = NR > NC ? NR : NC;
+    load_a(0); load_b(0);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      if (d + 1 < NC) load_b(d + 1);
+      if (d + 1 < NR) load_a(d + 1);
+      if (d < NC) {
+#pragma unroll
+        for (int i = 0; i < (d < NR ? d : NR); ++i) block(i, d);
+      }
+      if (d < NR) {
+#pragma unroll
+        for (int j = 0; j <= (d < NC ? d : NC - 1); ++j) block(d, j);
       }
     }
     if constexpr (iss) {
