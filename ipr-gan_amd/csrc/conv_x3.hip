@@ -489,9 +489,18 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
     const unsigned foff = (unsigned)l15 * 64u + (unsigned)((lane >> 4) ^ ((4 - ((l15 >> 2) & 3)) & 3)) * 16u;      // + 1024 per 16-row block
     int cur = 0;
     X3WS_STAMP(0);
+#ifdef IPRGAN_X3WS_TIMING
+    unsigned long long bar_wait = 0;               // cycles this wave spends between arriving at the K-loop barrier and leaving it
+#endif
     for (int t = 0; t < nt; ++t) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef IPRGAN_X3WS_TIMING
+      const unsigned long long tb = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_barrier();
+      if (t > 0) bar_wait += __builtin_amdgcn_s_memtime() - tb;
+#else
+      __builtin_amdgcn_s_barrier();
+#endif
       if (t == 0) X3WS_STAMP(1);
       const char* sb = ldsc + cur * STAGE_BYTES;
       // Order of the 16 product blocks of this wave: along the "staircase" (0,0) (0,1) (1,0) (1,1) (0,2) (1,2) (2,0) ... so that
@@ -534,6 +543,9 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
       cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
     X3WS_STAMP(2);
+#ifdef IPRGAN_X3WS_TIMING
+    if (threadIdx.x == 0) { const unsigned bl = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); if (bl < 8192) g_x3ws_ts[bl * 8 + 7] = bar_wait; }
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // the epilogue reuses the ring
     if constexpr (PREF) wait_vmcnt<0>();
@@ -635,6 +647,10 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
 // 52-62 % of the stream-alone rate beside computing waves - the 64-column tiles sit ON it, and the 128x128 tile (48 KB per step
 // against 60) is balanced between it and its multiplying waves.  Only fewer bytes per MAC move these tiles (the halo form reads
 // a 3x3 layer's activations once instead of nine times, but steps 16 channels per barrier: 80-115 TFLOP/s on the same layers).
+// Inside the K-loop barrier a multiplying wave of the 128x128 tile spends 60-73 cycles per step (256x64: 710-770, waiting for its
+// loaders; 128x64 two per CU: 1 300-1 400): the 128x128 tile loses nothing to synchronisation - its ~290 cycles per step beyond
+// the MFMAs are operand waits on an LDS pipe that is 66 % busy (a FULL / FREE word handshake instead of the barrier has nothing
+// to win there).
 // With half the DMA the same cycles pass 14 % faster in wall time (1 705 -> 1 465 us on the north-star layer): the DMA's watts
 // come out of the clock.  Reading the next step's first fragments under the last MFMAs of a step (unsynchronised timing probe)
 // made the step LONGER (2 090); 64x64 tiles at two or three blocks per CU: slower on every layer.

@@ -42,12 +42,13 @@ for name, cin, cout, k, s, p, tr, H, B in LAYERS:
     bm, bn = {36: (128, 128), 35: (256, 64), 37: (128, 64)}[tile]
     nb = min(8192, (M // bm) * max(1, cout // bn))
     t = ts[:nb]
-    t = t[(t[:, :7] > 0).all(axis=1)]
+    t = t[(t[:, :7] > 0).all(axis=1)]          # (column 7: cycles of wave 0 inside the K-loop barrier, summed over the steps)
     dif = np.diff(t[:, :7], axis=1).astype(np.float64)          # shader-clock cycles (s_memtime; every XCD has its own base: only differences inside a block mean anything)
     names = ['prologue (entry -> stage 0 landed)', 'K loop', 'final barrier + acc sum', 'acc -> LDS + barrier', 'row passes', 'store ack']
     steps = cin * k * k // 32
     row = dict(layer=name, tile=tile, blocks=int(len(t)), launch_us=round(a.elapsed_time(b) * 1e3, 1), k_steps=steps,
                mean_cycles={n_: int(dif[:, i].mean()) for i, n_ in enumerate(names)},
                p90_cycles={n_: int(np.percentile(dif[:, i], 90)) for i, n_ in enumerate(names)},
-               cycles_per_k_step=round(float(dif[:, 1].mean() / steps), 1), block_cycles=int((t[:, 6] - t[:, 0]).mean()))
+               cycles_per_k_step=round(float(dif[:, 1].mean() / steps), 1), block_cycles=int((t[:, 6] - t[:, 0]).mean()),
+               barrier_wait_cycles_per_k_step=round(float(t[:, 7].mean() / max(1, steps - 1)), 1))
     print(json.dumps(row), flush=True)
