@@ -650,7 +650,10 @@ __global__ __launch_bounds__(512, MINW) void gconv_x3ws_kernel(const GConvArgs a
 // Inside the K-loop barrier a multiplying wave of the 128x128 tile spends 60-73 cycles per step (256x64: 710-770, waiting for its
 // loaders; 128x64 two per CU: 1 300-1 400): the 128x128 tile loses nothing to synchronisation - its ~290 cycles per step beyond
 // the MFMAs are operand waits on an LDS pipe that is 66 % busy (a FULL / FREE word handshake instead of the barrier has nothing
-// to win there).
+// to win there).  Built on top of that and removed: every loader publishes a "landed" count in an LDS word as soon as its share of
+// a stage is there, and a multiplying wave that finds all four counts ahead reads the first fragment triple of step t + 1 under the
+// last ring of step t (correct: the words make the early read safe) - 7 % SLOWER (K step 1.17 -> 1.25 us): 255 registers
+// instead of 196, and the flag read plus the conditional reads serialise the tail of the step.
 // With half the DMA the same cycles pass 14 % faster in wall time (1 705 -> 1 465 us on the north-star layer): the DMA's watts
 // come out of the clock.  Reading the next step's first fragments under the last MFMAs of a step (unsynchronised timing probe)
 // made the step LONGER (2 090); 64x64 tiles at two or three blocks per CU: slower on every layer.
