@@ -28,6 +28,13 @@ Extra objects on the JSON line:
                 the MFMA peak of the math mode (157.3 TFLOP/s fp32, 2500 bf16; MI355X_MICROARCH.md).  ``traffic`` and
                 ``mfma_util_pct_pmc`` are NOT measured in this run: they are read from the committed rocprofv3 --pmc
                 passes under profiles/ and carry their file name in ``*_source``.
+  step_roofline SURVEY.md 8(d)'s bounding roofline of the whole step: sum over the step's entry-point calls of
+                max(2*MACs / MFMA peak of the math mode, operand + result bytes / 6.3 TB/s), from a host-side accounting of one
+                eager step (iprgan/_lib.py: acct_*); frac = bound_ms / ms_per_step
+  north_star_conv  BASELINE.json's target layer (3x3 256->256 reflect-padded, 64x64 maps, batch 64) forward / backward-data /
+                backward-weight in the run's math mode and on the exact fp32 MFMA, timed after the timed region
+  eager_ms_per_step / host_enqueue_ms_per_eager_step  device and host cost of a step enqueued kernel by kernel (what N > 1 runs
+                under the default `--graph auto`), from a window behind the timed region
   cpu_baseline  the CPU oracle (oracle/gan.py, plain PyTorch fp32: the reference's own arithmetic) timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N=1), BEFORE the GPU section
 """
@@ -254,6 +261,76 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+HBM_ACHIEVABLE = 6.3e12          # B/s: what a streaming kernel reaches of the 8 TB/s spec (MI355X_MICROARCH.md)
+
+
+def step_roofline(recs, peak_mfma, ms_measured):
+    """SURVEY.md section 8(d) "bounding roofline" of one step: sum over the step's entry-point calls of
+    max(flops / peak_mfma, algorithmic bytes / achievable HBM rate).  ``recs`` = _lib.acct_end() of ONE eagerly enqueued step:
+    flops = 2 * MACs of the convolution family, bytes = every operand and result of a call counted once (workspaces excluded)."""
+    mfma = sum(f for _, f, _ in recs) / peak_mfma
+    hbm = sum(b for _, _, b in recs) / HBM_ACHIEVABLE
+    bound = sum(max(f / peak_mfma, b / HBM_ACHIEVABLE) for _, f, b in recs)
+    mfma_bound_ops = sum(1 for _, f, b in recs if f / peak_mfma >= b / HBM_ACHIEVABLE and f > 0)
+    by = {}
+    for name, f, b in recs:
+        e = by.setdefault(name.replace('iprgan_', ''), [0, 0.0, 0.0, 0.0])
+        e[0] += 1; e[1] += f; e[2] += b; e[3] += max(f / peak_mfma, b / HBM_ACHIEVABLE)
+    top = sorted(by.items(), key=lambda kv: -kv[1][3])[:8]
+    return {'bound_ms': round(bound * 1e3, 4), 'mfma_ms': round(mfma * 1e3, 4), 'hbm_ms': round(hbm * 1e3, 4),
+            'frac': round(bound * 1e3 / ms_measured, 4) if ms_measured else None,
+            'peak_mfma_tflops': round(peak_mfma / 1e12, 1), 'hbm_tb_s': HBM_ACHIEVABLE / 1e12,
+            'calls': len(recs), 'calls_mfma_bound': mfma_bound_ops,
+            'algorithmic_gflop': round(sum(f for _, f, _ in recs) / 1e9, 2),
+            'algorithmic_mb': round(sum(b for _, _, b in recs) / 1e6, 1),
+            'by_entry_point': {k: {'calls': v[0], 'gflop': round(v[1] / 1e9, 2), 'mb': round(v[2] / 1e6, 1),
+                                   'bound_ms': round(v[3] * 1e3, 4)} for k, v in top},
+            'definition': 'sum over the calls of one step of max(2*MACs / peak_mfma, operand+result bytes / hbm_tb_s); '
+                          'frac = bound_ms / ms_per_step'}
+
+
+def north_star_conv(device, modes, n=8):
+    """BASELINE.json north_star microbench: the 3x3 256->256 stride-1 reflection-padded convolution of Resnet9Blocks on a
+    64x3x256x256 batch (networks/resnet_generator.py:44-49: 64x64 maps, batch 64), forward / backward-data /
+    backward-weight through the C ABI, per math mode: mean of ``n`` launches behind two untimed ones (the first autotunes),
+    device time from events on the launch stream.  Runs AFTER the timed region; never part of `value`."""
+    from iprgan import _lib, ops
+    out = {}
+    keep = _lib.get_math()
+    B, H, Cc = 64, 64, 256
+    for mode in modes:
+        _lib.set_math(mode)
+        peak = {'fp32': PEAK_FP32_MFMA, 'fp32x3': PEAK_X3_MFMA}.get(mode, PEAK_BF16_MFMA)
+        spec = ops.ConvSpec(Cc, Cc, 3, 1, 1, pad_mode=1)
+        d = spec.desc(B, H, H)
+        g = torch.Generator(device='cpu').manual_seed(7)
+        x = ops.to_kind(torch.randn(B, H, H, Cc, generator=g).to(device), d.x_bf16)
+        dy = ops.to_kind(torch.randn(B, H, H, Cc, generator=g).to(device), d.y_bf16)
+        w = (torch.randn(Cc, Cc, 3, 3, generator=g) * 0.05).to(device)
+        wf, wb = ops.conv_prep(spec, d, w, None, True, True)
+        flops = ops.conv_flops(spec, d)
+        res = {}
+        for name, fn in (('fwd', lambda: ops.conv_fwd(spec, d, x, wf, None)),
+                         ('dgrad', lambda: ops.conv_bwd_data(spec, d, dy, wb)),
+                         ('wgrad', lambda: ops.conv_bwd_weight(spec, d, x, dy, tuple(w.shape), False))):
+            fn(); fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / n
+            res[name] = {'ms': round(ms, 4), 'tflops': round(flops / ms / 1e9, 1), 'frac': round(flops / (ms * 1e-3) / peak, 4)}
+        res['peak_tflops'] = round(peak / 1e12, 1)
+        out[mode] = res
+        del x, dy, w, wf, wb
+    _lib.set_math(keep)
+    out['shape'] = f'Conv2d 256->256 k3 s1 ReflectionPad2d(1), {H}x{H} maps, batch {B} (the residual-block conv of Resnet9Blocks on 64x3x256x256); {n} launches each'
+    return out
+
+
 def _latest_profile(pattern):
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
     return files[-1] if files else None
@@ -279,6 +356,10 @@ def main():
     ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
                     help="capture the whole step in one HIP graph (iprgan/graphs.py): 'auto' = where the step is "
                          "capturable (all workloads; N > 1: opt-in with 'on', through the C ABI's communicator); the per-kernel timer's steps run eagerly AFTER the timed region")
+    ap.add_argument('--north-star', choices=['on', 'off'], default='on',
+                    help="after the timed region of a single-GPU fp32 / fp32x3 run, time the north-star convolution (3x3 256->256 "
+                         "reflect-padded, 64x64 maps, batch 64: forward / backward-data / backward-weight) in the run's math mode "
+                         "and on the exact fp32 MFMA and report it under 'north_star_conv'")
     ap.add_argument('--clock-warm-ms', type=float, default=float(os.environ.get('IPRGAN_BENCH_CLOCK_WARM_MS', '0')),
                     help="keep the GPU busy for this long with convolutions on SCRATCH tensors (no model state touched) right before "
                          "the timed region: the chip needs ~0.2 s under load to settle its clocks (a 20-step window behind 5 warm-up steps "
@@ -422,6 +503,26 @@ def main():
     if os.environ.get('IPRGAN_BENCH_STAMPS'):
         log('per-step host ms: ' + ' '.join(f'{(b - a) * 1e3:.1f}' for a, b in zip([t0] + stamps[:-1], stamps)) +
             f' | final sync {(t0 + elapsed - stamps[-1]) * 1e3:.1f}')
+    # eager window (behind the closing fence, never in `value`): the same steps enqueued kernel by kernel WITHOUT instrumentation -
+    # what a step costs the device and the host when it is not a graph replay.  A data-parallel run under `--graph auto` is eager
+    # in its timed region already (graphs.py: capture at N > 1 is opt-in), so these two fields are what makes the N = 1 line
+    # comparable with the N > 1 lines.
+    eager = None
+    n_eager = max(2, min(10, args.steps))
+    if graphed is not None or world == 1:
+        em = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        em[0].record()
+        for i in range(n_eager):
+            if graphed is not None:
+                step_fn(args.steps + i, eager=True)
+            else:
+                step_fn(args.steps + i)
+        em[1].record()
+        host_e = time.perf_counter() - te
+        torch.cuda.synchronize()
+        eager = {'ms': em[0].elapsed_time(em[1]) / n_eager, 'host_ms': host_e / n_eager * 1e3, 'steps': n_eager}
     # second window: the same steps enqueued kernel by kernel with a HIP-event pair on every conv-family dispatch
     prof_steps = PROF_STEPS if PROF_STEPS > 0 else max(2, min(25, args.steps // 4))
     _lib.prof_results()
@@ -443,6 +544,17 @@ def main():
                 f"ms/step={r['ms'] / prof_steps:7.3f} TF={r['flops'] / r['ms'] / 1e9 if r['ms'] else 0:6.1f}")
     metrics = model.get_metrics()
     assert all(v == v for v in metrics.values()), f'non-finite metrics {metrics}'
+    # accounting step: ONE more eager step with the host-side work accounting of _lib on (flops and operand / result bytes of
+    # every entry-point call; nothing extra is launched) -> `step_roofline`
+    _lib.acct_begin()
+    try:
+        if graphed is not None:
+            step_fn(args.steps + prof_steps + n_eager, eager=True)
+        else:
+            step_fn(args.steps + prof_steps + n_eager)
+    finally:
+        acct = _lib.acct_end()
+    torch.cuda.synchronize()
 
     # Second, separately reported measurement of the same workload in math mode 'fp32x3' (fp32 tensors, fp32-grade
     # products from six bf16 MFMAs per block).  It never enters `value`: the headline stays on the fp32 MFMA.
@@ -474,6 +586,14 @@ def main():
         finally:
             _lib.set_math(args.math)
         log(f'alt math {args.alt_math}: {alt}')
+
+    ns = None
+    if world == 1 and rank == 0 and args.north_star != 'off' and args.math in ('fp32', 'fp32x3'):
+        try:                                          # (a failure here must never cost the headline line)
+            ns = north_star_conv(device, [args.math] + (['fp32'] if args.math != 'fp32' else []))
+        except Exception as e:                        # noqa: BLE001
+            ns = {'error': f'{type(e).__name__}: {e}'}
+        log(f'north-star conv: {ns}')
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -526,8 +646,9 @@ def main():
                     'peak': round(peak / 1e12, 1), 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                     'launches': dom['launches'], 'avg_launch_us': round(dom['ms'] * 1e3 / dom['launches'], 2),
-                    'source': f'HIP events on the launch stream, this run: second window of {prof_steps} eager steps behind '
-                              'the closing fence of the timed region (no instrumented step inside `value`)'}
+                    'source': f'HIP events on the launch stream, this run: a window of {prof_steps} EAGER (kernel-by-kernel) steps behind '
+                              'the closing fence of the timed region - not the graph replays `value` is made of, which cannot carry '
+                              'per-kernel events (the committed rocprofv3 --kernel-trace of replays agrees within 2 %: profiles/)'}
             # the three-plane ring exists under three __global__ names (same stages, same six-MFMA product block, same epilogue;
             # four multiplying+loading waves / the 16x16x32 form / dedicated loader waves): the tuner deals a layer to whichever
             # is fastest, so one name alone shows the layers it was dealt, not the algorithm - report the three together as well
@@ -568,13 +689,22 @@ def main():
             'host_enqueue_ms_per_step': round(host_elapsed / args.steps * 1e3, 3),
             # ... of the steps replayed from the captured graph alone (= all timed steps once the step is captured)
             'host_enqueue_ms_per_replayed_step': round(host_replayed / n_replayed * 1e3, 3) if n_replayed else None,
-            'graph': ({'captured': graphed.graph is not None, 'replays_in_timed_region': replays_timed,
+            # what a step costs when it is NOT a graph replay (the eager window behind the timed region; at N > 1 under
+            # `--graph auto` the timed region itself is eager): device time per step and host time to enqueue it
+            'eager_ms_per_step': round(eager['ms'], 3) if eager else None,
+            'host_enqueue_ms_per_eager_step': round(eager['host_ms'], 3) if eager else None,
+            'eager_steps_sampled': eager['steps'] if eager else None,
+            'graph': ({'policy': args.graph, 'captured': graphed.graph is not None, 'replays_in_timed_region': replays_timed,
                        'eager_steps_in_timed_region': args.steps - replays_timed, 'failed': graphed.failed}
-                      if graphed is not None else None),
+                      if graphed is not None else {'policy': args.graph, 'captured': False, 'replays_in_timed_region': 0,
+                                                   'eager_steps_in_timed_region': args.steps, 'failed': None}),
             'transport': comm['transport'], 'comm_nranks': comm['nranks'],
             'allreduce_exposed_ms_per_step': comm['exposed_ms'],
             'step_algorithmic_tflops': round(wl['gflop'] * B * world / ms, 2),
+            # (MFMA peak alone: kept for continuity with rounds 1-5; `step_roofline` below is the bound SURVEY 8(d) defines)
             'step_roofline_frac': round(wl['gflop'] * B * world / ms * 1e12 / peak_mode, 4),
+            'step_roofline': step_roofline(acct, peak_mode, ms),
+            'north_star_conv': ns,
             'metrics_last_step': {k: round(v, 5) for k, v in metrics.items()},
         }
         if baseline is not None:

@@ -438,6 +438,8 @@ int iprgan_debug_force_splitk(int splits);
  * written when `records` is not NULL.  import: inserts / overwrites (replace != 0: the table is cleared first).  The ranks of
  * a data-parallel job adopt rank 0's table after the first step (iprgan/parallel.py: sync_autotune), so that every replica
  * runs the same tiles; the reference's counterpart is cudnn.benchmark = True deciding per process (train.py:44-45). */
+/* export: records == NULL -> *count = table size; otherwise up to cap_records records are written and *count = the number
+ * written.  import: with IPRGAN_TUNE_CACHE set, the (per-rank) cache file is rewritten with the table as adopted. */
 #define IPRGAN_TUNE_RECORD_INTS 17
 int iprgan_tune_export(int* records, size_t cap_records, size_t* count);
 int iprgan_tune_import(const int* records, size_t n_records, int replace);

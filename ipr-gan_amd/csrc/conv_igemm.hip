@@ -3282,6 +3282,7 @@ int iprgan_tune_export(int* records, size_t cap_records, size_t* count) {
     memcpy(records + i * IPRGAN_TUNE_RECORD_INTS, it->first.v, sizeof(it->first.v));
     records[i * IPRGAN_TUNE_RECORD_INTS + 16] = it->second;
   }
+  *count = i;           // the records actually WRITTEN (another host thread may have tuned a geometry since the sizing call)
   return 0;
 }
 int iprgan_tune_import(const int* records, size_t n_records, int replace) {
@@ -3293,6 +3294,17 @@ int iprgan_tune_import(const int* records, size_t n_records, int replace) {
     TuneKey k;
     memcpy(k.v, records + i * IPRGAN_TUNE_RECORD_INTS, sizeof(k.v));
     g_tune[k] = records[i * IPRGAN_TUNE_RECORD_INTS + 16];
+  }
+  // the adopted table is what this process runs from now on: with a cache file configured it is rewritten, so that a restarted
+  // rank reloads the COMMON picks instead of its own earlier ones (and does not re-tune into a divergent table)
+  const std::string path = tune_path();
+  FILE* f = path.empty() ? nullptr : fopen(path.c_str(), "w");
+  if (f) {
+    for (auto& kv : g_tune) {
+      for (int j = 0; j < 16; ++j) fprintf(f, "%d ", kv.first.v[j]);
+      fprintf(f, "%d\n", kv.second);
+    }
+    fclose(f);
   }
   return 0;
 }

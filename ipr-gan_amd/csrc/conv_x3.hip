@@ -1315,17 +1315,15 @@ static int launch_x3ws_t(const GConvArgs& a_in, hipStream_t st, int* bm_out) {
   a.korder = korder >= 0 ? korder : ((a.isy == 2 && a.isx == 2) ? 3 : 0);       // (launch_x3p_t)
   constexpr bool can_pf = EpiGeom<WGM, WGN, WM, WN, NSTAGE * 3 * (BM + BN) * 64, WGM * WGN>::PF_FIRST;
   const bool pref = a.aux && a.aux16 == 1 && can_pf;
-  auto go = [&](auto kern) {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
-    prof_launch(kern, grid, dim3(512), smem, st, 33, a.flops, a);
-  };
+  // (x3p_go is templated on the kernel: the dynamic-LDS attribute is set once per INSTANTIATION - a generic lambda taking the
+  // kernel as a function pointer would share one `static` flag between the four STATS x PREF variants)
+  const dim3 block(512);
   if (a.stat_part) {
-    if constexpr (can_pf) { if (pref) { go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, true, MINW, M16>); IPR_LAUNCH_CHECK(); return 0; } }
-    go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, MINW, M16>);
+    if constexpr (can_pf) { if (pref) { x3p_go<gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, true, MINW, M16>, 33>(a, grid, block, smem, st); IPR_LAUNCH_CHECK(); return 0; } }
+    x3p_go<gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, true, false, MINW, M16>, 33>(a, grid, block, smem, st);
   } else {
-    if constexpr (can_pf) { if (pref) { go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, false, true, MINW, M16>); IPR_LAUNCH_CHECK(); return 0; } }
-    go(gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, false, false, MINW, M16>);
+    if constexpr (can_pf) { if (pref) { x3p_go<gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, false, true, MINW, M16>, 33>(a, grid, block, smem, st); IPR_LAUNCH_CHECK(); return 0; } }
+    x3p_go<gconv_x3ws_kernel<WGM, WGN, WM, WN, NSTAGE, false, false, MINW, M16>, 33>(a, grid, block, smem, st);
   }
   IPR_LAUNCH_CHECK();
   return 0;
@@ -1382,13 +1380,12 @@ static int launch_x3h_t(const GConvArgs& a, const X3HGeom& g, hipStream_t st, in
   const int mtiles = cdiv(a.B, g.NI) * g.tpy * g.tpx;
   dim3 grid(mtiles, cdiv(a.Ns, BN), a.nphase);
   *bm_out = 256;
-  auto go = [&](auto kern) {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
-    prof_launch(kern, grid, dim3(512), smem, st, 31, a.flops, a, g);
-  };
-  if (a.stat_part) go(gconv_x3h_kernel<WGN, WN, NSB, LH, HSTEPS, true>);
-  else go(gconv_x3h_kernel<WGN, WN, NSB, LH, HSTEPS, false>);
+  // (one attribute flag per kernel instantiation: both STATS variants have the same function-pointer type)
+#define X3H_GO(K) { static bool s = false; if (!s) { (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); s = true; } \
+                    prof_launch(K, grid, dim3(512), smem, st, 31, a.flops, a, g); }
+  if (a.stat_part) { auto k = gconv_x3h_kernel<WGN, WN, NSB, LH, HSTEPS, true>; X3H_GO(k) }
+  else { auto k = gconv_x3h_kernel<WGN, WN, NSB, LH, HSTEPS, false>; X3H_GO(k) }
+#undef X3H_GO
   IPR_LAUNCH_CHECK();
   return 0;
 }

@@ -163,6 +163,77 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed ({rc}): {lib.iprgan_last_error().decode()}')
+    if _acct is not None:
+        _acct_close(name)
+
+
+# ---- algorithmic work accounting (bench.py: `step_roofline`) -----------------------------------------------------------
+# While acct_begin() ... acct_end() is open, every entry-point call is recorded as (name, flops, bytes): bytes = the sizes of
+# the distinct tensors handed to it through ptr() / ptr_table() - each operand and result counted ONCE, whatever the kernels
+# behind the entry point re-read - minus the tensors the wrappers marked as scratch (acct_scratch: slabs, partials, padded
+# copies); flops = what the wrapper declared with acct_flops() (2 * MACs of the convolution family; nothing else is priced).
+# Host-side bookkeeping only: nothing is launched, timed or synchronised here, and it is off (None) outside bench.py's
+# accounting step.
+_acct = None
+_acct_pending = {}
+_acct_scratch = set()
+_acct_f = 0.0
+
+
+def acct_begin():
+    global _acct, _acct_f
+    _acct, _acct_f = [], 0.0
+    _acct_pending.clear()
+    _acct_scratch.clear()
+
+
+def acct_end():
+    """-> [(entry point, flops, bytes)] since acct_begin()."""
+    global _acct
+    out, _acct = _acct, None
+    _acct_pending.clear()
+    _acct_scratch.clear()
+    return out or []
+
+
+def acct_on():
+    return _acct is not None
+
+
+def acct_flops(f):
+    global _acct_f
+    if _acct is not None:
+        _acct_f += float(f)
+
+
+def acct_bytes(n):
+    """Bytes of tensors that reach the entry point through a pointer table built earlier (optim.Adam's cached tables)."""
+    if _acct is not None:
+        _acct_pending[-1] = _acct_pending.get(-1, 0) + int(n)
+
+
+def acct_scratch(t):
+    if _acct is not None and t is not None:
+        _acct_scratch.add(t.data_ptr())
+    return t
+
+
+def _acct_note(t):
+    p = t.data_ptr()
+    if p in _acct_scratch:
+        return
+    n = t.numel() * t.element_size()
+    if t.dtype == torch.bfloat16 and act_x3():       # a three-plane tensor is handed over as its h plane
+        n *= 3
+    if n > _acct_pending.get(p, 0):
+        _acct_pending[p] = n
+
+
+def _acct_close(name):
+    global _acct_f
+    _acct.append((name, _acct_f, float(sum(_acct_pending.values()))))
+    _acct_pending.clear()
+    _acct_f = 0.0
 
 
 def query(name, *args):
@@ -179,6 +250,8 @@ def ptr(t):
     if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous():
         raise RuntimeError(f'iprgan kernels need contiguous float32 (or, for activations in bf16-activation mode, '
                            f'bfloat16) tensors (got {t.dtype}, contiguous={t.is_contiguous()})')
+    if _acct is not None:
+        _acct_note(t)
     return t.data_ptr()
 
 

@@ -107,6 +107,8 @@ class GraphedStep:
         # host step counts as they stand: optimizers that already ran inside an aborted capture have counted a step the
         # device never executed (a checkpoint written later would resume with bias corrections one step ahead)
         saved = [(sh, sh['step']) for o in self.opts for sh in getattr(o, '_fast', {}).values()]
+        for sh, _ in saved:
+            sh.pop('in_graph', None)              # set again by Adam.step for every group the captured body steps
         try:
             # N > 1: RCCL's proxy threads make runtime calls of their own while this thread captures; in the default 'global'
             # mode any such call from ANY thread invalidates the capture ("operation not permitted when stream is capturing"),
@@ -120,10 +122,14 @@ class GraphedStep:
             # every optimizer the replay will book-keep for must have stepped on the device-counter path inside the capture:
             # a group the body never steps (or stepped on the host path) would make every replay advance device state and
             # then fail in Adam.replayed() on the host - decided HERE, once, not after the first replay
+            # (`step_dev` alone does not say that: the eager warm-up creates it.  Adam.step marks a group `in_graph` when it
+            # runs under capture; a group the warm-up stepped but the captured body did not would otherwise be book-kept as
+            # stepped on every replay while the graph never touches it)
             missing = [i for i, o in enumerate(self.opts) for gr in o.param_groups
-                       if gr['params'] and 'step_dev' not in getattr(o, '_fast', {}).get(id(gr), {})]
+                       if gr['params'] and not getattr(o, '_fast', {}).get(id(gr), {}).get('in_graph')]
             if missing:
-                self.failed = f'optimizer(s) {sorted(set(missing))} have a parameter group without a device-side step counter after the capture'
+                self.failed = (f'optimizer(s) {sorted(set(missing))} have a parameter group that the captured step did not update on '
+                               'the device-counter path (stepped only in the warm-up, on the host path, or not at all)')
         if nranks > 1:
             # one rank eager while its peers replay would still exchange matching buckets, but a rank that aborted mid-capture
             # and one that did not must not disagree about WHAT the next call does: agree on the outcome

@@ -28,6 +28,12 @@ def empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+def scratch(n, like):
+    """Workspace of ``n`` floats (slabs, partials of a reduction, padded copies): allocated like an output, but left out of the
+    algorithmic byte count of bench.py's accounting step (_lib.acct_scratch)."""
+    return L.acct_scratch(empty((n,), like))
+
+
 def _empty_like(t):
     if t.dtype == torch.bfloat16 and L.act_x3():
         return empty_kind(t.shape, t, ST_X3)
@@ -67,6 +73,13 @@ kind = is16
 def pstride(t):
     """Plane stride (elements) of a three-plane tensor; 0 for the other kinds (the descriptors' "contiguous" value)."""
     return t.untyped_storage().nbytes() // 6 if is16(t) == ST_X3 else 0
+
+
+def span_ok(t):
+    """A three-plane tensor is addressed through ONE 32-bit buffer descriptor from its h plane: the l plane of a batch slice
+    ends at 2 * plane stride + its own element count (a slice keeps its parent's stride).  False when that span leaves the
+    range - the convolution wrappers then hand the kernels an fp32 copy instead of failing inside a launch."""
+    return is16(t) != ST_X3 or (2 * pstride(t) + t.numel()) * 2 < 0x7fffffff
 
 
 def empty_kind(shape, like, k):
@@ -215,6 +228,12 @@ class ConvSpec:
                 and act_kind(self.cin) == ST_F32)
 
 
+def conv_flops(spec, d):
+    """2 * MACs of one pass (forward, backward-data or backward-weight) of the layer ``d`` describes."""
+    OH, OW = (d.H, d.W) if spec.transposed else spec.out_hw(d.H, d.W)
+    return 2.0 * d.B * OH * OW * spec.cin * spec.cout * spec.k * spec.k
+
+
 def conv_prep(spec, d, w, sigma=None, fwd=True, bwd=False):
     wf = wb = None
     if fwd:
@@ -244,17 +263,20 @@ def conv_fwd(spec, d, x, wfwd, bias, pair=None, stats=False):
     stats=True: also returns (partials, rows): per-tile column sums of the pre-bias accumulator for the norm layer that
     follows (include/iprgan.h: column statistics from the epilogue)."""
     OH, OW = spec.out_hw(d.H, d.W)
+    if not span_ok(x):
+        x, d = f32(x), _desc_with(d, x_bf16=ST_F32)
     if is16(x) != d.x_bf16:
         x = to_kind(x, d.x_bf16)
     y = empty_kind((d.B, OH, OW, c4(spec.cout)), x, d.y_bf16)
     if d.x_bf16 == ST_X3:
         d = _desc_with(d, x_pstride=pstride(x), y_pstride=0)
     nws = query('iprgan_conv_fwd_ws_floats', C.byref(d))
-    ws = empty((nws,), x) if nws else None
+    ws = scratch(nws, x) if nws else None
     p0, p1 = (ptr(pair[0]), ptr(pair[1])) if pair is not None else (None, None)
     part, rows = None, C.c_int(0)
     if stats:
         part = empty((query('iprgan_conv_stat_floats', C.byref(d), 0),), x)
+    L.acct_flops(conv_flops(spec, d))
     call('iprgan_conv_fwd', C.byref(d), ptr(x), ptr(wfwd), ptr(bias), ptr(y), ptr(ws), p0, p1, ptr(part),
          C.byref(rows), stream())
     y = _out(y)
@@ -265,6 +287,8 @@ def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_sl
                   residual=None):
     """colsums=True: also returns (partials, rows): per-tile column sums of dx (after the fused activation derivative),
     i.e. the bias gradient of the layer that produced this layer's input, up to ``colsum_partials``."""
+    if not span_ok(dy):
+        dy, d = f32(dy), _desc_with(d, y_bf16=ST_F32)
     if is16(dy) != d.y_bf16:
         dy = to_kind(dy, d.y_bf16)
     dx = empty_kind((d.B, d.H, d.W, c4(spec.cin)), dy, d.x_bf16)
@@ -277,11 +301,12 @@ def conv_bwd_data(spec, d, dy, wbwd, prev_out=None, prev_act=L.ACT_NONE, prev_sl
     if d.y_bf16 == ST_X3:
         d = _desc_with(d, y_pstride=pstride(dy), x_pstride=0)
     nws = query('iprgan_conv_bwd_data_ws_floats', C.byref(d))
-    ws = empty((nws,), dy) if nws else None
+    ws = scratch(nws, dy) if nws else None
     p0, p1 = (ptr(pair[0]), ptr(pair[1])) if pair is not None else (None, None)
     part, rows = None, C.c_int(0)
     if colsums:
         part = empty((query('iprgan_conv_stat_floats', C.byref(d), 1),), dy)
+    L.acct_flops(conv_flops(spec, d))
     call('iprgan_conv_bwd_data', C.byref(d), ptr(dy), ptr(wbwd), ptr(dx), ptr(ws), ptr(prev_out), prev_act,
          float(prev_slope), p0, p1, ptr(part), C.byref(rows), ptr(residual), stream())
     dx = _out(dx)
@@ -302,6 +327,7 @@ def conv_bwd_data_bn(spec, d, dy, wbwd, bn_x, mean, invstd, gamma, beta, act, sl
         raise RuntimeError('conv_bwd_data_bn: the norm input must have the storage type of the layer input')
     dz = empty((d.B, d.H, d.W, c4(spec.cin)), dy, torch.bfloat16 if d.x_bf16 else torch.float32)
     part, rows = empty((query('iprgan_conv_stat_floats', C.byref(d), 1),), dy), C.c_int(0)
+    L.acct_flops(conv_flops(spec, d))
     call('iprgan_conv_bwd_data_bn', C.byref(d), ptr(dy), ptr(wbwd), ptr(dz), ptr(bn_x), ptr(mean), ptr(invstd), ptr(gamma),
          ptr(beta), act, float(slope), ptr(part), C.byref(rows), stream())
     return dz, (part, rows.value)
@@ -320,12 +346,13 @@ def colsum(x2d_like, channels, out=None, beta=0.0):
     C_ = x2d_like.shape[-1]
     M = x2d_like.numel() // C_
     res = empty((channels,), x2d_like) if out is None else out
-    ws = empty((query('iprgan_colsum_ws_floats', M, C_),), x2d_like)
+    ws = scratch(query('iprgan_colsum_ws_floats', M, C_), x2d_like)
     call('iprgan_colsum', ptr(x2d_like), ptr(res), ptr(ws), M, C_, channels, float(beta), is16(x2d_like), stream())
     return res
 
 
 _DEFER_WGRAD = os.environ.get('IPRGAN_DEFER_WGRAD_REDUCE', '1') != '0'     # A/B switch: one slab reduce launch per backward pass
+_WGRAD_PENDING_BYTES = int(os.environ.get('IPRGAN_WGRAD_PENDING_MB', '1024')) << 20
 
 
 def wgrad_reduce_flush(pending):
@@ -346,6 +373,8 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
     ``defer`` (a list): the slab reduce into dw is NOT launched - it is appended to the list and runs with the other layers'
     in ``wgrad_reduce_flush(defer)``; until then dw is not valid."""
     d = ConvDesc(*[getattr(d, f) for f, _ in ConvDesc._fields_])
+    if not (span_ok(x) and span_ok(dy)):
+        x, dy = f32(x), f32(dy)
     if ST_X3 in (is16(x), is16(dy)) and is16(x) != is16(dy):
         if c4(spec.cin) % 32 == 0 and c4(spec.cout) % 32 == 0 and ST_BF16 not in (is16(x), is16(dy)):
             x, dy = to_kind(x, ST_X3), to_kind(dy, ST_X3)      # (a gradient that arrived as fp32: split, not the other side joined)
@@ -360,12 +389,19 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
         dw = empty(tuple(w_shape), x)
     if db is None and want_bias:
         db = empty((spec.cout,), x)
-    ws = empty((query('iprgan_conv_wgrad_ws_floats', C.byref(d)),), x)
+    ws = scratch(query('iprgan_conv_wgrad_ws_floats', C.byref(d)), x)
+    L.acct_flops(conv_flops(spec, d))
     if defer is not None and _DEFER_WGRAD:
         rec = L.WGradReduceRec()
         call('iprgan_conv_bwd_weight_deferred', C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db) if want_bias else None, ptr(ws),
              float(beta), stream(), C.byref(rec))
         if rec.pending:
+            # one destination per multi-launch (two records adding into the same dw view would race), and a bound on the slab
+            # workspaces a pass keeps alive until its flush (IPRGAN_WGRAD_PENDING_MB, default 1024: a DCGAN-64 pass holds
+            # ~0.6 GB, CycleGAN's generator pass reaches the bound every ~25 layers); ADVICE r05
+            if any(p_[2].data_ptr() == dw.data_ptr() for p_ in defer) or \
+                    sum(p_[1].numel() for p_ in defer) * 4 + ws.numel() * 4 > _WGRAD_PENDING_BYTES:
+                wgrad_reduce_flush(defer)
             defer.append((rec, ws, dw))
         return dw, (db if want_bias else None)
     call('iprgan_conv_bwd_weight', C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db) if want_bias else None, ptr(ws),
@@ -413,7 +449,8 @@ def _norm_fwd_kinds(x):
     count allows three planes gets a three-plane output: the convolution in front of a norm layer writes fp32 (4 instead
     of 6 bytes per element; engine.Conv: y_f32) and the norm layer is where the tensor is split."""
     k = is16(x)
-    if k == ST_F32 and _NORM_XF32 and L.act_x3() and x.dim() == 4 and x.shape[-1] % 32 == 0:
+    if k == ST_F32 and _NORM_XF32 and L.act_x3() and x.dim() == 4 and x.shape[-1] % 32 == 0 \
+            and x.numel() * 6 < 0x7fffffff:         # (the size rule of ConvSpec.desc: past 357 M elements a tensor stays fp32)
         return ST_X3_XF32, ST_X3
     return k, k
 
@@ -450,7 +487,7 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, training, a
     residual = _whole3(residual)
     mean, invstd = empty((C_,), x), empty((C_,), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
-    ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    ws = None if part is not None else scratch(query('iprgan_bn_ws_floats', M, C_), x)
     call('iprgan_bn_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
          ptr(mean), ptr(invstd), ptr(ws), M, C_, float(eps), float(momentum), 0 if training else 1,
          act, float(slope), ptr(part), int(rows), ptr(conv_bias) if part is not None else None,
@@ -466,7 +503,7 @@ def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None,
     st, dy, y = _norm_bwd_kinds(x, dy, y)
     dx = _empty_like(dy)
     dgamma, dbeta = empty((C_,), x), empty((C_,), x)
-    ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    ws = scratch(query('iprgan_bn_ws_floats', M, C_), x)
     call('iprgan_bn_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
          ptr(dgamma), ptr(dbeta), ptr(ws), M, C_, act, float(slope), ptr(dbias), dbias.numel() if dbias is not None else 0,
          float(dbias_beta), st, stream())
@@ -486,7 +523,7 @@ def bn_prelu_fwd(x, gamma, beta, running_mean, running_var, eps, momentum, train
     residual = _whole3(residual)
     mean, invstd = empty((C_,), x), empty((C_,), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
-    ws = None if part is not None else empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    ws = None if part is not None else scratch(query('iprgan_bn_ws_floats', M, C_), x)
     call('iprgan_bn_prelu_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(mean),
          ptr(invstd), ptr(ws), M, C_, float(eps), float(momentum), 0 if training else 1, ptr(slope_t), ptr(part), int(rows),
          ptr(conv_bias) if part is not None else None, counter.data_ptr() if counter is not None else None, ptr(residual),
@@ -500,7 +537,7 @@ def bn_prelu_bwd(x, dy, gamma, beta, mean, invstd, slope_t, dbias=None, dbias_be
     st, dy, _ = _norm_bwd_kinds(x, dy)
     dx = _empty_like(dy)
     dgamma, dbeta, dslope = empty((C_,), x), empty((C_,), x), empty((1,), x)
-    ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    ws = scratch(query('iprgan_bn_ws_floats', M, C_), x)
     call('iprgan_bn_prelu_bwd', ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(slope_t), ptr(dx),
          ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(ws), M, C_, ptr(dbias), dbias.numel() if dbias is not None else 0,
          float(dbias_beta), st, stream())
@@ -514,7 +551,7 @@ def bn_bwd_pre(x, dz, gamma, mean, invstd, partials, dbias=None, dbias_beta=0.0)
     part, rows = partials
     dx = _empty_like(x)
     dgamma, dbeta = empty((C_,), x), empty((C_,), x)
-    ws = empty((query('iprgan_bn_ws_floats', M, C_),), x)
+    ws = scratch(query('iprgan_bn_ws_floats', M, C_), x)
     call('iprgan_bn_bwd_pre', ptr(x), ptr(dz), ptr(gamma), ptr(mean), ptr(invstd), ptr(part), int(rows), ptr(dx),
          ptr(dgamma), ptr(dbeta), ptr(ws), M, C_, ptr(dbias), dbias.numel() if dbias is not None else 0,
          float(dbias_beta), is16(x), stream())
@@ -526,7 +563,7 @@ def sn_power_iter(w_orig, u, v, training, eps=1e-12):
     rows = w_orig.shape[0]
     cols = w_orig.numel() // rows
     sigma = empty((1,), w_orig)
-    ws = empty((query('iprgan_sn_ws_floats', rows, cols),), w_orig)
+    ws = scratch(query('iprgan_sn_ws_floats', rows, cols), w_orig)
     call('iprgan_sn_power_iter', ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(ws), rows, cols,
          float(eps), 1 if training else 0, stream())
     return sigma
@@ -542,7 +579,7 @@ def sn_power_iter_multi(weights, us, vs, training, eps=1e-12):
     u_out = [_empty_like(u) for u in us]
     v_out = [_empty_like(v) for v in vs]
     r, c = _int_table(rows), _int_table(cols)
-    ws = empty((query('iprgan_sn_multi_ws_floats', r, c, n),), weights[0])
+    ws = scratch(query('iprgan_sn_multi_ws_floats', r, c, n), weights[0])
     call('iprgan_sn_power_iter_multi', L.ptr_table(weights), L.ptr_table(us), L.ptr_table(vs),
          L.ptr_table(u_out), L.ptr_table(v_out), ptr(sig), ptr(ws), r, c, n, float(eps),
          1 if training else 0, stream())
@@ -553,7 +590,7 @@ def sn_bwd(dwsn, w_orig, u, v, sigma):
     rows = w_orig.shape[0]
     cols = w_orig.numel() // rows
     dw = _empty_like(w_orig)
-    ws = empty((query('iprgan_sn_ws_floats', rows, cols),), w_orig)
+    ws = scratch(query('iprgan_sn_ws_floats', rows, cols), w_orig)
     call('iprgan_sn_bwd', ptr(dwsn), ptr(w_orig), ptr(u), ptr(v), ptr(sigma), ptr(dw), ptr(ws), rows,
          cols, stream())
     return dw
@@ -566,7 +603,7 @@ def sn_bwd_multi(dwsns, weights, us, vs, sigmas, outs=None, beta=0.0):
     rows = [w.shape[0] for w in weights]
     cols = [w.numel() // w.shape[0] for w in weights]
     dws = [_empty_like(w) for w in weights] if outs is None else outs
-    ws = empty((64 * 16,), weights[0])
+    ws = scratch(64 * 16, weights[0])
     call('iprgan_sn_bwd_multi', L.ptr_table(dwsns), L.ptr_table(weights), L.ptr_table(us), L.ptr_table(vs),
          L.ptr_table(sigmas), L.ptr_table(dws), ptr(ws), _int_table(rows), _int_table(cols), n, float(beta), stream())
     return dws
@@ -575,7 +612,7 @@ def sn_bwd_multi(dwsns, weights, us, vs, sigmas, outs=None, beta=0.0):
 # ---- losses ---------------------------------------------------------------------------------------
 def loss_fwd(kind, x, y=None):
     out = empty((), x)
-    ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
+    ws = scratch(query('iprgan_loss_ws_floats', x.numel()), x)
     call('iprgan_loss_fwd', kind, ptr(x), ptr(y), ptr(out), ptr(ws), x.numel(), stream())
     return out
 
@@ -589,7 +626,7 @@ def loss_bwd(kind, x, y, gscale):
 def loss_sum_fwd(kind, x, y, scale):
     """scale * sum(term): the reduction='sum' / N losses of models/vae.py:36-48."""
     out = empty((), x)
-    ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
+    ws = scratch(query('iprgan_loss_ws_floats', x.numel()), x)
     call('iprgan_loss_sum_fwd', kind, ptr(x), ptr(y), ptr(out), ptr(ws), x.numel(), float(scale), stream())
     return out
 
@@ -606,7 +643,7 @@ def ssim_fwd(x, y, denorm, want_grad):
     B, Cc, H, W = x.shape
     planes = B * Cc
     out = empty((), x)
-    ws = empty((query('iprgan_ssim_ws_floats', planes, H, W),), x)
+    ws = scratch(query('iprgan_ssim_ws_floats', planes, H, W), x)
     gm = empty((query('iprgan_ssim_gmap_floats', planes, H, W),), x) if want_grad else None
     call('iprgan_ssim_fwd', ptr(x), ptr(y), ptr(out), ptr(gm), ptr(ws), planes, H, W, int(bool(denorm)), stream())
     return out, gm
@@ -638,7 +675,7 @@ def msssim_bwd(x, y, state, gscale, denorm):
     B, Cc, H, W = x.shape
     pyr, gm, small = state
     dx = _empty_like(x)
-    ws = empty((2 * B * Cc * ((H + 1) // 2) * ((W + 1) // 2),), x)
+    ws = scratch(2 * B * Cc * ((H + 1) // 2) * ((W + 1) // 2), x)
     call('iprgan_msssim_bwd', ptr(x), ptr(y), ptr(pyr), ptr(gm), ptr(small), ptr(gscale), ptr(dx), ptr(ws), B * Cc, H, W,
          int(bool(denorm)), stream())
     return dx
@@ -692,6 +729,8 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_
 
 def adam_step_tables(ptab, grads, mtab, vtab, sizes, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     """adam_step with the parameter / moment pointer tables and sizes built once by the caller (optim.Adam)."""
+    if L.acct_on():         # parameters and both moments are read and written (their tables are cached: not seen by ptr())
+        L.acct_bytes(24 * sum(sizes[i] for i in range(n)))
     call('iprgan_adam_step', ptab, L.ptr_table(grads), mtab, vtab, sizes, n, float(lr), float(beta1), float(beta2),
          float(eps), float(weight_decay), int(step), float(grad_scale), stream())
 
@@ -701,6 +740,8 @@ def adam_step_tables_dev(ptab, grads, mtab, vtab, sizes, n, lr, beta1, beta2, ep
     """adam_step_tables with the step count on the device (``step_dev`` int32[1] is incremented by the call; ``coef``
     float32[2] receives the bias corrections): nothing in the launch depends on the host's step number, so a captured
     HIP graph can replay it (graphs.py)."""
+    if L.acct_on():
+        L.acct_bytes(24 * sum(sizes[i] for i in range(n)))
     call('iprgan_adam_step_dev', ptab, L.ptr_table(grads), mtab, vtab, sizes, n, float(lr), float(beta1), float(beta2),
          float(eps), float(weight_decay), C.c_void_p(step_dev.data_ptr()), ptr(coef), float(grad_scale), stream())
 
@@ -729,7 +770,7 @@ def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias
     residual = _whole3(residual)
     mean, invstd = empty((B, C_), x), empty((B, C_), x)
     part, rows = conv_stats if conv_stats is not None else (None, 0)
-    ws = None if part is not None else empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
+    ws = None if part is not None else scratch(query('iprgan_instnorm_ws_floats', B, H * W, C_), x)
     call('iprgan_instnorm_fwd', ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(ws),
          B, H * W, C_, float(eps), act, float(slope), ptr(part), int(rows),
          ptr(conv_bias) if part is not None else None, ptr(residual), st, stream())
@@ -742,7 +783,7 @@ def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias
     dx = _empty_like(dy)
     dgamma = empty((C_,), x) if gamma is not None else None
     dbeta = empty((C_,), x) if gamma is not None else None
-    ws = empty((query('iprgan_instnorm_ws_floats', B, H * W, C_),), x)
+    ws = scratch(query('iprgan_instnorm_ws_floats', B, H * W, C_), x)
     call('iprgan_instnorm_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
          ptr(dgamma), ptr(dbeta), ptr(ws), B, H * W, C_, act, float(slope), ptr(dbias),
          dbias.numel() if dbias is not None else 0, float(dbias_beta), st, stream())
@@ -768,7 +809,7 @@ def prelu_bwd(x, dy, alpha):
     st, (x, dy) = _same_kind(x, dy)
     dx = _empty_like(x)
     dalpha = empty((1,), x)
-    ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
+    ws = scratch(query('iprgan_loss_ws_floats', x.numel()), x)
     call('iprgan_prelu_bwd', ptr(x), ptr(dy), ptr(alpha), ptr(dx), ptr(dalpha), ptr(ws), x.numel(), st, stream())
     return dx, dalpha
 
@@ -805,7 +846,7 @@ def pixel_shuffle2_prelu_bwd(x, dy, alpha):
     Cc = C4_ // 4
     dx = _empty_like(x)
     dalpha = empty((1,), x)
-    ws = empty((query('iprgan_loss_ws_floats', x.numel()),), x)
+    ws = scratch(query('iprgan_loss_ws_floats', x.numel()), x)
     call('iprgan_pixel_shuffle2_prelu_bwd', ptr(x), ptr(dy), ptr(alpha), ptr(dx), ptr(dalpha), ptr(ws), B, H, W, Cc, st, stream())
     return dx, dalpha
 

@@ -78,11 +78,11 @@ class Adam(Optimizer):
         state_dict reports, and the parameters' version counters (version-keyed caches, stale-graph check)."""
         for group in self.param_groups:
             sh = getattr(self, '_fast', {}).get(id(group))
-            if sh is None or 'step_dev' not in sh:
-                # not part of the captured step (an empty group, an optimizer the body never steps): nothing moved on the
-                # device, nothing to book-keep.  graphs.GraphedStep._capture refuses, ONCE, a capture that leaves a
-                # non-empty group of its optimizers without a device counter - never a crash behind a replay that has
-                # already advanced device state
+            if sh is None or not sh.get('in_graph'):
+                # not part of the captured step (an empty group, an optimizer the body never steps - whether or not the eager
+                # warm-up stepped it): nothing moved on the device, nothing to book-keep.  graphs.GraphedStep._capture
+                # refuses, ONCE, a capture whose body left a group unstepped that the warm-up had stepped - never a crash or a
+                # drifting host count behind replays that have already advanced device state
                 continue
             sh['step'] += 1
             sh['step_t'].fill_(sh['step'])
@@ -111,6 +111,11 @@ class Adam(Optimizer):
                             sh['coef'] = torch.zeros(2, dtype=torch.float32, device=params[0].device)
                         sh['step'] += 1
                         sh['step_t'].fill_(sh['step'])
+                        if torch.cuda.is_current_stream_capturing():
+                            # this group's update is part of the graph being captured: replayed() book-keeps for exactly the
+                            # groups that carry this mark (an optimizer stepped in the warm-up but not by the captured body has
+                            # a device counter too - it must not be advanced on the host behind every replay)
+                            sh['in_graph'] = True
                         ops.adam_step_tables_dev(sh['ptab'], grads, sh['mtab'], sh['vtab'], sh['sizes'], sh['n'],
                                                  group['lr'], beta1, beta2, group['eps'], group['weight_decay'],
                                                  sh['step_dev'], sh['coef'], self.grad_scale)

@@ -458,9 +458,10 @@ def tune_table():
     L.call('iprgan_tune_export', None, 0, C.byref(n))
     if not n.value:
         return []
-    buf = (C.c_int * (17 * n.value))()
-    L.call('iprgan_tune_export', buf, n.value, C.byref(n))
-    return [list(buf[i * 17:(i + 1) * 17]) for i in range(n.value)]
+    cap = n.value + 16                    # (head-room for geometries another host thread tunes between the two calls)
+    buf = (C.c_int * (17 * cap))()
+    L.call('iprgan_tune_export', buf, cap, C.byref(n))
+    return [list(buf[i * 17:(i + 1) * 17]) for i in range(min(cap, n.value))]   # n = records written
 
 
 def tune_adopt(records, replace=True):
