@@ -467,10 +467,13 @@ def _moments_full(model, opts):
     return out
 
 
-def run_late_step_pair(kind, lead, follow, lead_steps=2):
+def run_late_step_pair(kind, lead, follow, lead_steps=2, truth64=False):
     """``lead`` / ``follow`` = (make_cfg, models namespace, device list).  The leader runs ``lead_steps`` steps of the ``kind``
     fixture ('dcgan', 'srgan', 'cyclegan'); the follower loads the leader's state; both run ONE more step on the same inputs.
-    Returns (leader moments, follower moments, leader metrics, follower metrics) of that step, full tensors."""
+    Returns (leader moments, follower moments, leader metrics, follower metrics) of that step, full tensors.
+    truth64=True: a THIRD model - the follower's implementation with every network in float64 - loads the same state and runs
+    the same step: its moments (the exact ones, up to 1e-15) are returned as a fifth value, so that the caller can hold the
+    leader to a multiple of the follower's OWN distance from the truth instead of to bands fitted to observed runs."""
     def build(impl):
         make_cfg, models, device = impl
         if kind == 'dcgan':
@@ -490,23 +493,23 @@ def run_late_step_pair(kind, lead, follow, lead_steps=2):
             n.to(device[0])
         return models.WhiteBoxWrapper(m, make_cfg(wcfg)), seed
 
-    def step(model, seed, s):
+    def step(model, seed, s, cast=lambda v: v):
         if kind == 'dcgan':
-            x = torch.tanh(recipe.tensor(seed, 2000 + s, (4, 3, 64, 64)))
-            z = recipe.tensor(seed, 3000 + s, (4, 128))
+            x = cast(torch.tanh(recipe.tensor(seed, 2000 + s, (4, 3, 64, 64))))
+            z = cast(recipe.tensor(seed, 3000 + s, (4, 128)))
             model.update_d({'real_sample': x, 'latent': z})
             model.update_g({'fake_sample': model.fake_sample})
         elif kind == 'srgan':
-            lr = recipe.tensor(seed, 100 + 2 * s, (2, 3, 24, 24), dist='uniform')
-            hr = recipe.tensor(seed, 101 + 2 * s, (2, 3, 96, 96), dist='uniform')
+            lr = cast(recipe.tensor(seed, 100 + 2 * s, (2, 3, 24, 24), dist='uniform'))
+            hr = cast(recipe.tensor(seed, 101 + 2 * s, (2, 3, 96, 96), dist='uniform'))
             if s == 0:
                 model.update_g({'low_res': lr, 'high_res': hr, 'pretrain': True, 'inhibit_bbox': True})
             else:
                 model.update_g({'low_res': lr, 'high_res': hr, 'pretrain': False})
                 model.update_d({'high_res': model.high_res, 'super_res': model.super_res})
         else:
-            a = torch.tanh(recipe.tensor(seed, 200 + s, (1, 3, 64, 64)))
-            b = torch.tanh(recipe.tensor(seed, 300 + s, (1, 3, 64, 64)))
+            a = cast(torch.tanh(recipe.tensor(seed, 200 + s, (1, 3, 64, 64))))
+            b = cast(torch.tanh(recipe.tensor(seed, 300 + s, (1, 3, 64, 64))))
             model.update_g({'real_A': a, 'real_B': b})
             model.update_d({'real_A': model.real_A, 'real_B': model.real_B,
                             'fake_A': model.fake_A.detach(), 'fake_B': model.fake_B.detach()})
@@ -516,6 +519,29 @@ def run_late_step_pair(kind, lead, follow, lead_steps=2):
     b, _ = build(follow)
     for s in range(lead_steps):
         step(a, seed, s)
-    b.load_state_dict(_cpu_state(a.state_dict()), strict=True)
+    state = _cpu_state(a.state_dict())
+    b.load_state_dict(state, strict=True)
+    t64 = None
+    if truth64:
+        t, _ = build(follow)
+        _to_double(t)
+        t.load_state_dict(_cpu_state(state), strict=True)      # (torch's optimizer loader casts the moments to the parameters' dtype)
+        _to_double(t)
     ma, mb = step(a, seed, lead_steps), step(b, seed, lead_steps)
+    if truth64:
+        step(t, seed, lead_steps, cast=lambda v: v.double())
+        t64 = _moments_full(t, ('optG', 'optD'))
+        return _moments_full(a, ('optG', 'optD')), _moments_full(b, ('optG', 'optD')), ma, mb, t64
     return _moments_full(a, ('optG', 'optD')), _moments_full(b, ('optG', 'optD')), ma, mb
+
+
+def _to_double(model):
+    """Every network (and floating-point buffer) of an oracle model in float64, through the wrappers (model.model ...)."""
+    seen = set()
+    m = model
+    while m is not None and id(m) not in seen:
+        seen.add(id(m))
+        for v in list(getattr(m, '_modules', {}).values()) + list(m.__dict__.values()):
+            if isinstance(v, torch.nn.Module):
+                v.double()
+        m = m.__dict__.get('model', None) or getattr(m, '_modules', {}).get('model', None)

@@ -32,26 +32,15 @@ def compare(res, ref, rtol=RTOL, atol=ATOL, policy=None):
                                        err_msg=k)
     for p in sorted(summ):
         pol = tol(p)
-        if len(pol) == 3 and pol[2] == 'scale':          # (rtol, atol, 'scale'): only the overall magnitude is comparable
-            a, b = float(res[f'{p}::asum']), float(ref[f'{p}::asum'])
-            assert abs(a - b) <= pol[0] * abs(b) + pol[1], f'{p}::asum {a} vs {b}'
-            continue
-        if len(pol) == 3 and pol[2] == 'chaotic':
-            # (sum_rtol, hard_frac, 'chaotic'): a tensor two or three optimizer steps downstream of batch-1..4 fp32 rounding
-            # (round 5, scripts/probe/final_moment_dist.py: up to 40 % of the entries of DCGAN's last-step moments sit more than
-            # 1 % of the tensor's scale away from the reference's IN THE EXACT fp32 MODE TOO).  What still holds, and is
-            # checked: abs-sum AND L2 norm within sum_rtol, and EVERY sampled entry (head, 64 strided, up to 2048 dense) within
-            # hard_frac of the tensor's largest sampled entry.  The element-wise check of late-step moments at step-0
-            # tolerances is tests/test_gpu_models.py::test_late_step_moments_from_a_common_state.
-            big = float(max(np.abs(ref[f'{p}::samp']).max(), np.abs(ref[f'{p}::dense']).max() if f'{p}::dense' in ref else 0.0))
+        if len(pol) == 2 and pol[1] == 'norms':
+            # (rtol, 'norms'): abs-sum and L2 norm only.  For tensors two or three optimizer steps downstream of batch-1..4 fp32
+            # rounding (the Adam moments after the LAST step of a fixture): their entries are held element-wise, against a
+            # float64 step from a common state, by tests/test_gpu_models.py::test_late_step_moments_from_a_common_state; what
+            # the fixture still pins is their magnitude
             for f in ('asum', 'l2'):
                 if f'{p}::{f}' in ref:
                     a, b = float(res[f'{p}::{f}']), float(ref[f'{p}::{f}'])
                     assert abs(a - b) <= pol[0] * abs(b) + 1e-3, f'{p}::{f} {a} vs {b}'
-            for f in ('head', 'samp', 'dense'):
-                if f'{p}::{f}' in ref:
-                    d = np.abs(np.asarray(res[f'{p}::{f}'], np.float64) - ref[f'{p}::{f}'])
-                    assert float(d.max()) <= pol[1] * big + 1e-6, f'{p}::{f}: worst entry {float(d.max() / max(big, 1e-30)):.3f} of the scale'
             continue
         if len(pol) in (3, 5) and pol[2] == 'relmax':      # (rtol, frac, 'relmax'): absolute slack = frac * max|sample|
             r, frac = pol[0], pol[1]
