@@ -294,6 +294,23 @@ class VGG19Feature(_HipNet):
         self.net.eval()
         for p in self.parameters():
             p.requires_grad = False
+        # The reference downloads torchvision's ImageNet weights (networks/vgg.py:33: vgg19(pretrained=True)); a box without
+        # network access gets them from a file: IPRGAN_VGG19_WEIGHTS=<vgg19-*.pth> (torchvision's own checkpoint layout).
+        path = os.environ.get('IPRGAN_VGG19_WEIGHTS')
+        if path:
+            self.load_torchvision_state_dict(torch.load(path, map_location='cpu'))
+
+    def load_torchvision_state_dict(self, sd):
+        """Weights in torchvision's vgg19 layout (``features.<i>.weight / .bias`` with i the index inside ``features``;
+        ``classifier.*`` and the feature layers past this extractor's cut are ignored) -> ``self.net``, whose indices are
+        the same ones (networks/vgg.py:33 slices ``vgg19().features``).  Every convolution of the extractor must be covered."""
+        own = self.net.state_dict()
+        got = {k[len('features.'):]: v for k, v in sd.items() if k.startswith('features.') and k[len('features.'):] in own}
+        missing = sorted(set(own) - set(got))
+        if missing:
+            raise KeyError(f'VGG19Feature: the state_dict lacks features.{{{", ".join(missing[:4])}, ...}} ({len(missing)} of {len(own)} tensors)')
+        self.net.load_state_dict(got, strict=True)
+        return self
 
     def _build_chain(self):
         plan = [E.ToNHWC(3)]

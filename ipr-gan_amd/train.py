@@ -89,7 +89,9 @@ class Experiment:
     def configure_dataset(self):
         ds, hp = self.config.dataset, self.config.hparam
         size = ds.get('size', None) or ds.get('crop', None) or 96
-        self.data_loader = SyntheticLoader(self.kind, hp.bsz, size)
+        # (`dataset.synthetic_samples`: length of the synthetic stand-in dataset - the reference takes it from the files on
+        # disk; it sets the iterations per epoch of the translation experiment)
+        self.data_loader = SyntheticLoader(self.kind, hp.bsz, size, n_samples=int(ds.get('synthetic_samples', None) or 10000))
         if self.kind == 'translation':                          # iteration / log.freq are given in epochs
             # image_translation.py:38-40 with the reference's global batch bsz * ngpu (base.py:39): one epoch is
             # ceil(N / (bsz * world)) iterations of every rank

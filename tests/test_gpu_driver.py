@@ -97,3 +97,61 @@ def test_two_ranks_draw_different_data_and_hold_equal_parameters(tmp_path):
     sd = torch.load(os.path.join(log, 'checkpoint.pt'), map_location='cpu')
     assert sd['step'] == 'END'              # iteration 4 // world 2 = 2 steps per rank
     assert json.load(open(os.path.join(log, 'metrics.json')))['BER'] == 0.0
+
+
+def test_train_driver_srgan_pretrain_then_gan_phase(tmp_path):
+    """configs/SRGAN/*: ImageSuperResolution.train() (experiments/image_super_resolution.py:84-113) through the driver -
+    `pretrain_iter` content-loss-only generator steps (no discriminator update, black-box inhibited), then the GAN phase in
+    the reference's order (update_g, then update_d on the tensors update_g left), both learning rates x 0.1 at
+    pretrain_iter + iteration // 2; checkpoint in the reference layout, loadable by the CPU oracle."""
+    cfg = os.path.join(ROOT, 'tests', 'configs', 'srgan-wbox-tiny.yaml')
+    log = str(tmp_path / 'log')
+    subprocess.run([sys.executable, os.path.join(PKG, 'train.py'), '-c', cfg, '--log-path', log], check=True, timeout=900)
+    sd = torch.load(os.path.join(log, 'checkpoint.pt'), map_location='cpu')
+    assert sd['step'] == 'END' and list(sd) == ['G', 'D', 'optG', 'optD', 'sign', 'step']
+    rows = [json.loads(l) for l in open(os.path.join(log, 'metrics.jsonl'))]
+    assert [r['step'] for r in rows] == [1, 2, 3, 4, 5, 6]                 # pretrain_iter 2 + iteration 4
+    # pretraining: the generator's content loss only - the discriminator has not run, its metrics are absent or zero
+    for r in rows[:2]:
+        assert r['G/Con'] > 0 and r.get('G/Adv', 0.0) == 0.0 and r.get('D/Sum', 0.0) == 0.0, r
+    for r in rows[2:]:
+        assert r['G/Con'] > 0 and r['G/Adv'] > 0 and r['D/Sum'] > 0 and r['D/Real'] > 0 and r['D/Fake'] > 0, r
+    # lr *= 0.1 on both optimizers at step pretrain_iter + iteration // 2 = 4 (image_super_resolution.py:88-90)
+    assert abs(sd['optG']['param_groups'][0]['lr'] - 1e-5) < 1e-12 and abs(sd['optD']['param_groups'][0]['lr'] - 1e-5) < 1e-12
+    # Adam step counts: G stepped in all six iterations, D in the four of the GAN phase
+    assert {int(v['step']) for v in sd['optG']['state'].values()} == {6}
+    assert {int(v['step']) for v in sd['optD']['state'].values()} == {4}
+    assert json.load(open(os.path.join(log, 'metrics.json')))['BER'] == 0.0
+    from oracle import cases, gan
+    o = gan.WhiteBoxWrapper(gan.SRGAN(gan.Cfg(cases.SRGAN_CFG)), gan.Cfg(cases.WBOX_CFG))
+    o.load_state_dict({k: v for k, v in sd.items() if k != 'step'}, strict=True)
+
+
+def test_train_driver_cyclegan_epochs_pools_and_lr_decay(tmp_path):
+    """configs/CycleGAN/*: ImageTranslation.train() (experiments/image_translation.py:90-112) through the driver - iteration
+    and log.freq are EPOCHS (3 synthetic samples at batch 1 = 3 iterations each), update_lr() at the first iteration of every
+    epoch but the first, the LambdaLR rule of models/cyclegan.py:50-51 over model.epoch = 4 (1, 1, 1, 0.5), update_g before
+    update_d, image pools (size 2) past their fill; checkpoint in the reference layout (schedulers and pools included),
+    loadable by the CPU oracle; interrupted after 5 iterations and resumed."""
+    cfg = os.path.join(ROOT, 'tests', 'configs', 'cyclegan-wbox-tiny.yaml')
+    log = str(tmp_path / 'log')
+    cmd = [sys.executable, os.path.join(PKG, 'train.py'), '-c', cfg, '--log-path', log]
+    subprocess.run(cmd + ['--max-steps', '5'], check=True, timeout=900)
+    sd = torch.load(os.path.join(log, 'checkpoint.pt'), map_location='cpu')
+    assert sd['step'] == 3                                   # log.freq = 1 epoch = 3 iterations: the checkpoint of epoch 1
+    subprocess.run(cmd, check=True, timeout=900)             # resumes at iteration 4
+    sd = torch.load(os.path.join(log, 'checkpoint.pt'), map_location='cpu')
+    assert sd['step'] == 'END'
+    assert list(sd)[:4] == ['GA', 'GB', 'DA', 'DB'] and {'optG', 'optD', 'sign'} <= set(sd)
+    rows = [json.loads(l) for l in open(os.path.join(log, 'metrics.jsonl'))]
+    assert [r['step'] for r in rows] == [1, 2, 3, 4, 5] + list(range(4, 13))
+    lr = {r['step']: r['LR'] for r in rows[5:]}
+    assert all(abs(lr[s] - 2e-4) < 1e-12 for s in range(4, 10)), lr           # epochs 2, 3: factor 1
+    assert all(abs(lr[s] - 1e-4) < 1e-12 for s in range(10, 13)), lr          # epoch 4: 1 - (3 - 2) / 2
+    for r in rows:
+        assert all(r[k] > 0 for k in ('G/A', 'G/B', 'G/CycA', 'G/CycB', 'G/IdtA', 'G/IdtB', 'D/SumA', 'D/SumB')), r
+    assert json.load(open(os.path.join(log, 'metrics.json')))['BER'] == 0.0
+    from oracle import cases, gan
+    o = gan.WhiteBoxWrapper(gan.CycleGAN(gan.Cfg(dict(cases.CYCLEGAN_CFG, G='Resnet9Blocks', pool_size=2, epoch=4))),
+                            gan.Cfg(dict(cases.WBOX_CFG, target='GB')))
+    o.load_state_dict({k: v for k, v in sd.items() if k != 'step'}, strict=True)
