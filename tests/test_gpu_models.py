@@ -710,20 +710,26 @@ def test_dcgan128_networks_vs_oracle(which, dev):
         a, b = nets.SNDiscriminator(md=16), networks.SNDiscriminator(md=16)
         x = torch.tanh(recipe.tensor(9, 2, (2, 3, 128, 128)))
     recipe.fill(a, 9); recipe.fill(b, 9)
+    import copy
+    c = copy.deepcopy(a).double()          # (before any forward pass: a training-mode pass advances the spectral-norm vectors)
     b.to(dev)
-    a.train(); b.train()
+    a.train(); b.train(); c.train()
     xa, xb = x.clone().requires_grad_(), x.clone().to(dev).requires_grad_()
     ya, yb = a(xa), b(xb)
     np.testing.assert_allclose(yb.detach().cpu().numpy(), ya.detach().numpy(), rtol=RTOL, atol=ATOL)
     g = recipe.tensor(9, 3, tuple(ya.shape))
     ya.backward(g); yb.backward(g.to(dev))
-    # At batch 2 a single ReLU / BatchNorm-boundary element that rounds to the other side of zero changes a whole
-    # row of gradients by O(1e-3) (measured against an fp64 run, either the CPU fp32 oracle or this engine is the
-    # one that flips, depending on the case), so gradients are compared in the L2 norm, not element-wise.
-    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        ga, gb = pa.grad.double(), pb.grad.cpu().double()
-        rel = float((ga - gb).norm() / ga.norm())
-        assert rel < 3e-2, f'{k}: relative L2 error {rel:.2e}'      # one flipped element is worth ~1e-2 here
+    # At batch 2 a single ReLU / BatchNorm-boundary element that rounds to the other side of zero changes a whole row of
+    # gradients by O(1e-2) in relative L2, and either fp32 evaluation can be the one that flips.  So the gradients are held
+    # against the TRUTH: the same network in float64 (oracle, same weights and inputs), and the engine may sit at most 4 x as
+    # far from it as the fp32 oracle does, plus one flip (1e-2) - not a tolerance fitted to observed runs.
+    xc = x.clone().double().requires_grad_()
+    c(xc).backward(g.double())
+    for (k, pa), (_, pb), (_, pc) in zip(a.named_parameters(), b.named_parameters(), c.named_parameters()):
+        t = pc.grad
+        eh = float((pb.grad.cpu().double() - t).norm() / t.norm())
+        er = float((pa.grad.double() - t).norm() / t.norm())
+        assert eh <= 4.0 * er + 1e-2, f'{k}: relative L2 distance from the float64 gradient {eh:.2e} (engine) vs {er:.2e} (fp32 oracle)'
 
 
 def test_full_size_step_is_deterministic_and_keeps_watermark(dev):
