@@ -111,9 +111,9 @@ def test_train_driver_srgan_pretrain_then_gan_phase(tmp_path):
     assert sd['step'] == 'END' and list(sd) == ['G', 'D', 'optG', 'optD', 'sign', 'step']
     rows = [json.loads(l) for l in open(os.path.join(log, 'metrics.jsonl'))]
     assert [r['step'] for r in rows] == [1, 2, 3, 4, 5, 6]                 # pretrain_iter 2 + iteration 4
-    # pretraining: the generator's content loss only - the discriminator has not run, its metrics are absent or zero
+    # pretraining (models/srgan.py:76-79): pixel MSE only - no perceptual / adversarial term, the discriminator has not run
     for r in rows[:2]:
-        assert r['G/Con'] > 0 and r.get('G/Adv', 0.0) == 0.0 and r.get('D/Sum', 0.0) == 0.0, r
+        assert r['G/MSE'] > 0 and r['G/Sum'] == r['G/MSE'] and 'G/Adv' not in r and 'D/Sum' not in r, r
     for r in rows[2:]:
         assert r['G/Con'] > 0 and r['G/Adv'] > 0 and r['D/Sum'] > 0 and r['D/Real'] > 0 and r['D/Fake'] > 0, r
     # lr *= 0.1 on both optimizers at step pretrain_iter + iteration // 2 = 4 (image_super_resolution.py:88-90)
