@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 224
+#define IPRGAN_VERSION 225
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -96,6 +96,21 @@ int iprgan_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W
  * networks/conv_generator.py:26 and sn_discriminator.py:32) */
 /* beta: 0 overwrites dst, 1 accumulates (dst = beta*dst + permuted src) - see "gradient accumulation" below */
 int iprgan_permute_021(const float* src, float* dst, int A, int Bd, int K, float beta, void* stream);
+
+/* ---- Linear(K -> C*HW) feeding an NHWC map (replaces aten::addmm + view + relu and their backward for the first layer of
+ *      the generators: networks/conv_generator.py:26-30 `self.fc(z).view(-1, C, mg, mg)`, the VAE decoder's first layer).
+ * x [B][K] fp32; w [C*HW][K] and bias [C*HW] fp32 in PyTorch's row order c*HW + hw (the parameters themselves: no permuted
+ * copy, no prepared operand); y / dy [B][HW][C] in storage kind `kind` (IPRGAN_ST_*, plane stride in elements, 0 = B*HW*C).
+ *   fwd:  y[b][hw][c] = act(sum_k x[b][k] w[c*HW + hw][k] + bias[c*HW + hw])
+ *   bwd:  dz = dy * act'(y);  dw[c*HW + hw][k] = beta*dw + sum_b dz[b][hw][c] x[b][k];  db likewise (db may be NULL)
+ * One launch each, exact fp32 MFMA in every math mode, fixed summation order.  Shapes: K % 32 == 0, K <= 128, C % 64 == 0
+ * (iprgan_fc_nhwc_ok); other shapes go through the convolution family as a 1x1 layer.  dx is not produced here (the
+ * generators' latent needs none; a caller that does uses iprgan_conv_bwd_data on the 1x1 form). */
+int iprgan_fc_nhwc_ok(int B, int K, int C, int HW);
+int iprgan_fc_nhwc_fwd(const float* x, const float* w, const float* bias, void* y, int B, int K, int C, int HW, int act,
+                       float slope, int y_kind, size_t y_pstride, void* stream);
+int iprgan_fc_nhwc_bwd(const float* x, const void* y, const void* dy, float* dw, float* db, int B, int K, int C, int HW,
+                       int act, float slope, int kind, size_t y_pstride, size_t dy_pstride, float beta, void* stream);
 
 /* ---- convolution (replaces aten::conv2d / conv_transpose2d + their backward;
  *      networks/sn_discriminator.py:9-18, conv_generator.py:8,21, sr_resnet.py:22,
@@ -164,6 +179,10 @@ size_t iprgan_colsum_ws_floats(int M, int Cs);
 int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, float beta, int x_bf16, void* stream);
 /* the same from per-tile partials part[rows][2][Cs] (first of the two sums) written by a convolution epilogue */
 int iprgan_colsum_partials(const float* part, int rows, int Cs, int C, float* out, float beta, void* stream);
+/* the same for n layers in one launch (HOST arrays of device pointers / sizes): the bias gradients a backward pass owes,
+ * flushed together by the executor; bit-identical to n single calls */
+int iprgan_colsum_partials_multi(const float* const* parts, const int* rows, const int* Cs, const int* C, float* const* outs,
+                                 const float* betas, int n, void* stream);
 /* dw (PyTorch layout) = beta*dw + conv_bwd_weight(x, dy); db (optional, length Cout) = beta*db + sum dy.
  * beta = 0 overwrites; beta = 1 accumulates straight into a gradient bucket (what autograd's AccumulateGrad
  * add plus DDP's bucket copy do in two extra passes).  ws: workspace of iprgan_conv_wgrad_ws_floats(d) floats.

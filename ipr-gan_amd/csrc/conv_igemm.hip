@@ -1712,13 +1712,88 @@ __device__ __forceinline__ void wgrad_reduce_block(unsigned block, const float* 
       }
   }
 }
+// Row form (round 6): the block above finishes with 16 of its 256 threads scattering single floats, tap-strided, into dw (and
+// reading them back first when it accumulates) - the slab reduces of a DCGAN step moved their 0.5 GB at 2.4 TB/s.  Here a block
+// owns ONE weight row n and `cw` consecutive channels for ALL taps: its slab reads are runs of cw floats per tap (the whole
+// row [tap][c] when cw == Qs), its output is cw * ntap CONSECUTIVE floats of dw ([c][tap] order: PyTorch's), transposed through
+// LDS and written (or accumulated) as 16-byte vectors by every thread.  P = ntap * cw / 4 float4 positions x SL = 256 / P
+// split lanes; a lane sums its splits sl, sl + SL, ... into eight accumulators in a fixed pattern, the lanes are combined in
+// lane order: deterministic.  For Conv2d / ConvTranspose2d weight layouts with unpadded channels (wgrad_reduce_cw).
+__device__ __forceinline__ void wgrad_reduce_rows(unsigned block, const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
+                                                  int Nrows, int Kw, int Qs, int ntap, int cw, long long sn, float beta,
+                                                  f32x4 (*sh)[16], float* tile) {
+  const int cq = cw >> 2, P = ntap * cq, SL = 256 / P, groups = Qs / cw;
+  const int n = (int)(block / groups), c0 = (int)(block % groups) * cw;
+  const int tid = threadIdx.x, p = tid % P, sl = tid / P;
+  f32x4* part = &sh[0][0];                   // [SL][P] float4
+  if (sl < SL) {
+    const int tap = p / cq, q = p - tap * cq;
+    const float* src = ws + (size_t)n * Kw + (size_t)tap * Qs + c0 + 4 * q;
+    const size_t slab = (size_t)Nrows * Kw;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a0 = z, a1 = z, a2 = z, a3 = z, a4 = z, a5 = z, a6 = z, a7 = z;
+    int sp = sl;
+    for (; sp + 7 * SL < nsplit; sp += 8 * SL) {
+      a0 += *(const f32x4*)(src + (size_t)sp * slab);
+      a1 += *(const f32x4*)(src + (size_t)(sp + SL) * slab);
+      a2 += *(const f32x4*)(src + (size_t)(sp + 2 * SL) * slab);
+      a3 += *(const f32x4*)(src + (size_t)(sp + 3 * SL) * slab);
+      a4 += *(const f32x4*)(src + (size_t)(sp + 4 * SL) * slab);
+      a5 += *(const f32x4*)(src + (size_t)(sp + 5 * SL) * slab);
+      a6 += *(const f32x4*)(src + (size_t)(sp + 6 * SL) * slab);
+      a7 += *(const f32x4*)(src + (size_t)(sp + 7 * SL) * slab);
+    }
+    for (; sp < nsplit; sp += SL) a0 += *(const f32x4*)(src + (size_t)sp * slab);
+    part[sl * P + p] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  }
+  __syncthreads();
+  if (tid < P) {
+    f32x4 t = part[tid];
+    for (int l = 1; l < SL; ++l) t += part[l * P + tid];
+    const int tap = tid / cq, q = tid - tap * cq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[tap * (cw + 1) + 4 * q + j] = t[j];
+  }
+  __syncthreads();
+  if (tid < P) {                              // cw * ntap / 4 = P output vectors, consecutive in dw
+    float* dst = dw + (size_t)n * sn + (size_t)c0 * ntap + 4 * tid;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = 4 * tid + j, c = o / ntap, tap = o - c * ntap;
+      v[j] = tile[tap * (cw + 1) + c];
+    }
+    if (beta != 0.f) v += beta * *(const f32x4*)dst;       // beta = 1: accumulate into a gradient bucket view
+    *(f32x4*)dst = v;
+  }
+}
+// channels per block of the row form, 0 = the layout needs the generic block (padded channel counts, the role-swapped
+// layers' strides, more than 16 taps)
+static int wgrad_reduce_cw(const float* dw, int N, int C, int Qs, int ntap, long long sn, long long sc) {
+  if (((uintptr_t)dw & 15) != 0) return 0;         // (a gradient-bucket view behind a parameter with an odd element count)
+  if (C != Qs || sc != ntap || sn != (long long)C * ntap || ntap > 16 || (Qs % 16) != 0 || ((C * ntap) % 4) != 0) return 0;
+  static const int off = getenv("IPRGAN_WGRAD_REDUCE_ROWS") ? atoi(getenv("IPRGAN_WGRAD_REDUCE_ROWS")) == 0 : 0;     // A/B switch
+  if (off) return 0;
+  const int cands[3] = {64, 32, 16};
+  for (int i = 0; i < 3; ++i) {
+    const int cw = cands[i];
+    if ((Qs % cw) != 0 || ntap * cw / 4 > 256) continue;
+    if ((long long)N * (Qs / cw) >= 512 || cw == 16) return cw;
+  }
+  return 0;
+}
+static unsigned wgrad_reduce_blocks(int N, int Qs, int ntap, int cw) {
+  return cw ? (unsigned)(N * (Qs / cw)) : (unsigned)(((long long)N * ntap * Qs + 63) / 64);
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws,
                                                            float* __restrict__ dw, int nsplit, int Nrows,
                                                            int Kw, int N, int C, int Qs, int ntap,
                                                            FastDiv d_qs, FastDiv d_row, long long sn,
-                                                           long long sc, float beta) {
+                                                           long long sc, float beta, int cw) {
   __shared__ f32x4 sh[16][16];
-  wgrad_reduce_block(blockIdx.x, ws, dw, nsplit, Nrows, Kw, N, C, Qs, ntap, d_qs, d_row, sn, sc, beta, sh);
+  __shared__ float tile[16 * 65];
+  if (cw) wgrad_reduce_rows(blockIdx.x, ws, dw, nsplit, Nrows, Kw, Qs, ntap, cw, sn, beta, sh, tile);
+  else wgrad_reduce_block(blockIdx.x, ws, dw, nsplit, Nrows, Kw, N, C, Qs, ntap, d_qs, d_row, sn, sc, beta, sh);
 }
 // The slab reduces of SEVERAL layers in one launch (iprgan_wgrad_reduce_multi): a backward pass owes one per layer - 19 launches
 // of 5-17 us per DCGAN step, each behind a kernel boundary - and nothing reads a weight gradient before the pass flushes its
@@ -1733,15 +1808,21 @@ struct WGradReduceTable {
   int nsplit[WGRAD_MULTI_MAX], Nrows[WGRAD_MULTI_MAX], Kw[WGRAD_MULTI_MAX], N[WGRAD_MULTI_MAX], C[WGRAD_MULTI_MAX], Qs[WGRAD_MULTI_MAX],
       ntap[WGRAD_MULTI_MAX];
   float beta[WGRAD_MULTI_MAX];
+  int cw[WGRAD_MULTI_MAX];                    // > 0: row form with this many channels per block (wgrad_reduce_cw)
   unsigned first[WGRAD_MULTI_MAX + 1];        // first block of entry e; first[n] = grid size
   int n;
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WGradReduceTable t) {
   __shared__ f32x4 sh[16][16];
+  __shared__ float tile[16 * 65];
   int e = 0;
   while (e + 1 < t.n && blockIdx.x >= t.first[e + 1]) ++e;       // (block-uniform: scalar loads of the kernel arguments)
-  wgrad_reduce_block(blockIdx.x - t.first[e], t.ws[e], t.dw[e], t.nsplit[e], t.Nrows[e], t.Kw[e], t.N[e], t.C[e], t.Qs[e], t.ntap[e],
-                     t.d_qs[e], t.d_row[e], t.sn[e], t.sc[e], t.beta[e], sh);
+  if (t.cw[e])
+    wgrad_reduce_rows(blockIdx.x - t.first[e], t.ws[e], t.dw[e], t.nsplit[e], t.Nrows[e], t.Kw[e], t.Qs[e], t.ntap[e], t.cw[e],
+                      t.sn[e], t.beta[e], sh, tile);
+  else
+    wgrad_reduce_block(blockIdx.x - t.first[e], t.ws[e], t.dw[e], t.nsplit[e], t.Nrows[e], t.Kw[e], t.N[e], t.C[e], t.Qs[e], t.ntap[e],
+                       t.d_qs[e], t.d_row[e], t.sn[e], t.sc[e], t.beta[e], sh);
 }
 
 // prepared-weight builder: w[D0][D1][ntap] (PyTorch) -> ot[R0][K0] (row d0, k = tap*C4(D1)+d1)
@@ -3089,9 +3170,10 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
       const long long total = (long long)g.N * ntap * Qs;
       IPR_CHECK(total < (1ll << 31), "conv_bwd_weight: weight too large");
       if (wgrad_reduce_deferred(ws, dw_out, nsplit, Nrows, Kw, g.N, g.Cq, Qs, ntap, (long long)g.Cq * ntap, (long long)ntap, beta_out)) return 0;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, ws, dw_out, nsplit,
+      const int cw = wgrad_reduce_cw(dw_out, g.N, g.Cq, Qs, ntap, (long long)g.Cq * ntap, (long long)ntap);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(g.N, Qs, ntap, cw)), dim3(256), 0, st, ws, dw_out, nsplit,
                          Nrows, Kw, g.N, g.Cq, Qs, ntap, make_fastdiv(Qs), make_fastdiv(ntap * Qs),
-                         (long long)g.Cq * ntap, (long long)ntap, beta_out);
+                         (long long)g.Cq * ntap, (long long)ntap, beta_out, cw);
       IPR_LAUNCH_CHECK();
       return 0;
     }
@@ -3157,9 +3239,10 @@ int iprgan_conv_bwd_weight(const iprgan_conv_desc* d, const float* x, const floa
     // swapped roles: rows are Cin and the Q channel is Cout of a Conv2d weight
     const long long sn = g.swap ? p.ntap : (long long)p.Cq * p.ntap, sc = g.swap ? (long long)p.N * p.ntap : p.ntap;
     if (wgrad_reduce_deferred(ws, dw_out, p.nsplit, p.Nrows, p.Kw, p.N, p.Cq, p.Qs, p.ntap, sn, sc, beta_out)) return 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, ws, dw_out,
+    const int cw = wgrad_reduce_cw(dw_out, p.N, p.Cq, p.Qs, p.ntap, sn, sc);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(p.N, p.Qs, p.ntap, cw)), dim3(256), 0, st, ws, dw_out,
                        p.nsplit, p.Nrows, p.Kw, p.N, p.Cq, p.Qs, p.ntap, make_fastdiv(p.Qs),
-                       make_fastdiv(p.ntap * p.Qs), sn, sc, beta_out);
+                       make_fastdiv(p.ntap * p.Qs), sn, sc, beta_out, cw);
     IPR_LAUNCH_CHECK();
     return 0;
   };
@@ -3239,8 +3322,9 @@ int iprgan_wgrad_reduce_multi(const iprgan_wgrad_reduce_rec* recs, int n, void* 
       t.d_qs[e] = make_fastdiv(r.Qs); t.d_row[e] = make_fastdiv(r.ntap * r.Qs);
       t.nsplit[e] = r.nsplit; t.Nrows[e] = r.Nrows; t.Kw[e] = r.Kw; t.N[e] = r.N; t.C[e] = r.C; t.Qs[e] = r.Qs; t.ntap[e] = r.ntap;
       t.beta[e] = r.beta;
+      t.cw[e] = wgrad_reduce_cw(r.dw, r.N, r.C, r.Qs, r.ntap, r.sn, r.sc);
       t.first[e] = blocks;
-      blocks += (unsigned)((total + 63) / 64);
+      blocks += wgrad_reduce_blocks(r.N, r.Qs, r.ntap, t.cw[e]);
       t.first[e + 1] = blocks;
     }
     if (!t.n) continue;

@@ -264,6 +264,30 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
   if (lane == 0 && c < C) out[c] = beta != 0.f ? beta * out[c] + s0 : s0;
 }
 
+// the column sums of SEVERAL layers' partials in one launch (iprgan_colsum_partials_multi): a discriminator's backward pass
+// owes one bias gradient per convolution - eight launches of 4-11 us with one to eight blocks each; every block does what its
+// colsum_final_kernel block would have done (bit-identical)
+#define COLSUM_MULTI_MAX 24
+struct ColsumTable {
+  const float* part[COLSUM_MULTI_MAX];
+  float* out[COLSUM_MULTI_MAX];
+  int NB[COLSUM_MULTI_MAX], Cs[COLSUM_MULTI_MAX], C[COLSUM_MULTI_MAX];
+  float beta[COLSUM_MULTI_MAX];
+  unsigned first[COLSUM_MULTI_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(1024) void colsum_final_multi_kernel(const ColsumTable t) {
+  __shared__ float sh[2][FL][64];
+  int e = 0;
+  while (e + 1 < t.n && blockIdx.x >= t.first[e + 1]) ++e;
+  const int blk = blockIdx.x - t.first[e];
+  const int c = blk * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+  float s0, s1;
+  final_sums(t.part[e], t.NB[e], t.Cs[e], c, lane, sh, s0, s1, false);
+  float* out = t.out[e];
+  if (lane == 0 && c < t.C[e]) out[c] = t.beta[e] != 0.f ? t.beta[e] * out[c] + s0 : s0;
+}
+
 __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ part,
                                                              const float* __restrict__ x, int NB, int M,
                                                              int C, float eps, float momentum,
@@ -636,6 +660,32 @@ int iprgan_colsum(const float* x, float* out, float* ws, int M, int Cs, int C, f
   return colsum_launch(x, out, ws, M, Cs, C, (hipStream_t)stream, beta, x_bf16, 0);
 }
 size_t iprgan_colsum_ws_floats(int M, int C) { return colsum_ws_floats(M, C); }
+int iprgan_colsum_partials_multi(const float* const* parts, const int* rows, const int* Cs, const int* C, float* const* outs,
+                                 const float* betas, int n, void* stream) {
+  IPR_CHECK(n >= 0 && (!n || (parts && rows && Cs && C && outs && betas)), "colsum_partials_multi: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int i = 0;
+  while (i < n) {
+    ColsumTable t;
+    memset(&t, 0, sizeof(t));
+    unsigned blocks = 0;
+    for (; i < n && t.n < COLSUM_MULTI_MAX; ++i) {
+      IPR_CHECK(rows[i] > 0 && C[i] <= Cs[i] && parts[i] && outs[i], "colsum_partials_multi: entry %d: %d rows, C=%d, Cs=%d", i, rows[i], C[i], Cs[i]);
+      const float* part = parts[i];
+      int r = rows[i];
+      if (compact_partials(part, r, 1, Cs[i], st)) return 2;       // (partials of thousands of rows: their own launch, as before)
+      const int e = t.n++;
+      t.part[e] = part; t.out[e] = outs[i]; t.NB[e] = r; t.Cs[e] = Cs[i]; t.C[e] = C[i]; t.beta[e] = betas[i];
+      t.first[e] = blocks;
+      blocks += (unsigned)cdiv(C[i], 64);
+      t.first[e + 1] = blocks;
+    }
+    hipLaunchKernelGGL(colsum_final_multi_kernel, dim3(blocks), dim3(64 * FL), 0, st, t);
+    IPR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 int iprgan_colsum_partials(const float* part, int rows, int Cs, int C, float* out, float beta, void* stream) {
   IPR_CHECK(rows > 0 && C <= Cs, "colsum_partials: %d rows, C=%d, Cs=%d", rows, C, Cs);
   if (compact_partials(part, rows, 1, Cs, (hipStream_t)stream)) return 2;

@@ -43,6 +43,9 @@ SIGNATURES = {
     'iprgan_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'iprgan_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'iprgan_permute_021': (_I, [_P, _P, _I, _I, _I, _F, _P]),
+    'iprgan_fc_nhwc_ok': (_I, [_I, _I, _I, _I]),
+    'iprgan_fc_nhwc_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _Z, _P]),
+    'iprgan_fc_nhwc_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _Z, _Z, _F, _P]),
     'iprgan_conv_wfwd_floats': (_Z, [_D]),
     'iprgan_conv_wbwd_floats': (_Z, [_D]),
     'iprgan_conv_wgrad_ws_floats': (_Z, [_D]),
@@ -52,6 +55,7 @@ SIGNATURES = {
     'iprgan_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int), _P]),
     'iprgan_conv_stat_floats': (_Z, [_D, _I]),
     'iprgan_colsum_partials': (_I, [_P, _I, _I, _I, _P, _F, _P]),
+    'iprgan_colsum_partials_multi': (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     'iprgan_conv_bwd_data_ws_floats': (_Z, [_D]),
     'iprgan_conv_bwd_data': (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, C.POINTER(C.c_int), _P, _P]),
     'iprgan_conv_bwd_data_bn_ok': (_I, [_D]),

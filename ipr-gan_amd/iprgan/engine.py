@@ -190,8 +190,13 @@ class Conv(Op):
             dwb, _ = ops.conv_bwd_weight(sp, dh, x_[B2:], dy[B2:], self.weight.shape, False, defer=st.get('wg_defer'))
             st['dwsn'] = [(dwa, st['uv'][0][0], st['uv'][0][1], pair[0]), (dwb, st['uv'][1][0], st['uv'][1][1], pair[1])]
             dbp = st.get('db_part')
-            db = (ops.colsum_partials(dbp[0], dbp[1], dy.shape[-1], sp.cout) if dbp is not None
-                  else ops.colsum(dy, sp.cout)) if has_b else None
+            db = None
+            if has_b and dbp is not None and sink is not None and st.get('cs_defer') is not None:
+                # straight into the bucket view, with the pass's other bias gradients in one launch (ChainFn.backward: flush)
+                st['cs_defer'].append((dbp[0], dbp[1], dy.shape[-1], sp.cout, sink.view_of(self.bias), 1.0))
+                db = DIRECT
+            elif has_b:
+                db = ops.colsum_partials(dbp[0], dbp[1], dy.shape[-1], sp.cout) if dbp is not None else ops.colsum(dy, sp.cout)
             grads = [dwa] + ([db] if has_b else [])
         elif need_w:
             has_b = self.bias is not None
@@ -199,7 +204,11 @@ class Conv(Op):
             db_done = st.get('db_done') if has_b else None      # ... or already accumulated by the norm layer above
             if db_done is None and dbp is not None:
                 if sink is not None:
-                    ops.colsum_partials(dbp[0], dbp[1], dy.shape[-1], sp.cout, out=sink.view_of(self.bias), beta=1.0)
+                    cs = st.get('cs_defer')
+                    if cs is not None:      # one launch for the pass's bias gradients (ChainFn.backward: flush)
+                        cs.append((dbp[0], dbp[1], dy.shape[-1], sp.cout, sink.view_of(self.bias), 1.0))
+                    else:
+                        ops.colsum_partials(dbp[0], dbp[1], dy.shape[-1], sp.cout, out=sink.view_of(self.bias), beta=1.0)
                     db_done = DIRECT
                 else:
                     db_done = ops.colsum_partials(dbp[0], dbp[1], dy.shape[-1], sp.cout)
@@ -268,6 +277,12 @@ class LinearNHWC(Op):
 
     def forward(self, x, st, train):
         B, K = x.shape
+        if x.dtype == torch.float32 and ops.fc_nhwc_ok(B, K, self.C, self.HW):
+            # one launch on the parameters as they are (csrc/fc.hip): no permuted copy, no prepared operand, no split of x
+            x = x.contiguous()
+            y = ops.fc_nhwc_fwd(x, self.weight, self.bias, self.C, self.HW, self.spec.act, self.spec.slope)
+            st.update(x=x, y=y, direct=True)
+            return y
         d = self.spec.desc(B, 1, 1)
         # the row-permuted copies are kept until the weight changes (the optimizer bumps the version counter)
         key = (self.weight._version, self.weight.data_ptr(), self.bias._version, self.bias.data_ptr())
@@ -285,7 +300,27 @@ class LinearNHWC(Op):
         return y
 
     def backward(self, dy, st, need_dx, need_w, prev_act, sink=None):
-        sp, d = self.spec, st['d']
+        sp = self.spec
+        if st.get('direct'):
+            act = L.ACT_NONE if st.get('dy_is_preact', False) else sp.act
+            grads = []
+            if need_w:
+                if sink is not None:       # straight into the bucket views, PyTorch layout (the kernel addresses rows c*HW + hw)
+                    ops.fc_nhwc_bwd(st['x'], st['y'], dy, self.weight.shape, self.C, self.HW, act, sp.slope,
+                                    dw=sink.view_of(self.weight), db=sink.view_of(self.bias), beta=1.0)
+                    grads = [DIRECT, DIRECT]
+                else:
+                    grads = list(ops.fc_nhwc_bwd(st['x'], st['y'], dy, self.weight.shape, self.C, self.HW, act, sp.slope))
+            dx = None
+            if need_dx:                     # (the VAE decoder: its latent comes from the encoder) - the 1x1 form of rounds 1-5
+                B, K = st['x'].shape
+                d = sp.desc(B, 1, 1)
+                dz = ops.act_bwd(dy, st['y'], sp.act, sp.slope) if act != L.ACT_NONE else dy
+                wp = ops.permute_021(self.weight, self.C, self.HW, K)
+                _, wb = ops.conv_prep(sp, d, wp.view(sp.cout, K, 1, 1), fwd=False, bwd=True)
+                dx = ops.f32(ops.conv_bwd_data(sp, d, dz.view(B, 1, 1, sp.cout), wb)).view(B, K)
+            return dx, grads
+        d = st['d']
         B, K = d.B, sp.cin
         if not st.get('dy_is_preact', False):
             dy = ops.act_bwd(dy, st['y'], sp.act, 0.0)
@@ -731,6 +766,7 @@ class ChainFn(torch.autograd.Function):
         grads_per_op = [None] * len(ops_list)
         small_dst, small_src, sn_wait = [], [], []
         wg_wait = []        # slab reduces the convolutions of this pass owe (ops.conv_bwd_weight(defer=...)): one launch in flush()
+        cs_wait = []        # bias gradients from dgrad-epilogue partials, straight into bucket views: one launch in flush()
 
         small_seen = set()
 
@@ -740,6 +776,7 @@ class ChainFn(torch.autograd.Function):
             gradients (one multi-tensor add); first of all the slab reduces of the weight gradients, which the spectral-norm
             backward reads"""
             ops.wgrad_reduce_flush(wg_wait)
+            ops.colsum_partials_flush(cs_wait)
             if sn_wait:
                 out_of = {i: (red.view_of(ops_list[i].weight) if sink is not None else torch.empty_like(ops_list[i].weight))
                           for i in sn_wait}
@@ -804,6 +841,7 @@ class ChainFn(torch.autograd.Function):
                 st['bn_fuse'] = (pst['x'], pst['mean'], pst['invstd'], prev.m.weight, prev.m.bias, prev.act, prev.slope)
             if isinstance(op, Conv):
                 st['wg_defer'] = wg_wait
+                st['cs_defer'] = cs_wait
             g, pg = op.backward(g, st, need_dx, op_need_w[i], fuse, sink)
             if 'bn_partials' in st:
                 stash[i - 1]['dz_partials'] = st.pop('bn_partials')

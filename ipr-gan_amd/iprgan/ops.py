@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib as L
-from ._lib import ConvDesc, call, ptr, query, stream
+from ._lib import ConvDesc, call, ptr, ptr32, query, stream
 
 
 def c4(c):
@@ -339,6 +339,21 @@ def colsum_partials(part, rows, Cs, channels, out=None, beta=0.0):
     return res
 
 
+def colsum_partials_flush(pending):
+    """The bias gradients that ``pending`` = [(partials, rows, Cs, channels, out, beta)] owe, in one launch (bit-identical to
+    one colsum_partials call each); the partials are kept alive by the list until the launch is enqueued."""
+    n = len(pending)
+    if not n:
+        return
+    if n == 1:
+        colsum_partials(*pending[0][:4], out=pending[0][4], beta=pending[0][5])
+    else:
+        call('iprgan_colsum_partials_multi', L.ptr_table([p_[0] for p_ in pending]), _int_table([int(p_[1]) for p_ in pending]),
+             _int_table([int(p_[2]) for p_ in pending]), _int_table([int(p_[3]) for p_ in pending]),
+             L.ptr_table([p_[4] for p_ in pending]), (C.c_float * n)(*[float(p_[5]) for p_ in pending]), n, stream())
+    del pending[:]
+
+
 def colsum(x2d_like, channels, out=None, beta=0.0):
     """Column sums of an activation tensor [..., C4] over all leading dims -> [channels] (bias gradient)."""
     if is16(x2d_like) == ST_X3 and pstride(x2d_like) != x2d_like.numel():     # a batch slice of a three-plane tensor
@@ -352,7 +367,7 @@ def colsum(x2d_like, channels, out=None, beta=0.0):
 
 
 _DEFER_WGRAD = os.environ.get('IPRGAN_DEFER_WGRAD_REDUCE', '1') != '0'     # A/B switch: one slab reduce launch per backward pass
-_WGRAD_PENDING_BYTES = int(os.environ.get('IPRGAN_WGRAD_PENDING_MB', '1024')) << 20
+_WGRAD_PENDING_BYTES = int(os.environ.get('IPRGAN_WGRAD_PENDING_MB', '6144')) << 20
 
 
 def wgrad_reduce_flush(pending):
@@ -397,8 +412,9 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
              float(beta), stream(), C.byref(rec))
         if rec.pending:
             # one destination per multi-launch (two records adding into the same dw view would race), and a bound on the slab
-            # workspaces a pass keeps alive until its flush (IPRGAN_WGRAD_PENDING_MB, default 1024: a DCGAN-64 pass holds
-            # ~0.6 GB, CycleGAN's generator pass reaches the bound every ~25 layers); ADVICE r05
+            # workspaces a pass keeps alive until its flush (IPRGAN_WGRAD_PENDING_MB, default 6144 of the 288 GB: a workspace is
+            # sized for the layer's LARGEST candidate - 0.1-0.3 GB per DCGAN layer, a discriminator pass of DCGAN-64 holds
+            # ~2.5 GB; 1024 cut that pass into six flushes instead of its two bucket boundaries); ADVICE r05
             if any(p_[2].data_ptr() == dw.data_ptr() for p_ in defer) or \
                     sum(p_[1].numel() for p_ in defer) * 4 + ws.numel() * 4 > _WGRAD_PENDING_BYTES:
                 wgrad_reduce_flush(defer)
@@ -406,6 +422,42 @@ def conv_bwd_weight(spec, d, x, dy, w_shape, want_bias, dw=None, db=None, beta=0
         return dw, (db if want_bias else None)
     call('iprgan_conv_bwd_weight', C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db) if want_bias else None, ptr(ws),
          float(beta), stream())
+    return dw, (db if want_bias else None)
+
+
+# ---- Linear feeding an NHWC map (csrc/fc.hip) ------------------------------------------------------------
+_FC_DIRECT = os.environ.get('IPRGAN_FC_DIRECT', '1') != '0'      # A/B switch: 0 = the layer as a 1x1 convolution (rounds 1-5)
+
+
+def fc_nhwc_ok(B, K, C, HW):
+    return _FC_DIRECT and bool(query('iprgan_fc_nhwc_ok', int(B), int(K), int(C), int(HW)))
+
+
+def fc_nhwc_fwd(x, w, bias, C, HW, act, slope=0.0):
+    """y[b, hw*C + c] = act(x @ w[c*HW + hw] + bias[c*HW + hw]): [B, HW*C] in the storage kind of a C-channel activation."""
+    B, K = x.shape
+    k = act_kind(C)
+    if k == ST_X3 and B * C * HW * 6 >= 0x7fffffff:
+        k = ST_F32
+    y = empty_kind((B, C * HW), x, k)
+    L.acct_flops(2.0 * B * K * C * HW)
+    call('iprgan_fc_nhwc_fwd', ptr32(x), ptr32(w), ptr32(bias), ptr(y), B, K, C, HW, act, float(slope), k, pstride(y), stream())
+    return y
+
+
+def fc_nhwc_bwd(x, y, dy, w_shape, C, HW, act, slope=0.0, dw=None, db=None, beta=0.0, want_bias=True):
+    """(dw, db) of fc_nhwc_fwd in PyTorch layout; dw / db given (gradient-bucket views): accumulated in place with ``beta``."""
+    B, K = x.shape
+    k = is16(y)
+    if is16(dy) != k:
+        dy = to_kind(f32(dy), k)
+    if dw is None:
+        dw = empty(tuple(w_shape), x)
+    if db is None and want_bias:
+        db = empty((C * HW,), x)
+    L.acct_flops(2.0 * B * K * C * HW)
+    call('iprgan_fc_nhwc_bwd', ptr32(x), ptr(y), ptr(dy), ptr32(dw), ptr32(db) if want_bias else None, B, K, C, HW, act,
+         float(slope), k, pstride(y), pstride(dy), float(beta), stream())
     return dw, (db if want_bias else None)
 
 

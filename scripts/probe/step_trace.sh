@@ -4,9 +4,9 @@
 W=${1:-dcgan64}; M=${2:-fp32x3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O/prof
 export IPRGAN_TUNE_CACHE=$O/tune_cache_trace_$W.txt
-cd $R && timeout 600 python bench.py --workload $W --math $M --alt-math none --no-cpu-baseline --north-star off --steps 6 --warmup 6 > /dev/null 2>&1
+cd $R && timeout 600 python bench.py --workload $W --math $M --alt-math none --no-cpu-baseline --north-star off --steps ${STEPS:-6} --warmup ${WARM:-6} > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace -d $O/prof -o trace_$W --output-format csv -- python3 $R/bench.py --workload $W --math $M --alt-math none --no-cpu-baseline --north-star off --graph off --steps 6 --warmup 6 > /dev/null 2> $O/trace_$W.err
+timeout 600 rocprofv3 --kernel-trace -d $O/prof -o trace_$W --output-format csv -- python3 $R/bench.py --workload $W --math $M --alt-math none --no-cpu-baseline --north-star off --graph off --steps ${STEPS:-6} --warmup ${WARM:-6} > /dev/null 2> $O/trace_$W.err
 cd $R
 python3 - "$O/prof" "trace_$W" "$O/step_trace_$W.txt" <<'PY'
 import csv, glob, sys, re
@@ -15,9 +15,10 @@ f = sorted(glob.glob(f'{d}/**/{tag}_kernel_trace.csv', recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-# one step = between two consecutive adam_prep launches of the same optimizer: take the LAST full period of 2 adam_kernel launches
-idx = [i for i, n in enumerate(names) if 'adam_kernel' in n]
-a, b = idx[-5] + 1, idx[-3] + 1          # two Adam steps = one G+D step, taken from the timed region's tail
+# one step = between two consecutive sign_loss_fwd launches (exactly one per step in every workload: the white-box term of
+# update_g), taken from the tail of the run
+idx = [i for i, n in enumerate(names) if 'sign_loss_fwd' in n]
+a, b = idx[-3], idx[-2]
 with open(out, 'w') as o:
     tot = 0
     for r in rows[a:b]:

@@ -1308,3 +1308,58 @@ def test_reflect_pad_dgrad_without_the_padded_grid(dev, cfg):
     close(from_nhwc(ops.f32(dx).cpu(), cin), want, what='reflect dgrad, direct form')
     dx0 = ops.conv_bwd_data(spec, d, to_nhwc(g).to(dev), wb)
     close(from_nhwc(ops.f32(dx0).cpu(), cin), xr.grad, what='reflect dgrad, direct form, plain')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'fp32x3', 'bf16act'])
+@pytest.mark.parametrize('B,K,C,HW,act', [(128, 128, 512, 64, 1), (5, 32, 64, 3, 0), (130, 96, 128, 4, 2), (32, 64, 64, 1, 1)])
+def test_fc_nhwc_direct_kernels(B, K, C, HW, act, mode, dev):
+    """csrc/fc.hip: Linear(K -> C*HW) + activation feeding an NHWC map, forward and backward-weight in one launch each, on
+    the parameters in PyTorch layout (networks/conv_generator.py:26-30: `self.fc(z).view(-1, C, mg, mg)`), against
+    torch.nn.functional.linear on the CPU.  Every storage kind of the output (fp32 / bf16 / three planes), ragged batches
+    (5 rows; 130 = two chunks), accumulation into an existing gradient (beta = 1).  Exact fp32 MFMA: 2e-4 of the tensor's
+    scale as for the convolutions; a bf16 OUTPUT carries its own rounding (2^-8)."""
+    from iprgan import _lib, ops
+    _lib.set_math(mode)
+    try:
+        assert ops.fc_nhwc_ok(B, K, C, HW)
+        N = C * HW
+        x, w, b = rnd(B, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+        slope = 0.2
+        z = F.linear(x, w, b)                                    # [B, N], PyTorch column order c*HW + hw
+        yr = {0: z, 1: torch.relu(z), 2: F.leaky_relu(z, slope)}[act]
+        nhwc = lambda t: t.view(B, C, HW).permute(0, 2, 1).reshape(B, N)          # noqa: E731  -> column order hw*C + c
+        y = ops.fc_nhwc_fwd(x.to(dev), w.to(dev), b.to(dev), C, HW, act, slope)
+        kind = ops.is16(y)
+        assert kind == {'fp32': 0, 'fp32x3': 2, 'bf16act': 1}[mode] and tuple(y.shape) == (B, N)
+        tol = 2e-4 if kind != 1 else 6e-3
+        close(ops.f32(y), nhwc(yr), tol, 'fc forward')
+        # backward: dy in the output's kind; the activation derivative is taken from the STORED y, as the engine does
+        dy = rnd(B, N, seed=4)
+        dyd = ops.to_kind(nhwc(dy).contiguous().to(dev), kind)
+        ys = ops.f32(y).cpu().view(B, HW, C).permute(0, 2, 1).reshape(B, N)       # stored y back in PyTorch column order
+        dyq = ops.f32(dyd).cpu().view(B, HW, C).permute(0, 2, 1).reshape(B, N)
+        dz = dyq * {0: torch.ones_like(ys), 1: (ys > 0).float(), 2: torch.where(ys > 0, 1.0, slope)}[act]
+        dw_ref, db_ref = dz.t() @ x, dz.sum(0)
+        dw, db = ops.fc_nhwc_bwd(x.to(dev), y, dyd, (N, K), C, HW, act, slope)
+        close(dw, dw_ref, 2e-4, 'fc dW')
+        close(db, db_ref, 2e-4, 'fc db')
+        # accumulate into existing gradients (the bucket views of the executor's gradient sink)
+        g0, b0 = rnd(N, K, seed=5), rnd(N, seed=6)
+        dw2, db2 = g0.clone().to(dev), b0.clone().to(dev)
+        ops.fc_nhwc_bwd(x.to(dev), y, dyd, (N, K), C, HW, act, slope, dw=dw2, db=db2, beta=1.0)
+        close(dw2, g0 + dw_ref, 2e-4, 'fc dW accumulate')
+        close(db2, b0 + db_ref, 2e-4, 'fc db accumulate')
+        # bit-for-bit repeatable
+        dw3, db3 = ops.fc_nhwc_bwd(x.to(dev), y, dyd, (N, K), C, HW, act, slope)
+        assert torch.equal(dw3, dw) and torch.equal(db3, db)
+        assert torch.equal(ops.f32(ops.fc_nhwc_fwd(x.to(dev), w.to(dev), b.to(dev), C, HW, act, slope)), ops.f32(y))
+    finally:
+        _lib.set_math('fp32')
+
+
+def test_fc_nhwc_refuses_unsupported_shapes(dev):
+    from iprgan import _lib, ops
+    assert not ops.fc_nhwc_ok(8, 2048, 128, 1)          # the VAE encoder heads: K too deep for the direct kernel's LDS tile
+    assert not ops.fc_nhwc_ok(8, 128, 96, 4)            # C not a multiple of 64
+    with pytest.raises(RuntimeError, match='unsupported shape'):
+        _lib.call('iprgan_fc_nhwc_fwd', None, None, None, None, 8, 2048, 128, 1, 0, 0.0, 0, 0, None)
