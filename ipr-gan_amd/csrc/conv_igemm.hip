@@ -2607,8 +2607,12 @@ int launch_wgrad_halo_f32(const iprgan_conv_desc* d, const float* x, const float
                           hipStream_t st, int* nsplit_out, int* Nrows_out, int* Kw_out);
 #define WGRAD_NH32 3                        // candidates WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB + {0, 1, 2}: fp32 halo form
 static const int g_h32_targets[WGRAD_NH32] = {256, 512, 1024};
-#define WGRAD_NX3H 3                        // the next three candidates: halo form for three-plane tensors (wgrad_x3.hip)
-static const int g_x3h_targets[WGRAD_NX3H] = {256, 512, 1024};
+// the next candidates: halo form for three-plane tensors (wgrad_x3.hip) at a target block count.  64 / 128 blocks (round 6,
+// appended: the indices of the first three are unchanged) are for layers whose whole weight is ONE tile - SRResNet's 33
+// 64 -> 64 k3 layers at 24x24: 256 blocks of 2.25 patches each wrote 256 slabs of 147 KB for a 147 KB gradient, 38 MB per layer
+// to write and to read back (the slab reduces were 1.2 ms of the 26 ms SRGAN step)
+#define WGRAD_NX3H 5
+static const int g_x3h_targets[WGRAD_NX3H] = {256, 512, 1024, 128, 64};
 #define WGRAD_X3H0 (WGRAD_NCAND + WGRAD_NHALO + WGRAD_NRGB + WGRAD_NH32)
 #define WGRAD_NALL (WGRAD_X3H0 + WGRAD_NX3H)
 #define WGRAD_NRGB 2                        // candidates WGRAD_NCAND + WGRAD_NHALO + {0, 1}: 256 / 512 blocks

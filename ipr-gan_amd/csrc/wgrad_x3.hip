@@ -330,6 +330,8 @@ int launch_wgrad_x3h(const iprgan_conv_desc* d, const void* x, const void* dy, f
   a.flops = 2.0 * a.B * (double)a.PH * a.PW * d->Cout * d->Cin * d->KH * d->KW;
   *nsplit_out = nsplit; *Nrows_out = a.Nrows; *Kw_out = a.Kw;
   dim3 grid(a.Ls / (32 * x3h_cb(d)), a.Ss / 64, nsplit);
+  // (measured in round 6 and not kept: 16 waves = 8 tap groups of 2 taps, 106 registers, four waves per SIMD: -8 ... +5 % per
+  // layer against run-to-run differences of the same size)
   if (d->KH == 4) return launch_wx3<4, 4, 2, 4, 4, 1, 3>(a, grid, st);       // 8 waves: 4 tap groups x 2 halves of S; 3 stages of 48 KB
   return launch_wx3<3, 3, 1, 8, 3, 2, 2>(a, grid, st);                       // 12 waves: 3 tap groups x 2 x 2; 2 stages of 72 KB
 }

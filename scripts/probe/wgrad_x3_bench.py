@@ -39,7 +39,7 @@ for name, cin, cout, k, s, p, tr, H, B in LAYERS:
     wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
     flops = 2.0 * B * (H * H if tr else OH * OW) * cin * cout * k * k
     row = dict(layer=name)
-    for cand in (-1, 0, 3, 74, 75, 76):
+    for cand in [int(c) for c in os.environ.get("WX3_CANDS", "-1,0,3,74,75,76").split(",")]:
         _lib.call('iprgan_debug_force_tiles', -1, cand)
         t = timeit(lambda: ops.conv_bwd_weight(spec, d, x, dy, wshape, False))
         row['c%d' % cand] = round(flops / t / 1e9, 1)

@@ -167,7 +167,7 @@ X3H_SHAPES = [  # B, cin, cout, k, stride, pad, H, W, transposed, reflect
 ]
 
 
-@pytest.mark.parametrize('cand', [-1, 0, 74, 75, 76])
+@pytest.mark.parametrize('cand', [-1, 0, 74, 75, 76, 77, 78])
 @pytest.mark.parametrize('shape', X3H_SHAPES, ids=lambda c: '-'.join(map(str, c)))
 def test_wgrad_halo_for_three_plane_tensors(shape, cand, dev):
     """Backward-weight of three-plane tensors: the halo form (csrc/wgrad_x3.hip, candidates 74-76; k3 s1 and k4 s2, Conv2d
