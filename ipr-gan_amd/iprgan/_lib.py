@@ -163,7 +163,7 @@ def load():
 
 
 def call(name, *args):
-    lib = load()
+    lib = _lib or load()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed ({rc}): {lib.iprgan_last_error().decode()}')

@@ -95,22 +95,26 @@ class Conv(Op):
         self.spec, self.m, self.is_sn = spec, module, sn
         self.out_act = (spec.act, spec.slope)
 
-    # tensors are fetched from the module at call time: .to()/load_state_dict may replace buffers
+    # tensors are fetched from the module at call time: .to()/load_state_dict may replace buffers.  Straight from the module's
+    # parameter / buffer dicts: nn.Module.__getattr__ (the slow path every `m.weight` takes) was ~550 calls = 0.4 ms of host
+    # time per eager DCGAN step
     @property
     def weight(self):
-        return self.m.weight_orig if self.is_sn else self.m.weight
+        return self.m._parameters['weight_orig' if self.is_sn else 'weight']
 
     @property
     def bias(self):
-        return self.m.bias
+        return self.m._parameters.get('bias')
 
     @property
     def sn(self):
-        return (self.m.weight_u, self.m.weight_v) if self.is_sn else None
+        b = self.m._buffers
+        return (b['weight_u'], b['weight_v']) if self.is_sn else None
 
     @property
     def params(self):
-        return (self.weight,) + ((self.bias,) if self.bias is not None else ())
+        w, b = self.weight, self.bias
+        return (w,) if b is None else (w, b)
 
     # prepared operands ('wf' forward, 'wb' backward-data) of layers WITHOUT spectral norm, keyed on the weight's
     # version counter and storage (optimizer steps, load_state_dict and .to() all change the key)
@@ -265,15 +269,16 @@ class LinearNHWC(Op):
 
     @property
     def weight(self):
-        return self.m.weight
+        return self.m._parameters['weight']
 
     @property
     def bias(self):
-        return self.m.bias
+        return self.m._parameters['bias']
 
     @property
     def params(self):
-        return (self.m.weight, self.m.bias)
+        p = self.m._parameters
+        return (p['weight'], p['bias'])
 
     def forward(self, x, st, train):
         B, K = x.shape
@@ -356,7 +361,8 @@ class BatchNorm(Op):
 
     @property
     def params(self):
-        return (self.m.weight, self.m.bias) + ((self.prelu.weight,) if self.prelu is not None else ())
+        p = self.m._parameters
+        return (p['weight'], p['bias']) + ((self.prelu._parameters['weight'],) if self.prelu is not None else ())
 
     def forward(self, x, st, train):
         m = self.m
@@ -417,27 +423,29 @@ class GemvHead(Op):
 
     @property
     def weight(self):
-        return self.m.weight_orig
+        return self.m._parameters['weight_orig']
 
     @property
     def bias(self):
-        return self.m.bias
+        return self.m._parameters['bias']
 
     @property
     def sn(self):
-        return (self.m.weight_u, self.m.weight_v)
+        b = self.m._buffers
+        return (b['weight_u'], b['weight_v'])
 
     @property
     def u(self):
-        return self.m.weight_u
+        return self.m._buffers['weight_u']
 
     @property
     def v(self):
-        return self.m.weight_v
+        return self.m._buffers['weight_v']
 
     @property
     def params(self):
-        return (self.m.weight_orig, self.m.bias)
+        p = self.m._parameters
+        return (p['weight_orig'], p['bias'])
 
     def forward(self, x, st, train):
         B = x.shape[0]
@@ -720,6 +728,7 @@ class ChainFn(torch.autograd.Function):
             h = op.forward(h, st, train)
             shared.pop('conv_stats', None) if not isinstance(op, Conv) else None
         ctx.chain, ctx.stash, ctx.red = chain, stash, red
+        ctx.plist = params                  # (the parameter objects of this pass, in op order: backward walks them again)
         # the backward pass reads the live parameters (weights for the data gradients, spectral-norm factors):
         # remember their versions so that a step taken between this forward and its backward is an error, as it
         # is in PyTorch for tensors saved by autograd
@@ -735,7 +744,8 @@ class ChainFn(torch.autograd.Function):
         need_x = ctx.needs_input_grad[2]
         need_p = ctx.needs_input_grad[3:]
         ops_list = chain.ops
-        for p, v in zip(chain.params, ctx.versions):
+        plist = ctx.plist
+        for p, v in zip(plist, ctx.versions):
             if p._version != v:
                 raise RuntimeError('a parameter of this network was modified in place (optimizer step?) between the '
                                    'forward pass and its backward pass: the gradients would be computed with the '
@@ -757,11 +767,11 @@ class ChainFn(torch.autograd.Function):
         # gradients are returned to autograd
         wants = any(op_need_w)
         sink = red if (wants and red is not None and red.armed
-                       and all(red.owns(p) for p, n in zip(chain.params, need_p) if n)) else None
+                       and all(red.owns(p) for p, n in zip(plist, need_p) if n)) else None
         counted = wants and red is not None
         final = red.begin_pass() if counted else False
         if sink is not None and final:          # parameters of the optimizer's OTHER networks are final already
-            mine = set(chain.params)
+            mine = set(plist)
             red.params_done([p for p in red.params if p not in mine])
         grads_per_op = [None] * len(ops_list)
         small_dst, small_src, sn_wait = [], [], []

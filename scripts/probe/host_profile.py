@@ -35,5 +35,28 @@ for i in range(N):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(40)
-st.sort_stats('cumulative').print_stats(45)
+st.sort_stats('tottime').print_stats(30)
+st.sort_stats('cumulative').print_stats(30)
+# the backward passes run on the autograd engine's own (C++-created) thread, which the profiler above does not see: profile the
+# bodies of the executor's backward functions from inside that thread
+from iprgan import engine, tools  # noqa: E402
+prb = cProfile.Profile()
+orig = engine.ChainFn.backward
+
+
+def wrapped(ctx, dy):
+    prb.enable()
+    try:
+        return orig(ctx, dy)
+    finally:
+        prb.disable()
+
+
+engine.ChainFn.backward = staticmethod(wrapped)
+for i in range(N):
+    step(i)
+torch.cuda.synchronize()
+print('==== inside ChainFn.backward (autograd thread), %d steps' % N)
+sb = pstats.Stats(prb)
+sb.sort_stats('tottime').print_stats(35)
+sb.sort_stats('cumulative').print_stats(30)
