@@ -78,7 +78,11 @@ enum { IPRGAN_ST_F32 = 0, IPRGAN_ST_BF16 = 1, IPRGAN_ST_X3 = 2,
        /* the `act_bf16` argument of the norm entry points (iprgan_bn_*, iprgan_instnorm_*, iprgan_bn_prelu_*) only: the layer's
         * INPUT x is fp32 while y, dy, dx and the residual are three-plane tensors - the convolution in front of a norm layer
         * then writes 4 instead of 6 bytes per element (y_bf16 = IPRGAN_ST_F32 in its descriptor) and x is read three times */
-       IPRGAN_ST_X3_XF32 = 3 };
+       IPRGAN_ST_X3_XF32 = 3,
+       /* the BACKWARD norm entry points (iprgan_bn_bwd, iprgan_bn_prelu_bwd, iprgan_instnorm_bwd) only: x AND dy are fp32, dx (and y) are
+        * three-plane tensors - the backward-data pass that produced dy wrote 4 instead of 6 bytes per element as well
+        * (x_bf16 = IPRGAN_ST_F32 in its descriptor), and dy is read twice (reduction, apply) */
+       IPRGAN_ST_X3_XDF32 = 4 };
 /* bf16 activations ("bf16 in HBM", BASELINE config 5): only with IPRGAN_MATH_BF16 and only for tensors whose padded
  * channel count is a multiple of 64; such a tensor is bf16 for EVERY entry point that touches it (element offsets and
  * shapes are unchanged, the `float*` in the signatures is then a bf16 buffer).  Prepared weights follow the operand

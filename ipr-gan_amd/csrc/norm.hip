@@ -53,8 +53,13 @@ __device__ __forceinline__ void stv(float* base, size_t e, const f32x4& v, size_
 // Storage kind 3 (norm entry points only, IPRGAN_ST_X3_XF32): the layer's INPUT x is fp32 - the convolution in front of a norm
 // layer writes 4 instead of 6 bytes per element, and x is read three times (apply, backward reduction, backward apply) -
 // while y, dy, dx and the residual are three-plane tensors.  SX / SY: the kind of x / of every other tensor.
-#define SX (ST == 3 ? 0 : ST)
-#define SY (ST == 3 ? 2 : ST)
+// Storage kind 4 (backward entry points only, IPRGAN_ST_X3_XDF32, round 6): x AND dy are fp32 - the backward-data pass that
+// feeds a norm backward writes 4 instead of 6 bytes per element too, and dy is read twice (reduction, apply) - while dx (and
+// y) are three-plane tensors.  SG: the kind of dy.
+#define SX ((ST == 3 || ST == 4) ? 0 : ST)
+#define SY ((ST == 3 || ST == 4) ? 2 : ST)
+#define SG (ST == 4 ? 0 : SY)
+#define ST_PICK_BWD(kind, K, ...) ((kind) == 4 ? K<__VA_ARGS__, 4> : ST_PICK(kind, K, __VA_ARGS__))
 // launch-time choice of a kernel instantiation by storage kind
 #define ST_PICK(kind, K, ...) ((kind) == 3 ? K<__VA_ARGS__, 3> : (kind) == 2 ? K<__VA_ARGS__, 2> : (kind) == 1 ? K<__VA_ARGS__, 1> : K<__VA_ARGS__, 0>)
 
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
       for (int u = 0; u < 4; ++u) {
         const size_t off = gofs + (size_t)(r + u * TR) * C + cq * 4;
         xv[u] = ldv<SX>(x, off, ps);
-        if (MODE == 2) gv[u] = ldv<SY>(dy, off, ps);
+        if (MODE == 2) gv[u] = ldv<SG>(dy, off, ps);
         if (need_y) yv[u] = ldv<SY>(y, off, ps);
       }
 #pragma unroll
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     for (; r < r1; r += TR) {
       const size_t off = gofs + (size_t)r * C + cq * 4;
       const f32x4 xv = ldv<SX>(x, off, ps);
-      const f32x4 gv = MODE == 2 ? ldv<SY>(dy, off, ps) : xv;
+      const f32x4 gv = MODE == 2 ? ldv<SG>(dy, off, ps) : xv;
       const f32x4 yv = need_y ? ldv<SY>(y, off, ps) : xv;
       accumulate(xv, gv, yv);
     }
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   auto body = [&](size_t idx, const f32x4& g, const f32x4& b, const f32x4& m, const f32x4& is, const f32x4& s1,
                   const f32x4& s2) {
-    const f32x4 xv = ldv<SX>(x, idx * 4, ps), gv = ldv<SY>(dy, idx * 4, ps);
+    const f32x4 xv = ldv<SX>(x, idx * 4, ps), gv = ldv<SG>(dy, idx * 4, ps);
     f32x4 yv = {0.f, 0.f, 0.f, 0.f};
     if (!from_x && !no_act) yv = ldv<SY>(y, idx * 4, ps);
     f32x4 o;
@@ -589,7 +594,7 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64), 1), dim3(64 * FL), 0, st, pp, rows, C, sums, dgamma, dbeta);
     IPR_LAUNCH_CHECK();
   } else {
-    auto kr2 = ST_PICK(b16, colreduce_kernel, 2);
+    auto kr2 = ST_PICK_BWD(b16, colreduce_kernel, 2);
     hipLaunchKernelGGL(kr2, dim3(g.NB, g.gy, G), dim3(256), 0, st,
                        x, y, dy, save_mean, save_invstd, ws, M, C, g.TC, g.rows_per_block, act, slope, gamma, beta, slope_ptr, ps);
     IPR_LAUNCH_CHECK();
@@ -617,7 +622,7 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
     if (blocks > cap) blocks = cap;
     colpart = sums + (size_t)G * 2 * C;
   }
-  auto kern = fixed ? ST_PICK(b16, bn_bwd_apply_kernel, true) : ST_PICK(b16, bn_bwd_apply_kernel, false);
+  auto kern = fixed ? ST_PICK_BWD(b16, bn_bwd_apply_kernel, true) : ST_PICK_BWD(b16, bn_bwd_apply_kernel, false);
   hipLaunchKernelGGL(kern, dim3(blocks, gy), dim3(256), 0, st, x, y, dy, dx, gamma, beta, save_mean, save_invstd, sums,
                      (unsigned)(fixed ? n4g : n4), C / 4, C,
                      make_fastdiv(C / 4), make_fastdiv((uint32_t)n4g), 1.0f / (float)M, act, slope,
@@ -636,7 +641,7 @@ static int norm_bwd(const float* x, const float* y, const float* dy, const float
                          dbias_prev, dbias_beta);
       IPR_LAUNCH_CHECK();
     } else {                 // channel counts that do not divide the block: the separate column-sum pass
-      const int rc = colsum_launch(dx, dbias_prev, ws, G * M, C, dbias_n, st, dbias_beta, b16 == 3 ? 2 : b16, ps);
+      const int rc = colsum_launch(dx, dbias_prev, ws, G * M, C, dbias_n, st, dbias_beta, (b16 == 3 || b16 == 4) ? 2 : b16, ps);
       if (rc) return rc;
     }
   }

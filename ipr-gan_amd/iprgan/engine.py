@@ -239,13 +239,18 @@ class Conv(Op):
             if st.get('open_skip'):         # this conv opens a residual branch: the skip gradient is added in its epilogue
                 res = st['ctx']['skip_grads'][-1]
                 st['ctx']['skip_grad_fused'] = True
+            dd = d
+            if st.get('dx_f32') and res is None and pair is None and prev_act is None and d.x_bf16 == ops.ST_X3:
+                # the layer below is a norm layer: its backward reads this gradient twice - it leaves as fp32 (4 instead of 6
+                # bytes per element) and the norm backward emits the three-plane dx (ops._norm_bwd_kinds: ST_X3_XDF32)
+                dd = ops._desc_with(d, x_bf16=ops.ST_F32)
             bnf = st.pop('bn_fuse', None)
             if bnf is not None and res is None and pair is None and prev_act is None:
                 # the layer below is a BatchNorm (+ReLU / LeakyReLU): its activation derivative and both reductions of its
                 # backward are taken in this epilogue (include/iprgan.h: iprgan_conv_bwd_data_bn)
                 dx, st['bn_partials'] = ops.conv_bwd_data_bn(sp, d, dy, wb, *bnf)
                 return dx, grads
-            dx = ops.conv_bwd_data(sp, d, dy, wb, pa[0], pa[1], pa[2], pair=pair, colsums=want_cs, residual=res)
+            dx = ops.conv_bwd_data(sp, dd, dy, wb, pa[0], pa[1], pa[2], pair=pair, colsums=want_cs, residual=res)
             if want_cs:
                 dx, st['dx_colsums'] = dx
         return dx, grads
@@ -849,6 +854,10 @@ class ChainFn(torch.autograd.Function):
                     and i - 1 >= first_needed):
                 pst = stash[i - 1]
                 st['bn_fuse'] = (pst['x'], pst['mean'], pst['invstd'], prev.m.weight, prev.m.bias, prev.act, prev.slope)
+            if (isinstance(op, Conv) and need_dx and isinstance(prev, (BatchNorm, InstanceNorm)) and ops._NORM_DYF32
+                    and ops._NORM_XF32 and i - 1 >= first_needed and 'x' in stash[i - 1]
+                    and ops.is16(stash[i - 1]['x']) == ops.ST_F32 and ops._norm_splits_here(stash[i - 1]['x'])):
+                st['dx_f32'] = True         # (the norm layer's saved input is fp32: the norm backward takes an fp32 dy beside it)
             if isinstance(op, Conv):
                 st['wg_defer'] = wg_wait
                 st['cs_defer'] = cs_wait

@@ -500,6 +500,7 @@ def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_
 # ---- batch norm -----------------------------------------------------------------------------------
 ST_X3_XF32 = 3          # norm entry points only (include/iprgan.h): x fp32; y, dy, dx, residual three planes
 _NORM_XF32 = os.environ.get('IPRGAN_NORM_XF32', '1') != '0'
+_NORM_DYF32 = os.environ.get('IPRGAN_NORM_DYF32', '1') != '0'     # A/B switch: fp32 gradients on the conv -> norm edges of the backward pass
 
 
 def _whole3(t):
@@ -511,13 +512,21 @@ def _whole3(t):
     return t
 
 
+ST_X3_XDF32 = 4         # backward norm entry points only: x and dy fp32, dx (and y) three planes
+
+
+def _norm_splits_here(x):
+    """True when this fp32 norm input belongs to a layer whose output is three planes (the norm layer is where the tensor is
+    split): 'fp32x3' mode, an NHWC tensor whose channel count allows planes, under the 2 GiB size rule of ConvSpec.desc."""
+    return (_NORM_XF32 and L.act_x3() and x.dim() == 4 and x.shape[-1] % 32 == 0 and x.numel() * 6 < 0x7fffffff)
+
+
 def _norm_fwd_kinds(x):
     """(storage-kind argument of the norm entry point, kind of its output y).  In 'fp32x3' mode an fp32 input whose channel
     count allows three planes gets a three-plane output: the convolution in front of a norm layer writes fp32 (4 instead
     of 6 bytes per element; engine.Conv: y_f32) and the norm layer is where the tensor is split."""
     k = is16(x)
-    if k == ST_F32 and _NORM_XF32 and L.act_x3() and x.dim() == 4 and x.shape[-1] % 32 == 0 \
-            and x.numel() * 6 < 0x7fffffff:         # (the size rule of ConvSpec.desc: past 357 M elements a tensor stays fp32)
+    if k == ST_F32 and _norm_splits_here(x):
         return ST_X3_XF32, ST_X3
     return k, k
 
@@ -533,6 +542,12 @@ def _norm_bwd_kinds(x, dy, y=None):
         if y is not None and is16(y) != ST_X3:
             y = to_kind(y, ST_X3)
         return ST_X3_XF32, dy, y
+    if k == ST_F32 and is16(dy) == ST_F32 and _NORM_DYF32 and _norm_splits_here(x) and dy.shape == x.shape:
+        # the backward-data pass above wrote an fp32 gradient (engine.Conv.backward: dx_f32): read it as it is, emit dx as
+        # three planes for the convolution below
+        if y is not None and is16(y) != ST_X3:
+            y = to_kind(y, ST_X3)
+        return ST_X3_XDF32, dy, y
     if is16(dy) != k:
         dy = to_kind(dy, k)
     if y is not None and is16(y) != k:
@@ -568,7 +583,7 @@ def bn_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None,
     C_ = x.shape[-1]
     M = x.numel() // C_
     st, dy, y = _norm_bwd_kinds(x, dy, y)
-    dx = _empty_like(dy)
+    dx = empty_kind(dy.shape, dy, ST_X3) if st == ST_X3_XDF32 else _empty_like(dy)
     dgamma, dbeta = empty((C_,), x), empty((C_,), x)
     ws = scratch(query('iprgan_bn_ws_floats', M, C_), x)
     call('iprgan_bn_bwd', ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
@@ -602,7 +617,7 @@ def bn_prelu_bwd(x, dy, gamma, beta, mean, invstd, slope_t, dbias=None, dbias_be
     C_ = x.shape[-1]
     M = x.numel() // C_
     st, dy, _ = _norm_bwd_kinds(x, dy)
-    dx = _empty_like(dy)
+    dx = empty_kind(dy.shape, dy, ST_X3) if st == ST_X3_XDF32 else _empty_like(dy)
     dgamma, dbeta, dslope = empty((C_,), x), empty((C_,), x), empty((1,), x)
     ws = scratch(query('iprgan_bn_ws_floats', M, C_), x)
     call('iprgan_bn_prelu_bwd', ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(slope_t), ptr(dx),
@@ -847,7 +862,7 @@ def instnorm_fwd(x, gamma, beta, eps, act, slope=0.0, conv_stats=None, conv_bias
 def instnorm_bwd(x, y, dy, gamma, mean, invstd, act, slope=0.0, beta=None, dbias=None, dbias_beta=0.0):
     B, H, W, C_ = x.shape
     st, dy, y = _norm_bwd_kinds(x, dy, y)
-    dx = _empty_like(dy)
+    dx = empty_kind(dy.shape, dy, ST_X3) if st == ST_X3_XDF32 else _empty_like(dy)
     dgamma = empty((C_,), x) if gamma is not None else None
     dbeta = empty((C_,), x) if gamma is not None else None
     ws = scratch(query('iprgan_instnorm_ws_floats', B, H * W, C_), x)

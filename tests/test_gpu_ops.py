@@ -1363,3 +1363,38 @@ def test_fc_nhwc_refuses_unsupported_shapes(dev):
     assert not ops.fc_nhwc_ok(8, 128, 96, 4)            # C not a multiple of 64
     with pytest.raises(RuntimeError, match='unsupported shape'):
         _lib.call('iprgan_fc_nhwc_fwd', None, None, None, None, 8, 2048, 128, 1, 0, 0.0, 0, 0, None)
+
+
+@pytest.mark.parametrize('norm', ['batch', 'instance', 'batch_prelu'])
+def test_norm_backward_with_an_fp32_gradient_is_bit_identical_to_the_three_plane_one(norm, dev):
+    """IPRGAN_ST_X3_XDF32 (round 6): on the conv -> norm edges of a backward pass the gradient reaches the norm layer as fp32
+    (the backward-data pass writes 4 instead of 6 bytes per element) and the norm backward emits the three-plane dx.  A
+    three-plane tensor holds its fp32 values exactly, so the result must equal, bit for bit, the one from the same gradient
+    handed over as three planes (IPRGAN_ST_X3_XF32)."""
+    from iprgan import _lib, ops
+    _lib.set_math('fp32x3')
+    try:
+        B, H, W, C = 6, 12, 10, 96
+        x = (rnd(B, H, W, C, seed=1) * 1.7 + 0.2).to(dev)
+        dy = rnd(B, H, W, C, seed=2).to(dev)
+        gamma, beta = (rnd(C, seed=3, scale=0.5) + 1.0).to(dev), rnd(C, seed=4, scale=0.2).to(dev)
+        dyp = ops.to_kind(dy, ops.ST_X3)
+        assert torch.equal(ops.f32(dyp), dy)
+        if norm == 'batch':
+            y, mean, invstd = ops.bn_fwd(x, gamma, beta, None, None, 1e-5, 0.0, True, _lib.ACT_RELU)
+            run = lambda g: ops.bn_bwd(x, y, g, gamma, mean, invstd, _lib.ACT_RELU, beta=beta,            # noqa: E731
+                                       dbias=torch.zeros(C, device=dev))
+        elif norm == 'instance':
+            y, mean, invstd = ops.instnorm_fwd(x, gamma, beta, 1e-5, _lib.ACT_LRELU, 0.2)
+            run = lambda g: ops.instnorm_bwd(x, y, g, gamma, mean, invstd, _lib.ACT_LRELU, 0.2, beta=beta)     # noqa: E731
+        else:
+            alpha = torch.tensor([0.25], device=dev)
+            y, mean, invstd = ops.bn_prelu_fwd(x, gamma, beta, None, None, 1e-5, 0.0, True, alpha)
+            run = lambda g: ops.bn_prelu_bwd(x, g, gamma, beta, mean, invstd, alpha)                       # noqa: E731
+        assert ops.is16(y) == ops.ST_X3
+        a, b = run(dyp), run(dy)
+        assert ops.is16(a[0]) == ops.ST_X3 and ops.is16(b[0]) == ops.ST_X3, 'dx leaves as three planes either way'
+        for ta, tb, name in zip(a, b, ('dx', 'dgamma', 'dbeta', 'dslope')):
+            assert torch.equal(ops.f32(ta), ops.f32(tb)), name
+    finally:
+        _lib.set_math('fp32')
