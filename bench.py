@@ -289,6 +289,31 @@ def step_roofline(recs, peak_mfma, ms_measured):
                           'frac = bound_ms / ms_per_step'}
 
 
+def layer_bytes(tag):
+    """Algorithmic bytes of one launch of a conv-family layer from its profiler tag ("fwd B256 64x64 64->64 k4x4 s2 p1 x2 y2":
+    pass, geometry, storage kinds of the input / output side): each operand and the result once - activations at 4 / 2 / 6 bytes
+    per element of their padded channel count (fp32 / bf16 / three planes), weights fp32 for backward-weight and in the operand's
+    kind otherwise."""
+    import re
+    m = re.match(r'(\w+)\s+B(\d+) (\d+)x(\d+) (\d+)->(\d+) k(\d+)x(\d+) s(\d+) p(\d+)( T)?( reflect)? x(\d) y(\d)', tag)
+    if not m:
+        return 0.0
+    ps, B, H, W, cin, cout, kh, kw, st, pad = m.group(1), *[int(m.group(i)) for i in range(2, 11)]
+    tr, xk, yk = bool(m.group(11)), int(m.group(13)), int(m.group(14))
+    if tr:
+        OH, OW = (H - 1) * st - 2 * pad + kh, (W - 1) * st - 2 * pad + kw
+    else:
+        OH, OW = (H + 2 * pad - kh) // st + 1, (W + 2 * pad - kw) // st + 1
+    esz = {0: 4, 1: 2, 2: 6}
+    c4 = lambda c: (c + 3) & ~3          # noqa: E731
+    xb, yb = B * H * W * c4(cin) * esz[xk], B * OH * OW * c4(cout) * esz[yk]
+    wn = cin * cout * kh * kw
+    if ps == 'wgrad':
+        return float(xb + yb + 4 * wn)
+    wb = wn * esz[xk if ps == 'fwd' else yk]
+    return float(xb + yb + wb)
+
+
 def north_star_conv(device, modes, n=8):
     """BASELINE.json north_star microbench: the 3x3 256->256 stride-1 reflection-padded convolution of Resnet9Blocks on a
     64x3x256x256 batch (networks/resnet_generator.py:44-49: 64x64 maps, batch 64), forward / backward-data /
@@ -538,10 +563,19 @@ def main():
     if os.environ.get('IPRGAN_BENCH_LAYERS') and rank == 0:     # per-layer table of the sampled steps, to stderr
         rows = sorted(_lib.prof_layers(), key=lambda r: -r['ms'])
         tot = sum(r['ms'] for r in rows)
-        log(f'conv-family layers, {prof_steps} sampled step(s), {tot / prof_steps:.3f} ms/step:')
+        peak_l = {'fp32': PEAK_FP32_MFMA, 'fp32x3': PEAK_X3_MFMA}.get(args.math, PEAK_BF16_MFMA)
+        bound_tot = 0.0
+        log(f'conv-family layers, {prof_steps} sampled step(s), {tot / prof_steps:.3f} ms/step; bound = max(FLOPs / {peak_l / 1e12:.1f} TFLOP/s, '
+            f'operand + result bytes / {HBM_ACHIEVABLE / 1e12:.1f} TB/s) per launch:')
         for r in rows:
-            log(f"  {r['name']:58s} n/step={r['launches'] / prof_steps:5.1f} us={r['ms'] / r['launches'] * 1e3:8.1f} "
-                f"ms/step={r['ms'] / prof_steps:7.3f} TF={r['flops'] / r['ms'] / 1e9 if r['ms'] else 0:6.1f}")
+            us = r['ms'] / r['launches'] * 1e3
+            byt = layer_bytes(r['name'])
+            bound = max(r['flops'] / r['launches'] / peak_l, byt / HBM_ACHIEVABLE) * 1e6 if byt else 0.0
+            bound_tot += bound * r['launches'] / prof_steps
+            log(f"  {r['name']:58s} n/step={r['launches'] / prof_steps:5.1f} us={us:8.1f} "
+                f"ms/step={r['ms'] / prof_steps:7.3f} TF={r['flops'] / r['ms'] / 1e9 if r['ms'] else 0:6.1f} "
+                f"bound_us={bound:7.1f} ({'hbm ' if byt / HBM_ACHIEVABLE > r['flops'] / r['launches'] / peak_l else 'mfma'}) x{us / bound if bound else 0:5.2f}")
+        log(f'  sum of the layers\' bounds {bound_tot / 1e3:.3f} ms/step = {bound_tot / 1e3 / (tot / prof_steps):.3f} of their measured time')
     metrics = model.get_metrics()
     assert all(v == v for v in metrics.values()), f'non-finite metrics {metrics}'
     # accounting step: ONE more eager step with the host-side work accounting of _lib on (flops and operand / result bytes of

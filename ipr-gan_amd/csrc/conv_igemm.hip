@@ -57,9 +57,9 @@ static int g_cur_tag = -1;
 static void prof_tag(const char* pass, const iprgan_conv_desc* d) {
   if (!g_prof_on) return;
   char buf[160];
-  snprintf(buf, sizeof(buf), "%-5s B%d %dx%d %d->%d k%dx%d s%d p%d%s%s%s", pass, d->B, d->H, d->W, d->Cin, d->Cout, d->KH,
-           d->KW, d->stride, d->pad, d->transposed ? " T" : "", d->pad_mode ? " reflect" : "",
-           d->x_bf16 || d->y_bf16 ? " b16" : "");
+  // (x<kind> y<kind>: storage kinds of the layer's input / output side - bench.py prices a layer's algorithmic bytes from them)
+  snprintf(buf, sizeof(buf), "%-5s B%d %dx%d %d->%d k%dx%d s%d p%d%s%s x%d y%d", pass, d->B, d->H, d->W, d->Cin, d->Cout, d->KH,
+           d->KW, d->stride, d->pad, d->transposed ? " T" : "", d->pad_mode ? " reflect" : "", d->x_bf16, d->y_bf16);
   auto it = g_tag_index.find(buf);
   if (it == g_tag_index.end()) {
     g_cur_tag = (int)g_tag_names.size();
@@ -605,6 +605,119 @@ __global__ __launch_bounds__(256) void fewin_conv_kernel(const GConvArgs a, int 
     const int oy = y0 + i;
     if (oy >= a.OH) break;
     fewin_store<SIMPLE>(a, acc[i], bias4, rs, neg_act, neg_aux, ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Ns + n, n);
+  }
+}
+
+// Three-plane output form of fewin_conv_kernel (round 6): the stem writes 6 bytes per element and is bound by that write - with
+// a thread owning 4 channels a plane store is 8 bytes per lane, 512 contiguous bytes per wave-instruction, and the kernel moved
+// 3.9 TB/s of output.  Here a thread owns EIGHT consecutive channels of one pixel column (tile = 32 pixels wide x 8 rows, the same
+// 64 accumulator floats): a plane store is 16 bytes per lane and a wave-instruction covers 8 consecutive pixels x 128 bytes = 1 KB
+// of one plane; the fused-derivative operand (h plane) is one 16-byte load.  SIMPLE activations, no residual, Ns % 64 == 0.
+#define FEWIN8_W 32
+#define FEWIN8_H 8
+__global__ __launch_bounds__(256) void fewin_conv8_kernel(const GConvArgs a, int lds_w, int lds_h, float neg_act, float neg_aux) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 flds[];
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const Phase& ph = a.ph[0];
+  const int ntap = ph.ntap, tw = ph.tw, th = ph.th;
+  f32x4* X = flds;                                   // [lds_h][lds_w] input pixels (4 channels each)
+  f32x4* Wl = flds + lds_h * lds_w;                  // [ntap chunk][4 input channels][16 quads]
+  const int tiles_x = (a.OW + FEWIN8_W - 1) / FEWIN8_W, tiles_y = (a.OH + FEWIN8_H - 1) / FEWIN8_H;
+  const int tile = blockIdx.x, b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
+  const int y0 = (tr / tiles_x) * FEWIN8_H, x0 = (tr % tiles_x) * FEWIN8_W;
+  const int n0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, o = tid & 7, pc = tid >> 3;
+  const int dyl = ph.dys < 0 ? (th - 1) * ph.dys : 0, dxl = ph.dxs < 0 ? (tw - 1) * ph.dxs : 0;
+  const int iy_lo = y0 * a.isy + ph.dy0 + dyl, ix_lo = x0 * a.isx + ph.dx0 + dxl;
+  const bool reflect = a.pad_mode == IPRGAN_PAD_REFLECT;
+  for (int i = tid; i < lds_h * lds_w; i += 256) {
+    const int r = i / lds_w, c = i - r * lds_w;
+    int iy = iy_lo + r, ix = ix_lo + c;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    bool ok = true;
+    if (reflect) { iy = reflect_idx(iy, a.IH); ix = reflect_idx(ix, a.IW); ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW; }
+    else ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+    if (ok) v = *(const f32x4*)(a.in + ((size_t)(b * a.IH + iy) * a.IW + ix) * 4);
+    X[i] = v;
+  }
+  f32x4 acc[FEWIN8_H][2];
+#pragma unroll
+  for (int i = 0; i < FEWIN8_H; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int cx = pc * a.isx - dxl;
+  for (int t0 = 0; t0 < ntap; t0 += FEWIN_TAPS) {
+    const int tn = ntap - t0 < FEWIN_TAPS ? ntap - t0 : FEWIN_TAPS;
+    if (t0) __syncthreads();
+    for (int i = tid; i < tn * 64; i += 256) {        // Wl[t][c][quad] = (W[4 quad + k][t][c])_k, as fewin_conv_kernel
+      const int tl = i >> 6, n = i & 63, t = t0 + tl;
+      const int ty = t / tw, tx = t - ty * tw;
+      const f32x4 v = *(const f32x4*)(a.wt + (size_t)(n0 + n) * a.Kp + (size_t)(ph.wbase + ty * ph.wsy + tx * ph.wsx) * 4);
+      float* wf = (float*)Wl;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wf[((tl * 4 + c) * 16 + (n >> 2)) * 4 + (n & 3)] = v[c];
+    }
+    __syncthreads();
+    for (int tl = 0; tl < tn; ++tl) {
+      const int t = t0 + tl;
+      const int ty = t / tw, tx = t - ty * tw;
+      f32x4 w[4][2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { w[c][0] = Wl[(tl * 4 + c) * 16 + 2 * o]; w[c][1] = Wl[(tl * 4 + c) * 16 + 2 * o + 1]; }
+      const f32x4* xp = X + (ty * ph.dys - dyl) * lds_w + cx + tx * ph.dxs;
+      const int xstep = a.isy * lds_w;
+#pragma unroll
+      for (int i = 0; i < FEWIN8_H; ++i) {
+        const f32x4 xin = xp[i * xstep];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          acc[i][h] += w[0][h] * xin.x;
+          acc[i][h] += w[1][h] * xin.y;
+          acc[i][h] += w[2][h] * xin.z;
+          acc[i][h] += w[3][h] * xin.w;
+        }
+      }
+    }
+  }
+  const int n = n0 + 8 * o, ox = x0 + pc;
+  if (ox >= a.OW) return;
+  float rsc0 = 1.f, rsc1 = 1.f;
+  if (a.rs0) { rsc0 = 1.f / *a.rs0; rsc1 = 1.f / *a.rs1; }
+  const float rs = b < (a.B >> 1) ? rsc0 : rsc1;
+  const f32x4 bias0 = fewin_bias4(a, n), bias1 = fewin_bias4(a, n + 4);
+  const size_t ps = a.out_ps / 2;
+#pragma unroll
+  for (int i = 0; i < FEWIN8_H; ++i) {
+    const int oy = y0 + i;
+    if (oy >= a.OH) break;
+    const size_t idx = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Ns + n;
+    f32x4 v0 = acc[i][0], v1 = acc[i][1];
+    if (a.rs0) { v0 *= rs; v1 *= rs; }
+    v0 += bias0; v1 += bias1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v0[k] = v0[k] > 0.f ? v0[k] : (neg_act == 0.f ? 0.f : v0[k] * neg_act);
+      v1[k] = v1[k] > 0.f ? v1[k] : (neg_act == 0.f ? 0.f : v1[k] * neg_act);
+    }
+    if (a.aux) {             // fused derivative of the producer's activation: its sign, from the h plane (aux16 = 1) or fp32
+      f32x4 o0, o1;
+      if (a.aux16) {
+        const u32x4_t r = *(const u32x4_t*)((const __bf16*)a.aux + idx);
+        o0 = f32x4{__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                   __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u)};
+        o1 = f32x4{__builtin_bit_cast(float, r.z << 16), __builtin_bit_cast(float, r.z & 0xffff0000u),
+                   __builtin_bit_cast(float, r.w << 16), __builtin_bit_cast(float, r.w & 0xffff0000u)};
+      } else {
+        o0 = *(const f32x4*)(a.aux + idx); o1 = *(const f32x4*)(a.aux + idx + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v0[k] *= o0[k] > 0.f ? 1.f : neg_aux; v1[k] *= o1[k] > 0.f ? 1.f : neg_aux; }
+    }
+    unsigned p0[3], p1[3], p2[3], p3[3];
+    split3_pair(v0.x, v0.y, p0[0], p0[1], p0[2]);
+    split3_pair(v0.z, v0.w, p1[0], p1[1], p1[2]);
+    split3_pair(v1.x, v1.y, p2[0], p2[1], p2[2]);
+    split3_pair(v1.z, v1.w, p3[0], p3[1], p3[2]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *(u32x4_t*)((__bf16*)a.out + idx + (size_t)p * ps) = u32x4_t{p0[p], p1[p], p2[p], p3[p]};
   }
 }
 
@@ -2305,6 +2418,20 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
         } else {
           prof_launch(fewin_mfma_kernel<false>, grid, dim3(256), smem16, st, 18, a.flops, a, lw, lh, kpad, neg_act, neg_aux, ntiles);
         }
+        IPR_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+    static const int g_fewin8 = getenv("IPRGAN_FEWIN8") ? atoi(getenv("IPRGAN_FEWIN8")) : 1;      // A/B switch
+    if (g_fewin8 && simple && a.out16 == 2 && !a.res && (a.Ns % 64) == 0) {      // three-plane output: 8 channels per thread, 16-byte plane stores
+      const int lw8 = (FEWIN8_W - 1) * a.isx + (p.tw - 1) * (p.dxs < 0 ? -p.dxs : p.dxs) + 1;
+      const int lh8 = (FEWIN8_H - 1) * a.isy + (p.th - 1) * (p.dys < 0 ? -p.dys : p.dys) + 1;
+      const size_t smem8 = ((size_t)lw8 * lh8 + (size_t)(p.ntap < FEWIN_TAPS ? p.ntap : FEWIN_TAPS) * 64) * sizeof(f32x4);
+      if (smem8 <= 64 * 1024) {
+        static bool attr8_set = false;
+        if (!attr8_set) { (void)hipFuncSetAttribute((const void*)fewin_conv8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr8_set = true; }
+        dim3 grid((unsigned)(a.B * cdiv(a.OH, FEWIN8_H) * cdiv(a.OW, FEWIN8_W)), (unsigned)(a.Ns / 64));
+        prof_launch(fewin_conv8_kernel, grid, dim3(256), smem8, st, 18, a.flops, a, lw8, lh8, neg_act, neg_aux);
         IPR_LAUNCH_CHECK();
         return 0;
       }
