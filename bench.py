@@ -519,6 +519,12 @@ def main():
         marks[i + 1].record()
         stamps.append(time.perf_counter())
     host_elapsed = time.perf_counter() - t0          # the host has ENQUEUED all steps (no sync inside the loop)
+    sclk = None
+    if rank == 0:         # the shader clock WHILE the queued steps run (amdsmi through torch; the host has nothing else to do here)
+        try:
+            sclk = int(torch.cuda.clock_rate())
+        except Exception:                             # noqa: BLE001
+            sclk = None
     replays_timed = (graphed.replays - replays_before) if graphed is not None else 0
     fence()
     elapsed = time.perf_counter() - t0
@@ -711,6 +717,10 @@ def main():
                                    ', Adam',
                        'global_batch': B * world, 'parallelism': f'dp{world}'},
             'roofline': roof,
+            # the board's shader clock sampled while the timed steps were running; the MFMA peaks above assume 2400 MHz - the
+            # six-MFMA kernels run the board at its power cap, below that
+            'sclk_mhz_in_timed_region': sclk,
+            'mfma_peak_at_that_clock_tflops': round(peak_mode / 1e12 * sclk / 2400.0, 1) if sclk else None,
             'conv_kernels': {'device_ms_per_step': round(conv_ms / prof_steps, 3), 'steps_sampled': prof_steps,
                              'tflops': round(conv_flops / max(conv_ms, 1e-9) / 1e9, 2),
                              'mfma_util_pct': round(100 * conv_flops / max(conv_ms, 1e-9) / 1e-3 / peak_mode, 1),
