@@ -320,6 +320,20 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(int kind, const float
   s = block_sum(s, sh);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
+// n <= 256 (the logits of a DCGAN / SRGAN discriminator pass): the one block's sum IS the loss - no partial array, no second
+// launch; the same additions in the same order as loss_partial_kernel + loss_final_kernel with one block (bit-identical)
+__global__ __launch_bounds__(256) void loss_small_kernel(int kind, const float* __restrict__ x, const float* __restrict__ y,
+                                                         float* __restrict__ loss, size_t n, float scale) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) s += loss_term(kind, x[i], y ? y[i] : 0.f);
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    t += s;
+    *loss = t * scale;
+  }
+}
 __global__ void loss_final_kernel(const float* __restrict__ part, int nb, float inv_n, float* __restrict__ loss) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float s = 0.f;
@@ -1192,6 +1206,11 @@ int iprgan_loss_sum_fwd(int kind, const float* x, const float* y, float* loss, f
   IPR_CHECK(n > 0, "loss_fwd: empty input");
   IPR_CHECK(!loss_needs_y(kind) || y, "loss_fwd: kind %d needs a second input", kind);
   const int nb = grid_for(n, LOSS_BLOCKS);
+  if (nb == 1) {
+    hipLaunchKernelGGL(loss_small_kernel, dim3(1), dim3(256), 0, st, kind, x, y, loss, n, scale);
+    IPR_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, st, kind, x, y, ws, n);
   IPR_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, ws, nb, scale, loss);
