@@ -723,17 +723,27 @@ def test_dcgan128_networks_vs_oracle(which, dev):
     np.testing.assert_allclose(yb.detach().cpu().numpy(), ya.detach().numpy(), rtol=RTOL, atol=ATOL)
     g = recipe.tensor(9, 3, tuple(ya.shape))
     ya.backward(g); yb.backward(g.to(dev))
-    # At batch 2 a single ReLU / BatchNorm-boundary element that rounds to the other side of zero changes a whole row of
-    # gradients by O(1e-2) in relative L2, and either fp32 evaluation can be the one that flips.  So the gradients are held
-    # against the TRUTH: the same network in float64 (oracle, same weights and inputs), and the engine may sit at most 4 x as
-    # far from it as the fp32 oracle does, plus one flip (1e-2) - not a tolerance fitted to observed runs.
+    # At batch 2 a ReLU / LeakyReLU / BatchNorm-boundary element that rounds to the other side of zero changes the gradient of
+    # everything UPSTREAM of it by O(1e-2) in relative L2 (a bias gradient of the 128x128 discriminator's second layer: 1.3e-2
+    # from one element), and either fp32 evaluation can be the one that flips.  So the gradients are held against the TRUTH:
+    # the same network in float64 (oracle, same weights and inputs).  Upstream of possible flips the engine may sit 4 x as far
+    # from it as the fp32 oracle does plus three flips' worth (3e-2: what this test allowed outright before round 6); the LAST
+    # parameterised layer, whose gradients no flip can reach (they multiply the flipped element's own, vanishing, activation),
+    # must be fp32-grade: within 2 x of the oracle's distance (+ 5e-6) - a bf16-grade product would miss that by 1000 x.
     xc = x.clone().double().requires_grad_()
     c(xc).backward(g.double())
+    names = [k for k, _ in a.named_parameters()]
+    last = names[-1].rsplit('.', 1)[0]              # module path of the last parameterised layer
+    n_last = 0
     for (k, pa), (_, pb), (_, pc) in zip(a.named_parameters(), b.named_parameters(), c.named_parameters()):
         t = pc.grad
         eh = float((pb.grad.cpu().double() - t).norm() / t.norm())
         er = float((pa.grad.double() - t).norm() / t.norm())
-        assert eh <= 4.0 * er + 1e-2, f'{k}: relative L2 distance from the float64 gradient {eh:.2e} (engine) vs {er:.2e} (fp32 oracle)'
+        assert eh <= 4.0 * er + 3e-2, f'{k}: relative L2 distance from the float64 gradient {eh:.2e} (engine) vs {er:.2e} (fp32 oracle)'
+        if k.rsplit('.', 1)[0] == last:
+            n_last += 1
+            assert eh <= 2.0 * er + 5e-6, f'{k} (next to the output): {eh:.2e} (engine) vs {er:.2e} (fp32 oracle) from the float64 gradient'
+    assert n_last >= 1
 
 
 def test_full_size_step_is_deterministic_and_keeps_watermark(dev):
