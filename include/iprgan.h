@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IPRGAN_VERSION 225
+#define IPRGAN_VERSION 226
 
 enum { IPRGAN_ACT_NONE = 0, IPRGAN_ACT_RELU = 1, IPRGAN_ACT_LRELU = 2, IPRGAN_ACT_TANH = 3,
        IPRGAN_ACT_SIGMOID_PM1 = 4 };   /* sigmoid(x)*2-1: nn.Sigmoid + Decoder32.Normalize (networks/decoder.py:14-16,31-32) */
@@ -208,6 +208,14 @@ int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const flo
 int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float* inv_scale, float* dx,
                     float* dw, float* db, const float* prev_out, int prev_act, float prev_slope, int B,
                     int K, int x_bf16, size_t x_pstride, size_t dx_pstride, void* stream);
+/* Paired pass (two half-batches of B / 2 rows, each with its own sigma: DESIGN.md section 4): the two iprgan_gemv_fwd / _bwd
+ * calls of the halves as one launch per kernel.  dw2 [2][K] and db2 [2] receive the gradients of the first / second half
+ * (three-plane x only; x_pstride as for the whole tensor).  Bit-identical to the per-half calls. */
+int iprgan_gemv_fwd_pair(const float* x, const float* w, const float* bias, const float* inv_scale0, const float* inv_scale1,
+                         float* y, int B, int K, int x_bf16, size_t x_pstride, void* stream);
+int iprgan_gemv_bwd_pair(const float* x, const float* w, const float* dy, const float* inv_scale0, const float* inv_scale1,
+                         float* dx, float* dw2, float* db2, const float* prev_out, int prev_act, float prev_slope, int B, int K,
+                         int x_bf16, size_t x_pstride, size_t dx_pstride, void* stream);
 
 /* ---- BatchNorm2d (networks/conv_generator.py:9, sr_resnet.py:23, discriminator_96.py:31) -- */
 size_t iprgan_bn_ws_floats(int M, int C);
@@ -339,6 +347,12 @@ int iprgan_loss_fwd(int kind, const float* x, const float* y, float* loss, float
 /* dx = (*gscale) * dloss/dx ; gscale is a device scalar (upstream gradient), may be NULL (=1). */
 int iprgan_loss_bwd(int kind, const float* x, const float* y, const float* gscale, float* dx,
                     size_t n, void* stream);
+/* Two one-input mean losses over the two halves of one vector x[0 .. n_half) / x[n_half .. 2 n_half) and their sum, one launch each
+ * way (the paired discriminator pass: models/dcgan.py:33-37 LossR, LossF, LossD = LossR + LossF).  out3 = {loss_a, loss_b,
+ * loss_a + loss_b}; bwd: dx[2 n_half] = gscale * d(loss_a + loss_b)/dx.  n_half <= 256; bit-identical to two
+ * iprgan_loss_fwd / _bwd calls and an fp32 add. */
+int iprgan_loss_pair_fwd(int kind_a, int kind_b, const float* x, size_t n_half, float* out3, void* stream);
+int iprgan_loss_pair_bwd(int kind_a, int kind_b, const float* x, const float* gscale, float* dx, size_t n_half, void* stream);
 /* same kernels with an explicit reduction: loss = scale * sum_i term_i (reduction='sum' / N, models/vae.py:41-47) */
 int iprgan_loss_sum_fwd(int kind, const float* x, const float* y, float* loss, float* ws, size_t n,
                         float scale, void* stream);

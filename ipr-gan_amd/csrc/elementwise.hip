@@ -134,8 +134,11 @@ __device__ __forceinline__ void st4e(float* p, size_t i, float4 v, int b16, size
 __global__ __launch_bounds__(1024) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ inv_scale,
-                                                        float* __restrict__ y, int K, int x16, size_t ps) {
+                                                        float* __restrict__ y, int K, int x16, size_t ps,
+                                                        const float* __restrict__ inv_scale1 = nullptr, int half = 0) {
+  // inv_scale1 / half (paired pass): rows >= half are divided by the second sigma
   __shared__ float sh[16];
+  if (inv_scale1 && (int)blockIdx.x >= half) inv_scale = inv_scale1;
   const size_t row = (size_t)blockIdx.x * K;
   const int stride = blockDim.x * 4;
   float s = 0.f;
@@ -161,9 +164,11 @@ __global__ __launch_bounds__(1024) void gemv_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void gemv_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
                                    const float* __restrict__ inv_scale, float* __restrict__ dx,
                                    const float* __restrict__ prev_out, int prev_act, float prev_slope,
-                                   int B, int K, int x16, size_t ps_dx, size_t ps_prev) {
-  const float sc = inv_scale ? *inv_scale : 1.f;
+                                   int B, int K, int x16, size_t ps_dx, size_t ps_prev,
+                                   const float* __restrict__ inv_scale1 = nullptr, int half = 0) {
   const int b = blockIdx.y;
+  if (inv_scale1 && b >= half) inv_scale = inv_scale1;        // paired pass: the second half-batch's sigma
+  const float sc = inv_scale ? *inv_scale : 1.f;
   const float g = dy[b];
   for (int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4; k < K; k += gridDim.x * blockDim.x * 4) {
     const float4 wv = *(const float4*)(w + k);
@@ -180,6 +185,11 @@ __global__ __launch_bounds__(256) void gemv_bwd_dx_kernel(const float* __restric
 // dw of a three-plane x: 4 columns per thread, four samples in flight
 __global__ __launch_bounds__(64) void gemv_bwd_dw3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dw, float* __restrict__ db, int B, int K, size_t ps) {
+  // blockIdx.y = group (paired pass: one weight / bias gradient per half-batch): rows [g B, (g + 1) B), dw + g K, db + g
+  x = (const float*)((const __bf16*)x + (size_t)blockIdx.y * B * K);
+  dy += (size_t)blockIdx.y * B;
+  if (dw) dw += (size_t)blockIdx.y * K;
+  if (db) db += blockIdx.y;
   const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (k < K && dw) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -333,6 +343,32 @@ __global__ __launch_bounds__(256) void loss_small_kernel(int kind, const float* 
     t += s;
     *loss = t * scale;
   }
+}
+// Two mean losses over the two halves of ONE vector and their sum, in one launch each way: the paired discriminator pass hands
+// D(real) and D(fake) over as one [2B] tensor, and the reference's LossD = LossR + LossF (models/dcgan.py:33-37) on slices of it
+// cost ten launches per step (two partial + final pairs, an ATen add, two gradient kernels, and the zero-fill + copy + add of
+// autograd's two slice gradients).  n <= 256 per half: the additions of loss_small_kernel per half, then one fp32 add -
+// bit-identical to the separate launches.
+__global__ __launch_bounds__(256) void loss_pair_small_kernel(int kind_a, int kind_b, const float* __restrict__ x, int n,
+                                                              float scale, float* __restrict__ out3) {
+  __shared__ float sh[16];
+  float sa = 0.f, sb = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) sa += loss_term(kind_a, x[i], 0.f);
+  sa = block_sum(sa, sh);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) sb += loss_term(kind_b, x[n + i], 0.f);
+  sb = block_sum(sb, sh);
+  if (threadIdx.x == 0) {
+    float ta = 0.f, tb = 0.f;
+    ta += sa; tb += sb;
+    const float la = ta * scale, lb = tb * scale;
+    out3[0] = la; out3[1] = lb; out3[2] = la + lb;
+  }
+}
+__global__ void loss_pair_bwd_kernel(int kind_a, int kind_b, const float* __restrict__ x, const float* __restrict__ gscale,
+                                     float* __restrict__ dx, int n, float inv_n) {
+  const float g = (gscale ? *gscale : 1.f) * inv_n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += gridDim.x * blockDim.x)
+    dx[i] = g * loss_grad(i < n ? kind_a : kind_b, x[i], 0.f);
 }
 __global__ void loss_final_kernel(const float* __restrict__ part, int nb, float inv_n, float* __restrict__ loss) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1026,6 +1062,36 @@ int iprgan_gemv_fwd(const float* x, const float* w, const float* bias, const flo
   IPR_LAUNCH_CHECK();
   return 0;
 }
+int iprgan_gemv_fwd_pair(const float* x, const float* w, const float* bias, const float* inv_scale0, const float* inv_scale1,
+                         float* y, int B, int K, int x_bf16, size_t x_pstride, void* stream) {
+  IPR_CHECK(K % 4 == 0 && (B & 1) == 0 && inv_scale0 && inv_scale1, "gemv_fwd_pair: K=%d, B=%d (even), two sigmas", K, B);
+  if (B == 0) return 0;
+  const size_t ps = x_pstride ? x_pstride : (size_t)B * K;
+  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(B), dim3(K >= 16384 ? 1024 : 256), 0, (hipStream_t)stream, x, w, bias, inv_scale0, y, K,
+                     x_bf16, ps, inv_scale1, B / 2);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_gemv_bwd_pair(const float* x, const float* w, const float* dy, const float* inv_scale0, const float* inv_scale1,
+                         float* dx, float* dw2, float* db2, const float* prev_out, int prev_act, float prev_slope, int B, int K,
+                         int x_bf16, size_t x_pstride, size_t dx_pstride, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  IPR_CHECK(K % 4 == 0 && (B & 1) == 0 && inv_scale0 && inv_scale1, "gemv_bwd_pair: K=%d, B=%d (even), two sigmas", K, B);
+  IPR_CHECK(x_bf16 == 2 || !(dw2 || db2), "gemv_bwd_pair: the per-half weight gradients are built for three-plane activations");
+  if (B == 0) return 0;
+  const size_t ps = x_pstride ? x_pstride : (size_t)B * K, ps_dx = dx_pstride ? dx_pstride : (size_t)B * K;
+  if (dx) {
+    const int gx = cdiv(K / 4, 256) < 64 ? cdiv(K / 4, 256) : 64;
+    hipLaunchKernelGGL(gemv_bwd_dx_kernel, dim3(gx, B), dim3(256), 0, st, w, dy, inv_scale0, dx, prev_out, prev_act, prev_slope, B, K,
+                       x_bf16, ps_dx, ps, inv_scale1, B / 2);
+    IPR_LAUNCH_CHECK();
+  }
+  if (dw2 || db2) {          // dw2 [2][K], db2 [2]: gradient of the first / second half-batch
+    hipLaunchKernelGGL(gemv_bwd_dw3_kernel, dim3(cdiv(K, 256), 2), dim3(64), 0, st, x, dy, dw2, db2, B / 2, K, ps);
+    IPR_LAUNCH_CHECK();
+  }
+  return 0;
+}
 int iprgan_gemv_bwd(const float* x, const float* w, const float* dy, const float* inv_scale, float* dx,
                     float* dw, float* db, const float* prev_out, int prev_act, float prev_slope, int B,
                     int K, int x_bf16, size_t x_pstride, size_t dx_pstride, void* stream) {
@@ -1224,6 +1290,24 @@ int iprgan_loss_sum_bwd(int kind, const float* x, const float* y, const float* g
   if (!n) return 0;
   hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, kind, x, y,
                      gscale, dx, n, scale);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_loss_pair_fwd(int kind_a, int kind_b, const float* x, size_t n_half, float* out3, void* stream) {
+  IPR_CHECK(kind_a >= 0 && kind_a <= IPRGAN_LOSS_L1_DENORM && kind_b >= 0 && kind_b <= IPRGAN_LOSS_L1_DENORM &&
+            !loss_needs_y(kind_a) && !loss_needs_y(kind_b), "loss_pair_fwd: kinds %d / %d (one-input losses only)", kind_a, kind_b);
+  IPR_CHECK(n_half > 0 && n_half <= 256, "loss_pair_fwd: %zu elements per half (1 .. 256)", n_half);
+  hipLaunchKernelGGL(loss_pair_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kind_a, kind_b, x, (int)n_half,
+                     1.0f / (float)n_half, out3);
+  IPR_LAUNCH_CHECK();
+  return 0;
+}
+int iprgan_loss_pair_bwd(int kind_a, int kind_b, const float* x, const float* gscale, float* dx, size_t n_half, void* stream) {
+  IPR_CHECK(kind_a >= 0 && kind_a <= IPRGAN_LOSS_L1_DENORM && kind_b >= 0 && kind_b <= IPRGAN_LOSS_L1_DENORM &&
+            !loss_needs_y(kind_a) && !loss_needs_y(kind_b), "loss_pair_bwd: kinds %d / %d (one-input losses only)", kind_a, kind_b);
+  IPR_CHECK(n_half > 0 && n_half <= 256, "loss_pair_bwd: %zu elements per half (1 .. 256)", n_half);
+  hipLaunchKernelGGL(loss_pair_bwd_kernel, dim3(cdiv((int)(2 * n_half), 256)), dim3(256), 0, (hipStream_t)stream, kind_a, kind_b, x,
+                     gscale, dx, (int)n_half, 1.0f / (float)n_half);
   IPR_LAUNCH_CHECK();
   return 0;
 }

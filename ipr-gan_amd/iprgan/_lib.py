@@ -71,6 +71,8 @@ SIGNATURES = {
     'iprgan_wgrad_reduce_multi': (_I, [_P, _I, _P]),
     'iprgan_gemv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _Z, _P]),
     'iprgan_gemv_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _Z, _Z, _P]),
+    'iprgan_gemv_fwd_pair': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _Z, _P]),
+    'iprgan_gemv_bwd_pair': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _Z, _Z, _P]),
     'iprgan_bn_ws_floats': (_Z, [_I, _I]),
     'iprgan_bn_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _I, _F, _P, _I, _P, _P, _P, _I, _P]),
     'iprgan_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _F, _I, _P]),
@@ -100,6 +102,8 @@ SIGNATURES = {
     'iprgan_loss_ws_floats': (_Z, [_Z]),
     'iprgan_loss_fwd': (_I, [_I, _P, _P, _P, _P, _Z, _P]),
     'iprgan_loss_bwd': (_I, [_I, _P, _P, _P, _P, _Z, _P]),
+    'iprgan_loss_pair_fwd': (_I, [_I, _I, _P, _Z, _P, _P]),
+    'iprgan_loss_pair_bwd': (_I, [_I, _I, _P, _P, _P, _Z, _P]),
     'iprgan_loss_sum_fwd': (_I, [_I, _P, _P, _P, _P, _Z, _F, _P]),
     'iprgan_loss_sum_bwd': (_I, [_I, _P, _P, _P, _P, _Z, _F, _P]),
     'iprgan_reparam_fwd': (_I, [_P, _P, _P, _P, _Z, _P]),

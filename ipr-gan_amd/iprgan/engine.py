@@ -24,6 +24,7 @@ _FUSE_STATS = os.environ.get('IPRGAN_FUSE_STATS', '1') != '0'       # A/B switch
 # short-K layers, and keeps the 256x256 / four-phase / persistent tiles out of those passes: DCGAN-128 bf16act 17.15 ->
 # 17.68 ms, SRGAN 33.30 -> 33.53 ms, DCGAN-64 11.52 -> 11.53 ms (round 3, same box, back to back).
 _FUSE_BN_BWD = os.environ.get('IPRGAN_FUSE_BN_BWD', '0') != '0'
+_GEMV_PAIR = os.environ.get('IPRGAN_GEMV_PAIR', '1') != '0'        # A/B switch: the head of a paired pass in one launch per kernel
 
 
 class Op:
@@ -466,10 +467,13 @@ class GemvHead(Op):
         wp = self._perm
         x2 = x.view(B, K)
         if pair is not None:                # paired pass: each half-batch with its own sigma
-            B2 = B // 2
-            y = ops.empty((B,), x2)
-            ops.gemv_fwd(x2[:B2], wp, self.bias, pair[0], out=y[:B2])
-            ops.gemv_fwd(x2[B2:], wp, self.bias, pair[1], out=y[B2:])
+            if _GEMV_PAIR:                  # both halves in one launch (rows >= B / 2 take the second sigma): bit-identical
+                y = ops.gemv_fwd_pair(x2, wp, self.bias, pair[0], pair[1])
+            else:
+                B2 = B // 2
+                y = ops.empty((B,), x2)
+                ops.gemv_fwd(x2[:B2], wp, self.bias, pair[0], out=y[:B2])
+                ops.gemv_fwd(x2[B2:], wp, self.bias, pair[1], out=y[B2:])
         else:
             y = ops.gemv_fwd(x2, wp, self.bias, sigma)
         st.update(x=x2, xshape=tuple(x.shape), wp=wp, sigma=sigma)
@@ -480,6 +484,15 @@ class GemvHead(Op):
         pair = st.get('pair')
         dy = dy.contiguous()
         unperm = lambda t: ops.permute_021(t, self.HW, self.C, 1).view(1, -1)
+        if pair is not None and _GEMV_PAIR and ops.is16(st['x']) == ops.ST_X3 and ops.pstride(st['x']) == st['x'].numel():
+            x2 = st['x']
+            dx, dw2, db2 = ops.gemv_bwd_pair(x2, st['wp'], dy, pair[0], pair[1], need_dx, need_w,
+                                             x2 if prev_act is not None else None, pa, ps)
+            grads = []
+            if need_w:
+                st['dwsn'] = [(unperm(dw2[h]), st['uv'][h][0], st['uv'][h][1], pair[h]) for h in (0, 1)]
+                grads = [st['dwsn'][0][0], ops.add(db2[0:1], db2[1:2])]
+            return (dx.view(st['xshape']) if dx is not None else None), grads
         if pair is not None:
             x2 = st['x']
             B2 = x2.shape[0] // 2

@@ -15,7 +15,7 @@ import torch
 from . import _lib as L
 from . import networks, ops, optim, tools
 from .parallel import GradReducer, Replica, broadcast_module
-from .tools import loss_sum, loss_value
+from .tools import PAIR_LOSS_MAX, loss_pair, loss_sum, loss_value
 
 import os
 
@@ -23,6 +23,7 @@ import os
 # (exact: its norm layers are per sample).  A/B switch.
 _BATCH_PASSES = os.environ.get('IPRGAN_BATCH_PASSES', '1') != '0'
 _PAIR_D = os.environ.get('IPRGAN_PAIR_D', '1') != '0'       # A/B switch for the paired discriminator pass
+_PAIR_LOSS = os.environ.get('IPRGAN_PAIR_LOSS', '1') != '0'    # A/B switch: both hinge terms of a paired pass in one launch each way
 
 __all__ = ['Model', 'Wrapper', 'DCGAN', 'SRGAN', 'CycleGAN', 'VAE', 'ImagePool', 'BlackBoxWrapper',
            'WhiteBoxWrapper', 'DisableBatchNormStats']
@@ -137,6 +138,11 @@ class DCGAN(Model):
         return t.to(self.device[0], non_blocking=True)
 
     def compute_d_loss(self):
+        flat = self.__dict__.get('_pair_logits')
+        if flat is not None and _PAIR_LOSS and flat.numel() <= 2 * PAIR_LOSS_MAX:
+            # the paired pass's [2B] logits: both hinge terms and their sum in one launch each way (bit-identical)
+            self.LossR, self.LossF, self.LossD = loss_pair(L.LOSS_HINGE_REAL, L.LOSS_HINGE_FAKE, flat, flat.numel() // 2)
+            return
         self.LossR = loss_value(L.LOSS_HINGE_REAL, self.real_logits)
         self.LossF = loss_value(L.LOSS_HINGE_FAKE, self.fake_logits)
         self.LossD = self.LossR + self.LossF
@@ -153,8 +159,11 @@ class DCGAN(Model):
         if _PAIR_D and hasattr(self.D.module, 'forward_pair') and fake.shape == self.real_sample.shape \
                 and self.D.module.can_pair(fake):
             # D(real) and D(fake) as one pass of twice the batch (each half with its own spectral-norm sigma)
-            self.real_logits, self.fake_logits = self.D.module.forward_pair(self.real_sample, fake)
+            flat = self.D.module.forward_pair_flat(self.real_sample, fake)
+            n = fake.shape[0]
+            self.real_logits, self.fake_logits, self._pair_logits = flat[:n], flat[n:], flat
         else:
+            self._pair_logits = None
             self.real_logits = self.D(self.real_sample)
             self.fake_logits = self.D(fake)
 

@@ -138,9 +138,14 @@ class SNDiscriminator(_HipNet):
         form of the reference's two consecutive calls, models/dcgan.py:47-48).  The spectral-norm power iteration runs
         twice, as for two calls, and each half is normalised by its own sigma; the buffers end where two calls leave
         them.  Launches of twice the size fill the GPU better (+5-10 % per layer at batch 128 + 128)."""
-        out = self.chain()(torch.cat([xa, xb]), self.training, pair=True).view(-1)
+        out = self.forward_pair_flat(xa, xb)
         n = xa.shape[0]
         return out[:n], out[n:]
+
+    def forward_pair_flat(self, xa, xb):
+        """forward_pair's two results as ONE [2B] tensor (first half D(xa)): what a fused pair loss consumes without autograd's
+        slice gradients (tools.loss_pair)."""
+        return self.chain()(torch.cat([xa, xb]), self.training, pair=True).view(-1)
 
     @staticmethod
     def can_pair(x):

@@ -497,6 +497,25 @@ def gemv_bwd(x2d, w, dy, sigma, need_dx, need_dw, prev_out=None, prev_act=L.ACT_
     return dx, dw, db
 
 
+def gemv_fwd_pair(x2d, w, bias, sigma0, sigma1):
+    """gemv_fwd of the two half-batches of a paired pass (rows [:B/2] / [B/2:] divided by sigma0 / sigma1) in one launch."""
+    B, K = x2d.shape
+    y = empty((B,), x2d)
+    call('iprgan_gemv_fwd_pair', ptr(x2d), ptr(w), ptr(bias), ptr(sigma0), ptr(sigma1), ptr(y), B, K, is16(x2d), pstride(x2d), stream())
+    return y
+
+
+def gemv_bwd_pair(x2d, w, dy, sigma0, sigma1, need_dx, need_dw, prev_out=None, prev_act=L.ACT_NONE, prev_slope=0.0):
+    """gemv_bwd of both halves in one launch per kernel: (dx [B, K], dw2 [2, K], db2 [2]); three-plane x for the weight side."""
+    B, K = x2d.shape
+    dx = _empty_like(x2d) if need_dx else None
+    dw2 = empty((2, K), x2d) if need_dw else None
+    db2 = empty((2,), x2d) if need_dw else None
+    call('iprgan_gemv_bwd_pair', ptr(x2d), ptr(w), ptr(dy), ptr(sigma0), ptr(sigma1), ptr(dx), ptr(dw2), ptr(db2), ptr(prev_out),
+         prev_act, float(prev_slope), B, K, is16(x2d), pstride(x2d), pstride(dx) if dx is not None else 0, stream())
+    return dx, dw2, db2
+
+
 # ---- batch norm -----------------------------------------------------------------------------------
 ST_X3_XF32 = 3          # norm entry points only (include/iprgan.h): x fp32; y, dy, dx, residual three planes
 _NORM_XF32 = os.environ.get('IPRGAN_NORM_XF32', '1') != '0'
@@ -702,6 +721,19 @@ def loss_fwd(kind, x, y=None):
 def loss_bwd(kind, x, y, gscale):
     dx = _empty_like(x)
     call('iprgan_loss_bwd', kind, ptr(x), ptr(y), ptr(gscale), ptr(dx), x.numel(), stream())
+    return dx
+
+
+def loss_pair_fwd(kind_a, kind_b, x, n_half):
+    """[mean_a(x[:n]), mean_b(x[n:]), their sum] as one 3-float tensor (n <= 256 per half)."""
+    out = empty((3,), x)
+    call('iprgan_loss_pair_fwd', kind_a, kind_b, ptr(x), int(n_half), ptr(out), stream())
+    return out
+
+
+def loss_pair_bwd(kind_a, kind_b, x, n_half, gscale):
+    dx = _empty_like(x)
+    call('iprgan_loss_pair_bwd', kind_a, kind_b, ptr(x), ptr(gscale), ptr(dx), int(n_half), stream())
     return dx
 
 

@@ -142,6 +142,32 @@ def loss_sum(kind, x, y=None, scale=1.0):
     return _LossSumFn.apply(kind, float(scale), x, y)
 
 
+class _LossPairFn(torch.autograd.Function):
+    """(loss_a over the first half, loss_b over the second, their sum) of one vector; the gradient flows from the SUM only."""
+
+    @staticmethod
+    def forward(ctx, kind_a, kind_b, x, n_half):
+        xd = x.detach().contiguous()
+        ctx.kinds, ctx.x, ctx.n = (kind_a, kind_b), xd, n_half
+        out = ops.loss_pair_fwd(kind_a, kind_b, xd, n_half)
+        la, lb, ls = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(la, lb)
+        return la, lb, ls
+
+    @staticmethod
+    def backward(ctx, ga, gb, gs):
+        return None, None, ops.loss_pair_bwd(ctx.kinds[0], ctx.kinds[1], ctx.x, ctx.n, gs.contiguous()), None
+
+
+PAIR_LOSS_MAX = 256
+
+
+def loss_pair(kind_a, kind_b, x, n_half):
+    """The mean losses of the two halves of ``x`` ([2 * n_half], n_half <= PAIR_LOSS_MAX) and their sum, one launch each way
+    (include/iprgan.h: iprgan_loss_pair_*); bit-identical to two ``loss_value`` calls on the halves and an add."""
+    return _LossPairFn.apply(kind_a, kind_b, x, int(n_half))
+
+
 def loss_value(kind, x, y=None):
     """Mean-reduced loss of ``kind`` (include/iprgan.h IPRGAN_LOSS_*); gradient flows to ``x`` only."""
     return _LossFn.apply(kind, x, y)
