@@ -1398,3 +1398,42 @@ def test_norm_backward_with_an_fp32_gradient_is_bit_identical_to_the_three_plane
             assert torch.equal(ops.f32(ta), ops.f32(tb)), name
     finally:
         _lib.set_math('fp32')
+
+
+def test_pair_loss_and_pair_head_are_bit_identical_to_the_per_half_calls(dev):
+    """Round 6 launch diet of the paired discriminator pass: iprgan_loss_pair_* (both hinge terms + their sum, one launch each way)
+    and iprgan_gemv_*_pair (the GEMV head of both half-batches, each with its own sigma, one launch per kernel) must reproduce,
+    bit for bit, the per-half calls they replace."""
+    from iprgan import _lib, ops, tools
+    _lib.set_math('fp32x3')
+    try:
+        B, K = 24, 2048
+        x = ops.to_kind(rnd(B, K, seed=1).to(dev), ops.ST_X3)
+        w, bias = rnd(K, seed=2, scale=K ** -0.5).to(dev), rnd(1, seed=3).to(dev)
+        s0, s1 = torch.tensor([1.7], device=dev), torch.tensor([0.6], device=dev)
+        y = ops.gemv_fwd_pair(x, w, bias, s0, s1)
+        ya, yb = ops.gemv_fwd(x[:B // 2], w, bias, s0), ops.gemv_fwd(x[B // 2:], w, bias, s1)
+        assert torch.equal(y, torch.cat([ya, yb]))
+        dy = rnd(B, seed=4).to(dev)
+        dx, dw2, db2 = ops.gemv_bwd_pair(x, w, dy, s0, s1, True, True, x, _lib.ACT_LRELU, 0.1)
+        ref = ops._empty_like(x)
+        halves = []
+        for h, (sl, sg) in enumerate(((slice(0, B // 2), s0), (slice(B // 2, None), s1))):
+            _, dwp, db = ops.gemv_bwd(x[sl], w, dy[sl].contiguous(), sg, True, True, x[sl], _lib.ACT_LRELU, 0.1, dx_out=ref[sl])
+            halves.append((dwp, db))
+        assert torch.equal(ops.f32(dx), ops.f32(ref))
+        for h in (0, 1):
+            assert torch.equal(dw2[h], halves[h][0]) and torch.equal(db2[h:h + 1], halves[h][1])
+        # losses: hinge(real) over the first half, hinge(fake) over the second, their sum; gradient of the sum
+        logits = (rnd(2 * 100, seed=5) * 2).to(dev).requires_grad_()
+        la, lb, ls = tools.loss_pair(_lib.LOSS_HINGE_REAL, _lib.LOSS_HINGE_FAKE, logits, 100)
+        ls.backward(torch.tensor(0.7, device=dev))
+        l2 = logits.detach().clone().requires_grad_()
+        ra, rb = tools.loss_value(_lib.LOSS_HINGE_REAL, l2[:100]), tools.loss_value(_lib.LOSS_HINGE_FAKE, l2[100:])
+        (ra + rb).backward(torch.tensor(0.7, device=dev))
+        assert torch.equal(la, ra) and torch.equal(lb, rb) and torch.equal(ls, ra + rb)
+        assert torch.equal(logits.grad, l2.grad)
+        with pytest.raises(RuntimeError, match='per half'):
+            ops.loss_pair_fwd(_lib.LOSS_HINGE_REAL, _lib.LOSS_HINGE_FAKE, torch.zeros(1024, device=dev), 512)
+    finally:
+        _lib.set_math('fp32')
