@@ -21,6 +21,7 @@
 // PyTorch layout by wgrad_reduce_kernel (deterministic).
 // Reference layers: networks/sn_discriminator.py:9-18, conv_generator.py:8, sr_resnet.py:22, resnet_generator.py:40-49.
 #include "conv_shared.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace iprgan {
@@ -271,10 +272,11 @@ bool wgrad_x3h_eligible(const iprgan_conv_desc* d) {
   if (d->x_bf16 != 2 || d->y_bf16 != 2) return false;
   if ((d->Cin % 64) != 0 || (d->Cout % 64) != 0 || d->KH != d->KW) return false;
   if (d->pad_mode == IPRGAN_PAD_REFLECT && (d->transposed || d->pad >= d->H || d->pad >= d->W)) return false;
-  return (d->KH == 3 && d->stride == 1) || (d->KH == 4 && d->stride == 2);
+  static const int k3s2 = getenv("IPRGAN_WX3_K3S2") ? atoi(getenv("IPRGAN_WX3_K3S2")) : 1;     // A/B switch (round 6)
+  return (d->KH == 3 && d->stride == 1) || (d->KH == 4 && d->stride == 2) || (k3s2 && d->KH == 3 && d->stride == 2);
 }
-static int x3h_ty(const iprgan_conv_desc* d) { return d->KH == 3 ? 8 : 4; }
-static int x3h_cb(const iprgan_conv_desc* d) { return d->KH == 3 ? 2 : 1; }
+static int x3h_ty(const iprgan_conv_desc* d) { return d->KH == 3 && d->stride == 1 ? 8 : 4; }
+static int x3h_cb(const iprgan_conv_desc* d) { return d->KH == 3 && d->stride == 1 ? 2 : 1; }
 
 // nsplit for a target number of blocks (the caller sizes the slabs with the same function)
 int wgrad_x3h_nsplit(const iprgan_conv_desc* d, int target_blocks) {
@@ -332,6 +334,10 @@ int launch_wgrad_x3h(const iprgan_conv_desc* d, const void* x, const void* dy, f
   dim3 grid(a.Ls / (32 * x3h_cb(d)), a.Ss / 64, nsplit);
   // (measured in round 6 and not kept: 16 waves = 8 tap groups of 2 taps, 106 registers, four waves per SIMD: -8 ... +5 % per
   // layer against run-to-run differences of the same size)
+  // k3 s2 (round 6: the downsampling convolutions of Discriminator96 / ResnetGenerator and its ConvTranspose upsamplers ran on
+  // the split-M GEMM tiles at 65-140 TFLOP/s): the same geometry class as k4 s2 - four residue planes of the halo, a 4 x 8 patch -
+  // with 9 taps: 6 waves = 3 tap groups x 2 halves of S, 3 stages of 48 KB
+  if (d->KH == 3 && d->stride == 2) return launch_wx3<3, 3, 2, 4, 3, 1, 3>(a, grid, st);
   if (d->KH == 4) return launch_wx3<4, 4, 2, 4, 4, 1, 3>(a, grid, st);       // 8 waves: 4 tap groups x 2 halves of S; 3 stages of 48 KB
   return launch_wx3<3, 3, 1, 8, 3, 2, 2>(a, grid, st);                       // 12 waves: 3 tap groups x 2 x 2; 2 stages of 72 KB
 }

@@ -164,6 +164,9 @@ X3H_SHAPES = [  # B, cin, cout, k, stride, pad, H, W, transposed, reflect
     (2, 128, 128, 3, 1, 1, 16, 24, False, True), (4, 64, 64, 4, 2, 1, 32, 32, False, False),
     (3, 128, 192, 4, 2, 1, 20, 28, False, False), (4, 128, 64, 4, 2, 1, 8, 8, True, False),
     (2, 256, 128, 4, 2, 1, 6, 10, True, False),
+    # k3 s2 (round 6): Discriminator96 / ResnetGenerator downsampling, ragged odd maps, ConvTranspose with and without output padding
+    (4, 64, 128, 3, 2, 1, 32, 32, False, False), (3, 128, 64, 3, 2, 1, 21, 13, False, False),
+    (2, 256, 128, 3, 2, 1, 8, 12, True, False), (3, 128, 64, 3, 2, 1, 9, 7, True, False, 1),
 ]
 
 
@@ -175,9 +178,10 @@ def test_wgrad_halo_for_three_plane_tensors(shape, cand, dev):
     (candidate 0), against float64 next to the fp32 mode's own distance; and on a batch slice of a larger tensor (the
     paired discriminator pass hands such slices: plane stride of the whole tensor)."""
     from iprgan import ops, _lib
-    B, cin, cout, k, s, p, H, W, tr, refl = shape
+    B, cin, cout, k, s, p, H, W, tr, refl = shape[:10]
+    op = shape[10] if len(shape) > 10 else 0                 # output_padding of a ConvTranspose2d (resnet_generator.py:27-30)
     g = torch.Generator().manual_seed(99 + cin + cout + H)
-    spec = ops.ConvSpec(cin, cout, k, s, p, 0, tr, pad_mode=1 if refl else 0)
+    spec = ops.ConvSpec(cin, cout, k, s, p, op, tr, pad_mode=1 if refl else 0)
     OH, OW = spec.out_hw(H, W)
     x = torch.randn(B, H, W, cin, generator=g).to(dev)
     dy = torch.randn(B, OH, OW, cout, generator=g).to(dev)
@@ -186,7 +190,7 @@ def test_wgrad_halo_for_three_plane_tensors(shape, cand, dev):
     if refl:
         x64 = F.pad(x64, (p, p, p, p), mode='reflect')
     w64 = torch.zeros(*wshape, dtype=torch.float64, requires_grad=True)
-    y64 = F.conv_transpose2d(x64, w64, None, s, p) if tr else F.conv2d(x64, w64, None, s, 0 if refl else p)
+    y64 = F.conv_transpose2d(x64, w64, None, s, p, op) if tr else F.conv2d(x64, w64, None, s, 0 if refl else p)
     y64.backward(dy.double().cpu().permute(0, 3, 1, 2))
     want = w64.grad
     rel = lambda got, ref: float((got.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())      # noqa: E731
@@ -202,7 +206,7 @@ def test_wgrad_halo_for_three_plane_tensors(shape, cand, dev):
         # the first B - 1 samples as a slice of the B-sample tensors (plane stride of the whole tensor)
         if B > 2:
             w64.grad = None
-            y2 = F.conv_transpose2d(x64[:B - 1], w64, None, s, p) if tr else F.conv2d(x64[:B - 1], w64, None, s, 0 if refl else p)
+            y2 = F.conv_transpose2d(x64[:B - 1], w64, None, s, p, op) if tr else F.conv2d(x64[:B - 1], w64, None, s, 0 if refl else p)
             y2.backward(dy[:B - 1].double().cpu().permute(0, 3, 1, 2))
             es = rel(ops.conv_bwd_weight(spec, spec.desc(B - 1, H, W), xp[:B - 1], dyp[:B - 1], wshape, False)[0], w64.grad)
             assert es < 4e-7, f'cand {cand}, batch slice: {es:.3e}'
@@ -284,7 +288,7 @@ def test_wgrad_of_rgb_layers_reads_the_three_plane_side_directly(shape, cand, de
     if refl:
         x64 = F.pad(x64, (p, p, p, p), mode='reflect')
     w64 = torch.zeros(*wshape, dtype=torch.float64, requires_grad=True)
-    y64 = F.conv_transpose2d(x64, w64, None, s, p) if tr else F.conv2d(x64, w64, None, s, 0 if refl else p)
+    y64 = F.conv_transpose2d(x64, w64, None, s, p, op) if tr else F.conv2d(x64, w64, None, s, 0 if refl else p)
     y64.backward(dy[..., :cout].double().cpu().permute(0, 3, 1, 2))
     want = w64.grad
     rel = lambda got, ref: float((got.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())      # noqa: E731
