@@ -288,7 +288,7 @@ def test_wgrad_of_rgb_layers_reads_the_three_plane_side_directly(shape, cand, de
     if refl:
         x64 = F.pad(x64, (p, p, p, p), mode='reflect')
     w64 = torch.zeros(*wshape, dtype=torch.float64, requires_grad=True)
-    y64 = F.conv_transpose2d(x64, w64, None, s, p, op) if tr else F.conv2d(x64, w64, None, s, 0 if refl else p)
+    y64 = F.conv_transpose2d(x64, w64, None, s, p) if tr else F.conv2d(x64, w64, None, s, 0 if refl else p)
     y64.backward(dy[..., :cout].double().cpu().permute(0, 3, 1, 2))
     want = w64.grad
     rel = lambda got, ref: float((got.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())      # noqa: E731
