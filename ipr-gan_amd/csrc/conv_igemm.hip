@@ -2378,7 +2378,7 @@ static int launch_gconv(const GConvArgs& ain, hipStream_t st) {
                                    : a.ksplit > 1 ? (unsigned long long)a.ksplit * a.ph[0].M * a.Ns
                                                   : (unsigned long long)a.B * a.OH * a.OW * a.Ns;
     unsigned long long outb = oel * (a.out16 ? 2ull : 4ull);
-    const unsigned long long auxb = oel * (a.aux16 ? 2ull : 4ull);
+    const unsigned long long auxb = a.aux ? oel * (a.aux16 ? 2ull : 4ull) : 0ull;      // (no operand: nothing to bound)
     if (a.out16 == 2) {
       IPR_CHECK(!a.planar_M && a.ksplit <= 1, "conv: three-plane output on a workspace pass");
       if (!a.out_ps) a.out_ps = (unsigned)outb;

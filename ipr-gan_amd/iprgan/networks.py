@@ -16,6 +16,7 @@ import os
 
 from . import _lib as L
 from . import engine as E
+from . import ops
 from .ops import ConvSpec, reparam_bwd as ops_reparam_bwd, reparam_fwd as ops_reparam_fwd
 
 _FUSE_PRELU = os.environ.get('IPRGAN_FUSE_PRELU', '1') != '0'      # A/B switch: PReLU folded into the BatchNorm in front of it
@@ -149,10 +150,14 @@ class SNDiscriminator(_HipNet):
 
     @staticmethod
     def can_pair(x):
-        """The largest activation of the paired pass ([2B, H, W, 64] floats behind the first convolution) must stay
-        below the 2 GiB tensor limit of the convolution entry points (include/iprgan.h)."""
+        """The largest activation of the paired pass ([2B, H, W, 64] behind the first convolution: 4 bytes per element as
+        fp32, 6 as three planes inside one buffer range) must stay below the 2 GiB tensor limit of the convolution entry
+        points (include/iprgan.h).  bf16 storage is held to the fp32 size: DCGAN-128 at batch 256 + 256 would fit as bf16 and
+        was measured in round 6 - 16.75 / 16.59 ms paired against 16.69 / 16.64 in two passes: layers of that size fill the
+        GPU either way."""
         B, _, H, W = x.shape
-        return 2 * B * H * W * 64 * 4 < (1 << 31)
+        bpe = 6 if ops.act_kind(64) == ops.ST_X3 else 4
+        return 2 * B * H * W * 64 * bpe < (1 << 31)
 
 
 def SNDiscriminator32():
